@@ -1,0 +1,93 @@
+/* lwm_hip.h -- C ABI of the MI355X-native LWM hot path (liblwm_hip.so).
+ *
+ * The reference (LargeWorldModel/LWM) has no FFI: its hot path sits behind
+ * Python callables.  Each entry point below names the reference interface it
+ * replaces; INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes; no torch / HIP types in signatures
+ *     (`stream` is a hipStream_t passed as void*; NULL = default stream);
+ *   - every pointer is DEVICE memory owned by the caller; the library never
+ *     allocates, frees or synchronises; kernels are enqueued on `stream`;
+ *   - return 0 (LWM_OK) or a negative LWM_E* code; lwm_last_error() returns a
+ *     thread-local message for the last failure on the calling thread;
+ *   - no global mutable state; one host thread per device is the supported
+ *     threading model.
+ */
+#ifndef LWM_HIP_H
+#define LWM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LWM_OK 0
+#define LWM_EINVAL (-1)       /* bad argument (null, misaligned, bad shape) */
+#define LWM_EUNSUPPORTED (-2) /* valid but not implemented (e.g. head_dim != 128) */
+#define LWM_ELAUNCH (-3)      /* HIP reported a launch error */
+
+/* A [B, S, H, D] tensor with D contiguous; strides in ELEMENTS.  This is the
+ * reference's q/k/v layout: heads are split by reshape, not transposed
+ * (lwm/llama.py:434-438), and shard_map hands the op (B, S/sp, H/tp, D) blocks
+ * (lwm/llama.py:559-566). */
+typedef struct LwmTensor4 {
+    void* ptr;
+    int64_t stride_b, stride_s, stride_h;
+} LwmTensor4;
+
+/* One ring step of blockwise attention: local queries [q_start, q_start+Sq)
+ * against the K/V block holding global positions [k_start, k_start+Sk).
+ *
+ * Replaces: ringattention(q,k,v,attn_bias,segment_ids, axis_name="sp",
+ *   float32_logits=True, blockwise_kwargs=dict(causal_block_size=1, ...))
+ *   -- call site lwm/llama.py:539-569 -- and its custom-VJP backward.
+ * Mask semantics (lwm/llama.py:425, :527-537, :546, :572-592):
+ *   visible(q,k) = (k_pos <= q_pos if causal) AND segment_ids_q[q]==segment_ids_k[k]
+ *                  AND key_valid[k] != 0
+ *   (attn_bias in the reference is the key-padding mask turned into
+ *   {0, finfo.min}; key_valid is that mask before the transform).
+ * Rows with no visible key produce out = 0, lse = -inf.
+ * Scores are q.k * scale in f32; softmax and all accumulators are f32
+ * (float32_logits=True, lwm/llama.py:543); operands are bf16; D must be 128.
+ */
+typedef struct LwmAttnArgs {
+    LwmTensor4 q, k, v;    /* bf16 in */
+    LwmTensor4 out;        /* bf16: fwd writes it when final_out; bwd reads it */
+    float* lse;            /* [B,H,Sq] natural-log LSE: fwd writes when final_out; bwd reads */
+    float* out_acc;        /* [B,Sq,H,D] f32 dense ring carry (normalised partial out) */
+    float* lse_acc;        /* [B,H,Sq]   f32 ring carry */
+    LwmTensor4 dout;       /* bf16 in (bwd) */
+    LwmTensor4 dq, dk, dv; /* bf16 out (bwd, when final_out) */
+    float* delta;          /* [B,H,Sq] f32: rowsum(dout*out); written by lwm_attn_bwd_delta */
+    float* dq_acc;         /* [B,Sq,H,D] f32 dense carry */
+    float* dk_acc;         /* [B,Sk,H,D] f32 dense carry (travels with the K/V block) */
+    float* dv_acc;
+    const int32_t* segment_ids_q; /* [B,Sq] or NULL */
+    const int32_t* segment_ids_k; /* [B,Sk] or NULL (both or neither) */
+    const uint8_t* key_valid;     /* [B,Sk] or NULL */
+    int32_t B, H, Sq, Sk, D;
+    int64_t q_start, k_start; /* global token position of local row 0 */
+    float scale;              /* 1/sqrt(D) in the reference */
+    int32_t causal;
+    int32_t carry_in;  /* 1: merge with the *_acc carries before writing */
+    int32_t final_out; /* 1: write bf16 out/lse (fwd) or dq / dk,dv (bwd); 0: write *_acc */
+} LwmAttnArgs;
+
+int lwm_attn_fwd(const LwmAttnArgs* args, void* stream);
+int lwm_attn_bwd_delta(const LwmAttnArgs* args, void* stream);
+int lwm_attn_bwd_dq(const LwmAttnArgs* args, void* stream);
+int lwm_attn_bwd_dkdv(const LwmAttnArgs* args, void* stream);
+
+/* Elementwise helpers of the ring driver (HBM-bound). */
+/* dst_bf16[n] = (bf16) src_f32[n] */
+int lwm_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+
+const char* lwm_last_error(void);
+int lwm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LWM_HIP_H */

@@ -1,0 +1,64 @@
+"""ctypes mirror of include/lwm_hip.h (struct layouts + prototypes).
+
+Pure declarations: no library is loaded here.  `lwm_amd._lib` binds these to
+liblwm_hip.so (the product); tests bind the same declarations to the
+host-emulated build of the kernels.
+"""
+import ctypes as C
+
+LWM_OK = 0
+LWM_EINVAL = -1
+LWM_EUNSUPPORTED = -2
+LWM_ELAUNCH = -3
+
+
+class LwmTensor4(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("stride_b", C.c_int64), ("stride_s", C.c_int64),
+                ("stride_h", C.c_int64)]
+
+
+class LwmAttnArgs(C.Structure):
+    _fields_ = [
+        ("q", LwmTensor4), ("k", LwmTensor4), ("v", LwmTensor4),
+        ("out", LwmTensor4),
+        ("lse", C.c_void_p), ("out_acc", C.c_void_p), ("lse_acc", C.c_void_p),
+        ("dout", LwmTensor4), ("dq", LwmTensor4), ("dk", LwmTensor4), ("dv", LwmTensor4),
+        ("delta", C.c_void_p), ("dq_acc", C.c_void_p), ("dk_acc", C.c_void_p),
+        ("dv_acc", C.c_void_p),
+        ("segment_ids_q", C.c_void_p), ("segment_ids_k", C.c_void_p), ("key_valid", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("Sq", C.c_int32), ("Sk", C.c_int32), ("D", C.c_int32),
+        ("q_start", C.c_int64), ("k_start", C.c_int64),
+        ("scale", C.c_float),
+        ("causal", C.c_int32), ("carry_in", C.c_int32), ("final_out", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/lwm_hip.h declares
+PROTOTYPES = {
+    "lwm_attn_fwd": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
+    "lwm_attn_bwd_delta": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
+    "lwm_attn_bwd_dq": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
+    "lwm_attn_bwd_dkdv": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
+    "lwm_cast_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "lwm_last_error": (C.c_char_p, []),
+    "lwm_version": (C.c_int, []),
+}
+
+
+def bind(lib):
+    """Attach restype/argtypes for every declared symbol; raises if one is missing."""
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+class LwmError(RuntimeError):
+    pass
+
+
+def check(lib, rc, what):
+    if rc != LWM_OK:
+        msg = lib.lwm_last_error()
+        raise LwmError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")

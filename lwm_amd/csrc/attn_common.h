@@ -1,0 +1,122 @@
+// attn_common.h -- shared tile geometry for the blockwise attention kernels.
+//
+// Requires a wave_ops.h (product: lwm_amd/csrc/wave_ops.h) to be included
+// first.  Restates, MI355X-first, the inner update of the reference's
+// blockwise ring attention: lwm/llama.py:539-569 calls
+// ringattention(q,k,v,bias,segment_ids, float32_logits=True,
+// causal_block_size=1, query/key chunk sizes) -- the arithmetic lives in the
+// un-vendored `ringattention` package; the in-tree mask specification is
+// lwm/llama.py:572-592.
+//
+// Geometry (all kernels): head_dim D = 128 (LWM-7B: lwm/llama.py:70-81),
+// bf16 operands, f32 logits/softmax/accumulators, v_mfma_f32_32x32x16_bf16.
+//
+// LDS tile image: rows of 128 bf16 = 256 B = 16 slots of 16 B.  Slot s of row r
+// is stored at physical slot  s ^ swz(r),  swz(r) = ((r&3)<<2) | ((r>>2)&3).
+//   * row-fragment reads (ds_read_b128, 16 lanes = 16 distinct r&15 at one
+//     logical slot) hit 16 distinct physical slots      -> conflict-free;
+//   * transpose reads (ds_read_b64_tr_b16, a half-wave = 4 consecutive rows x
+//     64 contiguous logical bytes) land in 4 distinct 64-B chunks, because the
+//     chunk index is XORed with r&3                     -> conflict-free.
+#pragma once
+
+namespace lwm {
+
+constexpr int kHeadDim = 128;
+constexpr int kRowBytes = kHeadDim * 2;  // 256
+
+struct AttnParams {
+    // forward operands
+    const bf16_t* q;
+    const bf16_t* k;
+    const bf16_t* v;
+    bf16_t* out;        // final bf16 output (final_out != 0)
+    float* lse;         // final natural-log LSE [B,H,Sq]
+    float* out_acc;     // f32 carry [B,Sq,H,D], normalised partial output
+    float* lse_acc;     // f32 carry [B,H,Sq]
+    // backward operands
+    const bf16_t* dout;
+    const float* delta;  // [B,H,Sq] rowsum(dO*O)
+    bf16_t* dq;
+    bf16_t* dk;
+    bf16_t* dv;
+    float* dq_acc;      // f32 carry [B,Sq,H,D]
+    float* dk_acc;      // f32 carry [B,Sk,H,D]
+    float* dv_acc;
+    // masks
+    const int32_t* seg_q;      // [B,Sq] or null
+    const int32_t* seg_k;      // [B,Sk] or null
+    const uint8_t* key_valid;  // [B,Sk] or null (0 = padded key)
+    // element strides (D is contiguous)
+    int64_t q_sb, q_ss, q_sh;
+    int64_t k_sb, k_ss, k_sh;
+    int64_t v_sb, v_ss, v_sh;
+    int64_t o_sb, o_ss, o_sh;    // out, dout, dq share q's logical shape
+    int64_t do_sb, do_ss, do_sh;
+    int64_t dq_sb, dq_ss, dq_sh;
+    int64_t dk_sb, dk_ss, dk_sh;
+    int64_t dv_sb, dv_ss, dv_sh;
+    int32_t B, H, Sq, Sk;
+    int64_t q_start, k_start;  // global token position of row 0 (ring offset)
+    float scale;               // softmax scale, 1/sqrt(D)
+    int32_t causal;
+    int32_t carry_in;          // merge with *_acc before writing
+    int32_t final_out;         // write bf16 results (else f32 *_acc)
+};
+
+LWM_DEVICE int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+LWM_DEVICE int tile_off(int row, int slot) { return row * kRowBytes + ((slot ^ swz(row)) << 4); }
+
+// Fragment of a row-major [rows][128] LDS tile for an MFMA operand whose
+// non-contracted index is the tile row and whose contracted index is d:
+// lane l gets tile[row0 + (l&31)][16*step + 8*(l>>5) + 0..7].
+LWM_DEVICE bf16x8 frag_rows(const char* tile, int row0, int step, int l31, int hi) {
+    return lds_read_b128(tile + tile_off(row0 + l31, 2 * step + hi));
+}
+
+// Transposed fragment: the MFMA operand's non-contracted index is d and the
+// contracted index is the tile row.  Lane l (d = d0 + (l&31)) gets, for
+// j = 0..7, tile[row0 + 4*(l>>5) + (j&3) + 8*(j>>2)][d]  -- i.e. exactly the
+// contracted-index order in which a 32x32 C/D fragment holds its rows in
+// registers 0..7 (+8 for the second half), so a C/D fragment converted to bf16
+// can be used as the other operand with no cross-lane traffic.
+LWM_DEVICE bf16x8 frag_cols_tr(const char* tile, int row0, int d0, int lane) {
+    int g = lane >> 4, i = lane & 15;
+    int hi = g >> 1;
+    int d = d0 + 16 * (g & 1) + 4 * (i & 3);
+    int r = row0 + 4 * hi + (i >> 2);
+    bf16x4 lo = lds_read_tr16(tile + tile_off(r, d >> 3) + (d & 7) * 2);
+    bf16x4 up = lds_read_tr16(tile + tile_off(r + 8, d >> 3) + (d & 7) * 2);
+    bf16x8 o;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+    o[4] = up[0]; o[5] = up[1]; o[6] = up[2]; o[7] = up[3];
+    return o;
+}
+
+// Row index (within a 32-row block) that register r of a C/D fragment holds.
+LWM_DEVICE int cd_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+LWM_DEVICE bf16x8 zero_bf16x8() {
+    bf16x8 z;
+    for (int j = 0; j < 8; ++j) z[j] = (bf16_t)0.0f;
+    return z;
+}
+
+LWM_DEVICE f32x16 zero_f32x16() {
+    f32x16 z;
+    for (int j = 0; j < 16; ++j) z[j] = 0.0f;
+    return z;
+}
+
+// 8 f32 (regs base..base+7 of a C/D fragment) -> bf16x8 operand.
+LWM_DEVICE bf16x8 cvt_frag(const f32x16& x, int base) {
+    bf16x8 o;
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)x[base + j];
+    return o;
+}
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr int32_t kSegInvalid = (int32_t)0x80000000;
+
+}  // namespace lwm

@@ -1,0 +1,260 @@
+// attn_fwd.h -- blockwise attention forward for one (q block, kv block) ring
+// step on gfx950.  Requires wave_ops.h + attn_common.h.
+//
+// Replaces the forward of `ringattention` as called at lwm/llama.py:539-569
+// (blockwise online-softmax update, fp32 logits, causal_block_size=1, masks per
+// lwm/llama.py:527-537 and :572-592).  One launch = the reference's whole
+// "scan over q chunks x scan over k chunks" for one ring step; chunk sizes are
+// an implementation detail here (256-query workgroup tile, 64-key LDS tile).
+//
+// Workgroup = 512 threads = 8 waves; wave w owns 32 query rows.  Scores are
+// computed TRANSPOSED, S^T = K Q^T, so a lane owns ONE query column of the
+// 32x32 C/D fragment: the row max / row sum of the online softmax are in-lane
+// reductions plus one half-wave exchange, and exp(S^T) converted to bf16 is
+// already the B operand of O^T += V^T P^T.
+#pragma once
+
+namespace lwm {
+
+constexpr int kFwdBQ = 256;    // queries per workgroup
+constexpr int kFwdBK = 64;     // keys per LDS tile
+constexpr int kFwdThreads = 512;
+constexpr int kFwdTileBytes = kFwdBK * kRowBytes;                  // 16 KiB
+constexpr int kFwdLdsBytes = 4 * kFwdTileBytes + 2 * kFwdBK * 4;  // K,V x2 + kseg x2
+
+struct FwdStage {
+    u32x4 k[2];
+    u32x4 v[2];
+    int32_t kseg;
+};
+
+LWM_DEVICE void fwd_stage_load(const AttnParams& p, const bf16_t* kb, const bf16_t* vb,
+                               int b, int kt, int tid, FwdStage& st) {
+    for (int i = 0; i < 2; ++i) {
+        int c = tid + kFwdThreads * i;
+        int row = c >> 4, slot = c & 15;
+        int krow = kt * kFwdBK + row;
+        if (krow < p.Sk) {
+            st.k[i] = global_load_b128(kb + (int64_t)krow * p.k_ss + slot * 8);
+            st.v[i] = global_load_b128(vb + (int64_t)krow * p.v_ss + slot * 8);
+        } else {
+            u32x4 z = {0u, 0u, 0u, 0u};
+            st.k[i] = z;
+            st.v[i] = z;
+        }
+    }
+    if (tid < kFwdBK) {
+        int krow = kt * kFwdBK + tid;
+        int32_t s = kSegInvalid;
+        if (krow < p.Sk) {
+            bool valid = p.key_valid ? (p.key_valid[(int64_t)b * p.Sk + krow] != 0) : true;
+            if (valid) s = p.seg_k ? p.seg_k[(int64_t)b * p.Sk + krow] : 0;
+        }
+        st.kseg = s;
+    }
+}
+
+LWM_DEVICE void fwd_stage_write(char* kbuf, char* vbuf, int32_t* ksegbuf, int tid,
+                                const FwdStage& st) {
+    for (int i = 0; i < 2; ++i) {
+        int c = tid + kFwdThreads * i;
+        int row = c >> 4, slot = c & 15;
+        lds_write_b128(kbuf + tile_off(row, slot), st.k[i]);
+        lds_write_b128(vbuf + tile_off(row, slot), st.v[i]);
+    }
+    if (tid < kFwdBK) ksegbuf[tid] = st.kseg;
+}
+
+LWM_KERNEL(kFwdThreads) void attn_fwd_kernel(AttnParams p) {
+    char* lds = dyn_lds();
+    const int tid = thread_idx();
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+
+    // ---- block -> (q tile, head, batch): longest q tiles first; all q tiles of
+    // one (b,h) stay on one XCD (block b runs on XCD b%8) so its K/V stream is
+    // shared in that XCD's L2.
+    const int nqt = (p.Sq + kFwdBQ - 1) / kFwdBQ;
+    const int HB = p.H * p.B;
+    int lin = block_idx_x(), qt, hb;
+    if ((HB & 7) == 0) {
+        int xcd = lin & 7, i = lin >> 3;
+        hb = xcd + 8 * (i / nqt);
+        qt = nqt - 1 - (i % nqt);
+    } else {
+        hb = lin / nqt;
+        qt = nqt - 1 - (lin % nqt);
+    }
+    const int b = hb / p.H, h = hb % p.H;
+
+    const bf16_t* qb = p.q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
+    const bf16_t* kb = p.k + (int64_t)b * p.k_sb + (int64_t)h * p.k_sh;
+    const bf16_t* vb = p.v + (int64_t)b * p.v_sb + (int64_t)h * p.v_sh;
+
+    char* kbuf[2] = {lds, lds + kFwdTileBytes};
+    char* vbuf[2] = {lds + 2 * kFwdTileBytes, lds + 3 * kFwdTileBytes};
+    int32_t* ksegbuf[2] = {(int32_t*)(lds + 4 * kFwdTileBytes),
+                           (int32_t*)(lds + 4 * kFwdTileBytes) + kFwdBK};
+
+    // ---- this lane's query row
+    const int q_row = qt * kFwdBQ + wave * 32 + l31;
+    const bool q_ok = q_row < p.Sq;
+    const int64_t q_pos = p.q_start + q_row;
+    bf16x8 qf[8];
+    for (int s = 0; s < 8; ++s) {
+        if (q_ok) {
+            u32x4 raw = global_load_b128(qb + (int64_t)q_row * p.q_ss + 16 * s + 8 * hi);
+            qf[s] = __builtin_bit_cast(bf16x8, raw);
+        } else {
+            qf[s] = zero_bf16x8();
+        }
+    }
+    const int32_t seg_q = (q_ok && p.seg_q) ? p.seg_q[(int64_t)b * p.Sq + q_row] : 0;
+    const bool has_kmeta = (p.seg_k != nullptr) || (p.key_valid != nullptr) || (p.Sk % kFwdBK != 0);
+
+    // ---- kv tile range (causal: skip tiles wholly in the future of this q tile)
+    const int nkt_all = (p.Sk + kFwdBK - 1) / kFwdBK;
+    int nkt = nkt_all;
+    const int q_last = (qt * kFwdBQ + kFwdBQ < p.Sq ? qt * kFwdBQ + kFwdBQ : p.Sq) - 1;
+    if (p.causal) {
+        int64_t d = p.q_start + q_last - p.k_start;  // last visible key index
+        if (d < 0) nkt = 0;
+        else {
+            int64_t t = d / kFwdBK + 1;
+            nkt = t < nkt_all ? (int)t : nkt_all;
+        }
+    }
+    // wave-level bounds (global positions of this wave's first/last query)
+    const int64_t wq_min = p.q_start + qt * kFwdBQ + wave * 32;
+    const int64_t wq_max = wq_min + 31;
+
+    const float c = p.scale * kLog2e;
+    float m_run = -INFINITY;  // running max of raw scores (q.k, unscaled)
+    float l_run = 0.0f;       // this half-wave's partial row sum
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) acc[i] = zero_f32x16();
+
+    FwdStage stg;
+    if (nkt > 0) {
+        fwd_stage_load(p, kb, vb, b, 0, tid, stg);
+        fwd_stage_write(kbuf[0], vbuf[0], ksegbuf[0], tid, stg);
+    }
+    block_sync();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nkt;
+        if (more) fwd_stage_load(p, kb, vb, b, kt + 1, tid, stg);
+
+        const int64_t k_pos0 = p.k_start + (int64_t)kt * kFwdBK;
+        const bool wave_active = !p.causal || k_pos0 <= wq_max;
+        if (wave_active) {
+            // ---- S^T = K Q^T  (rows = keys, cols = queries)
+            f32x16 st[2];
+            for (int kb2 = 0; kb2 < 2; ++kb2) {
+                st[kb2] = zero_f32x16();
+                for (int s = 0; s < 8; ++s) {
+                    bf16x8 a = frag_rows(kbuf[cur], 32 * kb2, s, l31, hi);
+                    st[kb2] = mfma_32x32x16(a, qf[s], st[kb2]);
+                }
+            }
+            // ---- masks (lwm/llama.py:572-592): causal, same segment, key valid
+            const bool need_mask = has_kmeta || (p.causal && k_pos0 + kFwdBK - 1 > wq_min);
+            if (need_mask) {
+                const int32_t* ks = ksegbuf[cur];
+                for (int kb2 = 0; kb2 < 2; ++kb2) {
+                    for (int r = 0; r < 16; ++r) {
+                        int kl = 32 * kb2 + cd_row(r, hi);
+                        bool vis = (ks[kl] == seg_q);
+                        if (p.causal) vis = vis && (k_pos0 + kl <= q_pos);
+                        st[kb2][r] = vis ? st[kb2][r] : -INFINITY;
+                    }
+                }
+            }
+            // ---- online softmax (per query column)
+            float mx = -INFINITY;
+            for (int kb2 = 0; kb2 < 2; ++kb2)
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb2][r]);
+            mx = fmaxf(mx, xhalf(mx));
+            const float m_new = fmaxf(m_run, mx);
+            const float m_safe = (m_new == -INFINITY) ? 0.0f : m_new;
+            const float alpha = fast_exp2((m_run - m_safe) * c);
+            const float msc = m_safe * c;
+            float psum = 0.0f;
+            for (int kb2 = 0; kb2 < 2; ++kb2)
+                for (int r = 0; r < 16; ++r) {
+                    float pv = fast_exp2(fmaf(st[kb2][r], c, -msc));
+                    st[kb2][r] = pv;
+                    psum += pv;
+                }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+            for (int i = 0; i < 4; ++i) acc[i] *= alpha;
+            // ---- O^T += V^T P^T
+            bf16x8 pb[2][2];
+            for (int kb2 = 0; kb2 < 2; ++kb2)
+                for (int t = 0; t < 2; ++t) pb[kb2][t] = cvt_frag(st[kb2], 8 * t);
+            for (int db = 0; db < 4; ++db)
+                for (int kb2 = 0; kb2 < 2; ++kb2)
+                    for (int t = 0; t < 2; ++t) {
+                        bf16x8 a = frag_cols_tr(vbuf[cur], 32 * kb2 + 16 * t, 32 * db, lane);
+                        acc[db] = mfma_32x32x16(a, pb[kb2][t], acc[db]);
+                    }
+        }
+        if (more) fwd_stage_write(kbuf[cur ^ 1], vbuf[cur ^ 1], ksegbuf[cur ^ 1], tid, stg);
+        block_sync();
+    }
+
+    // ---- epilogue: normalise, merge with the ring carry, store
+    const float l_tot = l_run + xhalf(l_run);
+    float inv = 0.0f, lse_b = -INFINITY;
+    if (l_tot > 0.0f) {
+        inv = 1.0f / l_tot;
+        lse_b = m_run * p.scale + logf(l_tot);
+    }
+    float w_a = 0.0f, w_b = 1.0f, lse_new = lse_b;
+    const int64_t lse_idx = ((int64_t)b * p.H + h) * p.Sq + q_row;
+    if (p.carry_in && q_ok) {
+        float lse_a = p.lse_acc[lse_idx];
+        float mx = fmaxf(lse_a, lse_b);
+        if (mx == -INFINITY) {
+            lse_new = -INFINITY;
+            w_a = 0.0f;
+            w_b = 0.0f;
+        } else {
+            float ea = expf(lse_a - mx), eb = expf(lse_b - mx);
+            lse_new = mx + logf(ea + eb);
+            w_a = ea / (ea + eb);
+            w_b = eb / (ea + eb);
+        }
+    }
+    if (q_ok) {
+        const float sc = inv * w_b;
+        const int64_t orow = (int64_t)b * p.o_sb + (int64_t)q_row * p.o_ss + (int64_t)h * p.o_sh;
+        // the f32 carry is dense [B,Sq,H,D]
+        const int64_t arow = (((int64_t)b * p.Sq + q_row) * p.H + h) * kHeadDim;
+        for (int db = 0; db < 4; ++db)
+            for (int rq = 0; rq < 4; ++rq) {
+                int d0 = 32 * db + 8 * rq + 4 * hi;
+                float o0 = acc[db][4 * rq + 0] * sc, o1 = acc[db][4 * rq + 1] * sc;
+                float o2 = acc[db][4 * rq + 2] * sc, o3 = acc[db][4 * rq + 3] * sc;
+                if (p.carry_in) {
+                    const float* a = p.out_acc + arow + d0;
+                    o0 += a[0] * w_a; o1 += a[1] * w_a; o2 += a[2] * w_a; o3 += a[3] * w_a;
+                }
+                if (p.final_out) {
+                    u32x2 pk = {pack_bf16x2(o0, o1), pack_bf16x2(o2, o3)};
+                    global_store_b64(p.out + orow + d0, pk);
+                } else {
+                    u32x4 pk = {__builtin_bit_cast(uint32_t, o0), __builtin_bit_cast(uint32_t, o1),
+                                __builtin_bit_cast(uint32_t, o2), __builtin_bit_cast(uint32_t, o3)};
+                    global_store_b128(p.out_acc + arow + d0, pk);
+                }
+            }
+        if (hi == 0) {
+            if (p.final_out) p.lse[lse_idx] = lse_new;
+            else p.lse_acc[lse_idx] = lse_new;
+        }
+    }
+}
+
+}  // namespace lwm

@@ -1,0 +1,35 @@
+// launch.h -- HIP launch glue for the C ABI (product build).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+namespace lwm {
+
+inline thread_local char g_err[512] = "";
+
+inline int fail(int code, const char* fmt, const char* a = "", long x = 0, long y = 0) {
+    snprintf(g_err, sizeof(g_err), fmt, a, x, y);
+    return code;
+}
+
+template <class... KArgs, class... Args>
+inline int launch(const char* name, void (*kernel)(KArgs...), long grid, int threads,
+                  size_t lds_bytes, void* stream, Args... args) {
+    if (grid <= 0) return 0;
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds_bytes);
+        if (e != hipSuccess) return fail(-3, "%s: hipFuncSetAttribute(LDS=%ld): %ld", name, (long)lds_bytes, (long)e);
+    }
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3((unsigned)threads), lds_bytes,
+                       (hipStream_t)stream, args...);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: launch failed: %s", name, hipGetErrorString(e));
+        return -3;
+    }
+    return 0;
+}
+
+}  // namespace lwm

@@ -1,0 +1,12 @@
+// lwm_hip.hip -- translation unit of liblwm_hip.so (gfx950).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC (see build.py).
+#include <string.h>
+#include <math.h>
+#include "wave_ops.h"
+#include "launch.h"
+#include "lwm_hip.h"
+#include "attn_common.h"
+#include "attn_fwd.h"
+#include "attn_bwd.h"
+#include "misc_kernels.h"
+#include "api.inc"

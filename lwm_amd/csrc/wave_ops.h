@@ -1,0 +1,88 @@
+// wave_ops.h -- the gfx950 (CDNA4) device vocabulary every kernel in this
+// directory is written against: wave64 lane ids, the 32x32x16 bf16 MFMA, the
+// LDS transpose read, half-wave exchange, block barrier, fast exp2.
+//
+// Kernels never spell a __builtin_amdgcn_* themselves; they call these
+// wrappers.  tests/emu/wave_ops.h provides the same names on the host (fibers,
+// one per lane) so kernel index math can be exercised without a GPU.  That
+// header is test infrastructure; this one is the product.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lwm {
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define LWM_DEVICE __device__ __forceinline__
+#define LWM_GLOBAL __global__
+#define LWM_KERNEL(max_threads) __global__ __launch_bounds__(max_threads)
+
+LWM_DEVICE int thread_idx() { return (int)threadIdx.x; }
+LWM_DEVICE int block_idx_x() { return (int)blockIdx.x; }
+LWM_DEVICE int block_idx_y() { return (int)blockIdx.y; }
+LWM_DEVICE int block_idx_z() { return (int)blockIdx.z; }
+LWM_DEVICE int grid_dim_x() { return (int)gridDim.x; }
+
+// Dynamic LDS base (16-byte aligned: no static __shared__ anywhere, see
+// cdna_hip_programming.md Guideline 17).
+LWM_DEVICE char* dyn_lds() {
+    extern __shared__ __attribute__((aligned(16))) char lwm_smem[];
+    return lwm_smem;
+}
+
+LWM_DEVICE void block_sync() { __syncthreads(); }
+
+// D = A(32x16) * B(16x32) + C(32x32), bf16 in / f32 accumulate.
+//   A: lane l holds A[row = l&31][k = 8*(l>>5) + j], j = 0..7
+//   B: lane l holds B[k = 8*(l>>5) + j][col = l&31]
+//   C/D: lane l, reg r holds C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
+LWM_DEVICE f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// ds_read_b64_tr_b16.  Per 16-lane group: lanes 4j..4j+3 each point at 4
+// consecutive bf16 of "row j" (so a group addresses a 4x16 block, rows
+// anywhere); lane i receives column i of that block: {row0[i], row1[i],
+// row2[i], row3[i]}.  `p` must be an 8-byte aligned LDS address.
+LWM_DEVICE bf16x4 lds_read_tr16(const char* p) {
+    typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 v4;
+    v4 r = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+        (__attribute__((address_space(3))) v4*)(p));
+    bf16x4 o;
+    o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3];
+    return o;
+}
+
+LWM_DEVICE bf16x8 lds_read_b128(const char* p) { return *(const bf16x8*)p; }
+LWM_DEVICE f32x4 lds_read_f32x4(const char* p) { return *(const f32x4*)p; }
+LWM_DEVICE void lds_write_b128(char* p, u32x4 v) { *(u32x4*)p = v; }
+
+// value held by lane (l ^ 32)
+LWM_DEVICE float xhalf(float x) {
+    return __shfl_xor(x, 32, 64);
+}
+LWM_DEVICE float shfl_xor_f(float x, int m) { return __shfl_xor(x, m, 64); }
+LWM_DEVICE int shfl_xor_i(int x, int m) { return __shfl_xor(x, m, 64); }
+
+LWM_DEVICE float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+LWM_DEVICE float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+
+LWM_DEVICE u32x4 global_load_b128(const void* p) { return *(const u32x4*)p; }
+LWM_DEVICE void global_store_b128(void* p, u32x4 v) { *(u32x4*)p = v; }
+LWM_DEVICE void global_store_b64(void* p, u32x2 v) { *(u32x2*)p = v; }
+
+LWM_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
+    union { bf16_t h[2]; uint32_t u; } x;
+    x.h[0] = (bf16_t)lo;
+    x.h[1] = (bf16_t)hi;
+    return x.u;
+}
+
+}  // namespace lwm

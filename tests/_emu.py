@@ -1,0 +1,150 @@
+"""Test helper: the HIP kernel headers compiled for the HOST (tests/emu/) and
+driven through the same C ABI with numpy buffers.  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from lwm_amd import _capi
+from oracle.attention_ref import from_bf16_bits, to_bf16_bits
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_SO = os.path.join(ROOT, "tests", "emu", "liblwm_emu.so")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+_lib = None
+
+
+def _sources():
+    out = []
+    for d in ("tests/emu", "lwm_amd/csrc", "include"):
+        for f in os.listdir(os.path.join(ROOT, d)):
+            if f.endswith((".h", ".inc", ".cpp")):
+                out.append(os.path.join(ROOT, d, f))
+    return out
+
+
+def build():
+    if os.path.exists(EMU_SO):
+        t = os.path.getmtime(EMU_SO)
+        if all(os.path.getmtime(s) <= t for s in _sources()):
+            return EMU_SO
+    cmd = [CLANG, "-O2", "-std=c++17", "-shared", "-fPIC", "-I", "tests", "-I", "lwm_amd/csrc",
+           "-I", "include", "tests/emu/lwm_emu.cpp", "-o", EMU_SO, "-lpthread"]
+    subprocess.run(cmd, cwd=ROOT, check=True)
+    return EMU_SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _capi.bind(C.CDLL(build()))
+    return _lib
+
+
+def _t4(arr):
+    """numpy uint16 (bf16 bits) array (B,S,H,D) -> LwmTensor4."""
+    assert arr.dtype == np.uint16 and arr.ndim == 4 and arr.strides[-1] == 2
+    sb, ss, sh, _ = (s // 2 for s in arr.strides)
+    return _capi.LwmTensor4(arr.ctypes.data, sb, ss, sh)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def aligned(shape, dtype):
+    """16-byte aligned zero array."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    raw = np.zeros(n + 16, dtype=np.uint8)
+    off = (-raw.ctypes.data) % 16
+    return raw[off:off + n].view(dtype).reshape(shape)
+
+
+def bf16_array(x):
+    a = aligned(x.shape, np.uint16)
+    a[...] = to_bf16_bits(x)
+    return a
+
+
+def base_args(q, k, v, *, causal, q_start, k_start, seg_q, seg_k, key_valid, scale):
+    B, Sq, H, D = q.shape
+    Sk = k.shape[1]
+    a = _capi.LwmAttnArgs()
+    a.q, a.k, a.v = _t4(q), _t4(k), _t4(v)
+    a.B, a.H, a.Sq, a.Sk, a.D = B, H, Sq, Sk, D
+    a.q_start, a.k_start = q_start, k_start
+    a.scale = scale if scale is not None else 1.0 / np.sqrt(D)
+    a.causal = int(causal)
+    keep = []
+    if seg_q is not None:
+        sq = np.ascontiguousarray(seg_q, dtype=np.int32)
+        sk = np.ascontiguousarray(seg_k, dtype=np.int32)
+        a.segment_ids_q, a.segment_ids_k = sq.ctypes.data, sk.ctypes.data
+        keep += [sq, sk]
+    if key_valid is not None:
+        kv = np.ascontiguousarray(key_valid, dtype=np.uint8)
+        a.key_valid = kv.ctypes.data
+        keep.append(kv)
+    return a, keep
+
+
+def attn_fwd(q, k, v, *, causal=True, q_start=0, k_start=0, seg_q=None, seg_k=None,
+             key_valid=None, scale=None, carry=None, final=True):
+    """q,k,v: float arrays (rounded to bf16 here).  Returns (out f32, lse f32) or the
+    updated carry (out_acc, lse_acc) when final=False."""
+    L = lib()
+    qb, kb, vb = bf16_array(q), bf16_array(k), bf16_array(v)
+    B, Sq, H, D = q.shape
+    a, keep = base_args(qb, kb, vb, causal=causal, q_start=q_start, k_start=k_start, seg_q=seg_q,
+                        seg_k=seg_k, key_valid=key_valid, scale=scale)
+    out = aligned((B, Sq, H, D), np.uint16)
+    lse = aligned((B, H, Sq), np.float32)
+    if carry is not None:
+        out_acc, lse_acc = carry
+        a.carry_in = 1
+    else:
+        out_acc, lse_acc = aligned((B, Sq, H, D), np.float32), aligned((B, H, Sq), np.float32)
+    a.out = _t4(out)
+    a.lse = lse.ctypes.data
+    a.out_acc, a.lse_acc = out_acc.ctypes.data, lse_acc.ctypes.data
+    a.final_out = int(final)
+    _capi.check(L, L.lwm_attn_fwd(C.byref(a), None), "lwm_attn_fwd")
+    if final:
+        return from_bf16_bits(out), lse
+    return out_acc, lse_acc
+
+
+def attn_bwd(q, k, v, out, lse, dout, *, causal=True, q_start=0, k_start=0, seg_q=None,
+             seg_k=None, key_valid=None, scale=None, carry=None, final=True):
+    """Returns (dq, dk, dv) as f32 (bf16-rounded when final) ."""
+    L = lib()
+    qb, kb, vb = bf16_array(q), bf16_array(k), bf16_array(v)
+    ob, dob = bf16_array(out), bf16_array(dout)
+    B, Sq, H, D = q.shape
+    Sk = k.shape[1]
+    a, keep = base_args(qb, kb, vb, causal=causal, q_start=q_start, k_start=k_start, seg_q=seg_q,
+                        seg_k=seg_k, key_valid=key_valid, scale=scale)
+    lse_a = aligned((B, H, Sq), np.float32)
+    lse_a[...] = lse
+    delta = aligned((B, H, Sq), np.float32)
+    dq, dk, dv = (aligned((B, Sq, H, D), np.uint16), aligned((B, Sk, H, D), np.uint16),
+                  aligned((B, Sk, H, D), np.uint16))
+    if carry is not None:
+        dq_acc, dk_acc, dv_acc = carry
+        a.carry_in = 1
+    else:
+        dq_acc = aligned((B, Sq, H, D), np.float32)
+        dk_acc = aligned((B, Sk, H, D), np.float32)
+        dv_acc = aligned((B, Sk, H, D), np.float32)
+    a.out, a.dout = _t4(ob), _t4(dob)
+    a.dq, a.dk, a.dv = _t4(dq), _t4(dk), _t4(dv)
+    a.lse, a.delta = lse_a.ctypes.data, delta.ctypes.data
+    a.dq_acc, a.dk_acc, a.dv_acc = dq_acc.ctypes.data, dk_acc.ctypes.data, dv_acc.ctypes.data
+    a.final_out = int(final)
+    _capi.check(L, L.lwm_attn_bwd_delta(C.byref(a), None), "lwm_attn_bwd_delta")
+    _capi.check(L, L.lwm_attn_bwd_dkdv(C.byref(a), None), "lwm_attn_bwd_dkdv")
+    _capi.check(L, L.lwm_attn_bwd_dq(C.byref(a), None), "lwm_attn_bwd_dq")
+    if final:
+        return from_bf16_bits(dq), from_bf16_bits(dk), from_bf16_bits(dv)
+    return dq_acc, dk_acc, dv_acc
