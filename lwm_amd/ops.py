@@ -1,0 +1,174 @@
+"""Thin torch-tensor front end of the C ABI (include/lwm_hip.h).
+
+Every function here enqueues hand-written HIP kernels from liblwm_hip.so on the
+current torch stream.  There is no PyTorch / CPU fallback: tensors must be
+bf16/f32 on a ROCm device and the shared library must be present.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _capi
+from ._lib import lib
+
+
+def _stream_ptr(stream=None):
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)
+
+
+def _t4(t, name):
+    if t is None:
+        return _capi.LwmTensor4(None, 0, 0, 0)
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a ROCm device tensor (lwm_amd has no CPU path)")
+    if t.dtype != torch.bfloat16 or t.dim() != 4 or t.stride(3) != 1:
+        raise ValueError(f"{name}: expected bf16 (B,S,H,D) with contiguous D, got "
+                         f"{t.dtype} {tuple(t.shape)} strides {t.stride()}")
+    return _capi.LwmTensor4(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2))
+
+
+def _f32(t, name, shape=None):
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous f32 device tensor")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t.data_ptr()
+
+
+def _base(q, k, v, *, q_start, k_start, causal, seg_q, seg_k, key_valid, scale):
+    B, Sq, H, D = q.shape
+    Sk = k.shape[1]
+    a = _capi.LwmAttnArgs()
+    a.q, a.k, a.v = _t4(q, "q"), _t4(k, "k"), _t4(v, "v")
+    a.B, a.H, a.Sq, a.Sk, a.D = B, H, Sq, Sk, D
+    a.q_start, a.k_start = int(q_start), int(k_start)
+    a.scale = float(scale) if scale is not None else 1.0 / math.sqrt(D)
+    a.causal = int(bool(causal))
+    if (seg_q is None) != (seg_k is None):
+        raise ValueError("seg_q and seg_k must be given together")
+    if seg_q is not None:
+        for n, s, L in (("seg_q", seg_q, Sq), ("seg_k", seg_k, Sk)):
+            if s.dtype != torch.int32 or not s.is_contiguous() or tuple(s.shape) != (B, L) or not s.is_cuda:
+                raise ValueError(f"{n}: expected contiguous int32 device tensor of shape {(B, L)}")
+        a.segment_ids_q, a.segment_ids_k = seg_q.data_ptr(), seg_k.data_ptr()
+    if key_valid is not None:
+        if key_valid.dtype != torch.uint8 or not key_valid.is_contiguous() or \
+                tuple(key_valid.shape) != (B, Sk) or not key_valid.is_cuda:
+            raise ValueError(f"key_valid: expected contiguous uint8 device tensor of shape {(B, Sk)}")
+        a.key_valid = key_valid.data_ptr()
+    return a
+
+
+def attn_fwd_block(q, k, v, *, q_start=0, k_start=0, causal=True, seg_q=None, seg_k=None,
+                   key_valid=None, scale=None, out=None, lse=None, out_acc=None, lse_acc=None,
+                   carry_in=False, final=True):
+    """One ring step of the forward (lwm_attn_fwd).  Returns (out, lse) when
+    `final`, else the updated (out_acc, lse_acc)."""
+    B, Sq, H, D = q.shape
+    a = _base(q, k, v, q_start=q_start, k_start=k_start, causal=causal, seg_q=seg_q, seg_k=seg_k,
+              key_valid=key_valid, scale=scale)
+    if final:
+        if out is None:
+            out = torch.empty((B, Sq, H, D), dtype=torch.bfloat16, device=q.device)
+        if lse is None:
+            lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
+        a.out = _t4(out, "out")
+        a.lse = _f32(lse, "lse", (B, H, Sq))
+    else:
+        if out_acc is None:
+            out_acc = torch.empty((B, Sq, H, D), dtype=torch.float32, device=q.device)
+        if lse_acc is None:
+            lse_acc = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
+    a.out_acc = _f32(out_acc, "out_acc", (B, Sq, H, D))
+    a.lse_acc = _f32(lse_acc, "lse_acc", (B, H, Sq))
+    a.carry_in = int(bool(carry_in))
+    a.final_out = int(bool(final))
+    L = lib()
+    _capi.check(L, L.lwm_attn_fwd(C.byref(a), _stream_ptr()), "lwm_attn_fwd")
+    return (out, lse) if final else (out_acc, lse_acc)
+
+
+def attn_bwd_delta(out, dout, delta=None):
+    """delta[b,h,q] = sum_d dout*out (lwm_attn_bwd_delta)."""
+    B, Sq, H, D = out.shape
+    if delta is None:
+        delta = torch.empty((B, H, Sq), dtype=torch.float32, device=out.device)
+    a = _capi.LwmAttnArgs()
+    a.out, a.dout = _t4(out, "out"), _t4(dout, "dout")
+    a.B, a.H, a.Sq, a.Sk, a.D = B, H, Sq, 0, D
+    a.delta = _f32(delta, "delta", (B, H, Sq))
+    L = lib()
+    _capi.check(L, L.lwm_attn_bwd_delta(C.byref(a), _stream_ptr()), "lwm_attn_bwd_delta")
+    return delta
+
+
+def _bwd_base(q, k, v, dout, lse, delta, kw):
+    B, Sq, H, D = q.shape
+    a = _base(q, k, v, **kw)
+    a.dout = _t4(dout, "dout")
+    a.lse = _f32(lse, "lse", (B, H, Sq))
+    a.delta = _f32(delta, "delta", (B, H, Sq))
+    return a
+
+
+def attn_bwd_dq_block(q, k, v, dout, lse, delta, *, q_start=0, k_start=0, causal=True,
+                      seg_q=None, seg_k=None, key_valid=None, scale=None, dq=None, dq_acc=None,
+                      carry_in=False, final=True):
+    B, Sq, H, D = q.shape
+    a = _bwd_base(q, k, v, dout, lse, delta,
+                  dict(q_start=q_start, k_start=k_start, causal=causal, seg_q=seg_q, seg_k=seg_k,
+                       key_valid=key_valid, scale=scale))
+    if final:
+        if dq is None:
+            dq = torch.empty((B, Sq, H, D), dtype=torch.bfloat16, device=q.device)
+        a.dq = _t4(dq, "dq")
+    elif dq_acc is None:
+        dq_acc = torch.empty((B, Sq, H, D), dtype=torch.float32, device=q.device)
+    a.dq_acc = _f32(dq_acc, "dq_acc", (B, Sq, H, D))
+    a.carry_in = int(bool(carry_in))
+    a.final_out = int(bool(final))
+    L = lib()
+    _capi.check(L, L.lwm_attn_bwd_dq(C.byref(a), _stream_ptr()), "lwm_attn_bwd_dq")
+    return dq if final else dq_acc
+
+
+def attn_bwd_dkdv_block(q, k, v, dout, lse, delta, *, q_start=0, k_start=0, causal=True,
+                        seg_q=None, seg_k=None, key_valid=None, scale=None, dk=None, dv=None,
+                        dk_acc=None, dv_acc=None, carry_in=False, final=True):
+    B, Sk, H, D = k.shape
+    a = _bwd_base(q, k, v, dout, lse, delta,
+                  dict(q_start=q_start, k_start=k_start, causal=causal, seg_q=seg_q, seg_k=seg_k,
+                       key_valid=key_valid, scale=scale))
+    if final:
+        if dk is None:
+            dk = torch.empty((B, Sk, H, D), dtype=torch.bfloat16, device=q.device)
+        if dv is None:
+            dv = torch.empty((B, Sk, H, D), dtype=torch.bfloat16, device=q.device)
+        a.dk, a.dv = _t4(dk, "dk"), _t4(dv, "dv")
+    else:
+        if dk_acc is None:
+            dk_acc = torch.empty((B, Sk, H, D), dtype=torch.float32, device=q.device)
+        if dv_acc is None:
+            dv_acc = torch.empty((B, Sk, H, D), dtype=torch.float32, device=q.device)
+    a.dk_acc = _f32(dk_acc, "dk_acc", (B, Sk, H, D))
+    a.dv_acc = _f32(dv_acc, "dv_acc", (B, Sk, H, D))
+    a.carry_in = int(bool(carry_in))
+    a.final_out = int(bool(final))
+    L = lib()
+    _capi.check(L, L.lwm_attn_bwd_dkdv(C.byref(a), _stream_ptr()), "lwm_attn_bwd_dkdv")
+    return (dk, dv) if final else (dk_acc, dv_acc)
+
+
+def cast_f32_to_bf16(src, dst=None):
+    if not src.is_cuda or src.dtype != torch.float32 or not src.is_contiguous():
+        raise ValueError("cast_f32_to_bf16: expected contiguous f32 device tensor")
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    L = lib()
+    _capi.check(L, L.lwm_cast_f32_to_bf16(src.data_ptr(), dst.data_ptr(), src.numel(),
+                                          _stream_ptr()), "lwm_cast_f32_to_bf16")
+    return dst

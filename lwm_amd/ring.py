@@ -1,0 +1,330 @@
+"""Ring driver: the sequence-parallel schedule around the per-block kernels.
+
+Reference behaviour being replaced (lwm/llama.py:539-569 + the `ringattention`
+package): the sequence is sharded over mesh axis "sp";
+for ring step t rank r holds the K/V block of rank (r - t) mod n, runs the
+blockwise update of its local queries against it, then K/V move i -> i+1
+(lax.ppermute).  The backward rotates k, v, dk, dv the same way.
+
+MI355X-first differences (results identical):
+  * the exchange is posted BEFORE the step's kernels (RCCL send/recv over xGMI
+    on its own stream) into a second buffer, and waited for after them, so the
+    transfer of block t+1 overlaps the MFMA work on block t;
+  * K/V blocks wholly in the causal future of the local queries launch nothing;
+  * an optional "zigzag" ownership (rank r owns half-chunks r and 2n-1-r)
+    balances causal work across ranks; ownership is a property of the layout
+    object, the kernels only ever see (q_start, k_start) global offsets.
+
+The driver is written against two small interfaces so the schedule can be
+exercised on CPU (gloo) in tests with a stand-in block backend:
+  block ops : fwd / bwd_delta / bwd_dq / bwd_dkdv / cast / zeros / empty
+  comm      : rank, size, rotate(list[tensor]) -> handle.wait() -> list[tensor]
+The product block ops (`HipBlockOps`) call liblwm_hip.so and nothing else.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import ops as _ops
+
+
+# ----------------------------------------------------------------- layouts
+class SeqLayout:
+    """Which global token positions a rank owns, as contiguous segments
+    (local_offset, length, global_start) of its local shard."""
+
+    def __init__(self, kind: str, n: int, seq_len: int):
+        if kind not in ("contiguous", "zigzag"):
+            raise ValueError(f"unknown layout {kind!r}")
+        if kind == "zigzag" and n == 1:
+            kind = "contiguous"
+        div = n if kind == "contiguous" else 2 * n
+        if seq_len % div:
+            raise ValueError(f"seq_len {seq_len} not divisible by {div} for layout {kind}")
+        self.kind, self.n, self.seq_len = kind, n, seq_len
+        self.local_len = seq_len // n
+
+    def segments(self, rank: int):
+        c = self.local_len
+        if self.kind == "contiguous":
+            return [(0, c, rank * c)]
+        h = c // 2
+        return [(0, h, rank * h), (h, h, (2 * self.n - 1 - rank) * h)]
+
+    def global_index(self, rank: int) -> torch.Tensor:
+        """Global positions of the rank's local rows (for sharding tensors in tests/loaders)."""
+        return torch.cat([torch.arange(g, g + ln) for _, ln, g in self.segments(rank)])
+
+
+def pair_visible(qseg, kseg, causal: bool) -> bool:
+    """False when the (q segment, k segment) pair is wholly above the causal diagonal."""
+    if not causal:
+        return True
+    _, qlen, qg = qseg
+    _, _, kg = kseg
+    return kg <= qg + qlen - 1
+
+
+# ----------------------------------------------------------------- comm
+class _Handle:
+    def __init__(self, reqs, bufs):
+        self.reqs, self.bufs = reqs, bufs
+
+    def wait(self):
+        for r in self.reqs:
+            r.wait()
+        return self.bufs
+
+
+class TorchRingComm:
+    """send to (rank+1)%n, receive from (rank-1)%n -- RCCL (backend "nccl") on
+    GPUs, gloo in the CPU tests."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.size = dist.get_world_size(group)
+        self._dst = dist.get_global_rank(group, (self.rank + 1) % self.size) if group is not None \
+            else (self.rank + 1) % self.size
+        self._src = dist.get_global_rank(group, (self.rank - 1) % self.size) if group is not None \
+            else (self.rank - 1) % self.size
+
+    def rotate(self, tensors):
+        bufs = [torch.empty_like(t) for t in tensors]
+        p2p = []
+        for t, b in zip(tensors, bufs):
+            p2p.append(dist.P2POp(dist.isend, t, self._dst, self.group))
+            p2p.append(dist.P2POp(dist.irecv, b, self._src, self.group))
+        reqs = dist.batch_isend_irecv(p2p)
+        return _Handle(reqs, bufs)
+
+
+class SingleComm:
+    rank, size = 0, 1
+
+    def rotate(self, tensors):
+        return _Handle([], list(tensors))
+
+
+# ----------------------------------------------------------------- block ops
+class HipBlockOps:
+    """The product backend: hand-written HIP kernels through the C ABI."""
+
+    fwd = staticmethod(_ops.attn_fwd_block)
+    bwd_delta = staticmethod(_ops.attn_bwd_delta)
+    bwd_dq = staticmethod(_ops.attn_bwd_dq_block)
+    bwd_dkdv = staticmethod(_ops.attn_bwd_dkdv_block)
+    cast = staticmethod(_ops.cast_f32_to_bf16)
+
+    @staticmethod
+    def empty(shape, dtype, like):
+        return torch.empty(shape, dtype=dtype, device=like.device)
+
+    @staticmethod
+    def zeros(shape, dtype, like):
+        return torch.zeros(shape, dtype=dtype, device=like.device)
+
+
+# ----------------------------------------------------------------- helpers
+def _mask_slices(segment_ids, key_valid, qseg, kseg):
+    _, qlen, qg = qseg
+    _, klen, kg = kseg
+    sq = sk = kv = None
+    if segment_ids is not None:
+        sq = segment_ids[:, qg:qg + qlen].contiguous()
+        sk = segment_ids[:, kg:kg + klen].contiguous()
+    if key_valid is not None:
+        kv = key_valid[:, kg:kg + klen].contiguous()
+    return sq, sk, kv
+
+
+def _rows(t, seg):
+    off, ln, _ = seg
+    return t[:, off:off + ln]
+
+
+def _fwd_plan(layout, rank, n, causal):
+    """[(t, qi, ki)] in execution order + index of the last entry per q segment."""
+    qsegs = layout.segments(rank)
+    plan = []
+    for t in range(n):
+        ksegs = layout.segments((rank - t) % n)
+        for qi, qs in enumerate(qsegs):
+            for ki, ks in enumerate(ksegs):
+                if pair_visible(qs, ks, causal):
+                    plan.append((t, qi, ki))
+    return plan
+
+
+# ----------------------------------------------------------------- forward
+def ring_forward(block, comm, q, k, v, *, layout, causal=True, segment_ids=None, key_valid=None,
+                 scale=None):
+    """Returns (out bf16 (B,c,H,D), [lse per q segment (B,H,len)])."""
+    n, r = comm.size, comm.rank
+    B, c, H, D = q.shape
+    qsegs = layout.segments(r)
+    plan = _fwd_plan(layout, r, n, causal)
+    first = {}
+    last = {}
+    for idx, (_, qi, _) in enumerate(plan):
+        first.setdefault(qi, idx)
+        last[qi] = idx
+    out = block.empty((B, c, H, D), q.dtype, q)
+    lses = [block.empty((B, H, ln), torch.float32, q) for _, ln, _ in qsegs]
+    acc_o = [None] * len(qsegs)
+    acc_l = [None] * len(qsegs)
+    for qi, (off, ln, _) in enumerate(qsegs):
+        if qi not in first:  # no visible key anywhere: defined as out = 0, lse = -inf
+            out[:, off:off + ln].zero_()
+            lses[qi].fill_(float("-inf"))
+        elif first[qi] != last[qi]:
+            acc_o[qi] = block.empty((B, ln, H, D), torch.float32, q)
+            acc_l[qi] = block.empty((B, H, ln), torch.float32, q)
+
+    k_cur = k if k.is_contiguous() else k.contiguous()
+    v_cur = v if v.is_contiguous() else v.contiguous()
+    keep = []
+    idx = 0
+    for t in range(n):
+        handle = comm.rotate([k_cur, v_cur]) if t < n - 1 else None
+        ksegs = layout.segments((r - t) % n)
+        while idx < len(plan) and plan[idx][0] == t:
+            _, qi, ki = plan[idx]
+            qs, ks = qsegs[qi], ksegs[ki]
+            sq, sk, kv = _mask_slices(segment_ids, key_valid, qs, ks)
+            fin = idx == last[qi]
+            block.fwd(_rows(q, qs), _rows(k_cur, ks), _rows(v_cur, ks), q_start=qs[2], k_start=ks[2],
+                      causal=causal, seg_q=sq, seg_k=sk, key_valid=kv, scale=scale,
+                      out=_rows(out, qs) if fin else None, lse=lses[qi] if fin else None,
+                      out_acc=acc_o[qi], lse_acc=acc_l[qi], carry_in=idx != first[qi], final=fin)
+            idx += 1
+        if handle is not None:
+            keep.append((k_cur, v_cur))
+            k_cur, v_cur = handle.wait()
+    return out, lses
+
+
+# ----------------------------------------------------------------- backward
+def ring_backward(block, comm, q, k, v, out, lses, dout, *, layout, causal=True,
+                  segment_ids=None, key_valid=None, scale=None):
+    """Returns (dq, dk, dv) bf16, each (B,c,H,D), for the local shard."""
+    n, r = comm.size, comm.rank
+    B, c, H, D = q.shape
+    qsegs = layout.segments(r)
+    if not dout.is_contiguous():
+        dout = dout.contiguous()
+    deltas = [block.bwd_delta(_rows(out, qs), _rows(dout, qs)) for qs in qsegs]
+
+    if n == 1 and len(qsegs) == 1:
+        # single block: write bf16 results straight from the accumulators
+        qs = qsegs[0]
+        sq, sk, kv = _mask_slices(segment_ids, key_valid, qs, qs)
+        kw = dict(q_start=qs[2], k_start=qs[2], causal=causal, seg_q=sq, seg_k=sk, key_valid=kv,
+                  scale=scale)
+        dk, dv = block.bwd_dkdv(q, k, v, dout, lses[0], deltas[0], final=True, **kw)
+        dq = block.bwd_dq(q, k, v, dout, lses[0], deltas[0], final=True, **kw)
+        return dq, dk, dv
+
+    dq_acc = [block.zeros((B, ln, H, D), torch.float32, q) for _, ln, _ in qsegs]
+    # f32 dk/dv accumulators of the block currently held; they travel with it
+    ksegs0 = layout.segments(r)
+    dk_acc = [block.zeros((B, ln, H, D), torch.float32, q) for _, ln, _ in ksegs0]
+    dv_acc = [block.zeros((B, ln, H, D), torch.float32, q) for _, ln, _ in ksegs0]
+    nks = len(ksegs0)
+
+    k_cur = k if k.is_contiguous() else k.contiguous()
+    v_cur = v if v.is_contiguous() else v.contiguous()
+    keep = []
+    dkv_handle = None
+    for t in range(n):
+        kv_handle = comm.rotate([k_cur, v_cur]) if t < n - 1 else None
+        ksegs = layout.segments((r - t) % n)
+        pairs = [(qi, ki) for qi, qs in enumerate(qsegs) for ki, ks in enumerate(ksegs)
+                 if pair_visible(qs, ks, causal)]
+        # dq first: it does not need the travelling dk/dv accumulators
+        for qi, ki in pairs:
+            qs, ks = qsegs[qi], ksegs[ki]
+            sq, sk, kv = _mask_slices(segment_ids, key_valid, qs, ks)
+            block.bwd_dq(_rows(q, qs), _rows(k_cur, ks), _rows(v_cur, ks), _rows(dout, qs), lses[qi],
+                         deltas[qi], q_start=qs[2], k_start=ks[2], causal=causal, seg_q=sq, seg_k=sk,
+                         key_valid=kv, scale=scale, dq_acc=dq_acc[qi], carry_in=True, final=False)
+        if dkv_handle is not None:
+            got = dkv_handle.wait()
+            dk_acc, dv_acc = got[:nks], got[nks:]
+        for qi, ki in pairs:
+            qs, ks = qsegs[qi], ksegs[ki]
+            sq, sk, kv = _mask_slices(segment_ids, key_valid, qs, ks)
+            block.bwd_dkdv(_rows(q, qs), _rows(k_cur, ks), _rows(v_cur, ks), _rows(dout, qs), lses[qi],
+                           deltas[qi], q_start=qs[2], k_start=ks[2], causal=causal, seg_q=sq,
+                           seg_k=sk, key_valid=kv, scale=scale, dk_acc=dk_acc[ki], dv_acc=dv_acc[ki],
+                           carry_in=True, final=False)
+        keep.append((dk_acc, dv_acc))
+        dkv_handle = comm.rotate(list(dk_acc) + list(dv_acc))  # n rotations bring them home
+        if kv_handle is not None:
+            keep.append((k_cur, v_cur))
+            k_cur, v_cur = kv_handle.wait()
+    got = dkv_handle.wait()
+    dk_acc, dv_acc = got[:nks], got[nks:]
+
+    dq = block.empty((B, c, H, D), q.dtype, q)
+    dk = block.empty((B, c, H, D), q.dtype, q)
+    dv = block.empty((B, c, H, D), q.dtype, q)
+    if len(qsegs) == 1:
+        block.cast(dq_acc[0], dq)
+        block.cast(dk_acc[0], dk)
+        block.cast(dv_acc[0], dv)
+    else:
+        for i, (off, ln, _) in enumerate(qsegs):
+            dq[:, off:off + ln].copy_(block.cast(dq_acc[i]))
+            dk[:, off:off + ln].copy_(block.cast(dk_acc[i]))
+            dv[:, off:off + ln].copy_(block.cast(dv_acc[i]))
+    return dq, dk, dv
+
+
+# ----------------------------------------------------------------- autograd
+class _RingAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, segment_ids, key_valid, cfg):
+        block, comm, layout, causal, scale = cfg
+        out, lses = ring_forward(block, comm, q, k, v, layout=layout, causal=causal,
+                                 segment_ids=segment_ids, key_valid=key_valid, scale=scale)
+        ctx.save_for_backward(q, k, v, out, *lses)
+        ctx.cfg = cfg
+        ctx.masks = (segment_ids, key_valid)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, *lses = ctx.saved_tensors
+        block, comm, layout, causal, scale = ctx.cfg
+        segment_ids, key_valid = ctx.masks
+        dq, dk, dv = ring_backward(block, comm, q, k, v, out, lses, dout, layout=layout,
+                                   causal=causal, segment_ids=segment_ids, key_valid=key_valid,
+                                   scale=scale)
+        return dq, dk, dv, None, None, None
+
+
+def ring_attention(q, k, v, *, group=None, causal=True, segment_ids=None, key_valid=None,
+                   scale=None, layout="contiguous", block_ops=None, comm=None):
+    """Differentiable ring attention on the local (B, S/n, H, D) shards.
+
+    segment_ids / key_valid are the FULL-length (B, S_global) tensors, replicated
+    on every rank, exactly as the reference passes attn_bias / segment_ids
+    un-sharded (lwm/llama.py:563-564).
+    """
+    if comm is None:
+        if group is None and not (dist.is_available() and dist.is_initialized()):
+            comm = SingleComm()
+        elif group is None and dist.get_world_size() == 1:
+            comm = SingleComm()
+        else:
+            comm = TorchRingComm(group)
+    block = block_ops if block_ops is not None else HipBlockOps
+    lay = layout if isinstance(layout, SeqLayout) else SeqLayout(layout, comm.size,
+                                                                 q.shape[1] * comm.size)
+    if segment_ids is not None and segment_ids.dtype != torch.int32:
+        segment_ids = segment_ids.to(torch.int32)
+    if key_valid is not None and key_valid.dtype != torch.uint8:
+        key_valid = (key_valid != 0).to(torch.uint8)
+    return _RingAttention.apply(q, k, v, segment_ids, key_valid, (block, comm, lay, causal, scale))

@@ -1,0 +1,63 @@
+"""Drop-in operator surface of the reference's `ringattention` package for the
+hot path, with torch.Tensor in place of jax.Array and a torch.distributed
+process group in place of the mesh axis name.
+
+Reference call sites:  lwm/llama.py:30 (import), :539-569 (training op),
+:729-734 (blockwise_feedforward).  Same argument names, meaning and error
+behaviour; tile sizes are the kernels' own (the reference's
+query/key_chunk_size only trade memory for speed and do not change results).
+"""
+import torch
+
+from .ring import ring_attention
+
+_SP_GROUP = {"group": None}
+
+
+def set_sp_group(group):
+    """Bind mesh axis name "sp" (lwm/llama.py:201-203) to a process group."""
+    _SP_GROUP["group"] = group
+
+
+def _resolve_axis(axis_name):
+    if axis_name is None or isinstance(axis_name, str):
+        return _SP_GROUP["group"]
+    return axis_name  # already a ProcessGroup
+
+
+def ringattention(q, k, v, attn_bias, segment_ids, axis_name="sp", float32_logits=True,
+                  cache_idx=None, blockwise_kwargs=None, layout="contiguous"):
+    """q,k,v: local (B, S/sp, H, D) bf16 shards.  attn_bias: (B,1,1,S_global)
+    additive key-padding bias {0, finfo.min} or None (lwm/llama.py:533-537);
+    segment_ids: (B, S_global) int or None -- both replicated on every rank
+    (lwm/llama.py:563-564).  Returns out with q's shape/dtype."""
+    kw = dict(blockwise_kwargs or {})
+    if cache_idx is not None:
+        raise NotImplementedError("cache_idx is None at every reference call site (lwm/llama.py:544)")
+    if float(kw.get("attn_pdrop", 0.0)) != 0.0 and not kw.get("deterministic", True):
+        raise NotImplementedError("attention dropout: attn_pdrop=0.0 in the reference config "
+                                  "(lwm/llama.py:151)")
+    cbs = kw.get("causal_block_size", 1)
+    if cbs not in (None, 1):
+        raise NotImplementedError("causal_block_size must be 1 (lwm/llama.py:546) or None")
+    if not float32_logits:
+        # logits are always f32 here; float32_logits=False would only lower precision
+        pass
+    key_valid = None
+    if attn_bias is not None:
+        if attn_bias.dim() != 4 or attn_bias.shape[1] != 1 or attn_bias.shape[2] != 1:
+            raise ValueError("attn_bias must be (B,1,1,S_global) as built at lwm/llama.py:527-537")
+        key_valid = (attn_bias[:, 0, 0, :].float() > -1e30).to(torch.uint8).contiguous()
+    return ring_attention(q, k, v, group=_resolve_axis(axis_name), causal=cbs == 1,
+                          segment_ids=segment_ids, key_valid=key_valid, layout=layout)
+
+
+def blockwise_feedforward(module, x, chunk_size, pre_remat=True):
+    """lwm/llama.py:729-734: apply a position-wise module over sequence chunks
+    (identical result to module(x); bounds peak activation memory)."""
+    S = x.shape[1]
+    if chunk_size is None or S <= chunk_size:
+        return module(x)
+    if S % chunk_size:
+        raise ValueError(f"sequence length {S} is not a multiple of chunk_size {chunk_size}")
+    return torch.cat([module(c) for c in x.split(chunk_size, dim=1)], dim=1)

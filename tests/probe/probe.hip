@@ -1,0 +1,52 @@
+// probe.hip -- GPU-side confirmation of the lane maps the kernels (and the host
+// emulator) assume: MFMA 32x32x16 A/B/C-D fragments, ds_read_b128 row fragments
+// and ds_read_b64_tr_b16 transposed fragments through the swizzled tile image.
+// TEST INFRASTRUCTURE (built by __graft_entry__.build(), used by tests/test_gpu_probe.py).
+#include "wave_ops.h"
+#include "attn_common.h"
+
+using namespace lwm;
+
+// A[32][16], B[16][32] bf16 row-major; C[32][32] f32.
+__global__ __launch_bounds__(64) void probe_mfma(const bf16_t* A, const bf16_t* Bm, float* Cm) {
+    int l = thread_idx(), l31 = l & 31, hi = l >> 5;
+    bf16x8 a, b;
+    for (int j = 0; j < 8; ++j) {
+        a[j] = A[l31 * 16 + 8 * hi + j];
+        b[j] = Bm[(8 * hi + j) * 32 + l31];
+    }
+    f32x16 c = mfma_32x32x16(a, b, zero_f32x16());
+    for (int r = 0; r < 16; ++r) Cm[cd_row(r, hi) * 32 + l31] = c[r];
+}
+
+// T[64][128] bf16 row-major -> swizzled LDS tile -> fragments.
+// rows_out[lane][8]  = frag_rows(tile, row0, step)
+// cols_out[lane][8]  = frag_cols_tr(tile, row0t, d0)
+__global__ __launch_bounds__(64) void probe_frags(const bf16_t* T, bf16_t* rows_out, bf16_t* cols_out,
+                                                  int row0, int step, int row0t, int d0) {
+    char* lds = dyn_lds();
+    int l = thread_idx();
+    for (int c = l; c < 64 * 16; c += 64) {
+        int row = c >> 4, slot = c & 15;
+        lds_write_b128(lds + tile_off(row, slot), global_load_b128(T + row * 128 + slot * 8));
+    }
+    block_sync();
+    bf16x8 fr = frag_rows(lds, row0, step, l & 31, l >> 5);
+    bf16x8 fc = frag_cols_tr(lds, row0t, d0, l);
+    for (int j = 0; j < 8; ++j) {
+        rows_out[l * 8 + j] = fr[j];
+        cols_out[l * 8 + j] = fc[j];
+    }
+}
+
+extern "C" int probe_run_mfma(const void* A, const void* B, float* C, void* stream) {
+    hipLaunchKernelGGL(probe_mfma, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)A,
+                       (const bf16_t*)B, C);
+    return (int)hipGetLastError();
+}
+extern "C" int probe_run_frags(const void* T, void* rows_out, void* cols_out, int row0, int step,
+                               int row0t, int d0, void* stream) {
+    hipLaunchKernelGGL(probe_frags, dim3(1), dim3(64), 64 * 256, (hipStream_t)stream,
+                       (const bf16_t*)T, (bf16_t*)rows_out, (bf16_t*)cols_out, row0, step, row0t, d0);
+    return (int)hipGetLastError();
+}

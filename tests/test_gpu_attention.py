@@ -1,0 +1,208 @@
+"""Parity of the HIP attention kernels (through the C ABI) against the fp64
+oracle, on seeded inputs at sizes the oracle finishes in seconds, plus
+size-independent properties at BASELINE.json's full size (S=32768, H=32).
+
+Tolerances (stated per north_star: "within a stated fp tolerance"): operands
+and results are bf16 with f32 accumulation, so
+  out / dq / dk / dv : max|err| <= 2e-2 * max|ref|  and cosine >= 0.9999
+  lse                : max|err| <= 2e-3
+"""
+import numpy as np
+import pytest
+
+from oracle import attention_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g).to(torch.bfloat16)
+
+
+def _np(t):
+    return t.detach().float().cpu().numpy()
+
+
+def _check(name, got, ref, tol=2e-2):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-9)
+    cos = (got * ref).sum() / max(np.sqrt((got ** 2).sum() * (ref ** 2).sum()), 1e-30)
+    assert err <= tol, f"{name}: rel max err {err:.3e} > {tol}"
+    assert cos >= 0.9999, f"{name}: cosine {cos}"
+
+
+def _masks(B, S, Sk, seg, kv, seed):
+    rng = np.random.default_rng(seed)
+    seg_q = seg_k = key_valid = None
+    if seg:
+        assert S == Sk
+        cuts = np.sort(rng.choice(np.arange(1, S), size=min(4, S - 1), replace=False))
+        s = np.zeros((B, S), np.int32)
+        for c in cuts:
+            s[:, c:] += 1
+        seg_q = seg_k = s
+    if kv:
+        key_valid = (rng.random((B, Sk)) > 0.15).astype(np.uint8)
+    return seg_q, seg_k, key_valid
+
+
+CASES = [
+    # B, Sq, Sk, H, causal, seg, kv
+    (1, 256, 256, 1, True, False, False),
+    (1, 1024, 1024, 2, True, False, False),
+    (2, 512, 512, 3, True, True, True),
+    (1, 777, 777, 2, True, False, False),      # ragged
+    (1, 300, 1000, 2, False, False, True),     # q_len != kv_len, padded keys
+    (1, 1, 513, 2, False, False, False),       # single query row
+    (1, 2048, 2048, 4, True, True, False),     # packed segments
+    (1, 64, 64, 8, True, False, False),
+]
+
+
+@pytest.mark.parametrize("B,Sq,Sk,H,causal,seg,kv", CASES)
+def test_fwd_bwd_vs_oracle(B, Sq, Sk, H, causal, seg, kv):
+    import torch
+    from lwm_amd import ops
+    q, k, v, do = _rand((B, Sq, H, 128), 1), _rand((B, Sk, H, 128), 2), _rand((B, Sk, H, 128), 3), \
+        _rand((B, Sq, H, 128), 4)
+    seg_q, seg_k, key_valid = _masks(B, Sq, Sk, seg, kv, 5)
+    t = lambda a, dt: None if a is None else torch.from_numpy(a).to(dt).cuda()
+    kw = dict(causal=causal, seg_q=t(seg_q, torch.int32), seg_k=t(seg_k, torch.int32),
+              key_valid=t(key_valid, torch.uint8))
+    qd, kd, vd, dod = q.cuda(), k.cuda(), v.cuda(), do.cuda()
+    out, lse = ops.attn_fwd_block(qd, kd, vd, **kw)
+    delta = ops.attn_bwd_delta(out, dod)
+    dk, dv = ops.attn_bwd_dkdv_block(qd, kd, vd, dod, lse, delta, **kw)
+    dq = ops.attn_bwd_dq_block(qd, kd, vd, dod, lse, delta, **kw)
+    torch.cuda.synchronize()
+    okw = dict(causal=causal, seg_q=seg_q, seg_k=seg_k, key_valid=key_valid)
+    ro, rl = R.dense_attention(_np(q), _np(k), _np(v), **okw)
+    _check("out", _np(out), ro)
+    fin = np.isfinite(rl)
+    assert np.array_equal(np.isfinite(_np(lse)), fin), "fully-masked rows must give lse=-inf"
+    if fin.any():
+        assert np.abs(_np(lse)[fin] - rl[fin]).max() <= 2e-3
+    # gradients: the oracle differentiates the exact function at the bf16 inputs
+    rq, rk, rv = R.dense_attention_bwd(_np(q), _np(k), _np(v), _np(do), **okw)
+    _check("dq", _np(dq), rq)
+    _check("dk", _np(dk), rk)
+    _check("dv", _np(dv), rv)
+
+
+def test_softmax_rescale_branch_is_exercised():
+    """A spiked key late in the sequence forces the running max to jump after
+    earlier tiles were accumulated (cdna_hip_programming.md rule 26)."""
+    import torch
+    from lwm_amd import ops
+    B, S, H = 1, 512, 1
+    q, k, v = _rand((B, S, H, 128), 11), _rand((B, S, H, 128), 12), _rand((B, S, H, 128), 13)
+    k[0, 400, 0] = (q[0, 450, 0].float() * 4).to(torch.bfloat16)   # huge score for query 450 at key 400
+    out, lse = ops.attn_fwd_block(q.cuda(), k.cuda(), v.cuda(), causal=True)
+    ro, rl = R.dense_attention(_np(q), _np(k), _np(v), causal=True)
+    _check("out(spike)", _np(out), ro)
+    assert np.abs(_np(lse) - rl).max() <= 2e-2
+
+
+def test_ring_carry_equals_single_shot():
+    """Two ring steps with the f32 carry == one shot (ring n == ring 1)."""
+    import torch
+    from lwm_amd import ops
+    B, S, H = 1, 1024, 2
+    q, k, v = (_rand((B, S, H, 128), s).cuda() for s in (21, 22, 23))
+    ref, rlse = ops.attn_fwd_block(q, k, v, causal=False)
+    h = S // 2
+    acc = ops.attn_fwd_block(q, k[:, :h], v[:, :h], causal=False, k_start=0, final=False)
+    out, lse = ops.attn_fwd_block(q, k[:, h:], v[:, h:], causal=False, k_start=h, out_acc=acc[0],
+                                  lse_acc=acc[1], carry_in=True, final=True)
+    torch.cuda.synchronize()
+    assert (out.float() - ref.float()).abs().max().item() <= 2e-2
+    assert (lse - rlse).abs().max().item() <= 1e-4
+
+
+def test_autograd_ring1_matches_oracle():
+    import torch
+    from lwm_amd.ringattention import ringattention
+    B, S, H = 1, 640, 2
+    q, k, v, do = (_rand((B, S, H, 128), s) for s in (31, 32, 33, 34))
+    seg = np.zeros((B, S), np.int32)
+    seg[:, 200:] = 1
+    seg[:, 450:] = 2
+    qd, kd, vd = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    out = ringattention(qd, kd, vd, None, torch.from_numpy(seg).cuda(), axis_name="sp",
+                        blockwise_kwargs=dict(causal_block_size=1, query_chunk_size=128,
+                                              key_chunk_size=128))
+    out.backward(do.cuda())
+    rq, rk, rv = R.dense_attention_bwd(_np(q), _np(k), _np(v), _np(do), causal=True, seg_q=seg, seg_k=seg)
+    ro, _ = R.dense_attention(_np(q), _np(k), _np(v), causal=True, seg_q=seg, seg_k=seg)
+    _check("out", _np(out), ro)
+    _check("dq", _np(qd.grad), rq)
+    _check("dk", _np(kd.grad), rk)
+    _check("dv", _np(vd.grad), rv)
+
+
+def test_errors_are_loud():
+    import torch
+    from lwm_amd import ops, _capi
+    q = _rand((1, 64, 2, 64), 1).cuda()  # head_dim 64: unsupported
+    with pytest.raises(_capi.LwmError):
+        ops.attn_fwd_block(q, q, q)
+    with pytest.raises(ValueError):
+        ops.attn_fwd_block(_rand((1, 64, 2, 128), 1), _rand((1, 64, 2, 128), 1), _rand((1, 64, 2, 128), 1))
+
+
+# ------------------------------------------------------------ full size (config #2)
+@pytest.fixture(scope="module")
+def full():
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(0)
+    mk = lambda: torch.randn(1, 32768, 32, 128, generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+    return mk(), mk(), mk(), mk()
+
+
+def test_full_size_properties(full):
+    """S=32768, H=32 (LWM-7B attention shapes, BASELINE config #2)."""
+    import torch
+    from lwm_amd import ops
+    q, k, v, do = full
+    out, lse = ops.attn_fwd_block(q, k, v, causal=True)
+    # (1) V = ones -> every output is exactly a convex combination of ones
+    ones = torch.ones_like(v)
+    o1, _ = ops.attn_fwd_block(q, k, ones, causal=True)
+    assert (o1.float() - 1).abs().max().item() <= 8e-3
+    # (2) linearity in V: scaling V by 2 is exact in bf16 -> bitwise 2x
+    o2, _ = ops.attn_fwd_block(q, k, (v.float() * 2).to(torch.bfloat16), causal=True)
+    assert torch.equal(o2.float(), out.float() * 2)
+    # (3) causality: changing the last 1024 keys/values leaves earlier rows bit-identical
+    k2, v2 = k.clone(), v.clone()
+    k2[:, -1024:] = -k2[:, -1024:]
+    v2[:, -1024:] = 0
+    o3, l3 = ops.attn_fwd_block(q, k2, v2, causal=True)
+    assert torch.equal(o3[:, :-1024], out[:, :-1024]) and torch.equal(l3[..., :-1024], lse[..., :-1024])
+    # (4) first row attends to itself only
+    assert (out[:, 0].float() - v[:, 0].float()).abs().max().item() <= 1e-2
+    # (5) one sampled (head, 512-row window) against the fp64 oracle
+    h, r0 = 17, 30000
+    ro, rl = R.dense_attention(_np(q[:, r0:r0 + 512, h:h + 1]), _np(k[:, :r0 + 512, h:h + 1]),
+                               _np(v[:, :r0 + 512, h:h + 1]), causal=True, q_start=r0, k_start=0)
+    _check("out window", _np(out[:, r0:r0 + 512, h:h + 1]), ro)
+    assert np.abs(_np(lse[:, h:h + 1, r0:r0 + 512]) - rl).max() <= 2e-3
+    # (6) backward identities: sum_k dv[k] == sum_q do[q] when V-gradient weights sum to 1;
+    #     and ring-split (two kv halves with carries) == single shot
+    delta = ops.attn_bwd_delta(out, do)
+    dk, dv = ops.attn_bwd_dkdv_block(q, k, v, do, lse, delta, causal=True)
+    dq = ops.attn_bwd_dq_block(q, k, v, do, lse, delta, causal=True)
+    sdv = dv.float().sum(dim=1)
+    sdo = do.float().sum(dim=1)
+    assert ((sdv - sdo).abs().max() / sdo.abs().max()).item() <= 2e-2
+    # softmax-Jacobian identity: sum over keys of dS is 0  =>  sum_q q.dq == sum_k k.dk per head
+    a = (q.float() * dq.float()).sum(dim=(1, 3))
+    b = (k.float() * dk.float()).sum(dim=(1, 3))
+    assert ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item() <= 5e-2
+    # sampled window of dq against the oracle (needs all keys <= window end)
+    h, r0, w = 5, 2048, 256
+    sl = slice(0, r0 + w)
+    rq, rk, rv = R.dense_attention_bwd(_np(q[:, sl, h:h + 1]), _np(k[:, sl, h:h + 1]), _np(v[:, sl, h:h + 1]),
+                                       _np(do[:, sl, h:h + 1]), causal=True)
+    _check("dq window", _np(dq[:, r0:r0 + w, h:h + 1]), rq[:, r0:r0 + w])

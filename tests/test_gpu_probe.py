@@ -1,0 +1,56 @@
+"""GPU confirmation of the lane maps assumed by the kernels and by the host
+emulator (tests/emu/wave_ops.h): MFMA 32x32x16 bf16 fragments, ds_read_b128 row
+fragments and ds_read_b64_tr_b16 transposed fragments of the swizzled tile."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def probe():
+    import torch  # noqa: F401  (maps torch's HIP runtime first)
+    lib = C.CDLL(os.path.join(ROOT, "tests", "probe", "libprobe.so"))
+    lib.probe_run_mfma.argtypes = [C.c_void_p] * 4
+    lib.probe_run_frags.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]
+    return lib
+
+
+def test_mfma_32x32x16_layout(probe):
+    import torch
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn(32, 16, generator=g).to(torch.bfloat16).cuda()
+    B = torch.randn(16, 32, generator=g).to(torch.bfloat16).cuda()  # asymmetric on purpose
+    Cm = torch.zeros(32, 32, dtype=torch.float32, device="cuda")
+    assert probe.probe_run_mfma(A.data_ptr(), B.data_ptr(), Cm.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    ref = A.float().cpu().double() @ B.float().cpu().double()
+    err = (Cm.cpu().double() - ref).abs().max().item()
+    assert err < 1e-4, f"MFMA fragment map differs from the documented one (max err {err})"
+
+
+@pytest.mark.parametrize("row0,step,row0t,d0", [(0, 0, 0, 0), (32, 5, 16, 32), (32, 7, 48, 96), (0, 3, 32, 64)])
+def test_lds_fragments(probe, row0, step, row0t, d0):
+    import torch
+    T = torch.arange(64 * 128, dtype=torch.float32).reshape(64, 128)
+    T = (T % 251 - 125).to(torch.bfloat16)  # exactly representable, position-revealing
+    Td = T.cuda()
+    rows = torch.zeros(64, 8, dtype=torch.bfloat16, device="cuda")
+    cols = torch.zeros(64, 8, dtype=torch.bfloat16, device="cuda")
+    rc = probe.probe_run_frags(Td.data_ptr(), rows.data_ptr(), cols.data_ptr(), row0, step, row0t, d0, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    Tf = T.float().numpy()
+    exp_rows = np.zeros((64, 8), np.float32)
+    exp_cols = np.zeros((64, 8), np.float32)
+    for l in range(64):
+        l31, hi = l & 31, l >> 5
+        for j in range(8):
+            exp_rows[l, j] = Tf[row0 + l31, 16 * step + 8 * hi + j]
+            exp_cols[l, j] = Tf[row0t + 4 * hi + (j & 3) + 8 * (j >> 2), d0 + l31]
+    assert np.array_equal(rows.float().cpu().numpy(), exp_rows), "ds_read_b128 row fragment map"
+    assert np.array_equal(cols.float().cpu().numpy(), exp_cols), "ds_read_b64_tr_b16 fragment map"
