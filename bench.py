@@ -1,0 +1,223 @@
+#!/usr/bin/env python
+"""bench.py -- LWM-7B RingAttention hot path, forward+backward, tokens/s.
+
+One "step" = the blockwise attention forward + backward of ALL 32 layers of
+LWM-7B (32 heads x 128, lwm/llama.py:70-81) over one synthetic packed batch
+(B=1), i.e. one pass of the north-star hot path.  q/k/v/dO are synthetic
+N(0,1) bf16 already resident in HBM when the timed region starts.
+
+  N=1 : BASELINE.json configs[1]  (S=32768, ring=1, no send/recv)
+  N>1 : BASELINE.json configs[2]'s problem (S=131072) ring-sharded over N GPUs
+        (zigzag ownership for causal balance), K/V (+dK/dV) rotated with RCCL.
+
+Prints ONE JSON line (rank 0).  `value` = whole-job tokens/s = S*steps/time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_LAYERS, N_HEADS, HEAD_DIM, D_MODEL = 32, 32, 128, 4096
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def gemm_unit_flops(S):
+    """One causal S x S x d_model GEMM 'unit' (SURVEY.md section 8d): fwd = 2 units,
+    bwd = 5 units algorithmic (the two-kernel backward executes 7)."""
+    return float(S) * S * D_MODEL
+
+
+def cpu_baseline(S_target):
+    """Port of the reference's blockwise attention on PyTorch-CPU fp32, timed on
+    a bounded sample (S=4096, 8 heads, 1 layer, fwd+bwd) and scaled to the
+    workload by the algorithmic FLOP count (7*S^2*d_model per layer)."""
+    import torch
+    from oracle.attention_torch_cpu import blockwise_fwd_bwd
+    S, H = 4096, 8
+    g = torch.Generator().manual_seed(0)
+    q, k, v, do = (torch.randn(1, S, H, HEAD_DIM, generator=g) for _ in range(4))
+    blockwise_fwd_bwd(q[:, :1024], k[:, :1024], v[:, :1024], do[:, :1024])  # warm the BLAS threads
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        blockwise_fwd_bwd(q, k, v, do)
+        reps += 1
+        if time.perf_counter() - t0 > 10.0 or reps >= 8:
+            break
+    dt = (time.perf_counter() - t0) / reps
+    flops_sample = 7.0 * S * S * (H * HEAD_DIM)
+    flops_per_s = flops_sample / dt
+    flops_workload = 7.0 * gemm_unit_flops(S_target) * N_LAYERS
+    return {
+        "value": S_target / (flops_workload / flops_per_s),
+        "unit": "tokens/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "gflops": flops_per_s / 1e9,
+        "sample": f"oracle/attention_torch_cpu.blockwise_fwd_bwd fp32, S={S}, {H} heads, 1 layer, "
+                  f"chunks 1024/1024, {reps} reps of {dt:.2f}s; scaled to S={S_target}, 32 heads, "
+                  f"32 layers by the 7*S^2*d_model FLOP law (extrapolated)",
+    }
+
+
+class KernelTimer:
+    """HIP events (torch.cuda.Event on the stream the kernels are launched on)
+    around every kernel launch of the timed region, aggregated per kernel."""
+
+    def __init__(self, torch):
+        self.torch = torch
+        self.spans = {}
+        self.enabled = False
+
+    def run(self, name, fn, *a, **kw):
+        if not self.enabled:
+            return fn(*a, **kw)
+        e0 = self.torch.cuda.Event(enable_timing=True)
+        e1 = self.torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a, **kw)
+        e1.record()
+        self.spans.setdefault(name, []).append((e0, e1))
+        return r
+
+    def summary(self):
+        out = {}
+        for name, evs in self.spans.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[name] = {"launches": len(ms), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms)}
+        return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--seq", type=int, default=0, help="override global sequence length")
+    ap.add_argument("--layers", type=int, default=N_LAYERS, help="(debug only; default = full 32)")
+    ap.add_argument("--layout", default="zigzag", choices=["zigzag", "contiguous"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from lwm_amd import ops
+    from lwm_amd.ring import (HipBlockOps, SeqLayout, SingleComm, TorchRingComm, ring_backward,
+                              ring_forward)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
+                         f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+        comm = TorchRingComm(None)
+    else:
+        comm = SingleComm()
+
+    S = args.seq or (32768 if world == 1 else 131072)
+    layout = SeqLayout(args.layout, world, S)
+    c = layout.local_len
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    mk = lambda: torch.randn(1, c, N_HEADS, HEAD_DIM, generator=g, device=dev,
+                             dtype=torch.float32).to(torch.bfloat16)
+    q, k, v, do = mk(), mk(), mk(), mk()
+    timer = KernelTimer(torch)
+
+    class TimedOps(HipBlockOps):
+        fwd = staticmethod(lambda *a, **kw: timer.run("attn_fwd_kernel", ops.attn_fwd_block, *a, **kw))
+        bwd_delta = staticmethod(lambda *a, **kw: timer.run("attn_bwd_delta_kernel", ops.attn_bwd_delta, *a, **kw))
+        bwd_dq = staticmethod(lambda *a, **kw: timer.run("attn_bwd_dq_kernel", ops.attn_bwd_dq_block, *a, **kw))
+        bwd_dkdv = staticmethod(lambda *a, **kw: timer.run("attn_bwd_dkdv_kernel", ops.attn_bwd_dkdv_block, *a, **kw))
+
+    def step():
+        for _ in range(args.layers):
+            out, lses = ring_forward(TimedOps, comm, q, k, v, layout=layout, causal=True)
+            ring_backward(TimedOps, comm, q, k, v, out, lses, do, layout=layout, causal=True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    timer.enabled = world == 1
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        tokens_per_s = S * args.steps / elapsed
+        unit = gemm_unit_flops(S)
+        algo_flops_step = 7.0 * unit * args.layers
+        res = {
+            "metric": "tokens/sec fwd+bwd, LWM-7B RingAttention hot path (32 layers x 32 heads x 128)",
+            "value": tokens_per_s,
+            "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "bf16 (f32 logits/softmax/accumulate)",
+            "data": "synthetic N(0,1) q/k/v/dO, seed 1234, resident in HBM",
+            "config": {
+                "workload": (f"LWM-7B attention fwd+bwd, {args.layers} layers, B=1, S={S}, H=32, D=128, "
+                             f"causal, ring={world}" + (f", layout={layout.kind}" if world > 1 else "")
+                             + (" [BASELINE configs[1]]" if world == 1 and S == 32768 else "")
+                             + (" [BASELINE configs[2] problem]" if world > 1 and S == 131072 else "")),
+                "seq_len": S, "ring": world, "layers": args.layers,
+            },
+            "tokens_per_s_per_gpu": tokens_per_s / world,
+            "path_algorithmic_tflops_per_gpu": algo_flops_step / (ms_per_step * 1e-3) / 1e12 / world,
+        }
+        if world == 1:
+            ks = timer.summary()
+            res["kernels"] = ks
+            # dominant kernel by total time; algorithmic FLOPs per launch: fwd = 2 GEMM
+            # units; the backward's 5 algorithmic units are apportioned to its two launches
+            # by executed share (dkdv 4/7, dq 3/7) -- DESIGN.md "Work accounting".
+            algo_units = {"attn_fwd_kernel": 2.0, "attn_bwd_dkdv_kernel": 5.0 * 4 / 7,
+                          "attn_bwd_dq_kernel": 5.0 * 3 / 7}
+            exec_units = {"attn_fwd_kernel": 2.0, "attn_bwd_dkdv_kernel": 4.0, "attn_bwd_dq_kernel": 3.0}
+            cand = {n: d for n, d in ks.items() if n in algo_units}
+            dom = max(cand, key=lambda n: cand[n]["total_ms"])
+            avg_s = cand[dom]["avg_ms"] * 1e-3
+            achieved = algo_units[dom] * unit / avg_s / 1e12
+            res["roofline"] = {
+                "kernel": dom, "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                "avg_launch_ms": cand[dom]["avg_ms"],
+                "executed_tflops": exec_units[dom] * unit / avg_s / 1e12,
+                "all_kernels_algorithmic_tflops": {
+                    n: algo_units[n] * unit / (d["avg_ms"] * 1e-3) / 1e12 for n, d in cand.items()},
+            }
+            if not args.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline(S)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,69 @@
+"""CPU port of the reference's blockwise attention (forward + backward) on
+PyTorch-CPU fp32 -- TEST/BASELINE INFRASTRUCTURE, NOT PRODUCT.
+
+This is the `cpu_baseline` leg of bench.py ("port"): the same algorithm as
+oracle/attention_ref.blockwise_ring_attention(+_bwd) (scan over q chunks x k
+chunks, online softmax carry, skip of chunk pairs above the diagonal; call site
+lwm/llama.py:539-569, chunk sizes 1024/1024 per lwm/llama.py:155-156), written
+with torch.matmul so that it uses every host core through the BLAS the wheel
+ships.  It stands in for "the reference's JAX/XLA CPU path", which cannot be
+installed here (PARITY UNPINNED, see oracle/attention_ref.py).
+
+tests/test_oracle.py checks it against the float64 dense oracle.
+"""
+import math
+
+import torch
+
+
+def blockwise_fwd_bwd(q, k, v, dout, *, q_chunk=1024, k_chunk=1024, causal=True):
+    """q,k,v,dout: (B,S,H,D) float32 CPU tensors.  Returns (out, dq, dk, dv)."""
+    B, S, H, D = q.shape
+    scale = 1.0 / math.sqrt(D)
+    qh, kh, vh, doh = (t.permute(0, 2, 1, 3).contiguous() for t in (q, k, v, dout))  # B,H,S,D
+    qc, kc = min(q_chunk, S), min(k_chunk, S)
+    out = torch.zeros_like(qh)
+    lse = torch.empty(B, H, S)
+    for q0 in range(0, S, qc):
+        qs = qh[:, :, q0:q0 + qc]
+        num = torch.zeros(B, H, qs.shape[2], D)
+        den = torch.zeros(B, H, qs.shape[2])
+        mx = torch.full((B, H, qs.shape[2]), float("-inf"))
+        for k0 in range(0, S, kc):
+            if causal and k0 > q0 + qs.shape[2] - 1:
+                continue
+            ks, vs = kh[:, :, k0:k0 + kc], vh[:, :, k0:k0 + kc]
+            s = torch.matmul(qs, ks.transpose(-1, -2)) * scale
+            if causal and k0 + ks.shape[2] - 1 > q0:
+                qi = torch.arange(q0, q0 + qs.shape[2])[:, None]
+                ki = torch.arange(k0, k0 + ks.shape[2])[None, :]
+                s = s.masked_fill(ki > qi, float("-inf"))
+            m_new = torch.maximum(mx, s.amax(dim=-1))
+            p = torch.exp(s - m_new[..., None])
+            corr = torch.exp(mx - m_new)
+            num = num * corr[..., None] + torch.matmul(p, vs)
+            den = den * corr + p.sum(dim=-1)
+            mx = m_new
+        out[:, :, q0:q0 + qc] = num / den[..., None]
+        lse[:, :, q0:q0 + qc] = mx + torch.log(den)
+    delta = (doh * out).sum(dim=-1)
+    dq, dk, dv = torch.zeros_like(qh), torch.zeros_like(kh), torch.zeros_like(vh)
+    for q0 in range(0, S, qc):
+        qs, dos = qh[:, :, q0:q0 + qc], doh[:, :, q0:q0 + qc]
+        for k0 in range(0, S, kc):
+            if causal and k0 > q0 + qs.shape[2] - 1:
+                continue
+            ks, vs = kh[:, :, k0:k0 + kc], vh[:, :, k0:k0 + kc]
+            s = torch.matmul(qs, ks.transpose(-1, -2)) * scale
+            p = torch.exp(s - lse[:, :, q0:q0 + qc, None])
+            if causal and k0 + ks.shape[2] - 1 > q0:
+                qi = torch.arange(q0, q0 + qs.shape[2])[:, None]
+                ki = torch.arange(k0, k0 + ks.shape[2])[None, :]
+                p = p.masked_fill(ki > qi, 0.0)
+            dv[:, :, k0:k0 + kc] += torch.matmul(p.transpose(-1, -2), dos)
+            dp = torch.matmul(dos, vs.transpose(-1, -2))
+            ds = p * (dp - delta[:, :, q0:q0 + qc, None]) * scale
+            dq[:, :, q0:q0 + qc] += torch.matmul(ds, ks)
+            dk[:, :, k0:k0 + kc] += torch.matmul(ds.transpose(-1, -2), qs)
+    back = lambda t: t.permute(0, 2, 1, 3).contiguous()
+    return back(out), back(dq), back(dk), back(dv)

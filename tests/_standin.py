@@ -1,0 +1,123 @@
+"""CPU stand-in for the per-block kernels, built on the oracle's mask/softmax
+definitions.  TEST INFRASTRUCTURE: lets the ring driver's schedule, carries and
+communication be exercised under gloo without a GPU.  Never used by lwm_amd."""
+import math
+
+import numpy as np
+import torch
+
+from oracle.attention_ref import visible_mask
+
+
+def _vis(q, k, q_start, k_start, causal, seg_q, seg_k, key_valid):
+    B, Sq = q.shape[0], q.shape[1]
+    Sk = k.shape[1]
+    n = lambda t: None if t is None else t.cpu().numpy()
+    m = visible_mask(Sq, Sk, causal=causal, q_start=q_start, k_start=k_start, seg_q=n(seg_q),
+                     seg_k=n(seg_k), key_valid=n(key_valid), B=B)
+    return torch.from_numpy(m)[:, None]  # B,1,Sq,Sk
+
+
+class OracleBlockOps:
+    @staticmethod
+    def empty(shape, dtype, like):
+        return torch.empty(shape, dtype=dtype)
+
+    @staticmethod
+    def zeros(shape, dtype, like):
+        return torch.zeros(shape, dtype=dtype)
+
+    @staticmethod
+    def cast(src, dst=None):
+        if dst is None:
+            return src.to(torch.bfloat16)
+        dst.copy_(src.to(torch.bfloat16))
+        return dst
+
+    @staticmethod
+    def fwd(q, k, v, *, q_start=0, k_start=0, causal=True, seg_q=None, seg_k=None, key_valid=None,
+            scale=None, out=None, lse=None, out_acc=None, lse_acc=None, carry_in=False, final=True):
+        D = q.shape[-1]
+        scale = scale or 1.0 / math.sqrt(D)
+        s = torch.einsum("bqhd,bkhd->bhqk", q.double(), k.double()) * scale
+        vis = _vis(q, k, q_start, k_start, causal, seg_q, seg_k, key_valid)
+        s = s.masked_fill(~vis, float("-inf"))
+        m = s.amax(dim=-1, keepdim=True)
+        m = torch.where(torch.isfinite(m), m, torch.zeros_like(m))
+        p = torch.exp(s - m)
+        l = p.sum(dim=-1, keepdim=True)
+        ob = torch.einsum("bhqk,bkhd->bqhd", p / l.clamp_min(1e-300), v.double())
+        lb = torch.where(l[..., 0] > 0, m[..., 0] + torch.log(l[..., 0].clamp_min(1e-300)),
+                         torch.full_like(l[..., 0], float("-inf")))
+        if carry_in:
+            la = lse_acc.double()
+            ln = torch.logaddexp(la, lb)
+            wa = torch.where(torch.isfinite(la), torch.exp(la - ln), torch.zeros_like(la))
+            wb = torch.where(torch.isfinite(lb), torch.exp(lb - ln), torch.zeros_like(lb))
+            wa, wb = (w.nan_to_num(0.0).permute(0, 2, 1)[..., None] for w in (wa, wb))
+            ob = out_acc.double() * wa + ob * wb
+            lb = ln
+        if final:
+            out.copy_(ob.to(out.dtype))
+            lse.copy_(lb.float())
+            return out, lse
+        out_acc.copy_(ob.float())
+        lse_acc.copy_(lb.float())
+        return out_acc, lse_acc
+
+    @staticmethod
+    def bwd_delta(out, dout, delta=None):
+        d = torch.einsum("bqhd,bqhd->bhq", out.double(), dout.double()).float()
+        if delta is not None:
+            delta.copy_(d)
+            return delta
+        return d
+
+    @staticmethod
+    def _ds(q, k, v, dout, lse, delta, q_start, k_start, causal, seg_q, seg_k, key_valid, scale):
+        D = q.shape[-1]
+        scale = scale or 1.0 / math.sqrt(D)
+        s = torch.einsum("bqhd,bkhd->bhqk", q.double(), k.double()) * scale
+        vis = _vis(q, k, q_start, k_start, causal, seg_q, seg_k, key_valid)
+        ok = vis & torch.isfinite(lse)[..., None]
+        p = torch.where(ok, torch.exp(torch.where(ok, s - lse.double()[..., None].nan_to_num(0, 0, 0), torch.zeros_like(s))),
+                        torch.zeros_like(s))
+        dp = torch.einsum("bqhd,bkhd->bhqk", dout.double(), v.double())
+        ds = p * (dp - delta.double()[..., None]) * scale
+        return p, ds
+
+    @classmethod
+    def bwd_dq(cls, q, k, v, dout, lse, delta, *, q_start=0, k_start=0, causal=True, seg_q=None,
+               seg_k=None, key_valid=None, scale=None, dq=None, dq_acc=None, carry_in=False, final=True):
+        _, ds = cls._ds(q, k, v, dout, lse, delta, q_start, k_start, causal, seg_q, seg_k, key_valid, scale)
+        r = torch.einsum("bhqk,bkhd->bqhd", ds, k.double())
+        if carry_in:
+            r = r + dq_acc.double()
+        if final:
+            if dq is None:
+                dq = torch.empty(q.shape, dtype=q.dtype)
+            dq.copy_(r.to(dq.dtype))
+            return dq
+        dq_acc.copy_(r.float())
+        return dq_acc
+
+    @classmethod
+    def bwd_dkdv(cls, q, k, v, dout, lse, delta, *, q_start=0, k_start=0, causal=True, seg_q=None,
+                 seg_k=None, key_valid=None, scale=None, dk=None, dv=None, dk_acc=None, dv_acc=None,
+                 carry_in=False, final=True):
+        p, ds = cls._ds(q, k, v, dout, lse, delta, q_start, k_start, causal, seg_q, seg_k, key_valid, scale)
+        rk = torch.einsum("bhqk,bqhd->bkhd", ds, q.double())
+        rv = torch.einsum("bhqk,bqhd->bkhd", p, dout.double())
+        if carry_in:
+            rk = rk + dk_acc.double()
+            rv = rv + dv_acc.double()
+        if final:
+            if dk is None:
+                dk = torch.empty(k.shape, dtype=k.dtype)
+                dv = torch.empty(k.shape, dtype=k.dtype)
+            dk.copy_(rk.to(dk.dtype))
+            dv.copy_(rv.to(dv.dtype))
+            return dk, dv
+        dk_acc.copy_(rk.float())
+        dv_acc.copy_(rv.float())
+        return dk_acc, dv_acc

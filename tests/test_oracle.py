@@ -1,0 +1,106 @@
+"""The oracle checked against itself along the structural identities the
+reference's code implies (the reference ships no golden
+vectors, so parity is UNPINNED -- see oracle/attention_ref.py):
+  blockwise == dense branch (lwm/llama.py:525-570 vs :571-614),
+  ring n == ring 1, packed == per-segment, analytic backward == autograd."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import attention_ref as R
+
+
+def _data(B, S, H, D, seed):
+    rng = np.random.default_rng(seed)
+    return [rng.standard_normal((B, S, H, D)).astype(np.float32) for _ in range(4)]
+
+
+@pytest.mark.parametrize("ring", [1, 2, 4])
+@pytest.mark.parametrize("causal", [True, False])
+def test_blockwise_ring_equals_dense(ring, causal):
+    q, k, v, _ = _data(2, 256, 2, 16, 0)
+    ref, rlse = R.dense_attention(q, k, v, causal=causal)
+    out, lse = R.blockwise_ring_attention(q, k, v, ring=ring, q_chunk=32, k_chunk=16, causal=causal,
+                                          return_stats=True)
+    assert np.abs(out - ref).max() < 2e-5
+    assert np.abs(lse - rlse).max() < 2e-5
+
+
+def test_packed_equals_per_segment_and_padding():
+    B, S, H, D = 1, 192, 2, 16
+    q, k, v, do = _data(B, S, H, D, 1)
+    bounds = [0, 50, 120, 192]
+    seg = np.zeros((B, S), np.int32)
+    for i in range(3):
+        seg[:, bounds[i]:bounds[i + 1]] = i
+    out, _ = R.dense_attention(q, k, v, causal=True, seg_q=seg, seg_k=seg)
+    blk = R.blockwise_ring_attention(q, k, v, ring=2, q_chunk=32, k_chunk=32, causal=True, segment_ids=seg)
+    dq, dk, dv = R.dense_attention_bwd(q, k, v, do, causal=True, seg_q=seg, seg_k=seg)
+    for i in range(3):
+        sl = slice(bounds[i], bounds[i + 1])
+        o_i, _ = R.dense_attention(q[:, sl], k[:, sl], v[:, sl], causal=True)
+        assert np.abs(out[:, sl] - o_i).max() < 1e-12
+        assert np.abs(blk[:, sl] - o_i).max() < 2e-5
+        gq, gk, gv = R.dense_attention_bwd(q[:, sl], k[:, sl], v[:, sl], do[:, sl], causal=True)
+        assert np.abs(dq[:, sl] - gq).max() < 1e-10 and np.abs(dk[:, sl] - gk).max() < 1e-10 \
+            and np.abs(dv[:, sl] - gv).max() < 1e-10
+    # key padding: padded keys never contribute; fully-masked rows are 0 / -inf
+    kvm = np.ones((B, S), np.uint8)
+    kvm[:, :7] = 0
+    out2, lse2 = R.dense_attention(q, k, v, causal=True, key_valid=kvm)
+    assert np.all(out2[:, :7] == 0) and np.all(np.isneginf(lse2[:, :, :7]))
+    o_ref, _ = R.dense_attention(q[:, 7:], k[:, 7:], v[:, 7:], causal=True)
+    assert np.abs(out2[:, 7:] - o_ref).max() < 1e-12
+
+
+def test_analytic_backward_matches_autograd():
+    B, S, H, D = 1, 96, 2, 16
+    q, k, v, do = _data(B, S, H, D, 2)
+    seg = np.zeros((B, S), np.int32)
+    seg[:, 40:] = 1
+    dq, dk, dv = R.dense_attention_bwd(q, k, v, do, causal=True, seg_q=seg, seg_k=seg)
+    tq, tk, tv = (torch.tensor(x, dtype=torch.float64, requires_grad=True) for x in (q, k, v))
+    s = torch.einsum("bqhd,bkhd->bhqk", tq, tk) / np.sqrt(D)
+    vis = torch.from_numpy(R.visible_mask(S, S, causal=True, seg_q=seg, seg_k=seg, B=B))[:, None]
+    p = torch.softmax(s.masked_fill(~vis, float("-inf")), dim=-1)
+    out = torch.einsum("bhqk,bkhd->bqhd", p, tv)
+    out.backward(torch.tensor(do, dtype=torch.float64))
+    assert np.abs(dq - tq.grad.numpy()).max() < 1e-10
+    assert np.abs(dk - tk.grad.numpy()).max() < 1e-10
+    assert np.abs(dv - tv.grad.numpy()).max() < 1e-10
+
+
+def test_blockwise_backward_equals_dense_backward():
+    q, k, v, do = _data(1, 128, 2, 16, 3)
+    ref = R.dense_attention_bwd(q, k, v, do, causal=True)
+    got = R.blockwise_ring_attention_bwd(q, k, v, do, ring=2, q_chunk=32, k_chunk=16, causal=True)
+    for a, b in zip(got, ref):
+        assert np.abs(a - b).max() < 5e-5
+
+
+def test_q_len_differs_from_kv_len_offsets():
+    """prefill-into-cache shape (lwm/llama.py:485-487): q block at a global offset."""
+    q, k, v, _ = _data(1, 160, 1, 16, 4)
+    full, _ = R.dense_attention(q, k, v, causal=True)
+    part, _ = R.dense_attention(q[:, 100:], k, v, causal=True, q_start=100, k_start=0)
+    assert np.abs(full[:, 100:] - part).max() < 1e-12
+
+
+def test_torch_cpu_port_matches_dense():
+    from oracle.attention_torch_cpu import blockwise_fwd_bwd
+    q, k, v, do = _data(1, 384, 2, 32, 5)
+    o, dq, dk, dv = blockwise_fwd_bwd(*(torch.from_numpy(x) for x in (q, k, v, do)), q_chunk=128, k_chunk=64)
+    ro, _ = R.dense_attention(q, k, v)
+    rq, rk, rv = R.dense_attention_bwd(q, k, v, do)
+    for a, b in ((o, ro), (dq, rq), (dk, rk), (dv, rv)):
+        assert np.abs(a.numpy() - b).max() < 2e-5
+
+
+def test_bf16_helpers_round_to_nearest_even():
+    x = np.array([1.0, 1.00390625, 1.0078125, -3.1415926, 65504.0, 1e-40, np.inf], np.float32)
+    got = R.round_bf16(x)
+    ref = torch.from_numpy(x).to(torch.bfloat16).float().numpy()
+    assert np.array_equal(got, ref)
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal(10000).astype(np.float32) * 100
+    assert np.array_equal(R.round_bf16(y), torch.from_numpy(y).to(torch.bfloat16).float().numpy())
