@@ -52,6 +52,7 @@ LWM_KERNEL(kDeltaThreads) void attn_bwd_delta_kernel(AttnParams p, float* delta)
 }
 
 // ------------------------------------------------------------------ dQ
+// LDS map: K tile 0 | K tile 1 | V tile 0 | V tile 1 (8 KiB each) | key meta 0 | 1
 constexpr int kDqBQ = 256;
 constexpr int kDqBK = 32;
 constexpr int kDqThreads = 512;
@@ -62,6 +63,17 @@ struct DqStage {
     u32x4 k;
     u32x4 v;
     int32_t kseg;
+};
+
+struct DqCtx {
+    RowFragAddr ka;   // K row fragments (tile 0); V tile 0 is +2*kDqTileBytes
+    TrFragAddr kta;   // K transposed fragments (tile 0)
+    lds_t stage_w, kseg_w, kseg_r;
+    int tid, hi;
+    int64_t q_pos, wq_min, wq_max;
+    int32_t seg_q;
+    bool has_kmeta;
+    float c, lse2, dlt;
 };
 
 LWM_DEVICE void dq_stage_load(const AttnParams& p, const bf16_t* kb, const bf16_t* vb, int b,
@@ -87,16 +99,65 @@ LWM_DEVICE void dq_stage_load(const AttnParams& p, const bf16_t* kb, const bf16_
     }
 }
 
-LWM_DEVICE void dq_stage_write(char* kbuf, char* vbuf, int32_t* ksegbuf, int tid,
-                               const DqStage& st) {
-    int row = tid >> 4, slot = tid & 15;
-    lds_write_b128(kbuf + tile_off(row, slot), st.k);
-    lds_write_b128(vbuf + tile_off(row, slot), st.v);
-    if (tid < kDqBK) ksegbuf[tid] = st.kseg;
+template <int BUF>
+LWM_DEVICE void dq_stage_write(const DqCtx& cx, const DqStage& st) {
+    lds_write_b128(cx.stage_w + BUF * kDqTileBytes, st.k);
+    lds_write_b128(cx.stage_w + (2 + BUF) * kDqTileBytes, st.v);
+    if (cx.tid < kDqBK) lds_write_i32(cx.kseg_w + BUF * kDqBK * 4, st.kseg);
+}
+
+template <int BUF>
+LWM_DEVICE void dq_tile(const AttnParams& p, const DqCtx& cx, const bf16x8 (&qf)[8],
+                        const bf16x8 (&dof)[8], int kt, f32x16 (&acc)[4]) {
+    const int64_t k_pos0 = p.k_start + (int64_t)kt * kDqBK;
+    if (p.causal && k_pos0 > cx.wq_max) return;
+    constexpr uint32_t KB = BUF * kDqTileBytes;
+    constexpr uint32_t VB = (2 + BUF) * kDqTileBytes;
+
+    f32x16 st = zero_f32x16(), dpt = zero_f32x16();
+    prio_hi();
+    for (int s = 0; s < 8; ++s) {
+        bf16x8 a = lds_read_b128(cx.ka.a[s] + KB);
+        st = mfma_32x32x16(a, qf[s], st);
+    }
+    for (int s = 0; s < 8; ++s) {
+        bf16x8 a = lds_read_b128(cx.ka.a[s] + VB);
+        dpt = mfma_32x32x16(a, dof[s], dpt);
+    }
+    prio_lo();
+    const bool need_mask = cx.has_kmeta || (p.causal && k_pos0 + kDqBK - 1 > cx.wq_min);
+    for (int r = 0; r < 16; ++r) st[r] = fast_exp2(fmaf(st[r], cx.c, -cx.lse2));
+    if (need_mask) {
+        int64_t rel64 = p.causal ? (cx.q_pos - k_pos0) : (int64_t)kDqBK;
+        const int rel = rel64 > kDqBK ? kDqBK : (rel64 < -1 ? -1 : (int)rel64);
+        for (int g = 0; g < 4; ++g) {
+            const int kl0 = 8 * g + 4 * cx.hi;
+            if (cx.has_kmeta) {
+                u32x4 sg = lds_read_u32x4(cx.kseg_r + BUF * kDqBK * 4 + 8 * g * 4);
+                for (int j = 0; j < 4; ++j) {
+                    bool vis = ((int32_t)sg[j] == cx.seg_q) && (kl0 + j <= rel);
+                    st[4 * g + j] = vis ? st[4 * g + j] : 0.0f;
+                }
+            } else {
+                for (int j = 0; j < 4; ++j)
+                    st[4 * g + j] = (kl0 + j <= rel) ? st[4 * g + j] : 0.0f;
+            }
+        }
+    }
+    for (int r = 0; r < 16; ++r) st[r] = st[r] * (dpt[r] - cx.dlt);  // dS^T (unscaled)
+    prio_hi();
+    for (int t = 0; t < 2; ++t) {
+        bf16x8 dsb = cvt_frag(st, 8 * t);
+        for (int db = 0; db < 4; ++db) {
+            bf16x8 a = read_tr_frag(cx.kta, db, KB + 16 * t * kRowBytes);
+            acc[db] = mfma_32x32x16(a, dsb, acc[db]);
+        }
+    }
+    prio_lo();
 }
 
 LWM_KERNEL(kDqThreads) void attn_bwd_dq_kernel(AttnParams p) {
-    char* lds = dyn_lds();
+    const lds_t lds = dyn_lds();
     const int tid = thread_idx();
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
 
@@ -118,14 +179,8 @@ LWM_KERNEL(kDqThreads) void attn_bwd_dq_kernel(AttnParams p) {
     const bf16_t* vb = p.v + (int64_t)b * p.v_sb + (int64_t)h * p.v_sh;
     const bf16_t* dob = p.dout + (int64_t)b * p.do_sb + (int64_t)h * p.do_sh;
 
-    char* kbuf[2] = {lds, lds + kDqTileBytes};
-    char* vbuf[2] = {lds + 2 * kDqTileBytes, lds + 3 * kDqTileBytes};
-    int32_t* ksegbuf[2] = {(int32_t*)(lds + 4 * kDqTileBytes),
-                           (int32_t*)(lds + 4 * kDqTileBytes) + kDqBK};
-
     const int q_row = qt * kDqBQ + wave * 32 + l31;
     const bool q_ok = q_row < p.Sq;
-    const int64_t q_pos = p.q_start + q_row;
     bf16x8 qf[8], dof[8];
     for (int s = 0; s < 8; ++s) {
         if (q_ok) {
@@ -138,15 +193,28 @@ LWM_KERNEL(kDqThreads) void attn_bwd_dq_kernel(AttnParams p) {
             dof[s] = zero_bf16x8();
         }
     }
+    DqCtx cx;
+    cx.tid = tid;
+    cx.hi = hi;
+    cx.ka = frag_rows_addr(lds, 0, l31, hi);
+    cx.kta = frag_tr_addr(lds, lane);
+    cx.stage_w = lds + tile_off(tid >> 4, tid & 15);
+    cx.kseg_w = lds + 4 * kDqTileBytes + tid * 4;
+    cx.kseg_r = lds + 4 * kDqTileBytes + 16 * hi;
+    cx.q_pos = p.q_start + q_row;
     const int64_t stat_idx = ((int64_t)b * p.H + h) * p.Sq + q_row;
-    float lse2 = INFINITY, dlt = 0.0f;
+    cx.lse2 = INFINITY;
+    cx.dlt = 0.0f;
     if (q_ok) {
         float l = p.lse[stat_idx];
-        lse2 = (l == -INFINITY) ? INFINITY : l * kLog2e;
-        dlt = p.delta[stat_idx];
+        cx.lse2 = (l == -INFINITY) ? INFINITY : l * kLog2e;
+        cx.dlt = p.delta[stat_idx];
     }
-    const int32_t seg_q = (q_ok && p.seg_q) ? p.seg_q[(int64_t)b * p.Sq + q_row] : 0;
-    const bool has_kmeta = (p.seg_k != nullptr) || (p.key_valid != nullptr) || (p.Sk % kDqBK != 0);
+    cx.seg_q = (q_ok && p.seg_q) ? p.seg_q[(int64_t)b * p.Sq + q_row] : 0;
+    cx.has_kmeta = (p.seg_k != nullptr) || (p.key_valid != nullptr) || (p.Sk % kDqBK != 0);
+    cx.wq_min = p.q_start + qt * kDqBQ + wave * 32;
+    cx.wq_max = cx.wq_min + 31;
+    cx.c = p.scale * kLog2e;
 
     const int nkt_all = (p.Sk + kDqBK - 1) / kDqBK;
     int nkt = nkt_all;
@@ -159,58 +227,28 @@ LWM_KERNEL(kDqThreads) void attn_bwd_dq_kernel(AttnParams p) {
             nkt = t < nkt_all ? (int)t : nkt_all;
         }
     }
-    const int64_t wq_min = p.q_start + qt * kDqBQ + wave * 32;
-    const int64_t wq_max = wq_min + 31;
 
-    const float c = p.scale * kLog2e;
     f32x16 acc[4];
     for (int i = 0; i < 4; ++i) acc[i] = zero_f32x16();
 
     DqStage stg;
     if (nkt > 0) {
         dq_stage_load(p, kb, vb, b, 0, tid, stg);
-        dq_stage_write(kbuf[0], vbuf[0], ksegbuf[0], tid, stg);
+        dq_stage_write<0>(cx, stg);
     }
     block_sync();
 
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nkt;
-        if (more) dq_stage_load(p, kb, vb, b, kt + 1, tid, stg);
-
-        const int64_t k_pos0 = p.k_start + (int64_t)kt * kDqBK;
-        const bool wave_active = !p.causal || k_pos0 <= wq_max;
-        if (wave_active) {
-            f32x16 st = zero_f32x16(), dpt = zero_f32x16();
-            for (int s = 0; s < 8; ++s) {
-                bf16x8 a = frag_rows(kbuf[cur], 0, s, l31, hi);
-                st = mfma_32x32x16(a, qf[s], st);
-            }
-            for (int s = 0; s < 8; ++s) {
-                bf16x8 a = frag_rows(vbuf[cur], 0, s, l31, hi);
-                dpt = mfma_32x32x16(a, dof[s], dpt);
-            }
-            const bool need_mask = has_kmeta || (p.causal && k_pos0 + kDqBK - 1 > wq_min);
-            const int32_t* ks = ksegbuf[cur];
-            for (int r = 0; r < 16; ++r) {
-                float pv = fast_exp2(fmaf(st[r], c, -lse2));
-                if (need_mask) {
-                    int kl = cd_row(r, hi);
-                    bool vis = (ks[kl] == seg_q);
-                    if (p.causal) vis = vis && (k_pos0 + kl <= q_pos);
-                    pv = vis ? pv : 0.0f;
-                }
-                st[r] = pv * (dpt[r] - dlt);  // dS^T (unscaled)
-            }
-            for (int t = 0; t < 2; ++t) {
-                bf16x8 dsb = cvt_frag(st, 8 * t);
-                for (int db = 0; db < 4; ++db) {
-                    bf16x8 a = frag_cols_tr(kbuf[cur], 16 * t, 32 * db, lane);
-                    acc[db] = mfma_32x32x16(a, dsb, acc[db]);
-                }
-            }
-        }
-        if (more) dq_stage_write(kbuf[cur ^ 1], vbuf[cur ^ 1], ksegbuf[cur ^ 1], tid, stg);
+    for (int kt = 0; kt < nkt; kt += 2) {
+        const bool more1 = kt + 1 < nkt;
+        if (more1) dq_stage_load(p, kb, vb, b, kt + 1, tid, stg);
+        dq_tile<0>(p, cx, qf, dof, kt, acc);
+        if (more1) dq_stage_write<1>(cx, stg);
+        block_sync();
+        if (!more1) break;
+        const bool more2 = kt + 2 < nkt;
+        if (more2) dq_stage_load(p, kb, vb, b, kt + 2, tid, stg);
+        dq_tile<1>(p, cx, qf, dof, kt + 1, acc);
+        if (more2) dq_stage_write<0>(cx, stg);
         block_sync();
     }
 
@@ -239,33 +277,58 @@ LWM_KERNEL(kDqThreads) void attn_bwd_dq_kernel(AttnParams p) {
 }
 
 // ------------------------------------------------------------------ dK, dV
-constexpr int kDkvBK = 256;   // keys per workgroup (32 per wave)
+// Workgroup = NW waves; wave w owns NKB blocks of 32 keys (keys
+// [w*NKB*32, (w+1)*NKB*32) of the workgroup's 256-key block) and keeps their
+// K fragments and f32 dK^T/dV^T accumulators in registers for the whole launch.
+// Two shapes are instantiated:
+//   <NW=8, NKB=1>  2 waves/SIMD, 256 registers each
+//   <NW=4, NKB=2>  1 wave/SIMD, the whole 512-register file; every Q/dO fragment
+//                  read from LDS feeds two MFMAs (half the LDS traffic per FLOP)
+// LDS map: V (resident, 64 KiB) | Q tile 0 | Q tile 1 | dO tile 0 | dO tile 1
+//          (8 KiB each) | stats 0 | stats 1 (lse2[32], delta[32], seg_q[32])
+constexpr int kDkvBK = 256;   // keys per workgroup
 constexpr int kDkvBQ = 32;    // queries per LDS tile
-constexpr int kDkvThreads = 512;
 constexpr int kDkvQTileBytes = kDkvBQ * kRowBytes;  // 8 KiB
 constexpr int kDkvVBytes = kDkvBK * kRowBytes;      // 64 KiB
-// V (resident) | Q x2 | dO x2 | stats x2 (lse2, delta, seg_q : 32 each)
 constexpr int kDkvStatBytes = 3 * kDkvBQ * 4;
 constexpr int kDkvLdsBytes = kDkvVBytes + 4 * kDkvQTileBytes + 2 * kDkvStatBytes;
 
 struct DkvStage {
-    u32x4 q;
-    u32x4 d;
+    u32x4 q[2];
+    u32x4 d[2];
     float lse2, delta;
     int32_t segq;
 };
 
+template <int NKB>
+struct DkvCtx {
+    RowFragAddr qa;   // Q row fragments (tile 0); dO tile 0 is +2*kDkvQTileBytes
+    RowFragAddr va;   // this wave's first 32 rows of the resident V tile
+    TrFragAddr qta;   // Q transposed fragments (tile 0); dO likewise +2 tiles
+    lds_t stage_w, stat_w, stat_r;
+    int tid, hi;
+    int64_t k_pos[NKB], wk_min, wk_max;
+    int32_t kseg[NKB];
+    bool has_meta;
+    float c;
+};
+
+template <int NW>
 LWM_DEVICE void dkv_stage_load(const AttnParams& p, const bf16_t* qb, const bf16_t* dob, int b,
                                int h, int qt, int tid, DkvStage& st) {
-    int row = tid >> 4, slot = tid & 15;
-    int qrow = qt * kDkvBQ + row;
-    if (qrow < p.Sq) {
-        st.q = global_load_b128(qb + (int64_t)qrow * p.q_ss + slot * 8);
-        st.d = global_load_b128(dob + (int64_t)qrow * p.do_ss + slot * 8);
-    } else {
-        u32x4 z = {0u, 0u, 0u, 0u};
-        st.q = z;
-        st.d = z;
+    constexpr int NT = NW * 64, NCH = 512 / NT;  // 16-B chunks per thread per tensor
+    for (int i = 0; i < NCH; ++i) {
+        int cidx = tid + NT * i;
+        int row = cidx >> 4, slot = cidx & 15;
+        int qrow = qt * kDkvBQ + row;
+        if (qrow < p.Sq) {
+            st.q[i] = global_load_b128(qb + (int64_t)qrow * p.q_ss + slot * 8);
+            st.d[i] = global_load_b128(dob + (int64_t)qrow * p.do_ss + slot * 8);
+        } else {
+            u32x4 z = {0u, 0u, 0u, 0u};
+            st.q[i] = z;
+            st.d[i] = z;
+        }
     }
     if (tid < kDkvBQ) {
         int qr = qt * kDkvBQ + tid;
@@ -282,20 +345,103 @@ LWM_DEVICE void dkv_stage_load(const AttnParams& p, const bf16_t* qb, const bf16
     }
 }
 
-LWM_DEVICE void dkv_stage_write(char* qbuf, char* dbuf, char* statbuf, int tid,
-                                const DkvStage& st) {
-    int row = tid >> 4, slot = tid & 15;
-    lds_write_b128(qbuf + tile_off(row, slot), st.q);
-    lds_write_b128(dbuf + tile_off(row, slot), st.d);
-    if (tid < kDkvBQ) {
-        ((float*)statbuf)[tid] = st.lse2;
-        ((float*)statbuf)[kDkvBQ + tid] = st.delta;
-        ((int32_t*)statbuf)[2 * kDkvBQ + tid] = st.segq;
+template <int NW, int NKB, int BUF>
+LWM_DEVICE void dkv_stage_write(const DkvCtx<NKB>& cx, const DkvStage& st) {
+    constexpr int NT = NW * 64, NCH = 512 / NT;
+    for (int i = 0; i < NCH; ++i) {
+        // chunk i lives NT/16 rows below chunk 0 (a multiple of 16 rows: same swizzle)
+        lds_write_b128(cx.stage_w + BUF * kDkvQTileBytes + i * (NT / 16) * kRowBytes, st.q[i]);
+        lds_write_b128(cx.stage_w + (2 + BUF) * kDkvQTileBytes + i * (NT / 16) * kRowBytes, st.d[i]);
+    }
+    if (cx.tid < kDkvBQ) {
+        lds_write_f32(cx.stat_w + BUF * kDkvStatBytes, st.lse2);
+        lds_write_f32(cx.stat_w + BUF * kDkvStatBytes + kDkvBQ * 4, st.delta);
+        lds_write_i32(cx.stat_w + BUF * kDkvStatBytes + 2 * kDkvBQ * 4, st.segq);
     }
 }
 
-LWM_KERNEL(kDkvThreads) void attn_bwd_dkdv_kernel(AttnParams p) {
-    char* lds = dyn_lds();
+template <int NKB, int BUF>
+LWM_DEVICE void dkv_tile(const AttnParams& p, const DkvCtx<NKB>& cx, const bf16x8 (&kf)[NKB][8],
+                         int qt, f32x16 (&dk)[NKB][4], f32x16 (&dv)[NKB][4]) {
+    const int64_t q_pos0 = p.q_start + (int64_t)qt * kDkvBQ;
+    if (p.causal && q_pos0 + kDkvBQ - 1 < cx.wk_min) return;  // all queries before this wave's keys
+    constexpr uint32_t QB = BUF * kDkvQTileBytes;
+    constexpr uint32_t DB = (2 + BUF) * kDkvQTileBytes;
+    constexpr uint32_t SB = BUF * kDkvStatBytes;
+
+    // S = Q K^T and dP = dO V^T  (rows = queries, cols = keys)
+    f32x16 s[NKB], dp[NKB];
+    for (int kb = 0; kb < NKB; ++kb) {
+        s[kb] = zero_f32x16();
+        dp[kb] = zero_f32x16();
+    }
+    prio_hi();
+    for (int st = 0; st < 8; ++st) {
+        bf16x8 a = lds_read_b128(cx.qa.a[st] + QB);
+        for (int kb = 0; kb < NKB; ++kb) s[kb] = mfma_32x32x16(a, kf[kb][st], s[kb]);
+    }
+    for (int st = 0; st < 8; ++st) {
+        bf16x8 a = lds_read_b128(cx.qa.a[st] + DB);
+        for (int kb = 0; kb < NKB; ++kb) {
+            bf16x8 vfr = lds_read_b128(cx.va.a[st] + kb * 32 * kRowBytes);
+            dp[kb] = mfma_32x32x16(a, vfr, dp[kb]);
+        }
+    }
+    prio_lo();
+    const bool need_mask = cx.has_meta || (p.causal && q_pos0 < cx.wk_max);
+    // row statistics of the 16 query rows this lane's C/D registers hold
+    for (int g = 0; g < 4; ++g) {
+        f32x4 l2 = lds_read_f32x4(cx.stat_r + SB + 8 * g * 4);
+        for (int kb = 0; kb < NKB; ++kb)
+            for (int j = 0; j < 4; ++j)
+                s[kb][4 * g + j] = fast_exp2(fmaf(s[kb][4 * g + j], cx.c, -l2[j]));
+    }
+    if (need_mask) {
+        for (int g = 0; g < 4; ++g) {
+            const int ql0 = 8 * g + 4 * cx.hi;
+            u32x4 sg = lds_read_u32x4(cx.stat_r + SB + 2 * kDkvBQ * 4 + 8 * g * 4);
+            for (int kb = 0; kb < NKB; ++kb) {
+                // query row ql sees this lane's key iff ql >= rel  (causal)
+                int64_t rel64 = p.causal ? (cx.k_pos[kb] - q_pos0) : (int64_t)-1;
+                const int rel = rel64 > kDkvBQ ? kDkvBQ : (rel64 < -1 ? -1 : (int)rel64);
+                for (int j = 0; j < 4; ++j) {
+                    bool vis = ((int32_t)sg[j] == cx.kseg[kb]) && (ql0 + j >= rel);
+                    s[kb][4 * g + j] = vis ? s[kb][4 * g + j] : 0.0f;
+                }
+            }
+        }
+    }
+    for (int g = 0; g < 4; ++g) {
+        f32x4 dl = lds_read_f32x4(cx.stat_r + SB + kDkvBQ * 4 + 8 * g * 4);
+        for (int kb = 0; kb < NKB; ++kb)
+            for (int j = 0; j < 4; ++j)
+                dp[kb][4 * g + j] = s[kb][4 * g + j] * (dp[kb][4 * g + j] - dl[j]);
+    }
+    bf16x8 pb[NKB][2], dsb[NKB][2];
+    for (int kb = 0; kb < NKB; ++kb)
+        for (int t = 0; t < 2; ++t) {
+            pb[kb][t] = cvt_frag(s[kb], 8 * t);
+            dsb[kb][t] = cvt_frag(dp[kb], 8 * t);
+        }
+    prio_hi();
+    for (int t = 0; t < 2; ++t)
+        for (int db = 0; db < 4; ++db) {
+            bf16x8 a = read_tr_frag(cx.qta, db, DB + 16 * t * kRowBytes);
+            for (int kb = 0; kb < NKB; ++kb) dv[kb][db] = mfma_32x32x16(a, pb[kb][t], dv[kb][db]);
+        }
+    for (int t = 0; t < 2; ++t)
+        for (int db = 0; db < 4; ++db) {
+            bf16x8 a = read_tr_frag(cx.qta, db, QB + 16 * t * kRowBytes);
+            for (int kb = 0; kb < NKB; ++kb) dk[kb][db] = mfma_32x32x16(a, dsb[kb][t], dk[kb][db]);
+        }
+    prio_lo();
+}
+
+template <int NW, int NKB>
+LWM_DEVICE void attn_bwd_dkdv_body(const AttnParams& p) {
+    static_assert(NW * NKB * 32 == kDkvBK, "workgroup covers 256 keys");
+    constexpr int NT = NW * 64;
+    const lds_t lds = dyn_lds();
     const int tid = thread_idx();
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
 
@@ -317,40 +463,52 @@ LWM_KERNEL(kDkvThreads) void attn_bwd_dkdv_kernel(AttnParams p) {
     const bf16_t* vb = p.v + (int64_t)b * p.v_sb + (int64_t)h * p.v_sh;
     const bf16_t* dob = p.dout + (int64_t)b * p.do_sb + (int64_t)h * p.do_sh;
 
-    char* vtile = lds;
-    char* qbuf[2] = {lds + kDkvVBytes, lds + kDkvVBytes + kDkvQTileBytes};
-    char* dbuf[2] = {lds + kDkvVBytes + 2 * kDkvQTileBytes, lds + kDkvVBytes + 3 * kDkvQTileBytes};
-    char* statbuf[2] = {lds + kDkvVBytes + 4 * kDkvQTileBytes,
-                        lds + kDkvVBytes + 4 * kDkvQTileBytes + kDkvStatBytes};
-
-    // ---- this lane's key
-    const int k_row = kbi * kDkvBK + wave * 32 + l31;
-    const bool k_ok = k_row < p.Sk;
-    const int64_t k_pos = p.k_start + k_row;
-    bf16x8 kf[8];
-    for (int s = 0; s < 8; ++s) {
-        if (k_ok)
-            kf[s] = __builtin_bit_cast(
-                bf16x8, global_load_b128(kb + (int64_t)k_row * p.k_ss + 16 * s + 8 * hi));
-        else
-            kf[s] = zero_bf16x8();
+    DkvCtx<NKB> cx;
+    cx.tid = tid;
+    cx.hi = hi;
+    // ---- this lane's keys
+    const int wave_row0 = wave * NKB * 32;
+    bf16x8 kf[NKB][8];
+#pragma unroll
+    for (int kbk = 0; kbk < NKB; ++kbk) {
+        const int k_row = kbi * kDkvBK + wave_row0 + 32 * kbk + l31;
+        const bool k_ok = k_row < p.Sk;
+        for (int s = 0; s < 8; ++s) {
+            if (k_ok)
+                kf[kbk][s] = __builtin_bit_cast(
+                    bf16x8, global_load_b128(kb + (int64_t)k_row * p.k_ss + 16 * s + 8 * hi));
+            else
+                kf[kbk][s] = zero_bf16x8();
+        }
+        cx.k_pos[kbk] = p.k_start + k_row;
+        cx.kseg[kbk] = kSegInvalid;
+        if (k_ok) {
+            bool valid = p.key_valid ? (p.key_valid[(int64_t)b * p.Sk + k_row] != 0) : true;
+            if (valid) cx.kseg[kbk] = p.seg_k ? p.seg_k[(int64_t)b * p.Sk + k_row] : 0;
+        }
     }
-    int32_t kseg = kSegInvalid;
-    if (k_ok) {
-        bool valid = p.key_valid ? (p.key_valid[(int64_t)b * p.Sk + k_row] != 0) : true;
-        if (valid) kseg = p.seg_k ? p.seg_k[(int64_t)b * p.Sk + k_row] : 0;
-    }
-    const bool has_meta =
+    const lds_t qtiles = lds + kDkvVBytes;
+    const lds_t stats = qtiles + 4 * kDkvQTileBytes;
+    cx.qa = frag_rows_addr(qtiles, 0, l31, hi);
+    cx.va = frag_rows_addr(lds + wave_row0 * kRowBytes, 0, l31, hi);
+    cx.qta = frag_tr_addr(qtiles, lane);
+    cx.stage_w = qtiles + tile_off(tid >> 4, tid & 15);
+    cx.stat_w = stats + tid * 4;
+    cx.stat_r = stats + 16 * hi;
+    cx.has_meta =
         (p.seg_k != nullptr) || (p.key_valid != nullptr) || (kbi * kDkvBK + kDkvBK > p.Sk);
+    cx.wk_min = p.k_start + (int64_t)kbi * kDkvBK + wave_row0;
+    cx.wk_max = cx.wk_min + NKB * 32 - 1;
+    cx.c = p.scale * kLog2e;
 
     // ---- resident V tile (this workgroup's 256 keys)
-    for (int i = 0; i < 8; ++i) {
-        int cidx = tid + kDkvThreads * i;
+    for (int i = 0; i < 4096 / NT; ++i) {
+        int cidx = tid + NT * i;
         int row = cidx >> 4, slot = cidx & 15;
         int kr = kbi * kDkvBK + row;
         u32x4 val = {0u, 0u, 0u, 0u};
         if (kr < p.Sk) val = global_load_b128(vb + (int64_t)kr * p.v_ss + slot * 8);
-        lds_write_b128(vtile + tile_off(row, slot), val);
+        lds_write_b128(lds + tile_off(row, slot), val);
     }
 
     // ---- q tile range (causal: skip q tiles wholly before this key block)
@@ -360,86 +518,49 @@ LWM_KERNEL(kDkvThreads) void attn_bwd_dkdv_kernel(AttnParams p) {
         int64_t d = p.k_start + (int64_t)kbi * kDkvBK - p.q_start;  // first q row that can see key 0
         if (d > 0) qt0 = (int)(d / kDkvBQ < nqt ? d / kDkvBQ : nqt);
     }
-    const int64_t wk_min = p.k_start + (int64_t)kbi * kDkvBK + wave * 32;
-    const int64_t wk_max = wk_min + 31;
 
-    const float c = p.scale * kLog2e;
-    f32x16 dk[4], dv[4];
-    for (int i = 0; i < 4; ++i) {
-        dk[i] = zero_f32x16();
-        dv[i] = zero_f32x16();
-    }
+    f32x16 dk[NKB][4], dv[NKB][4];
+    for (int kbk = 0; kbk < NKB; ++kbk)
+        for (int i = 0; i < 4; ++i) {
+            dk[kbk][i] = zero_f32x16();
+            dv[kbk][i] = zero_f32x16();
+        }
 
     DkvStage stg;
     if (qt0 < nqt) {
-        dkv_stage_load(p, qb, dob, b, h, qt0, tid, stg);
-        dkv_stage_write(qbuf[0], dbuf[0], statbuf[0], tid, stg);
+        dkv_stage_load<NW>(p, qb, dob, b, h, qt0, tid, stg);
+        dkv_stage_write<NW, NKB, 0>(cx, stg);
     }
     block_sync();
 
-    for (int qt = qt0; qt < nqt; ++qt) {
-        const int cur = (qt - qt0) & 1;
-        const bool more = qt + 1 < nqt;
-        if (more) dkv_stage_load(p, qb, dob, b, h, qt + 1, tid, stg);
-
-        const int64_t q_pos0 = p.q_start + (int64_t)qt * kDkvBQ;
-        const bool wave_active = !p.causal || q_pos0 + kDkvBQ - 1 >= wk_min;
-        if (wave_active) {
-            // S = Q K^T and dP = dO V^T  (rows = queries, cols = keys)
-            f32x16 s = zero_f32x16(), dp = zero_f32x16();
-            for (int st = 0; st < 8; ++st) {
-                bf16x8 a = frag_rows(qbuf[cur], 0, st, l31, hi);
-                s = mfma_32x32x16(a, kf[st], s);
-            }
-            for (int st = 0; st < 8; ++st) {
-                bf16x8 a = frag_rows(dbuf[cur], 0, st, l31, hi);
-                bf16x8 vfr = frag_rows(vtile, wave * 32, st, l31, hi);
-                dp = mfma_32x32x16(a, vfr, dp);
-            }
-            const bool need_mask = has_meta || (p.causal && q_pos0 < wk_max);
-            const float* lse2s = (const float*)statbuf[cur];
-            const float* dlts = lse2s + kDkvBQ;
-            const int32_t* segs = (const int32_t*)statbuf[cur] + 2 * kDkvBQ;
-            f32x16 ds;
-            for (int r = 0; r < 16; ++r) {
-                int ql = cd_row(r, hi);
-                float pv = fast_exp2(fmaf(s[r], c, -lse2s[ql]));
-                if (need_mask) {
-                    bool vis = (segs[ql] == kseg);
-                    if (p.causal) vis = vis && (k_pos <= q_pos0 + ql);
-                    pv = vis ? pv : 0.0f;
-                }
-                s[r] = pv;
-                ds[r] = pv * (dp[r] - dlts[ql]);
-            }
-            for (int t = 0; t < 2; ++t) {
-                bf16x8 pb = cvt_frag(s, 8 * t);
-                bf16x8 dsb = cvt_frag(ds, 8 * t);
-                for (int db = 0; db < 4; ++db) {
-                    bf16x8 a = frag_cols_tr(dbuf[cur], 16 * t, 32 * db, lane);
-                    dv[db] = mfma_32x32x16(a, pb, dv[db]);
-                }
-                for (int db = 0; db < 4; ++db) {
-                    bf16x8 a = frag_cols_tr(qbuf[cur], 16 * t, 32 * db, lane);
-                    dk[db] = mfma_32x32x16(a, dsb, dk[db]);
-                }
-            }
-        }
-        if (more) dkv_stage_write(qbuf[cur ^ 1], dbuf[cur ^ 1], statbuf[cur ^ 1], tid, stg);
+    for (int qt = qt0; qt < nqt; qt += 2) {
+        const bool more1 = qt + 1 < nqt;
+        if (more1) dkv_stage_load<NW>(p, qb, dob, b, h, qt + 1, tid, stg);
+        dkv_tile<NKB, 0>(p, cx, kf, qt, dk, dv);
+        if (more1) dkv_stage_write<NW, NKB, 1>(cx, stg);
+        block_sync();
+        if (!more1) break;
+        const bool more2 = qt + 2 < nqt;
+        if (more2) dkv_stage_load<NW>(p, qb, dob, b, h, qt + 2, tid, stg);
+        dkv_tile<NKB, 1>(p, cx, kf, qt + 1, dk, dv);
+        if (more2) dkv_stage_write<NW, NKB, 0>(cx, stg);
         block_sync();
     }
 
-    if (k_ok) {
+#pragma unroll
+    for (int kbk = 0; kbk < NKB; ++kbk) {
+        const int k_row = kbi * kDkvBK + wave_row0 + 32 * kbk + l31;
+        if (k_row < p.Sk) {
         const int64_t krow_o = (int64_t)b * p.dk_sb + (int64_t)k_row * p.dk_ss + (int64_t)h * p.dk_sh;
         const int64_t vrow_o = (int64_t)b * p.dv_sb + (int64_t)k_row * p.dv_ss + (int64_t)h * p.dv_sh;
         const int64_t arow = (((int64_t)b * p.Sk + k_row) * p.H + h) * kHeadDim;
         for (int db = 0; db < 4; ++db)
             for (int rq = 0; rq < 4; ++rq) {
                 int d0 = 32 * db + 8 * rq + 4 * hi;
-                float k0 = dk[db][4 * rq + 0] * p.scale, k1 = dk[db][4 * rq + 1] * p.scale;
-                float k2 = dk[db][4 * rq + 2] * p.scale, k3 = dk[db][4 * rq + 3] * p.scale;
-                float v0 = dv[db][4 * rq + 0], v1 = dv[db][4 * rq + 1];
-                float v2 = dv[db][4 * rq + 2], v3 = dv[db][4 * rq + 3];
+                float k0 = dk[kbk][db][4 * rq + 0] * p.scale, k1 = dk[kbk][db][4 * rq + 1] * p.scale;
+                float k2 = dk[kbk][db][4 * rq + 2] * p.scale, k3 = dk[kbk][db][4 * rq + 3] * p.scale;
+                float v0 = dv[kbk][db][4 * rq + 0], v1 = dv[kbk][db][4 * rq + 1];
+                float v2 = dv[kbk][db][4 * rq + 2], v3 = dv[kbk][db][4 * rq + 3];
                 if (p.carry_in) {
                     const float* ka = p.dk_acc + arow + d0;
                     const float* va = p.dv_acc + arow + d0;
@@ -460,7 +581,11 @@ LWM_KERNEL(kDkvThreads) void attn_bwd_dkdv_kernel(AttnParams p) {
                     global_store_b128(p.dv_acc + arow + d0, pv);
                 }
             }
+        }
     }
 }
+
+LWM_KERNEL(512) void attn_bwd_dkdv_kernel_w8(AttnParams p) { attn_bwd_dkdv_body<8, 1>(p); }
+LWM_KERNEL(256) void attn_bwd_dkdv_kernel_w4(AttnParams p) { attn_bwd_dkdv_body<4, 2>(p); }
 
 }  // namespace lwm

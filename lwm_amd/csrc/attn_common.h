@@ -65,28 +65,49 @@ struct AttnParams {
 };
 
 LWM_DEVICE int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
-LWM_DEVICE int tile_off(int row, int slot) { return row * kRowBytes + ((slot ^ swz(row)) << 4); }
-
-// Fragment of a row-major [rows][128] LDS tile for an MFMA operand whose
-// non-contracted index is the tile row and whose contracted index is d:
-// lane l gets tile[row0 + (l&31)][16*step + 8*(l>>5) + 0..7].
-LWM_DEVICE bf16x8 frag_rows(const char* tile, int row0, int step, int l31, int hi) {
-    return lds_read_b128(tile + tile_off(row0 + l31, 2 * step + hi));
+LWM_DEVICE uint32_t tile_off(int row, int slot) {
+    return (uint32_t)(row * kRowBytes + ((slot ^ swz(row)) << 4));
 }
 
-// Transposed fragment: the MFMA operand's non-contracted index is d and the
-// contracted index is the tile row.  Lane l (d = d0 + (l&31)) gets, for
-// j = 0..7, tile[row0 + 4*(l>>5) + (j&3) + 8*(j>>2)][d]  -- i.e. exactly the
-// contracted-index order in which a 32x32 C/D fragment holds its rows in
-// registers 0..7 (+8 for the second half), so a C/D fragment converted to bf16
-// can be used as the other operand with no cross-lane traffic.
-LWM_DEVICE bf16x8 frag_cols_tr(const char* tile, int row0, int d0, int lane) {
-    int g = lane >> 4, i = lane & 15;
-    int hi = g >> 1;
-    int d = d0 + 16 * (g & 1) + 4 * (i & 3);
-    int r = row0 + 4 * hi + (i >> 2);
-    bf16x4 lo = lds_read_tr16(tile + tile_off(r, d >> 3) + (d & 7) * 2);
-    bf16x4 up = lds_read_tr16(tile + tile_off(r + 8, d >> 3) + (d & 7) * 2);
+// ---- per-lane fragment addresses ------------------------------------------
+// All are relative to a tile's LDS base and depend only on the lane, so a
+// kernel computes them ONCE (8 + 8 VGPRs) and every read in the tile loop is
+// `base + compile-time constant` = one ds_read with an immediate offset:
+// adding a multiple of 16 rows (4096 B) to the row never changes swz().
+
+// Row fragment (ds_read_b128): the MFMA operand's non-contracted index is the
+// tile row, the contracted index is d.  Lane l, k-step s reads
+// tile[row0 + (l&31)][16*s + 8*(l>>5) + 0..7]  at  frag_rows_addr(...)[s] + row0*256
+// (row0 a multiple of 16).
+struct RowFragAddr { uint32_t a[8]; };
+LWM_DEVICE RowFragAddr frag_rows_addr(lds_t base, int row_in_16x, int l31, int hi) {
+    RowFragAddr r;
+    for (int s = 0; s < 8; ++s) r.a[s] = base + tile_off(row_in_16x + l31, 2 * s + hi);
+    return r;
+}
+
+// Transposed fragment (2 x ds_read_b64_tr_b16): the operand's non-contracted
+// index is d, the contracted index is the tile row.  Lane l (d = 32*db + (l&31))
+// gets, for j = 0..7, tile[row0 + 4*(l>>5) + (j&3) + 8*(j>>2)][d] -- exactly the
+// order in which a 32x32 C/D fragment holds its rows in registers 8t..8t+7, so
+// a C/D fragment converted to bf16 is the other operand with no lane traffic.
+// lo[db] addresses rows row0+4hi+0..3, up[db] rows row0+8+4hi+0..3; row0 a
+// multiple of 16 is added as row0*256.
+struct TrFragAddr { uint32_t lo[4], up[4]; };
+LWM_DEVICE TrFragAddr frag_tr_addr(lds_t base, int lane) {
+    TrFragAddr r;
+    const int g = lane >> 4, i = lane & 15, hi = g >> 1;
+    const int row = 4 * hi + (i >> 2);
+    for (int db = 0; db < 4; ++db) {
+        const int d = 32 * db + 16 * (g & 1) + 4 * (i & 3);
+        r.lo[db] = base + tile_off(row, d >> 3) + (d & 7) * 2;
+        r.up[db] = base + tile_off(row + 8, d >> 3) + (d & 7) * 2;
+    }
+    return r;
+}
+LWM_DEVICE bf16x8 read_tr_frag(const TrFragAddr& t, int db, uint32_t const_off) {
+    bf16x4 lo = lds_read_tr16(t.lo[db] + const_off);
+    bf16x4 up = lds_read_tr16(t.up[db] + const_off);
     bf16x8 o;
     o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
     o[4] = up[0]; o[5] = up[1]; o[6] = up[2]; o[7] = up[3];

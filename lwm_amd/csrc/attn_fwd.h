@@ -12,6 +12,10 @@
 // 32x32 C/D fragment: the row max / row sum of the online softmax are in-lane
 // reductions plus one half-wave exchange, and exp(S^T) converted to bf16 is
 // already the B operand of O^T += V^T P^T.
+//
+// LDS map (bytes from the dynamic base):
+//   [0,16K) K tile 0 | [16K,32K) K tile 1 | [32K,48K) V tile 0 | [48K,64K) V tile 1
+//   [64K, 64K+256) key meta 0 | [64K+256, 64K+512) key meta 1
 #pragma once
 
 namespace lwm {
@@ -26,6 +30,20 @@ struct FwdStage {
     u32x4 k[2];
     u32x4 v[2];
     int32_t kseg;
+};
+
+struct FwdCtx {
+    // per-lane constants of the tile loop
+    RowFragAddr ka;     // K row fragments (tile 0)
+    TrFragAddr va;      // V transposed fragments (tile 0)
+    lds_t stage_w;      // this thread's staging slot in K tile 0
+    lds_t kseg_w;       // this thread's key-meta slot (buffer 0), tid < 64
+    lds_t kseg_r;       // key-meta read base (buffer 0) + 16*hi
+    int tid, hi;
+    int64_t q_pos, wq_min, wq_max;
+    int32_t seg_q;
+    bool has_kmeta;
+    float c;
 };
 
 LWM_DEVICE void fwd_stage_load(const AttnParams& p, const bf16_t* kb, const bf16_t* vb,
@@ -54,19 +72,92 @@ LWM_DEVICE void fwd_stage_load(const AttnParams& p, const bf16_t* kb, const bf16
     }
 }
 
-LWM_DEVICE void fwd_stage_write(char* kbuf, char* vbuf, int32_t* ksegbuf, int tid,
-                                const FwdStage& st) {
+template <int BUF>
+LWM_DEVICE void fwd_stage_write(const FwdCtx& cx, const FwdStage& st) {
+    // thread's chunk i lives 32 rows (8 KiB) below chunk 0: same swizzle
     for (int i = 0; i < 2; ++i) {
-        int c = tid + kFwdThreads * i;
-        int row = c >> 4, slot = c & 15;
-        lds_write_b128(kbuf + tile_off(row, slot), st.k[i]);
-        lds_write_b128(vbuf + tile_off(row, slot), st.v[i]);
+        lds_write_b128(cx.stage_w + BUF * kFwdTileBytes + i * 32 * kRowBytes, st.k[i]);
+        lds_write_b128(cx.stage_w + (2 + BUF) * kFwdTileBytes + i * 32 * kRowBytes, st.v[i]);
     }
-    if (tid < kFwdBK) ksegbuf[tid] = st.kseg;
+    if (cx.tid < kFwdBK) lds_write_i32(cx.kseg_w + BUF * kFwdBK * 4, st.kseg);
+}
+
+// One 64-key tile held in LDS buffer BUF against this wave's 32 queries.
+template <int BUF>
+LWM_DEVICE void fwd_tile(const AttnParams& p, const FwdCtx& cx, const bf16x8 (&qf)[8], int kt,
+                         float& m_run, float& l_run, f32x16 (&acc)[4]) {
+    const int64_t k_pos0 = p.k_start + (int64_t)kt * kFwdBK;
+    if (p.causal && k_pos0 > cx.wq_max) return;  // wholly in this wave's future
+    constexpr uint32_t KB = BUF * kFwdTileBytes;
+    constexpr uint32_t VB = BUF * kFwdTileBytes;  // va already points at V tile 0
+
+    // ---- S^T = K Q^T  (rows = keys, cols = queries)
+    f32x16 st[2];
+    prio_hi();
+    for (int kb2 = 0; kb2 < 2; ++kb2) {
+        st[kb2] = zero_f32x16();
+        for (int s = 0; s < 8; ++s) {
+            bf16x8 a = lds_read_b128(cx.ka.a[s] + KB + kb2 * 32 * kRowBytes);
+            st[kb2] = mfma_32x32x16(a, qf[s], st[kb2]);
+        }
+    }
+    prio_lo();
+    // ---- masks (lwm/llama.py:572-592): causal, same segment, key valid
+    const bool need_mask = cx.has_kmeta || (p.causal && k_pos0 + kFwdBK - 1 > cx.wq_min);
+    if (need_mask) {
+        // key kl of this tile is causally visible iff kl <= rel
+        int64_t rel64 = p.causal ? (cx.q_pos - k_pos0) : (int64_t)kFwdBK;
+        const int rel = rel64 > kFwdBK ? kFwdBK : (rel64 < -1 ? -1 : (int)rel64);
+        for (int kb2 = 0; kb2 < 2; ++kb2)
+            for (int g = 0; g < 4; ++g) {
+                const int kl0 = 32 * kb2 + 8 * g + 4 * cx.hi;
+                if (cx.has_kmeta) {
+                    u32x4 sg = lds_read_u32x4(cx.kseg_r + BUF * kFwdBK * 4 + (32 * kb2 + 8 * g) * 4);
+                    for (int j = 0; j < 4; ++j) {
+                        bool vis = ((int32_t)sg[j] == cx.seg_q) && (kl0 + j <= rel);
+                        st[kb2][4 * g + j] = vis ? st[kb2][4 * g + j] : -INFINITY;
+                    }
+                } else {
+                    for (int j = 0; j < 4; ++j)
+                        st[kb2][4 * g + j] = (kl0 + j <= rel) ? st[kb2][4 * g + j] : -INFINITY;
+                }
+            }
+    }
+    // ---- online softmax (per query column)
+    float mx = -INFINITY;
+    for (int kb2 = 0; kb2 < 2; ++kb2)
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb2][r]);
+    mx = fmaxf(mx, xhalf(mx));
+    const float m_new = fmaxf(m_run, mx);
+    const float m_safe = (m_new == -INFINITY) ? 0.0f : m_new;
+    const float alpha = fast_exp2((m_run - m_safe) * cx.c);
+    const float msc = m_safe * cx.c;
+    float psum = 0.0f;
+    for (int kb2 = 0; kb2 < 2; ++kb2)
+        for (int r = 0; r < 16; ++r) {
+            float pv = fast_exp2(fmaf(st[kb2][r], cx.c, -msc));
+            st[kb2][r] = pv;
+            psum += pv;
+        }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    for (int i = 0; i < 4; ++i) acc[i] *= alpha;
+    // ---- O^T += V^T P^T
+    bf16x8 pb[2][2];
+    for (int kb2 = 0; kb2 < 2; ++kb2)
+        for (int t = 0; t < 2; ++t) pb[kb2][t] = cvt_frag(st[kb2], 8 * t);
+    prio_hi();
+    for (int kb2 = 0; kb2 < 2; ++kb2)
+        for (int t = 0; t < 2; ++t)
+            for (int db = 0; db < 4; ++db) {
+                bf16x8 a = read_tr_frag(cx.va, db, VB + (32 * kb2 + 16 * t) * kRowBytes);
+                acc[db] = mfma_32x32x16(a, pb[kb2][t], acc[db]);
+            }
+    prio_lo();
 }
 
 LWM_KERNEL(kFwdThreads) void attn_fwd_kernel(AttnParams p) {
-    char* lds = dyn_lds();
+    const lds_t lds = dyn_lds();
     const int tid = thread_idx();
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
 
@@ -90,15 +181,9 @@ LWM_KERNEL(kFwdThreads) void attn_fwd_kernel(AttnParams p) {
     const bf16_t* kb = p.k + (int64_t)b * p.k_sb + (int64_t)h * p.k_sh;
     const bf16_t* vb = p.v + (int64_t)b * p.v_sb + (int64_t)h * p.v_sh;
 
-    char* kbuf[2] = {lds, lds + kFwdTileBytes};
-    char* vbuf[2] = {lds + 2 * kFwdTileBytes, lds + 3 * kFwdTileBytes};
-    int32_t* ksegbuf[2] = {(int32_t*)(lds + 4 * kFwdTileBytes),
-                           (int32_t*)(lds + 4 * kFwdTileBytes) + kFwdBK};
-
     // ---- this lane's query row
     const int q_row = qt * kFwdBQ + wave * 32 + l31;
     const bool q_ok = q_row < p.Sq;
-    const int64_t q_pos = p.q_start + q_row;
     bf16x8 qf[8];
     for (int s = 0; s < 8; ++s) {
         if (q_ok) {
@@ -108,8 +193,21 @@ LWM_KERNEL(kFwdThreads) void attn_fwd_kernel(AttnParams p) {
             qf[s] = zero_bf16x8();
         }
     }
-    const int32_t seg_q = (q_ok && p.seg_q) ? p.seg_q[(int64_t)b * p.Sq + q_row] : 0;
-    const bool has_kmeta = (p.seg_k != nullptr) || (p.key_valid != nullptr) || (p.Sk % kFwdBK != 0);
+
+    FwdCtx cx;
+    cx.tid = tid;
+    cx.hi = hi;
+    cx.ka = frag_rows_addr(lds, 0, l31, hi);
+    cx.va = frag_tr_addr(lds + 2 * kFwdTileBytes, lane);
+    cx.stage_w = lds + tile_off(tid >> 4, tid & 15);
+    cx.kseg_w = lds + 4 * kFwdTileBytes + tid * 4;
+    cx.kseg_r = lds + 4 * kFwdTileBytes + 16 * hi;
+    cx.q_pos = p.q_start + q_row;
+    cx.seg_q = (q_ok && p.seg_q) ? p.seg_q[(int64_t)b * p.Sq + q_row] : 0;
+    cx.has_kmeta = (p.seg_k != nullptr) || (p.key_valid != nullptr) || (p.Sk % kFwdBK != 0);
+    cx.wq_min = p.q_start + qt * kFwdBQ + wave * 32;
+    cx.wq_max = cx.wq_min + 31;
+    cx.c = p.scale * kLog2e;
 
     // ---- kv tile range (causal: skip tiles wholly in the future of this q tile)
     const int nkt_all = (p.Sk + kFwdBK - 1) / kFwdBK;
@@ -123,11 +221,7 @@ LWM_KERNEL(kFwdThreads) void attn_fwd_kernel(AttnParams p) {
             nkt = t < nkt_all ? (int)t : nkt_all;
         }
     }
-    // wave-level bounds (global positions of this wave's first/last query)
-    const int64_t wq_min = p.q_start + qt * kFwdBQ + wave * 32;
-    const int64_t wq_max = wq_min + 31;
 
-    const float c = p.scale * kLog2e;
     float m_run = -INFINITY;  // running max of raw scores (q.k, unscaled)
     float l_run = 0.0f;       // this half-wave's partial row sum
     f32x16 acc[4];
@@ -136,71 +230,22 @@ LWM_KERNEL(kFwdThreads) void attn_fwd_kernel(AttnParams p) {
     FwdStage stg;
     if (nkt > 0) {
         fwd_stage_load(p, kb, vb, b, 0, tid, stg);
-        fwd_stage_write(kbuf[0], vbuf[0], ksegbuf[0], tid, stg);
+        fwd_stage_write<0>(cx, stg);
     }
     block_sync();
 
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nkt;
-        if (more) fwd_stage_load(p, kb, vb, b, kt + 1, tid, stg);
-
-        const int64_t k_pos0 = p.k_start + (int64_t)kt * kFwdBK;
-        const bool wave_active = !p.causal || k_pos0 <= wq_max;
-        if (wave_active) {
-            // ---- S^T = K Q^T  (rows = keys, cols = queries)
-            f32x16 st[2];
-            for (int kb2 = 0; kb2 < 2; ++kb2) {
-                st[kb2] = zero_f32x16();
-                for (int s = 0; s < 8; ++s) {
-                    bf16x8 a = frag_rows(kbuf[cur], 32 * kb2, s, l31, hi);
-                    st[kb2] = mfma_32x32x16(a, qf[s], st[kb2]);
-                }
-            }
-            // ---- masks (lwm/llama.py:572-592): causal, same segment, key valid
-            const bool need_mask = has_kmeta || (p.causal && k_pos0 + kFwdBK - 1 > wq_min);
-            if (need_mask) {
-                const int32_t* ks = ksegbuf[cur];
-                for (int kb2 = 0; kb2 < 2; ++kb2) {
-                    for (int r = 0; r < 16; ++r) {
-                        int kl = 32 * kb2 + cd_row(r, hi);
-                        bool vis = (ks[kl] == seg_q);
-                        if (p.causal) vis = vis && (k_pos0 + kl <= q_pos);
-                        st[kb2][r] = vis ? st[kb2][r] : -INFINITY;
-                    }
-                }
-            }
-            // ---- online softmax (per query column)
-            float mx = -INFINITY;
-            for (int kb2 = 0; kb2 < 2; ++kb2)
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb2][r]);
-            mx = fmaxf(mx, xhalf(mx));
-            const float m_new = fmaxf(m_run, mx);
-            const float m_safe = (m_new == -INFINITY) ? 0.0f : m_new;
-            const float alpha = fast_exp2((m_run - m_safe) * c);
-            const float msc = m_safe * c;
-            float psum = 0.0f;
-            for (int kb2 = 0; kb2 < 2; ++kb2)
-                for (int r = 0; r < 16; ++r) {
-                    float pv = fast_exp2(fmaf(st[kb2][r], c, -msc));
-                    st[kb2][r] = pv;
-                    psum += pv;
-                }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
-            for (int i = 0; i < 4; ++i) acc[i] *= alpha;
-            // ---- O^T += V^T P^T
-            bf16x8 pb[2][2];
-            for (int kb2 = 0; kb2 < 2; ++kb2)
-                for (int t = 0; t < 2; ++t) pb[kb2][t] = cvt_frag(st[kb2], 8 * t);
-            for (int db = 0; db < 4; ++db)
-                for (int kb2 = 0; kb2 < 2; ++kb2)
-                    for (int t = 0; t < 2; ++t) {
-                        bf16x8 a = frag_cols_tr(vbuf[cur], 32 * kb2 + 16 * t, 32 * db, lane);
-                        acc[db] = mfma_32x32x16(a, pb[kb2][t], acc[db]);
-                    }
-        }
-        if (more) fwd_stage_write(kbuf[cur ^ 1], vbuf[cur ^ 1], ksegbuf[cur ^ 1], tid, stg);
+    // two tiles per trip so the LDS buffer index is a compile-time constant
+    for (int kt = 0; kt < nkt; kt += 2) {
+        const bool more1 = kt + 1 < nkt;
+        if (more1) fwd_stage_load(p, kb, vb, b, kt + 1, tid, stg);
+        fwd_tile<0>(p, cx, qf, kt, m_run, l_run, acc);
+        if (more1) fwd_stage_write<1>(cx, stg);
+        block_sync();
+        if (!more1) break;
+        const bool more2 = kt + 2 < nkt;
+        if (more2) fwd_stage_load(p, kb, vb, b, kt + 2, tid, stg);
+        fwd_tile<1>(p, cx, qf, kt + 1, m_run, l_run, acc);
+        if (more2) fwd_stage_write<0>(cx, stg);
         block_sync();
     }
 

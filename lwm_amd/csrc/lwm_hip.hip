@@ -1,5 +1,6 @@
 // lwm_hip.hip -- translation unit of liblwm_hip.so (gfx950).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC (see build.py).
+#include <stdlib.h>
 #include <string.h>
 #include <math.h>
 #include "wave_ops.h"

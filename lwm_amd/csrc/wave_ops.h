@@ -30,11 +30,17 @@ LWM_DEVICE int block_idx_y() { return (int)blockIdx.y; }
 LWM_DEVICE int block_idx_z() { return (int)blockIdx.z; }
 LWM_DEVICE int grid_dim_x() { return (int)gridDim.x; }
 
+// LDS is addressed with 32-bit byte addresses (lds_t), never generic 64-bit
+// pointers: loop-invariant fragment addresses then cost one VGPR each and the
+// per-tile constants fold into the ds_read/ds_write immediate offset field.
+typedef uint32_t lds_t;
+#define LWM_LDS(T, a) ((__attribute__((address_space(3))) T*)(uintptr_t)(a))
+
 // Dynamic LDS base (16-byte aligned: no static __shared__ anywhere, see
 // cdna_hip_programming.md Guideline 17).
-LWM_DEVICE char* dyn_lds() {
+LWM_DEVICE lds_t dyn_lds() {
     extern __shared__ __attribute__((aligned(16))) char lwm_smem[];
-    return lwm_smem;
+    return (lds_t)(uintptr_t)((__attribute__((address_space(3))) char*)lwm_smem);
 }
 
 LWM_DEVICE void block_sync() { __syncthreads(); }
@@ -50,19 +56,27 @@ LWM_DEVICE f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
 // ds_read_b64_tr_b16.  Per 16-lane group: lanes 4j..4j+3 each point at 4
 // consecutive bf16 of "row j" (so a group addresses a 4x16 block, rows
 // anywhere); lane i receives column i of that block: {row0[i], row1[i],
-// row2[i], row3[i]}.  `p` must be an 8-byte aligned LDS address.
-LWM_DEVICE bf16x4 lds_read_tr16(const char* p) {
+// row2[i], row3[i]}.  `a` must be an 8-byte aligned LDS address.
+LWM_DEVICE bf16x4 lds_read_tr16(lds_t a) {
     typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 v4;
-    v4 r = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-        (__attribute__((address_space(3))) v4*)(p));
+    v4 r = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LWM_LDS(v4, a));
     bf16x4 o;
     o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3];
     return o;
 }
 
-LWM_DEVICE bf16x8 lds_read_b128(const char* p) { return *(const bf16x8*)p; }
-LWM_DEVICE f32x4 lds_read_f32x4(const char* p) { return *(const f32x4*)p; }
-LWM_DEVICE void lds_write_b128(char* p, u32x4 v) { *(u32x4*)p = v; }
+LWM_DEVICE bf16x8 lds_read_b128(lds_t a) { return *LWM_LDS(const bf16x8, a); }
+LWM_DEVICE f32x4 lds_read_f32x4(lds_t a) { return *LWM_LDS(const f32x4, a); }
+LWM_DEVICE u32x4 lds_read_u32x4(lds_t a) { return *LWM_LDS(const u32x4, a); }
+LWM_DEVICE void lds_write_b128(lds_t a, u32x4 v) { *LWM_LDS(u32x4, a) = v; }
+LWM_DEVICE void lds_write_i32(lds_t a, int32_t v) { *LWM_LDS(int32_t, a) = v; }
+LWM_DEVICE void lds_write_f32(lds_t a, float v) { *LWM_LDS(float, a) = v; }
+
+// Scheduling fence: the compiler may not move instructions across it.
+LWM_DEVICE void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// Raise/lower this wave's issue priority around an MFMA cluster (T5).
+LWM_DEVICE void prio_hi() { __builtin_amdgcn_s_setprio(1); }
+LWM_DEVICE void prio_lo() { __builtin_amdgcn_s_setprio(0); }
 
 // value held by lane (l ^ 32)
 LWM_DEVICE float xhalf(float x) {

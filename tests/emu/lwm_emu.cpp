@@ -1,6 +1,7 @@
 // lwm_emu.cpp -- host-emulated build of the SAME kernel headers and C ABI as
 // liblwm_hip.so (TEST INFRASTRUCTURE ONLY; see tests/emu/wave_ops.h).
 // Build: clang++ -O2 -std=c++17 -shared -fPIC -I tests/emu -I lwm_amd/csrc -I include
+#include <stdlib.h>
 #include <string.h>
 #include <math.h>
 #include "emu/wave_ops.h"

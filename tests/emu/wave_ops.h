@@ -33,6 +33,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define LWM_GLOBAL static
 #define LWM_KERNEL(max_threads) static
 #define LWM_EMU 1
+typedef uint32_t lds_t;
 
 namespace emu {
 
@@ -109,10 +110,15 @@ inline void lane_entry() {
     swapcontext(&g_lane->ctx, &g_sched);
 }
 
-inline void check_lds(const char* p, size_t n, size_t align) {
+// LDS byte address -> host pointer, with bounds and alignment checks.  The
+// emulated LDS base is a non-zero address (4096) so that code forgetting to add
+// the dynamic-LDS base is caught.
+constexpr uint32_t kLdsBase = 4096;
+inline char* lds_ptr(lds_t a, size_t n, size_t align) {
     Block& b = *g_blk;
-    if (p < b.lds || p + n > b.lds + b.lds_bytes) die("LDS access out of bounds");
-    if (((uintptr_t)(p - b.lds)) % align) die("LDS access misaligned");
+    if (a < kLdsBase || (size_t)(a - kLdsBase) + n > b.lds_bytes) die("LDS access out of bounds");
+    if ((a - kLdsBase) % align) die("LDS access misaligned");
+    return b.lds + (a - kLdsBase);
 }
 
 // Runs one block to completion on the calling OS thread.
@@ -196,7 +202,7 @@ LWM_DEVICE int block_idx_x() { return emu::g_blk->bx; }
 LWM_DEVICE int block_idx_y() { return emu::g_blk->by; }
 LWM_DEVICE int block_idx_z() { return emu::g_blk->bz; }
 LWM_DEVICE int grid_dim_x() { return emu::g_blk->gx; }
-LWM_DEVICE char* dyn_lds() { return emu::g_blk->lds; }
+LWM_DEVICE lds_t dyn_lds() { return emu::kLdsBase; }
 LWM_DEVICE void block_sync() { emu::block_barrier(); }
 
 LWM_DEVICE f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
@@ -221,8 +227,8 @@ LWM_DEVICE f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
     return d;
 }
 
-LWM_DEVICE bf16x4 lds_read_tr16(const char* p) {
-    emu::check_lds(p, 8, 8);
+LWM_DEVICE bf16x4 lds_read_tr16(lds_t a) {
+    const char* p = emu::lds_ptr(a, 8, 8);
     emu::Wave& w = emu::g_blk->waves[emu::g_lane->tid >> 6];
     int l = emu::g_lane->tid & 63;
     w.addr[l] = p;
@@ -237,22 +243,15 @@ LWM_DEVICE bf16x4 lds_read_tr16(const char* p) {
     return o;
 }
 
-LWM_DEVICE bf16x8 lds_read_b128(const char* p) {
-    emu::check_lds(p, 16, 16);
-    bf16x8 v;
-    memcpy(&v, p, 16);
-    return v;
-}
-LWM_DEVICE f32x4 lds_read_f32x4(const char* p) {
-    emu::check_lds(p, 16, 16);
-    f32x4 v;
-    memcpy(&v, p, 16);
-    return v;
-}
-LWM_DEVICE void lds_write_b128(char* p, u32x4 v) {
-    emu::check_lds(p, 16, 16);
-    memcpy(p, &v, 16);
-}
+LWM_DEVICE bf16x8 lds_read_b128(lds_t a) { bf16x8 v; memcpy(&v, emu::lds_ptr(a, 16, 16), 16); return v; }
+LWM_DEVICE f32x4 lds_read_f32x4(lds_t a) { f32x4 v; memcpy(&v, emu::lds_ptr(a, 16, 16), 16); return v; }
+LWM_DEVICE u32x4 lds_read_u32x4(lds_t a) { u32x4 v; memcpy(&v, emu::lds_ptr(a, 16, 16), 16); return v; }
+LWM_DEVICE void lds_write_b128(lds_t a, u32x4 v) { memcpy(emu::lds_ptr(a, 16, 16), &v, 16); }
+LWM_DEVICE void lds_write_i32(lds_t a, int32_t v) { memcpy(emu::lds_ptr(a, 4, 4), &v, 4); }
+LWM_DEVICE void lds_write_f32(lds_t a, float v) { memcpy(emu::lds_ptr(a, 4, 4), &v, 4); }
+LWM_DEVICE void sched_fence() {}
+LWM_DEVICE void prio_hi() {}
+LWM_DEVICE void prio_lo() {}
 
 LWM_DEVICE float shfl_xor_f(float x, int m) {
     emu::Wave& w = emu::g_blk->waves[emu::g_lane->tid >> 6];

@@ -20,19 +20,25 @@ __global__ __launch_bounds__(64) void probe_mfma(const bf16_t* A, const bf16_t* 
 }
 
 // T[64][128] bf16 row-major -> swizzled LDS tile -> fragments.
-// rows_out[lane][8]  = frag_rows(tile, row0, step)
-// cols_out[lane][8]  = frag_cols_tr(tile, row0t, d0)
+// rows_out[lane][8]  = row fragment  (rows row0.., k-step `step`)
+// cols_out[lane][8]  = transposed fragment (rows row0t.., d block d0/32)
 __global__ __launch_bounds__(64) void probe_frags(const bf16_t* T, bf16_t* rows_out, bf16_t* cols_out,
                                                   int row0, int step, int row0t, int d0) {
-    char* lds = dyn_lds();
+    lds_t lds = dyn_lds();
     int l = thread_idx();
     for (int c = l; c < 64 * 16; c += 64) {
         int row = c >> 4, slot = c & 15;
         lds_write_b128(lds + tile_off(row, slot), global_load_b128(T + row * 128 + slot * 8));
     }
     block_sync();
-    bf16x8 fr = frag_rows(lds, row0, step, l & 31, l >> 5);
-    bf16x8 fc = frag_cols_tr(lds, row0t, d0, l);
+    RowFragAddr ra = frag_rows_addr(lds, 0, l & 31, l >> 5);
+    TrFragAddr ta = frag_tr_addr(lds, l);
+    bf16x8 fr, fc;
+    // runtime-indexed on purpose here (probe only): select by loops over constants
+    for (int s = 0; s < 8; ++s)
+        if (s == step) fr = lds_read_b128(ra.a[s] + row0 * kRowBytes);
+    for (int db = 0; db < 4; ++db)
+        if (db == d0 / 32) fc = read_tr_frag(ta, db, row0t * kRowBytes);
     for (int j = 0; j < 8; ++j) {
         rows_out[l * 8 + j] = fr[j];
         cols_out[l * 8 + j] = fc[j];
