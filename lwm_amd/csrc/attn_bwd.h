@@ -63,6 +63,7 @@ struct DqStage {
     u32x4 k;
     u32x4 v;
     int32_t kseg;
+    uint8_t kvalid;
 };
 
 struct DqCtx {
@@ -76,34 +77,30 @@ struct DqCtx {
     float c, lse2, dlt;
 };
 
+// (meta loads first and mutually independent: see fwd_stage_load)
 LWM_DEVICE void dq_stage_load(const AttnParams& p, const bf16_t* kb, const bf16_t* vb, int b,
                               int kt, int tid, DqStage& st) {
+    if (tid < kDqBK) {
+        int krow = kt * kDqBK + tid;
+        int kr = krow < p.Sk ? krow : p.Sk - 1;
+        st.kvalid = p.key_valid ? p.key_valid[(int64_t)b * p.Sk + kr] : (uint8_t)1;
+        st.kseg = p.seg_k ? p.seg_k[(int64_t)b * p.Sk + kr] : 0;
+    }
     int row = tid >> 4, slot = tid & 15;
     int krow = kt * kDqBK + row;
-    if (krow < p.Sk) {
-        st.k = global_load_b128(kb + (int64_t)krow * p.k_ss + slot * 8);
-        st.v = global_load_b128(vb + (int64_t)krow * p.v_ss + slot * 8);
-    } else {
-        u32x4 z = {0u, 0u, 0u, 0u};
-        st.k = z;
-        st.v = z;
-    }
-    if (tid < kDqBK) {
-        int kr = kt * kDqBK + tid;
-        int32_t s = kSegInvalid;
-        if (kr < p.Sk) {
-            bool valid = p.key_valid ? (p.key_valid[(int64_t)b * p.Sk + kr] != 0) : true;
-            if (valid) s = p.seg_k ? p.seg_k[(int64_t)b * p.Sk + kr] : 0;
-        }
-        st.kseg = s;
-    }
+    int kr = krow < p.Sk ? krow : p.Sk - 1;
+    st.k = global_load_b128(kb + (int64_t)kr * p.k_ss + slot * 8);
+    st.v = global_load_b128(vb + (int64_t)kr * p.v_ss + slot * 8);
 }
 
 template <int BUF>
-LWM_DEVICE void dq_stage_write(const DqCtx& cx, const DqStage& st) {
+LWM_DEVICE void dq_stage_write(const DqCtx& cx, const DqStage& st, int kt, int Sk) {
     lds_write_b128(cx.stage_w + BUF * kDqTileBytes, st.k);
     lds_write_b128(cx.stage_w + (2 + BUF) * kDqTileBytes, st.v);
-    if (cx.tid < kDqBK) lds_write_i32(cx.kseg_w + BUF * kDqBK * 4, st.kseg);
+    if (cx.tid < kDqBK) {
+        const bool ok = (kt * kDqBK + cx.tid < Sk) && st.kvalid != 0;
+        lds_write_i32(cx.kseg_w + BUF * kDqBK * 4, ok ? st.kseg : kSegInvalid);
+    }
 }
 
 template <int BUF>
@@ -231,25 +228,25 @@ LWM_KERNEL(kDqThreads) void attn_bwd_dq_kernel(AttnParams p) {
     f32x16 acc[4];
     for (int i = 0; i < 4; ++i) acc[i] = zero_f32x16();
 
-    DqStage stg;
+    // (pipeline under `nkt > 0`: see attn_fwd_kernel)
     if (nkt > 0) {
+        DqStage stg;
         dq_stage_load(p, kb, vb, b, 0, tid, stg);
-        dq_stage_write<0>(cx, stg);
-    }
-    block_sync();
-
-    for (int kt = 0; kt < nkt; kt += 2) {
-        const bool more1 = kt + 1 < nkt;
-        if (more1) dq_stage_load(p, kb, vb, b, kt + 1, tid, stg);
-        dq_tile<0>(p, cx, qf, dof, kt, acc);
-        if (more1) dq_stage_write<1>(cx, stg);
+        dq_stage_write<0>(cx, stg, 0, p.Sk);
         block_sync();
-        if (!more1) break;
-        const bool more2 = kt + 2 < nkt;
-        if (more2) dq_stage_load(p, kb, vb, b, kt + 2, tid, stg);
-        dq_tile<1>(p, cx, qf, dof, kt + 1, acc);
-        if (more2) dq_stage_write<0>(cx, stg);
-        block_sync();
+        for (int kt = 0; kt < nkt; kt += 2) {
+            const bool more1 = kt + 1 < nkt;
+            if (more1) dq_stage_load(p, kb, vb, b, kt + 1, tid, stg);
+            dq_tile<0>(p, cx, qf, dof, kt, acc);
+            if (more1) dq_stage_write<1>(cx, stg, kt + 1, p.Sk);
+            block_sync();
+            if (!more1) break;
+            const bool more2 = kt + 2 < nkt;
+            if (more2) dq_stage_load(p, kb, vb, b, kt + 2, tid, stg);
+            dq_tile<1>(p, cx, qf, dof, kt + 1, acc);
+            if (more2) dq_stage_write<0>(cx, stg, kt + 2, p.Sk);
+            block_sync();
+        }
     }
 
     if (q_ok) {
@@ -293,9 +290,7 @@ constexpr int kDkvVBytes = kDkvBK * kRowBytes;      // 64 KiB
 constexpr int kDkvStatBytes = 3 * kDkvBQ * 4;
 constexpr int kDkvLdsBytes = kDkvVBytes + 4 * kDkvQTileBytes + 2 * kDkvStatBytes;
 
-struct DkvStage {
-    u32x4 q[2];
-    u32x4 d[2];
+struct DkvStage {  // only the row statistics travel through registers
     float lse2, delta;
     int32_t segq;
 };
@@ -305,56 +300,48 @@ struct DkvCtx {
     RowFragAddr qa;   // Q row fragments (tile 0); dO tile 0 is +2*kDkvQTileBytes
     RowFragAddr va;   // this wave's first 32 rows of the resident V tile
     TrFragAddr qta;   // Q transposed fragments (tile 0); dO likewise +2 tiles
-    lds_t stage_w, stat_w, stat_r;
-    int tid, hi;
+    lds_t qtiles, stat_w, stat_r;
+    int tid, hi, wave, lane_row, lane_slot;
     int64_t k_pos[NKB], wk_min, wk_max;
     int32_t kseg[NKB];
     bool has_meta;
     float c;
 };
 
-template <int NW>
-LWM_DEVICE void dkv_stage_load(const AttnParams& p, const bf16_t* qb, const bf16_t* dob, int b,
-                               int h, int qt, int tid, DkvStage& st) {
-    constexpr int NT = NW * 64, NCH = 512 / NT;  // 16-B chunks per thread per tensor
-    for (int i = 0; i < NCH; ++i) {
-        int cidx = tid + NT * i;
-        int row = cidx >> 4, slot = cidx & 15;
-        int qrow = qt * kDkvBQ + row;
-        if (qrow < p.Sq) {
-            st.q[i] = global_load_b128(qb + (int64_t)qrow * p.q_ss + slot * 8);
-            st.d[i] = global_load_b128(dob + (int64_t)qrow * p.do_ss + slot * 8);
-        } else {
-            u32x4 z = {0u, 0u, 0u, 0u};
-            st.q[i] = z;
-            st.d[i] = z;
-        }
+// Next Q/dO tile: global -> LDS directly (no VGPRs, no ds_write).  A wave
+// instruction fills 4 tile rows (1 KiB, lane-linear), so the XOR swizzle is
+// applied to the SOURCE column: lane l writes physical slot l&15 of row
+// 4*piece + (l>>4) and therefore fetches logical slot (l&15) ^ swz(row).  Each
+// instruction still covers 4 whole 256-B rows of global memory.
+template <int NW, int NKB, int BUF>
+LWM_DEVICE void dkv_stage_issue(const AttnParams& p, const DkvCtx<NKB>& cx, const bf16_t* qb,
+                                const bf16_t* dob, int b, int h, int qt, DkvStage& st) {
+    if (cx.tid < kDkvBQ) {
+        int qr = qt * kDkvBQ + cx.tid;
+        int qc = qr < p.Sq ? qr : p.Sq - 1;
+        int64_t idx = ((int64_t)b * p.H + h) * p.Sq + qc;
+        st.lse2 = p.lse[idx];
+        st.delta = p.delta[idx];
+        st.segq = p.seg_q ? p.seg_q[(int64_t)b * p.Sq + qc] : 0;
     }
-    if (tid < kDkvBQ) {
-        int qr = qt * kDkvBQ + tid;
-        st.lse2 = INFINITY;
-        st.delta = 0.0f;
-        st.segq = 0;
-        if (qr < p.Sq) {
-            int64_t idx = ((int64_t)b * p.H + h) * p.Sq + qr;
-            float l = p.lse[idx];
-            st.lse2 = (l == -INFINITY) ? INFINITY : l * kLog2e;
-            st.delta = p.delta[idx];
-            st.segq = p.seg_q ? p.seg_q[(int64_t)b * p.Sq + qr] : 0;
-        }
+    for (int j = 0; j < 8 / NW; ++j) {
+        const int piece = cx.wave + NW * j;
+        const int r = 4 * piece + cx.lane_row;
+        int qrow = qt * kDkvBQ + r;
+        // rows past Sq re-read the last row; their lse2 is +inf so p = 0
+        qrow = qrow < p.Sq ? qrow : p.Sq - 1;
+        const int col = ((cx.lane_slot ^ swz(r)) << 3);
+        glds_load_b128(qb + (int64_t)qrow * p.q_ss + col, cx.qtiles + BUF * kDkvQTileBytes + piece * 1024);
+        glds_load_b128(dob + (int64_t)qrow * p.do_ss + col,
+                       cx.qtiles + (2 + BUF) * kDkvQTileBytes + piece * 1024);
     }
 }
 
-template <int NW, int NKB, int BUF>
-LWM_DEVICE void dkv_stage_write(const DkvCtx<NKB>& cx, const DkvStage& st) {
-    constexpr int NT = NW * 64, NCH = 512 / NT;
-    for (int i = 0; i < NCH; ++i) {
-        // chunk i lives NT/16 rows below chunk 0 (a multiple of 16 rows: same swizzle)
-        lds_write_b128(cx.stage_w + BUF * kDkvQTileBytes + i * (NT / 16) * kRowBytes, st.q[i]);
-        lds_write_b128(cx.stage_w + (2 + BUF) * kDkvQTileBytes + i * (NT / 16) * kRowBytes, st.d[i]);
-    }
+template <int NKB, int BUF>
+LWM_DEVICE void dkv_stage_finish(const DkvCtx<NKB>& cx, const DkvStage& st, int qt, int Sq) {
     if (cx.tid < kDkvBQ) {
-        lds_write_f32(cx.stat_w + BUF * kDkvStatBytes, st.lse2);
+        const bool ok = (qt * kDkvBQ + cx.tid < Sq) && st.lse2 != -INFINITY;
+        lds_write_f32(cx.stat_w + BUF * kDkvStatBytes, ok ? st.lse2 * kLog2e : INFINITY);
         lds_write_f32(cx.stat_w + BUF * kDkvStatBytes + kDkvBQ * 4, st.delta);
         lds_write_i32(cx.stat_w + BUF * kDkvStatBytes + 2 * kDkvBQ * 4, st.segq);
     }
@@ -492,7 +479,10 @@ LWM_DEVICE void attn_bwd_dkdv_body(const AttnParams& p) {
     cx.qa = frag_rows_addr(qtiles, 0, l31, hi);
     cx.va = frag_rows_addr(lds + wave_row0 * kRowBytes, 0, l31, hi);
     cx.qta = frag_tr_addr(qtiles, lane);
-    cx.stage_w = qtiles + tile_off(tid >> 4, tid & 15);
+    cx.qtiles = qtiles;
+    cx.wave = wave_uniform(wave);
+    cx.lane_row = lane >> 4;
+    cx.lane_slot = lane & 15;
     cx.stat_w = stats + tid * 4;
     cx.stat_r = stats + 16 * hi;
     cx.has_meta =
@@ -526,25 +516,28 @@ LWM_DEVICE void attn_bwd_dkdv_body(const AttnParams& p) {
             dv[kbk][i] = zero_f32x16();
         }
 
-    DkvStage stg;
+    // (pipeline under `qt0 < nqt`: see attn_fwd_kernel)
     if (qt0 < nqt) {
-        dkv_stage_load<NW>(p, qb, dob, b, h, qt0, tid, stg);
-        dkv_stage_write<NW, NKB, 0>(cx, stg);
-    }
-    block_sync();
-
-    for (int qt = qt0; qt < nqt; qt += 2) {
-        const bool more1 = qt + 1 < nqt;
-        if (more1) dkv_stage_load<NW>(p, qb, dob, b, h, qt + 1, tid, stg);
-        dkv_tile<NKB, 0>(p, cx, kf, qt, dk, dv);
-        if (more1) dkv_stage_write<NW, NKB, 1>(cx, stg);
+        DkvStage stg;
+        dkv_stage_issue<NW, NKB, 0>(p, cx, qb, dob, b, h, qt0, stg);
+        dkv_stage_finish<NKB, 0>(cx, stg, qt0, p.Sq);
+        glds_wait_all();
         block_sync();
-        if (!more1) break;
-        const bool more2 = qt + 2 < nqt;
-        if (more2) dkv_stage_load<NW>(p, qb, dob, b, h, qt + 2, tid, stg);
-        dkv_tile<NKB, 1>(p, cx, kf, qt + 1, dk, dv);
-        if (more2) dkv_stage_write<NW, NKB, 0>(cx, stg);
-        block_sync();
+        for (int qt = qt0; qt < nqt; qt += 2) {
+            const bool more1 = qt + 1 < nqt;
+            if (more1) dkv_stage_issue<NW, NKB, 1>(p, cx, qb, dob, b, h, qt + 1, stg);
+            dkv_tile<NKB, 0>(p, cx, kf, qt, dk, dv);
+            if (more1) dkv_stage_finish<NKB, 1>(cx, stg, qt + 1, p.Sq);
+            glds_wait_all();
+            block_sync();
+            if (!more1) break;
+            const bool more2 = qt + 2 < nqt;
+            if (more2) dkv_stage_issue<NW, NKB, 0>(p, cx, qb, dob, b, h, qt + 2, stg);
+            dkv_tile<NKB, 1>(p, cx, kf, qt + 1, dk, dv);
+            if (more2) dkv_stage_finish<NKB, 0>(cx, stg, qt + 2, p.Sq);
+            glds_wait_all();
+            block_sync();
+        }
     }
 
 #pragma unroll

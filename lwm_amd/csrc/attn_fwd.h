@@ -30,6 +30,7 @@ struct FwdStage {
     u32x4 k[2];
     u32x4 v[2];
     int32_t kseg;
+    uint8_t kvalid;
 };
 
 struct FwdCtx {
@@ -46,40 +47,40 @@ struct FwdCtx {
     float c;
 };
 
+// Global loads of the next tile.  Key-meta loads go FIRST and are independent of
+// each other: the tile's s_waitcnt for them then leaves the four K/V loads in
+// flight (a dependent or later-issued meta load forces vmcnt(0) = a full HBM
+// round trip in front of the first MFMA of every tile).
 LWM_DEVICE void fwd_stage_load(const AttnParams& p, const bf16_t* kb, const bf16_t* vb,
                                int b, int kt, int tid, FwdStage& st) {
+    if (tid < kFwdBK) {
+        int krow = kt * kFwdBK + tid;
+        int kr = krow < p.Sk ? krow : p.Sk - 1;
+        st.kvalid = p.key_valid ? p.key_valid[(int64_t)b * p.Sk + kr] : (uint8_t)1;
+        st.kseg = p.seg_k ? p.seg_k[(int64_t)b * p.Sk + kr] : 0;
+    }
     for (int i = 0; i < 2; ++i) {
         int c = tid + kFwdThreads * i;
         int row = c >> 4, slot = c & 15;
         int krow = kt * kFwdBK + row;
-        if (krow < p.Sk) {
-            st.k[i] = global_load_b128(kb + (int64_t)krow * p.k_ss + slot * 8);
-            st.v[i] = global_load_b128(vb + (int64_t)krow * p.v_ss + slot * 8);
-        } else {
-            u32x4 z = {0u, 0u, 0u, 0u};
-            st.k[i] = z;
-            st.v[i] = z;
-        }
-    }
-    if (tid < kFwdBK) {
-        int krow = kt * kFwdBK + tid;
-        int32_t s = kSegInvalid;
-        if (krow < p.Sk) {
-            bool valid = p.key_valid ? (p.key_valid[(int64_t)b * p.Sk + krow] != 0) : true;
-            if (valid) s = p.seg_k ? p.seg_k[(int64_t)b * p.Sk + krow] : 0;
-        }
-        st.kseg = s;
+        // rows past Sk re-read the last row: their keys are masked via key meta
+        int kr = krow < p.Sk ? krow : p.Sk - 1;
+        st.k[i] = global_load_b128(kb + (int64_t)kr * p.k_ss + slot * 8);
+        st.v[i] = global_load_b128(vb + (int64_t)kr * p.v_ss + slot * 8);
     }
 }
 
 template <int BUF>
-LWM_DEVICE void fwd_stage_write(const FwdCtx& cx, const FwdStage& st) {
+LWM_DEVICE void fwd_stage_write(const FwdCtx& cx, const FwdStage& st, int kt, int Sk) {
     // thread's chunk i lives 32 rows (8 KiB) below chunk 0: same swizzle
     for (int i = 0; i < 2; ++i) {
         lds_write_b128(cx.stage_w + BUF * kFwdTileBytes + i * 32 * kRowBytes, st.k[i]);
         lds_write_b128(cx.stage_w + (2 + BUF) * kFwdTileBytes + i * 32 * kRowBytes, st.v[i]);
     }
-    if (cx.tid < kFwdBK) lds_write_i32(cx.kseg_w + BUF * kFwdBK * 4, st.kseg);
+    if (cx.tid < kFwdBK) {
+        const bool ok = (kt * kFwdBK + cx.tid < Sk) && st.kvalid != 0;
+        lds_write_i32(cx.kseg_w + BUF * kFwdBK * 4, ok ? st.kseg : kSegInvalid);
+    }
 }
 
 // One 64-key tile held in LDS buffer BUF against this wave's 32 queries.
@@ -227,26 +228,29 @@ LWM_KERNEL(kFwdThreads) void attn_fwd_kernel(AttnParams p) {
     f32x16 acc[4];
     for (int i = 0; i < 4; ++i) acc[i] = zero_f32x16();
 
-    FwdStage stg;
+    // The whole pipeline sits under `nkt > 0` so that no CFG path reaches the
+    // tile loop without passing the prologue's s_waitcnt (otherwise the Q-fragment
+    // loads count as possibly pending at the loop's first MFMA and the compiler
+    // drains vmcnt to 0 there every tile, serialising the staging loads).
     if (nkt > 0) {
+        FwdStage stg;
         fwd_stage_load(p, kb, vb, b, 0, tid, stg);
-        fwd_stage_write<0>(cx, stg);
-    }
-    block_sync();
-
-    // two tiles per trip so the LDS buffer index is a compile-time constant
-    for (int kt = 0; kt < nkt; kt += 2) {
-        const bool more1 = kt + 1 < nkt;
-        if (more1) fwd_stage_load(p, kb, vb, b, kt + 1, tid, stg);
-        fwd_tile<0>(p, cx, qf, kt, m_run, l_run, acc);
-        if (more1) fwd_stage_write<1>(cx, stg);
+        fwd_stage_write<0>(cx, stg, 0, p.Sk);
         block_sync();
-        if (!more1) break;
-        const bool more2 = kt + 2 < nkt;
-        if (more2) fwd_stage_load(p, kb, vb, b, kt + 2, tid, stg);
-        fwd_tile<1>(p, cx, qf, kt + 1, m_run, l_run, acc);
-        if (more2) fwd_stage_write<0>(cx, stg);
-        block_sync();
+        // two tiles per trip so the LDS buffer index is a compile-time constant
+        for (int kt = 0; kt < nkt; kt += 2) {
+            const bool more1 = kt + 1 < nkt;
+            if (more1) fwd_stage_load(p, kb, vb, b, kt + 1, tid, stg);
+            fwd_tile<0>(p, cx, qf, kt, m_run, l_run, acc);
+            if (more1) fwd_stage_write<1>(cx, stg, kt + 1, p.Sk);
+            block_sync();
+            if (!more1) break;
+            const bool more2 = kt + 2 < nkt;
+            if (more2) fwd_stage_load(p, kb, vb, b, kt + 2, tid, stg);
+            fwd_tile<1>(p, cx, qf, kt + 1, m_run, l_run, acc);
+            if (more2) fwd_stage_write<0>(cx, stg, kt + 2, p.Sk);
+            block_sync();
+        }
     }
 
     // ---- epilogue: normalise, merge with the ring carry, store

@@ -72,6 +72,27 @@ LWM_DEVICE void lds_write_b128(lds_t a, u32x4 v) { *LWM_LDS(u32x4, a) = v; }
 LWM_DEVICE void lds_write_i32(lds_t a, int32_t v) { *LWM_LDS(int32_t, a) = v; }
 LWM_DEVICE void lds_write_f32(lds_t a, float v) { *LWM_LDS(float, a) = v; }
 
+// Direct global -> LDS copy (global_load_lds_dwordx4): lane l's 16 bytes at `g`
+// land at LDS address wave_base + 16*l.  `wave_base` must be wave-uniform (an
+// SGPR: kernel args, blockIdx, wave_uniform()).  No VGPR round trip.
+// Issued from inline asm ON PURPOSE: hipcc does not count it, so it inserts no
+// s_waitcnt vmcnt(0) in front of later ds_reads of the OTHER tile buffer (with the
+// builtin it drains the DMA at the first transposed read of every tile).  The
+// kernel owns the wait: glds_wait_all() by every wave, then block_sync(), before
+// anyone reads the destination (cdna_hip_programming.md section 5.7 item 1).
+LWM_DEVICE void glds_load_b128(const void* g, lds_t wave_base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(g), "s"(wave_base)
+        : "memory");
+}
+LWM_DEVICE void glds_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Make a value that IS the same in every lane provably uniform (SGPR).
+LWM_DEVICE int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
 // Scheduling fence: the compiler may not move instructions across it.
 LWM_DEVICE void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // Raise/lower this wave's issue priority around an MFMA cluster (T5).

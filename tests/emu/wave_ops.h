@@ -249,6 +249,12 @@ LWM_DEVICE u32x4 lds_read_u32x4(lds_t a) { u32x4 v; memcpy(&v, emu::lds_ptr(a, 1
 LWM_DEVICE void lds_write_b128(lds_t a, u32x4 v) { memcpy(emu::lds_ptr(a, 16, 16), &v, 16); }
 LWM_DEVICE void lds_write_i32(lds_t a, int32_t v) { memcpy(emu::lds_ptr(a, 4, 4), &v, 4); }
 LWM_DEVICE void lds_write_f32(lds_t a, float v) { memcpy(emu::lds_ptr(a, 4, 4), &v, 4); }
+LWM_DEVICE void glds_load_b128(const void* g, lds_t wave_base) {
+    int l = emu::g_lane->tid & 63;
+    memcpy(emu::lds_ptr(wave_base + 16 * l, 16, 16), g, 16);
+}
+LWM_DEVICE void glds_wait_all() {}
+LWM_DEVICE int wave_uniform(int x) { return x; }
 LWM_DEVICE void sched_fence() {}
 LWM_DEVICE void prio_hi() {}
 LWM_DEVICE void prio_lo() {}
