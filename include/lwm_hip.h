@@ -84,6 +84,53 @@ int lwm_attn_bwd_dkdv(const LwmAttnArgs* args, void* stream);
 /* dst_bf16[n] = (bf16) src_f32[n] */
 int lwm_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 
+/* ------------------------------------------------------------------ VQGAN
+ * Primitives of the video tokeniser, lwm/vqgan.py.  All tensors are f32, NHWC,
+ * dense; results are bit-exact with oracle/vqgan_ref.c (exact-f32 MFMA, fixed
+ * summation order -- see DESIGN.md "VQGAN arithmetic contract").
+ */
+
+/* flax nn.Conv (kernel HWIO [KH,KW,Cin,Cout], bias) on x [B,Hin,Win,Cin] ->
+ * y [B,Ho,Wo,Cout].  Output (oy,ox), tap (kh,kw) reads the virtual input
+ * (x upsampled nearest by 2^up_shift) at (oy*stride+kh-pad, ox*stride+kw-pad),
+ * zero outside.  Replaces:
+ *   3x3 SAME  (stride 1, pad 1)                     lwm/vqgan.py:155,163,172-175,183,253,257
+ *   1x1       (stride 1, pad 0)                     lwm/vqgan.py:114-115,262
+ *   Downsample (stride 2, pad 0, Ho=Hin/2: the jnp.pad of one zero row/column at
+ *              bottom/right is the zero fill)       lwm/vqgan.py:286-303
+ *   Upsample  (up_shift 1, stride 1, pad 1)         lwm/vqgan.py:306-319
+ * residual (same shape as y, may be NULL) is added after the bias
+ * (ResnetBlock, lwm/vqgan.py:263); clip != 0 clamps to [-1,1] (lwm/vqgan.py:141). */
+typedef struct LwmConvArgs {
+    const float* x;
+    const float* w;
+    const float* bias;     /* [Cout] or NULL */
+    const float* residual; /* [B,Ho,Wo,Cout] or NULL */
+    float* y;
+    int32_t B, Hin, Win, Cin, Cout, KH, KW, stride, pad, up_shift, Ho, Wo, clip;
+} LwmConvArgs;
+int lwm_conv2d_nhwc_f32(const LwmConvArgs* args, void* stream);
+
+/* flax nn.GroupNorm (num_groups G, eps, affine) over x [B,HW,C], optionally
+ * followed by nn.silu (lwm/vqgan.py:161-162,181-182,251-255).  `workspace` is
+ * caller-owned device memory of lwm_groupnorm_workspace_bytes() bytes (f64
+ * partial sums); y may alias x. */
+int64_t lwm_groupnorm_workspace_bytes(int32_t B, int64_t HW, int32_t C, int32_t G);
+int lwm_groupnorm_silu_f32(const float* x, const float* gamma, const float* beta, float* y,
+                           void* workspace, int32_t B, int64_t HW, int32_t C, int32_t G, float eps,
+                           int32_t silu, void* stream);
+
+/* VectorQuantizer (lwm/vqgan.py:187-221), D = 64.
+ * lwm_vq_sqnorm_f32 : se[e] = |codebook[e]|^2 (once per codebook)
+ * lwm_vq_argmin_f32 : idx[n] = first argmin_e (|z_n|^2 + se[e]) - 2 z_n.e   (:207-212)
+ * lwm_vq_gather_f32 : out[n] = codebook[idx[n]] (z NULL; decode path :204-205) or the
+ *                     forward value of z + stop_gradient(z_q - z) (:214) */
+int lwm_vq_sqnorm_f32(const float* codebook, float* se, int32_t E, int32_t D, void* stream);
+int lwm_vq_argmin_f32(const float* z, const float* codebook, const float* se, int32_t* idx,
+                      int64_t N, int32_t E, int32_t D, void* stream);
+int lwm_vq_gather_f32(const float* codebook, const int32_t* idx, const float* z, float* out,
+                      int64_t N, int32_t E, int32_t D, void* stream);
+
 const char* lwm_last_error(void);
 int lwm_version(void);
 

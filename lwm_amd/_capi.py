@@ -33,6 +33,13 @@ class LwmAttnArgs(C.Structure):
     ]
 
 
+class LwmConvArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p),
+                ("y", C.c_void_p)] + [(n, C.c_int32) for n in (
+                    "B", "Hin", "Win", "Cin", "Cout", "KH", "KW", "stride", "pad", "up_shift", "Ho",
+                    "Wo", "clip")]
+
+
 # name -> (restype, argtypes); every symbol include/lwm_hip.h declares
 PROTOTYPES = {
     "lwm_attn_fwd": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
@@ -40,6 +47,13 @@ PROTOTYPES = {
     "lwm_attn_bwd_dq": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
     "lwm_attn_bwd_dkdv": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
     "lwm_cast_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "lwm_conv2d_nhwc_f32": (C.c_int, [C.POINTER(LwmConvArgs), C.c_void_p]),
+    "lwm_groupnorm_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int64, C.c_int32, C.c_int32]),
+    "lwm_groupnorm_silu_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int32, C.c_int64, C.c_int32, C.c_int32,
+                                                            C.c_float, C.c_int32, C.c_void_p]),
+    "lwm_vq_sqnorm_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "lwm_vq_argmin_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "lwm_vq_gather_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "lwm_last_error": (C.c_char_p, []),
     "lwm_version": (C.c_int, []),
 }

@@ -1,0 +1,236 @@
+// vqgan_conv.h -- NHWC f32 convolution as an implicit GEMM on the exact-f32 MFMA
+// (v_mfma_f32_32x32x2_f32) for the VQGAN encoder/decoder.  Requires wave_ops.h.
+//
+// Replaces flax nn.Conv as used by lwm/vqgan.py: 3x3 SAME (:155,:163,:172-175,
+// :183,:253,:257), 1x1 (:114-115,:262), Downsample = zero pad bottom/right +
+// 3x3 stride-2 VALID (:291-300), Upsample = nearest x2 + 3x3 SAME (:312-318),
+// the ResnetBlock residual add (:263) and VQGANModel.decode's clip (:141) as
+// epilogue options.  Kernel tensor stays in flax's HWIO layout.
+//
+// GEMM view: M = B*Ho*Wo output pixels, N = Cout, K = taps x Cin.  Arithmetic
+// contract (identical to oracle/vqgan_ref.c, so results are bit-exact):
+//   out = ((P_0 + P_1) + ... + P_{T-1}) + bias [+ residual]
+//   P_t = fmaf chain over c_in = 0..Cin-1 starting from 0, taps in (kh,kw) order.
+// The f32 MFMA IS that chain: each instruction does two fused multiply-adds per
+// output element in k order with one rounding each, so walking c_in in order on
+// one accumulator per tap reproduces it exactly.  Out-of-image taps contribute
+// exact zeros.
+//
+// Workgroup = 256 threads = WM x WN waves; wave tile = (32*MB) pixels x (32*NB)
+// channels = MB*NB accumulators; K is walked in chunks of 32 input channels of
+// one tap, double buffered through LDS:
+//   A tile [BM pixels][32 cin] f32, 128-B rows, 16-B slot s of row r stored at
+//     slot s ^ ((r>>1)&7): a ds_read_b128 lane group (16 distinct r mod 16) then
+//     covers all 16 slots of a 256-B bank row -> conflict-free; the staging
+//     ds_write_b128 (8 lanes = one row) is a contiguous 128 B.
+//   B tile [32 cin][BN cout] f32, linear; fragments are ds_read_b32 rows
+//     (32 consecutive floats per half-wave) -> conflict-free.
+// A fragment: lane (i, hi) reads 4 consecutive cin of pixel i and feeds
+// k-pair (4u+2t, 4u+2t+1) with element 2t+hi, so c_in is consumed in natural
+// order.  This kernel is MFMA-bound (64 cycles per instruction per SIMD, 157 TF
+// chip peak); LDS and L2 traffic are far below their limits by construction.
+#pragma once
+
+namespace lwm {
+
+struct ConvParams {
+    const float* x;
+    const float* w;
+    const float* bias;  // [Cout] or null
+    const float* res;   // [M, Cout] or null
+    float* y;           // [M, Cout]
+    int32_t B, Hin, Win, Cin, Cout, KH, KW, stride, pad, up_shift, Ho, Wo, clip;
+    int64_t M;  // B*Ho*Wo
+};
+
+constexpr int kConvKC = 32;  // input channels per K chunk
+
+template <int WM, int WN, int MB, int NB>
+struct ConvCfg {
+    static constexpr int NT = 64 * WM * WN;
+    static constexpr int BM = 32 * MB * WM;
+    static constexpr int BN = 32 * NB * WN;
+    static constexpr int A_BYTES = BM * kConvKC * 4;
+    static constexpr int B_BYTES = kConvKC * BN * 4;
+    static constexpr int BUF_BYTES = A_BYTES + B_BYTES;
+    static constexpr int LDS_BYTES = 2 * BUF_BYTES;
+    static constexpr int APX = NT / 8;         // pixels staged per pass (8 lanes x 16 B per pixel)
+    static constexpr int AP = BM / APX;        // A staging passes
+    static constexpr int BROWS = NT * 4 / BN;  // B rows staged per pass
+    static constexpr int BP = kConvKC / BROWS; // B staging passes
+    static_assert(BM % APX == 0 && AP >= 1, "A staging shape");
+    static_assert(kConvKC % BROWS == 0 && BP >= 1 && BN / 4 <= NT, "B staging shape");
+};
+
+LWM_DEVICE f32x4 zero_f32x4() {
+    f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+    return z;
+}
+
+template <int WM, int WN, int MB, int NB>
+LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
+    using Cfg = ConvCfg<WM, WN, MB, NB>;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, AP = Cfg::AP, BP = Cfg::BP;
+    const lds_t lds = dyn_lds();
+    const int tid = thread_idx();
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int ntn = (p.Cout + BN - 1) / BN;
+    const int64_t bm = block_idx_x() / ntn;
+    const int bn = block_idx_x() % ntn;
+    const int64_t m0 = bm * BM;
+    const int n0 = bn * BN;
+
+    // ---- staging roles (fixed for the whole launch)
+    const int a_slot = tid & 7;
+    int a_oy[AP], a_ox[AP];
+    int64_t a_base[AP];  // element offset of (b, 0, 0, 0) in x; -1 = pixel past M
+    for (int ps = 0; ps < AP; ++ps) {
+        const int px = ps * Cfg::APX + (tid >> 3);
+        const int64_t m = m0 + px;
+        if (m < p.M) {
+            const int ox = (int)(m % p.Wo);
+            const int64_t t = m / p.Wo;
+            a_ox[ps] = ox * p.stride - p.pad;
+            a_oy[ps] = (int)(t % p.Ho) * p.stride - p.pad;
+            a_base[ps] = (t / p.Ho) * (int64_t)p.Hin * p.Win * p.Cin;
+        } else {
+            a_ox[ps] = 0;
+            a_oy[ps] = 0;
+            a_base[ps] = -1;
+        }
+    }
+    const lds_t a_w = lds + (uint32_t)(tid >> 3) * 128;  // + pass*APX*128 + swizzled slot
+    const int b_row = tid / (BN / 4);
+    const int b_col = (tid % (BN / 4)) * 4;
+    const lds_t b_w = lds + Cfg::A_BYTES + (uint32_t)(b_row * BN + b_col) * 4;
+    const int Hv = p.Hin << p.up_shift, Wv = p.Win << p.up_shift;
+    const bool cin_vec = (p.Cin & 3) == 0;
+    const bool cout_vec = (p.Cout & 3) == 0;
+
+    const int nch = (p.Cin + kConvKC - 1) / kConvKC;
+    const int ntap = p.KH * p.KW;
+    const int nit = ntap * nch;
+
+    f32x4 sa[AP], sb[BP];
+
+    auto stage_load = [&](int it) {
+        const int tap = it / nch, ch = it - tap * nch;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        const int c0 = ch * kConvKC + a_slot * 4;
+        for (int ps = 0; ps < AP; ++ps) {
+            f32x4 v = zero_f32x4();
+            const int vy = a_oy[ps] + kh, vx = a_ox[ps] + kw;
+            if (a_base[ps] >= 0 && vy >= 0 && vy < Hv && vx >= 0 && vx < Wv && c0 < p.Cin) {
+                const float* src = p.x + a_base[ps] +
+                                   ((int64_t)(vy >> p.up_shift) * p.Win + (vx >> p.up_shift)) * p.Cin + c0;
+                if (cin_vec) {
+                    v = global_load_f32x4(src);
+                } else {
+                    for (int j = 0; j < 4; ++j)
+                        if (c0 + j < p.Cin) v[j] = src[j];
+                }
+            }
+            sa[ps] = v;
+        }
+        const float* wt = p.w + (int64_t)tap * p.Cin * p.Cout;
+        for (int ps = 0; ps < BP; ++ps) {
+            f32x4 v = zero_f32x4();
+            const int k = ch * kConvKC + ps * Cfg::BROWS + b_row;
+            const int col = n0 + b_col;
+            if (k < p.Cin && col < p.Cout) {
+                const float* src = wt + (int64_t)k * p.Cout + col;
+                if (cout_vec) {
+                    v = global_load_f32x4(src);
+                } else {
+                    for (int j = 0; j < 4; ++j)
+                        if (col + j < p.Cout) v[j] = src[j];
+                }
+            }
+            sb[ps] = v;
+        }
+    };
+    auto stage_write = [&](int buf) {
+        const uint32_t bo = (uint32_t)buf * Cfg::BUF_BYTES;
+        for (int ps = 0; ps < AP; ++ps) {
+            const int px = ps * Cfg::APX + (tid >> 3);
+            lds_write_f32x4(a_w + bo + (uint32_t)ps * Cfg::APX * 128 + ((a_slot ^ ((px >> 1) & 7)) << 4),
+                           sa[ps]);
+        }
+        for (int ps = 0; ps < BP; ++ps)
+            lds_write_f32x4(b_w + bo + (uint32_t)ps * Cfg::BROWS * BN * 4, sb[ps]);
+    };
+
+    f32x16 acc[MB][NB], acc_tap[MB][NB];
+    for (int i = 0; i < MB; ++i)
+        for (int j = 0; j < NB; ++j) {
+            acc[i][j] = zero_f32x16();
+            acc_tap[i][j] = zero_f32x16();
+        }
+
+    // fragment addresses (buffer 0)
+    uint32_t a_r[MB];
+    int a_sw[MB];
+    for (int i = 0; i < MB; ++i) {
+        const int px = (wm * MB + i) * 32 + l31;
+        a_r[i] = lds + (uint32_t)px * 128;
+        a_sw[i] = (px >> 1) & 7;
+    }
+    const lds_t b_r = lds + Cfg::A_BYTES + (uint32_t)(hi * BN + wn * NB * 32 + l31) * 4;
+
+    stage_load(0);
+    stage_write(0);
+    block_sync();
+    for (int it = 0; it < nit; ++it) {
+        const int buf = it & 1;
+        const bool more = it + 1 < nit;
+        if (more) stage_load(it + 1);
+        const uint32_t bo = (uint32_t)buf * Cfg::BUF_BYTES;
+        for (int u = 0; u < 8; ++u) {
+            f32x4 ar[MB];
+            for (int i = 0; i < MB; ++i) ar[i] = lds_read_f32x4(a_r[i] + bo + ((u ^ a_sw[i]) << 4));
+            for (int t = 0; t < 2; ++t) {
+                float bf[NB], af[MB];
+                for (int j = 0; j < NB; ++j)
+                    bf[j] = lds_read_f32(b_r + bo + (uint32_t)((4 * u + 2 * t) * BN + j * 32) * 4);
+                for (int i = 0; i < MB; ++i) af[i] = hi ? ar[i][2 * t + 1] : ar[i][2 * t];
+                for (int i = 0; i < MB; ++i)
+                    for (int j = 0; j < NB; ++j) acc_tap[i][j] = mfma_32x32x2_f32(af[i], bf[j], acc_tap[i][j]);
+            }
+        }
+        if ((it + 1) % nch == 0) {  // tap finished: s = s + P_t
+            for (int i = 0; i < MB; ++i)
+                for (int j = 0; j < NB; ++j) {
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] + acc_tap[i][j][r];
+                    acc_tap[i][j] = zero_f32x16();
+                }
+        }
+        if (more) stage_write(buf ^ 1);
+        block_sync();
+    }
+
+    // ---- epilogue: + bias [+ residual] [clip], one float per (pixel, channel)
+    for (int i = 0; i < MB; ++i)
+        for (int j = 0; j < NB; ++j) {
+            const int co = n0 + (wn * NB + j) * 32 + l31;
+            if (co >= p.Cout) continue;
+            const float bv = p.bias ? p.bias[co] : 0.0f;
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + (wm * MB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r];
+                if (p.bias) v = v + bv;
+                if (p.res) v = v + p.res[m * p.Cout + co];
+                if (p.clip) v = v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);
+                p.y[m * p.Cout + co] = v;
+            }
+        }
+}
+
+LWM_KERNEL(256) void conv_igemm_128x128(ConvParams p) { conv_igemm_body<2, 2, 2, 2>(p); }
+LWM_KERNEL(256) void conv_igemm_128x64(ConvParams p) { conv_igemm_body<4, 1, 1, 2>(p); }
+LWM_KERNEL(256) void conv_igemm_128x32(ConvParams p) { conv_igemm_body<4, 1, 1, 1>(p); }
+LWM_KERNEL(256) void conv_igemm_32x128(ConvParams p) { conv_igemm_body<1, 4, 1, 1>(p); }
+
+}  // namespace lwm

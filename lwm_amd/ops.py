@@ -172,3 +172,92 @@ def cast_f32_to_bf16(src, dst=None):
     _capi.check(L, L.lwm_cast_f32_to_bf16(src.data_ptr(), dst.data_ptr(), src.numel(),
                                           _stream_ptr()), "lwm_cast_f32_to_bf16")
     return dst
+
+
+# ---------------------------------------------------------------- VQGAN primitives
+def _f32c(t, name):
+    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous f32 ROCm device tensor (lwm_amd has no CPU path)")
+    return t.data_ptr()
+
+
+def conv2d_nhwc(x, w, bias=None, residual=None, *, stride=1, pad=None, up_shift=0, out_hw=None,
+                clip=False, out=None):
+    """flax nn.Conv on NHWC f32 (lwm_conv2d_nhwc_f32).  x (B,H,W,Cin), w (KH,KW,Cin,Cout) HWIO.
+    pad=None = 'SAME' for stride 1.  Downsample: stride=2, pad=0, out_hw=(H//2, W//2);
+    Upsample+conv: up_shift=1."""
+    B, Hin, Win, Cin = x.shape
+    KH, KW, Cin2, Cout = w.shape
+    if Cin2 != Cin:
+        raise ValueError(f"conv2d_nhwc: kernel expects {Cin2} input channels, x has {Cin}")
+    if pad is None:
+        pad = (KH - 1) // 2
+    Hv, Wv = Hin << up_shift, Win << up_shift
+    if out_hw is None:
+        out_hw = ((Hv + 2 * pad - KH) // stride + 1, (Wv + 2 * pad - KW) // stride + 1)
+    Ho, Wo = out_hw
+    if out is None:
+        out = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+    if residual is not None and tuple(residual.shape) != tuple(out.shape):
+        raise ValueError("conv2d_nhwc: residual shape mismatch")
+    a = _capi.LwmConvArgs(_f32c(x, "x"), _f32c(w, "w"),
+                          None if bias is None else _f32c(bias, "bias"),
+                          None if residual is None else _f32c(residual, "residual"),
+                          _f32c(out, "out"), B, Hin, Win, Cin, Cout, KH, KW, stride, pad, up_shift,
+                          Ho, Wo, int(bool(clip)))
+    L = lib()
+    _capi.check(L, L.lwm_conv2d_nhwc_f32(C.byref(a), _stream_ptr()), "lwm_conv2d_nhwc_f32")
+    return out
+
+
+def groupnorm_silu(x, gamma, beta, *, groups=32, eps=1e-6, silu=True, out=None, workspace=None):
+    """flax nn.GroupNorm (+ nn.silu) over NHWC / (B, ..., C) f32 (lwm_groupnorm_silu_f32)."""
+    B, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * Cc) if B else 0
+    L = lib()
+    need = L.lwm_groupnorm_workspace_bytes(B, HW, Cc, groups)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty((max(need, 16) + 7) // 8, dtype=torch.float64, device=x.device)
+    if out is None:
+        out = torch.empty_like(x)
+    _capi.check(L, L.lwm_groupnorm_silu_f32(_f32c(x, "x"), _f32c(gamma, "gamma"), _f32c(beta, "beta"),
+                                            _f32c(out, "out"), workspace.data_ptr(), B, HW, Cc, groups,
+                                            float(eps), int(bool(silu)), _stream_ptr()),
+                "lwm_groupnorm_silu_f32")
+    return out
+
+
+def vq_sqnorm(codebook):
+    E, D = codebook.shape
+    se = torch.empty(E, dtype=torch.float32, device=codebook.device)
+    L = lib()
+    _capi.check(L, L.lwm_vq_sqnorm_f32(_f32c(codebook, "codebook"), se.data_ptr(), E, D, _stream_ptr()),
+                "lwm_vq_sqnorm_f32")
+    return se
+
+
+def vq_argmin(z, codebook, se=None):
+    """First argmin over the codebook of the f32 squared distances (lwm_vq_argmin_f32)."""
+    E, D = codebook.shape
+    if z.shape[-1] != D:
+        raise ValueError("vq_argmin: embed dim mismatch")
+    if se is None:
+        se = vq_sqnorm(codebook)
+    N = z.numel() // D
+    idx = torch.empty(z.shape[:-1], dtype=torch.int32, device=z.device)
+    L = lib()
+    _capi.check(L, L.lwm_vq_argmin_f32(_f32c(z, "z"), _f32c(codebook, "codebook"), _f32c(se, "se"),
+                                       idx.data_ptr(), N, E, D, _stream_ptr()), "lwm_vq_argmin_f32")
+    return idx
+
+
+def vq_gather(codebook, idx, z=None):
+    E, D = codebook.shape
+    if idx.dtype != torch.int32 or not idx.is_contiguous() or not idx.is_cuda:
+        raise ValueError("vq_gather: idx must be a contiguous int32 device tensor")
+    out = torch.empty(tuple(idx.shape) + (D,), dtype=torch.float32, device=codebook.device)
+    L = lib()
+    _capi.check(L, L.lwm_vq_gather_f32(_f32c(codebook, "codebook"), idx.data_ptr(),
+                                       None if z is None else _f32c(z, "z"), out.data_ptr(),
+                                       idx.numel(), E, D, _stream_ptr()), "lwm_vq_gather_f32")
+    return out

@@ -29,7 +29,8 @@ def build():
         t = os.path.getmtime(EMU_SO)
         if all(os.path.getmtime(s) <= t for s in _sources()):
             return EMU_SO
-    cmd = [CLANG, "-O2", "-std=c++17", "-shared", "-fPIC", "-I", "tests", "-I", "lwm_amd/csrc",
+    cmd = [CLANG, "-O2", "-std=c++17", "-mavx2", "-mfma", "-ffp-contract=off", "-shared", "-fPIC",
+           "-I", "tests", "-I", "lwm_amd/csrc",
            "-I", "include", "tests/emu/lwm_emu.cpp", "-o", EMU_SO, "-lpthread"]
     subprocess.run(cmd, cwd=ROOT, check=True)
     return EMU_SO
@@ -148,3 +149,71 @@ def attn_bwd(q, k, v, out, lse, dout, *, causal=True, q_start=0, k_start=0, seg_
     if final:
         return from_bf16_bits(dq), from_bf16_bits(dk), from_bf16_bits(dv)
     return dq_acc, dk_acc, dv_acc
+
+
+# ---------------------------------------------------------------- VQGAN primitives
+def _af32(x):
+    a = aligned(np.shape(x), np.float32)
+    a[...] = x
+    return a
+
+
+def conv2d(x, w, bias=None, residual=None, *, stride=1, pad=None, up_shift=0, out_hw=None,
+           clip=False):
+    L = lib()
+    x, w = _af32(x), _af32(w)
+    B, Hin, Win, Cin = x.shape
+    KH, KW, _, Cout = w.shape
+    if pad is None:
+        pad = (KH - 1) // 2
+    Hv, Wv = Hin << up_shift, Win << up_shift
+    if out_hw is None:
+        out_hw = ((Hv + 2 * pad - KH) // stride + 1, (Wv + 2 * pad - KW) // stride + 1)
+    Ho, Wo = out_hw
+    y = aligned((B, Ho, Wo, Cout), np.float32)
+    b = None if bias is None else _af32(bias)
+    r = None if residual is None else _af32(residual)
+    a = _capi.LwmConvArgs(x.ctypes.data, w.ctypes.data, _ptr(b), _ptr(r), y.ctypes.data, B, Hin, Win,
+                          Cin, Cout, KH, KW, stride, pad, up_shift, Ho, Wo, int(clip))
+    _capi.check(L, L.lwm_conv2d_nhwc_f32(C.byref(a), None), "lwm_conv2d_nhwc_f32")
+    return y
+
+
+def groupnorm(x, gamma, beta, *, groups=32, eps=1e-6, silu=False):
+    L = lib()
+    x = _af32(x)
+    B, Cc = x.shape[0], x.shape[-1]
+    HW = int(np.prod(x.shape[1:-1]))
+    y = aligned(x.shape, np.float32)
+    g, bt = _af32(gamma), _af32(beta)
+    ws = aligned((max(L.lwm_groupnorm_workspace_bytes(B, HW, Cc, groups), 16) // 8,), np.float64)
+    _capi.check(L, L.lwm_groupnorm_silu_f32(x.ctypes.data, g.ctypes.data, bt.ctypes.data, y.ctypes.data,
+                                            ws.ctypes.data, B, HW, Cc, groups, eps, int(silu), None),
+                "lwm_groupnorm_silu_f32")
+    return y
+
+
+def vq_argmin(z, codebook):
+    L = lib()
+    z, cb = _af32(z), _af32(codebook)
+    E, D = cb.shape
+    N = z.size // D
+    se = aligned((E,), np.float32)
+    _capi.check(L, L.lwm_vq_sqnorm_f32(cb.ctypes.data, se.ctypes.data, E, D, None), "lwm_vq_sqnorm_f32")
+    idx = aligned(z.shape[:-1], np.int32)
+    _capi.check(L, L.lwm_vq_argmin_f32(z.ctypes.data, cb.ctypes.data, se.ctypes.data, idx.ctypes.data,
+                                       N, E, D, None), "lwm_vq_argmin_f32")
+    return idx
+
+
+def vq_gather(codebook, idx, z=None):
+    L = lib()
+    cb = _af32(codebook)
+    E, D = cb.shape
+    ia = aligned(np.shape(idx), np.int32)
+    ia[...] = idx
+    out = aligned(ia.shape + (D,), np.float32)
+    zz = None if z is None else _af32(z)
+    _capi.check(L, L.lwm_vq_gather_f32(cb.ctypes.data, ia.ctypes.data, _ptr(zz), out.ctypes.data,
+                                       ia.size, E, D, None), "lwm_vq_gather_f32")
+    return out

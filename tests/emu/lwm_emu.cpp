@@ -12,3 +12,6 @@
 #include "attn_bwd.h"
 #include "misc_kernels.h"
 #include "api.inc"
+#include "vqgan_conv.h"
+#include "vqgan_misc.h"
+#include "vqgan_api.inc"

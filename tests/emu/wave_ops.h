@@ -42,6 +42,7 @@ struct Wave {
     bf16x8 b[64];
     const char* addr[64];
     float f[64];
+    float fa[64], fb[64];
     int i[64];
     int arrived = 0;
     unsigned gen = 0;
@@ -227,6 +228,24 @@ LWM_DEVICE f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
     return d;
 }
 
+// v_mfma_f32_32x32x2_f32: exact f32, k = 0 (lanes 0-31) then k = 1 (lanes 32-63).
+LWM_DEVICE f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) {
+    emu::Wave& w = emu::g_blk->waves[emu::g_lane->tid >> 6];
+    int l = emu::g_lane->tid & 63;
+    w.fa[l] = a;
+    w.fb[l] = b;
+    emu::wave_sync();
+    f32x16 d;
+    int col = l & 31, hi = l >> 5;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float s = fmaf(w.fa[row], w.fb[col], c[r]);
+        d[r] = fmaf(w.fa[32 + row], w.fb[32 + col], s);
+    }
+    emu::wave_sync();
+    return d;
+}
+
 LWM_DEVICE bf16x4 lds_read_tr16(lds_t a) {
     const char* p = emu::lds_ptr(a, 8, 8);
     emu::Wave& w = emu::g_blk->waves[emu::g_lane->tid >> 6];
@@ -247,8 +266,13 @@ LWM_DEVICE bf16x8 lds_read_b128(lds_t a) { bf16x8 v; memcpy(&v, emu::lds_ptr(a, 
 LWM_DEVICE f32x4 lds_read_f32x4(lds_t a) { f32x4 v; memcpy(&v, emu::lds_ptr(a, 16, 16), 16); return v; }
 LWM_DEVICE u32x4 lds_read_u32x4(lds_t a) { u32x4 v; memcpy(&v, emu::lds_ptr(a, 16, 16), 16); return v; }
 LWM_DEVICE void lds_write_b128(lds_t a, u32x4 v) { memcpy(emu::lds_ptr(a, 16, 16), &v, 16); }
+LWM_DEVICE void lds_write_f32x4(lds_t a, f32x4 v) { memcpy(emu::lds_ptr(a, 16, 16), &v, 16); }
 LWM_DEVICE void lds_write_i32(lds_t a, int32_t v) { memcpy(emu::lds_ptr(a, 4, 4), &v, 4); }
 LWM_DEVICE void lds_write_f32(lds_t a, float v) { memcpy(emu::lds_ptr(a, 4, 4), &v, 4); }
+LWM_DEVICE float lds_read_f32(lds_t a) { float v; memcpy(&v, emu::lds_ptr(a, 4, 4), 4); return v; }
+LWM_DEVICE int32_t lds_read_i32(lds_t a) { int32_t v; memcpy(&v, emu::lds_ptr(a, 4, 4), 4); return v; }
+LWM_DEVICE void lds_write_f64(lds_t a, double v) { memcpy(emu::lds_ptr(a, 8, 8), &v, 8); }
+LWM_DEVICE double lds_read_f64(lds_t a) { double v; memcpy(&v, emu::lds_ptr(a, 8, 8), 8); return v; }
 LWM_DEVICE void glds_load_b128(const void* g, lds_t wave_base) {
     int l = emu::g_lane->tid & 63;
     memcpy(emu::lds_ptr(wave_base + 16 * l, 16, 16), g, 16);
@@ -289,6 +313,8 @@ LWM_DEVICE u32x4 global_load_b128(const void* p) {
 }
 LWM_DEVICE void global_store_b128(void* p, u32x4 v) { memcpy(p, &v, 16); }
 LWM_DEVICE void global_store_b64(void* p, u32x2 v) { memcpy(p, &v, 8); }
+LWM_DEVICE f32x4 global_load_f32x4(const float* p) { f32x4 v; memcpy(&v, p, 16); return v; }
+LWM_DEVICE void global_store_f32x4(float* p, f32x4 v) { memcpy(p, &v, 16); }
 
 LWM_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
     union { bf16_t h[2]; uint32_t u; } x;

@@ -56,3 +56,21 @@ extern "C" int probe_run_frags(const void* T, void* rows_out, void* cols_out, in
                        (const bf16_t*)T, (bf16_t*)rows_out, (bf16_t*)cols_out, row0, step, row0t, d0);
     return (int)hipGetLastError();
 }
+
+// f32 MFMA: A[32][K] row-major, B[K][32] row-major, K even; C[32][32] =
+// chain of v_mfma_f32_32x32x2_f32 over k-pairs starting from C0.  The test
+// compares bitwise with the host fmaf chain in k order.
+__global__ __launch_bounds__(64) void probe_mfma_f32(const float* A, const float* Bm, const float* C0,
+                                                     float* Cm, int K) {
+    int l = thread_idx(), l31 = l & 31, hi = l >> 5;
+    f32x16 c;
+    for (int r = 0; r < 16; ++r) c[r] = C0[cd_row(r, hi) * 32 + l31];
+    for (int s = 0; s < K / 2; ++s)
+        c = mfma_32x32x2_f32(A[l31 * K + 2 * s + hi], Bm[(2 * s + hi) * 32 + l31], c);
+    for (int r = 0; r < 16; ++r) Cm[cd_row(r, hi) * 32 + l31] = c[r];
+}
+extern "C" int probe_run_mfma_f32(const float* A, const float* B, const float* C0, float* C, int K,
+                                  void* stream) {
+    hipLaunchKernelGGL(probe_mfma_f32, dim3(1), dim3(64), 0, (hipStream_t)stream, A, B, C0, C, K);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,98 @@
+"""The VQGAN HIP kernel sources (lwm_amd/csrc/vqgan_*.h) compiled for the host
+and run one fiber per lane (tests/emu/), through the same C ABI, against the C
+oracle (oracle/vqgan_ref.c).  The contract is BIT-EXACT: the exact-f32 MFMA is
+emulated as the ordered fmaf pair it is documented to be (confirmed on hardware
+by tests/test_gpu_probe.py::test_mfma_f32_is_ordered_fma_chain)."""
+import numpy as np
+import pytest
+
+from oracle import vqgan_ref as R
+from tests import _emu
+
+
+def _rng(seed):
+    return np.random.default_rng(seed)
+
+
+def _conv_case(seed, B, H, W, Cin, Cout, k, **kw):
+    g = _rng(seed)
+    x = g.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (g.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
+    b = g.standard_normal(Cout).astype(np.float32)
+    return x, w, b
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,kw", [
+    (1, 12, 12, 32, 128, 3, {}),                                   # 32x128 tile (few workgroups)
+    (2, 10, 6, 64, 160, 3, {}),                                    # ragged M and ragged Cout tile
+    (1, 8, 8, 3, 128, 3, {}),                                      # conv_in: Cin = 3 (scalar staging)
+    (1, 8, 8, 128, 3, 3, dict(clip=True)),                         # decoder out: Cout = 3, clip
+    (1, 8, 8, 40, 64, 3, {}),                                      # Cin not a multiple of 32; 128x64 tile
+    (1, 16, 16, 64, 64, 1, {}),                                    # 1x1 (quant_conv)
+    (1, 16, 16, 32, 128, 3, dict(stride=2, pad=0, out_hw=(8, 8))), # Downsample
+    (1, 6, 6, 32, 128, 3, dict(up_shift=1)),                       # Upsample
+])
+def test_conv_bit_exact(B, H, W, Cin, Cout, k, kw):
+    x, w, b = _conv_case(1, B, H, W, Cin, Cout, k)
+    got = _emu.conv2d(x, w, b, **kw)
+    ref = R.conv2d(x, w, b, **kw)
+    assert got.shape == ref.shape
+    assert np.array_equal(got, ref), np.abs(got - ref).max()
+
+
+def test_conv_residual_and_no_bias():
+    x, w, b = _conv_case(2, 1, 9, 9, 32, 128, 3)
+    res = _rng(3).standard_normal((1, 9, 9, 128)).astype(np.float32)
+    assert np.array_equal(_emu.conv2d(x, w, b, residual=res), R.conv2d(x, w, b, residual=res))
+    assert np.array_equal(_emu.conv2d(x, w, None), R.conv2d(x, w, None))
+
+
+def test_conv_large_tile_variant():
+    """M*N large enough for the 128x128 workgroup tile (>= 256 tiles)."""
+    x, w, b = _conv_case(4, 1, 128, 128, 8, 256, 3)
+    got = _emu.conv2d(x, w, b)
+    assert np.array_equal(got, R.conv2d(x, w, b))
+
+
+@pytest.mark.parametrize("C,HW,silu", [(128, 100, True), (256, 64, True), (512, 33, False), (768, 16, True)])
+def test_groupnorm_silu_bit_exact(C, HW, silu):
+    g = _rng(5)
+    x = (g.standard_normal((2, HW, C)) * 2 + 0.3).astype(np.float32)
+    gamma = (1 + 0.1 * g.standard_normal(C)).astype(np.float32)
+    beta = (0.1 * g.standard_normal(C)).astype(np.float32)
+    got = _emu.groupnorm(x, gamma, beta, silu=silu)
+    ref = R.groupnorm(x, gamma, beta, silu=silu)
+    assert np.array_equal(got, ref), np.abs(got - ref).max()
+
+
+def test_groupnorm_many_slices():
+    g = _rng(6)
+    x = g.standard_normal((1, 70 * 70, 128)).astype(np.float32)
+    gamma, beta = np.ones(128, np.float32), np.zeros(128, np.float32)
+    assert np.array_equal(_emu.groupnorm(x, gamma, beta, silu=True), R.groupnorm(x, gamma, beta, silu=True))
+
+
+@pytest.mark.parametrize("N,E", [(40, 512), (256, 1024)])
+def test_vq_argmin_and_gather(N, E):
+    g = _rng(7)
+    cb = g.uniform(-1.0 / E, 1.0 / E, (E, 64)).astype(np.float32)
+    z = (g.standard_normal((N, 64)) * 2.0 / E).astype(np.float32)
+    z[3] = cb[5]                    # exact hit
+    cb[9] = cb[4]                   # duplicate code: first index must win
+    z[7] = cb[9]
+    idx = _emu.vq_argmin(z, cb)
+    ref = R.vq_argmin(z, cb)
+    assert np.array_equal(idx, ref)
+    assert idx[3] == 5 and idx[7] == 4
+    assert np.array_equal(_emu.vq_gather(cb, idx), R.vq_gather(cb, ref))
+    assert np.array_equal(_emu.vq_gather(cb, idx, z), R.vq_gather(cb, ref, z))
+
+
+def test_validation_errors_are_loud():
+    import ctypes as C
+    from lwm_amd import _capi
+    L = _emu.lib()
+    a = _capi.LwmConvArgs()
+    assert L.lwm_conv2d_nhwc_f32(C.byref(a), None) == _capi.LWM_EINVAL
+    assert L.lwm_vq_argmin_f32(1, 1, 1, 1, 4, 8, 32, None) == _capi.LWM_EUNSUPPORTED
+    assert L.lwm_groupnorm_silu_f32(16, 16, 16, 16, 16, 1, 4, 6, 3, 1e-6, 1, None) == _capi.LWM_EUNSUPPORTED

@@ -54,3 +54,34 @@ def test_lds_fragments(probe, row0, step, row0t, d0):
             exp_cols[l, j] = Tf[row0t + 4 * hi + (j & 3) + 8 * (j >> 2), d0 + l31]
     assert np.array_equal(rows.float().cpu().numpy(), exp_rows), "ds_read_b128 row fragment map"
     assert np.array_equal(cols.float().cpu().numpy(), exp_cols), "ds_read_b64_tr_b16 fragment map"
+
+
+def test_mfma_f32_is_ordered_fma_chain(probe):
+    """v_mfma_f32_32x32x2_f32 == fmaf(a[k1], b[k1], fmaf(a[k0], b[k0], c)), bitwise.
+    The VQGAN kernels' bit-exact contract (oracle/vqgan_ref.c) and the host
+    emulator both rest on this.  Data with large cancellations makes any other
+    association or a wider internal accumulator visible."""
+    import torch
+    probe.probe_run_mfma_f32.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_void_p]
+    K = 64
+    g = np.random.default_rng(11)
+    A = (g.standard_normal((32, K)) * 10.0 ** g.integers(-3, 4, (32, K))).astype(np.float32)
+    B = (g.standard_normal((K, 32)) * 10.0 ** g.integers(-3, 4, (K, 32))).astype(np.float32)
+    C0 = g.standard_normal((32, 32)).astype(np.float32)
+    Ad, Bd, Cd = (torch.from_numpy(t).cuda() for t in (A, B, C0))
+    out = torch.zeros(32, 32, dtype=torch.float32, device="cuda")
+    assert probe.probe_run_mfma_f32(Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr(), out.data_ptr(), K, None) == 0
+    torch.cuda.synchronize()
+    # float32 fma chain on the host through libm's correctly rounded fmaf
+    libm = C.CDLL("libm.so.6")
+    libm.fmaf.restype = C.c_float
+    libm.fmaf.argtypes = [C.c_float] * 3
+    ref = C0.copy()
+    for i in range(32):
+        for j in range(32):
+            c = float(C0[i, j])
+            for k in range(K):
+                c = libm.fmaf(float(A[i, k]), float(B[k, j]), c)
+            ref[i, j] = c
+    got = out.cpu().numpy()
+    assert np.array_equal(got, ref), f"max diff {np.abs(got - ref).max()}"
