@@ -65,6 +65,84 @@ def cpu_baseline(S_target):
     }
 
 
+VQGAN_ENC_GFLOP, VQGAN_DEC_GFLOP = 216.6, 477.4   # per 256x256 frame, SURVEY.md Appendix B
+MFMA_F32_PEAK_TFLOPS = 157.3                      # exact-f32 MFMA, MI355X_MICROARCH.md
+
+
+def vqgan_leg(torch, frames=8, reps=3):
+    """Secondary leg (not part of `value`): VQGAN encode/decode of synthetic
+    256x256 frames U(-1,1), random weights of the default VQGANConfig
+    (lwm/vqgan.py:62-77), frames resident in HBM; plus the C oracle on the host
+    cores for one frame (cpu_baseline of this leg)."""
+    import numpy as np
+    from lwm_amd.vqgan import VQGAN, VQGANConfig, random_params
+    cfg = VQGANConfig.get_default_config()
+    params = random_params(cfg, 0)
+    vq = VQGAN(params=params, config=cfg)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    px = torch.rand(frames, 256, 256, 3, generator=g, device="cuda") * 2 - 1
+    _, idx = vq.encode(px[:1])
+    vq.decode(idx)
+    torch.cuda.synchronize()
+
+    def timed(fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps, out
+
+    t_enc, (_, idx) = timed(lambda: vq.encode(px))
+    t_dec, _ = timed(lambda: vq.decode(idx))
+    res = {
+        "workload": f"VQGAN default config, {frames} frames 256x256, f32 (exact-f32 MFMA), random weights",
+        "encode_frames_per_s": frames / t_enc, "decode_frames_per_s": frames / t_dec,
+        "encode_tflops": frames * VQGAN_ENC_GFLOP / t_enc / 1e3,
+        "decode_tflops": frames * VQGAN_DEC_GFLOP / t_dec / 1e3,
+        "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TFLOPS,
+                     "achieved": frames * VQGAN_DEC_GFLOP / t_dec / 1e3,
+                     "frac": frames * VQGAN_DEC_GFLOP / t_dec / 1e3 / MFMA_F32_PEAK_TFLOPS,
+                     "kernel": "conv_igemm (decode pass)"},
+    }
+    try:
+        from oracle import vqgan_ref as R
+        x1 = px[:1].cpu().numpy()
+        t0 = time.perf_counter()
+        _, ridx = R.encode(params, x1, cfg.as_dict())
+        t1 = time.perf_counter()
+        R.decode(params, ridx, cfg.as_dict())
+        t2 = time.perf_counter()
+        res["cpu_baseline"] = {"encode_frames_per_s": 1.0 / (t1 - t0), "decode_frames_per_s": 1.0 / (t2 - t1),
+                               "cores": os.cpu_count(), "kind": "port",
+                               "sample": "oracle/vqgan_ref (C, OpenMP) encode+decode of 1 frame"}
+        res["indices_match_oracle"] = bool((idx[0].cpu().numpy() == ridx[0]).all())
+    except Exception as e:  # the oracle is a checker; its absence must not break the bench line
+        res["cpu_baseline"] = {"error": repr(e)}
+    return res
+
+
+def pmc_traffic(kernel, S):
+    """HBM bytes per launch of `kernel` from the committed PMC passes of this same
+    command (profiles/*pmc_attention*.json: FETCH_SIZE x2 gfx950 correction +
+    WRITE_SIZE, separate rocprofv3 --pmc passes).  bench.py cannot collect
+    counters itself; null when no profile of this workload is committed."""
+    if S != 32768:
+        return None
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_attention*.json"))):
+        try:
+            ks = json.load(open(f))["kernels"]
+        except Exception:
+            continue
+        for name, d in ks.items():
+            if name.startswith(kernel) and "hbm_traffic_bytes" in d:
+                best = {"bytes": d["hbm_traffic_bytes"], "unit": "B/launch", "source": os.path.basename(f)}
+    return best
+
+
 class KernelTimer:
     """HIP events (torch.cuda.Event on the stream the kernels are launched on)
     around every kernel launch of the timed region, aggregated per kernel."""
@@ -102,6 +180,7 @@ def main():
     ap.add_argument("--layers", type=int, default=N_LAYERS, help="(debug only; default = full 32)")
     ap.add_argument("--layout", default="zigzag", choices=["zigzag", "contiguous"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vqgan", action="store_true", help="skip the secondary VQGAN leg")
     args = ap.parse_args()
 
     import torch
@@ -206,7 +285,8 @@ def main():
             achieved = algo_units[dom] * unit / avg_s / 1e12
             res["roofline"] = {
                 "kernel": dom, "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
+                "traffic": pmc_traffic(dom, S),
                 "avg_launch_ms": cand[dom]["avg_ms"],
                 "executed_tflops": exec_units[dom] * unit / avg_s / 1e12,
                 "all_kernels_algorithmic_tflops": {
@@ -214,6 +294,8 @@ def main():
             }
             if not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(S)
+            if not args.no_vqgan:
+                res["vqgan"] = vqgan_leg(torch)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
