@@ -187,17 +187,30 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
         const bool more = it + 1 < nit;
         if (more) stage_load(it + 1);
         const uint32_t bo = (uint32_t)buf * Cfg::BUF_BYTES;
-        for (int u = 0; u < 8; ++u) {
-            f32x4 ar[MB];
-            for (int i = 0; i < MB; ++i) ar[i] = lds_read_f32x4(a_r[i] + bo + ((u ^ a_sw[i]) << 4));
-            for (int t = 0; t < 2; ++t) {
-                float bf[NB], af[MB];
+        // fragments of k-quad u+1 are fetched while the MFMAs of k-quad u run
+        f32x4 ar[2][MB];
+        float bf[2][2][NB];
+        auto load_frag = [&](int u, int set) {
+            for (int i = 0; i < MB; ++i) ar[set][i] = lds_read_f32x4(a_r[i] + bo + ((u ^ a_sw[i]) << 4));
+            for (int t = 0; t < 2; ++t)
                 for (int j = 0; j < NB; ++j)
-                    bf[j] = lds_read_f32(b_r + bo + (uint32_t)((4 * u + 2 * t) * BN + j * 32) * 4);
-                for (int i = 0; i < MB; ++i) af[i] = hi ? ar[i][2 * t + 1] : ar[i][2 * t];
+                    bf[set][t][j] = lds_read_f32(b_r + bo + (uint32_t)((4 * u + 2 * t) * BN + j * 32) * 4);
+        };
+        load_frag(0, 0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int set = u & 1;
+            if (u + 1 < 8) load_frag(u + 1, set ^ 1);
+            sched_fence();  // keep the prefetch ABOVE this k-quad's MFMAs (hipcc sinks it otherwise)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float af[MB];
+                for (int i = 0; i < MB; ++i) af[i] = hi ? ar[set][i][2 * t + 1] : ar[set][i][2 * t];
                 for (int i = 0; i < MB; ++i)
-                    for (int j = 0; j < NB; ++j) acc_tap[i][j] = mfma_32x32x2_f32(af[i], bf[j], acc_tap[i][j]);
+                    for (int j = 0; j < NB; ++j)
+                        acc_tap[i][j] = mfma_32x32x2_f32(af[i], bf[set][t][j], acc_tap[i][j]);
             }
+            sched_fence();
         }
         if ((it + 1) % nch == 0) {  // tap finished: s = s + P_t
             for (int i = 0; i < MB; ++i)
@@ -228,7 +241,7 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
         }
 }
 
-LWM_KERNEL(256) void conv_igemm_128x128(ConvParams p) { conv_igemm_body<2, 2, 2, 2>(p); }
+LWM_KERNEL_OCC(256, 2) void conv_igemm_128x128(ConvParams p) { conv_igemm_body<2, 2, 2, 2>(p); }
 LWM_KERNEL(256) void conv_igemm_128x64(ConvParams p) { conv_igemm_body<4, 1, 1, 2>(p); }
 LWM_KERNEL(256) void conv_igemm_128x32(ConvParams p) { conv_igemm_body<4, 1, 1, 1>(p); }
 LWM_KERNEL(256) void conv_igemm_32x128(ConvParams p) { conv_igemm_body<1, 4, 1, 1>(p); }

@@ -23,6 +23,8 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define LWM_DEVICE __device__ __forceinline__
 #define LWM_GLOBAL __global__
 #define LWM_KERNEL(max_threads) __global__ __launch_bounds__(max_threads)
+// second argument = minimum waves per SIMD the register allocation must allow
+#define LWM_KERNEL_OCC(max_threads, waves_per_simd) __global__ __launch_bounds__(max_threads, waves_per_simd)
 
 LWM_DEVICE int thread_idx() { return (int)threadIdx.x; }
 LWM_DEVICE int block_idx_x() { return (int)blockIdx.x; }

@@ -32,6 +32,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define LWM_DEVICE static inline __attribute__((always_inline))
 #define LWM_GLOBAL static
 #define LWM_KERNEL(max_threads) static
+#define LWM_KERNEL_OCC(max_threads, waves_per_simd) static
 #define LWM_EMU 1
 typedef uint32_t lds_t;
 
