@@ -139,8 +139,38 @@ def pmc_traffic(kernel, S):
             continue
         for name, d in ks.items():
             if name.startswith(kernel) and "hbm_traffic_bytes" in d:
-                best = {"bytes": d["hbm_traffic_bytes"], "unit": "B/launch", "source": os.path.basename(f)}
+                best = d["hbm_traffic_bytes"]
     return best
+
+
+def decode_leg(torch, K=131072):
+    """Secondary leg: one cached-decode attention step of LWM-7B (Q = 1, 32 heads)
+    over a K-token KV cache resident in HBM -- ringattention_inference's path
+    (lwm/llama.py:571-614).  HBM-bound: algorithmic bytes = the K and V cache read
+    once = 2*K*4096*2 B (+ the (B,1,1,K) u8 mask)."""
+    from lwm_amd import ops
+    from lwm_amd.ring import _pick_splits
+    g = torch.Generator(device="cuda").manual_seed(0)
+    mk = lambda n: torch.randn(1, n, N_HEADS, HEAD_DIM, generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+    k, v, q = mk(K), mk(K), mk(1)
+    mask = torch.ones(1, 1, K, dtype=torch.uint8, device="cuda")
+    ns = _pick_splits(1, 1, N_HEADS, K)
+    fn = lambda: ops.attn_combine(*ops.attn_fwd_splitk(q, k, v, k_splits=ns, dense_mask=mask))
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / reps
+    nbytes = 2.0 * K * D_MODEL * 2 + K
+    return {"workload": f"decode attention step, Q=1, cache K={K}, 32 heads x 128, bf16, k_splits={ns}",
+            "us_per_layer_step": t * 1e6,
+            "roofline": {"bound": "hbm", "unit": "GB/s", "achieved": nbytes / t / 1e9, "peak": 8000.0,
+                         "frac": nbytes / t / 1e9 / 8000.0, "kernel": "attn_fwd_infer_kernel + attn_combine_kernel"}}
 
 
 class KernelTimer:
@@ -296,6 +326,7 @@ def main():
                 res["cpu_baseline"] = cpu_baseline(S)
             if not args.no_vqgan:
                 res["vqgan"] = vqgan_leg(torch)
+                res["decode"] = decode_leg(torch)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

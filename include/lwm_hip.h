@@ -73,12 +73,42 @@ typedef struct LwmAttnArgs {
     int32_t causal;
     int32_t carry_in;  /* 1: merge with the *_acc carries before writing */
     int32_t final_out; /* 1: write bf16 out/lse (fwd) or dq / dk,dv (bwd); 0: write *_acc */
+    /* Forward only -- the dense-mask / decode flavour (ringattention_inference,
+     * lwm/llama.py:571-614): an arbitrary boolean mask (B,1,Q,K) as u8, combined
+     * (AND) with the masks above; element (b,q,k) of THIS K/V block is
+     * dense_mask[b*mask_stride_b + q*mask_stride_q + k].  NULL = none. */
+    const uint8_t* dense_mask;
+    int64_t mask_stride_b, mask_stride_q;
+    /* Forward only -- split-K ("flash decoding") for short query blocks: the key
+     * range is cut into k_splits contiguous pieces, each handled by its own
+     * workgroups; piece s writes its normalised partial to
+     * out_acc + s*B*Sq*H*D and lse_acc + s*B*H*Sq (requires final_out = 0,
+     * carry_in = 0); merge with lwm_attn_combine.  0 or 1 = no split. */
+    int32_t k_splits;
 } LwmAttnArgs;
 
 int lwm_attn_fwd(const LwmAttnArgs* args, void* stream);
 int lwm_attn_bwd_delta(const LwmAttnArgs* args, void* stream);
 int lwm_attn_bwd_dq(const LwmAttnArgs* args, void* stream);
 int lwm_attn_bwd_dkdv(const LwmAttnArgs* args, void* stream);
+
+/* Merge P normalised partial attention results (split-K pieces of one launch, or
+ * the per-rank partials of a sequence-sharded K/V cache, lwm/llama.py:599-614):
+ *   o_parts [P][B,Sq,H,D] f32, lse_parts [P][B,H,Sq] f32  ->
+ *   out bf16 [B,Sq,H,D] (strided) if out.ptr != NULL, else out_f32 [B,Sq,H,D];
+ *   lse [B,H,Sq] f32 (may be NULL).  Rows whose every partial is empty
+ *   (lse = -inf) give out = 0, lse = -inf. */
+int lwm_attn_combine(const float* o_parts, const float* lse_parts, int32_t P, LwmTensor4 out,
+                     float* out_f32, float* lse, int32_t B, int32_t Sq, int32_t H, int32_t D,
+                     void* stream);
+
+/* KV-cache write (lwm/llama.py:440-492): cache[b, dst_row0 + i, :] = src[b, src_row0 + i, :]
+ * for i < nrows; rows are row_elems bf16 (= H*D) contiguous; batch strides in
+ * elements.  The caller decides which rows land in its shard (decode: only the
+ * owning sp shard writes, :454-467). */
+int lwm_kv_cache_write(void* cache, const void* src, int32_t B, int64_t cache_stride_b,
+                       int64_t src_stride_b, int64_t dst_row0, int64_t src_row0, int64_t nrows,
+                       int32_t row_elems, void* stream);
 
 /* Elementwise helpers of the ring driver (HBM-bound). */
 /* dst_bf16[n] = (bf16) src_f32[n] */

@@ -30,6 +30,8 @@ class LwmAttnArgs(C.Structure):
         ("q_start", C.c_int64), ("k_start", C.c_int64),
         ("scale", C.c_float),
         ("causal", C.c_int32), ("carry_in", C.c_int32), ("final_out", C.c_int32),
+        ("dense_mask", C.c_void_p), ("mask_stride_b", C.c_int64), ("mask_stride_q", C.c_int64),
+        ("k_splits", C.c_int32),
     ]
 
 
@@ -46,6 +48,10 @@ PROTOTYPES = {
     "lwm_attn_bwd_delta": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
     "lwm_attn_bwd_dq": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
     "lwm_attn_bwd_dkdv": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
+    "lwm_attn_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, LwmTensor4, C.c_void_p, C.c_void_p,
+                                  C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "lwm_kv_cache_write": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64,
+                                    C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
     "lwm_cast_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "lwm_conv2d_nhwc_f32": (C.c_int, [C.POINTER(LwmConvArgs), C.c_void_p]),
     "lwm_groupnorm_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int64, C.c_int32, C.c_int32]),

@@ -62,6 +62,10 @@ struct AttnParams {
     int32_t causal;
     int32_t carry_in;          // merge with *_acc before writing
     int32_t final_out;         // write bf16 results (else f32 *_acc)
+    // forward only: dense boolean mask and split-K (see include/lwm_hip.h)
+    const uint8_t* dense_mask;
+    int64_t msk_sb, msk_sq;
+    int32_t k_splits;
 };
 
 LWM_DEVICE int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }

@@ -44,6 +44,8 @@ struct FwdCtx {
     int64_t q_pos, wq_min, wq_max;
     int32_t seg_q;
     bool has_kmeta;
+    bool wave_idle;             // none of this wave's 32 query rows exists (q tail / decode)
+    const uint8_t* mask_row;    // this lane's row of the dense mask, or null
     float c;
 };
 
@@ -84,10 +86,13 @@ LWM_DEVICE void fwd_stage_write(const FwdCtx& cx, const FwdStage& st, int kt, in
 }
 
 // One 64-key tile held in LDS buffer BUF against this wave's 32 queries.
-template <int BUF>
+// INFER = the dense-mask / split-K flavour (ringattention_inference); the training
+// kernel is compiled without that code.
+template <int BUF, bool INFER>
 LWM_DEVICE void fwd_tile(const AttnParams& p, const FwdCtx& cx, const bf16x8 (&qf)[8], int kt,
                          float& m_run, float& l_run, f32x16 (&acc)[4]) {
     const int64_t k_pos0 = p.k_start + (int64_t)kt * kFwdBK;
+    if (INFER && cx.wave_idle) return;           // staging only (short query blocks)
     if (p.causal && k_pos0 > cx.wq_max) return;  // wholly in this wave's future
     constexpr uint32_t KB = BUF * kFwdTileBytes;
     constexpr uint32_t VB = BUF * kFwdTileBytes;  // va already points at V tile 0
@@ -124,6 +129,16 @@ LWM_DEVICE void fwd_tile(const AttnParams& p, const FwdCtx& cx, const bf16x8 (&q
                 }
             }
     }
+    // ---- arbitrary boolean mask (ringattention_inference, lwm/llama.py:577-614)
+    if (INFER && cx.mask_row) {
+        const uint8_t* mr = cx.mask_row + (int64_t)kt * kFwdBK;
+        for (int kb2 = 0; kb2 < 2; ++kb2)
+            for (int r = 0; r < 16; ++r) {
+                const int kl = 32 * kb2 + cd_row(r, cx.hi);
+                const bool in = kt * kFwdBK + kl < p.Sk;
+                if (!in || mr[kl] == 0) st[kb2][r] = -INFINITY;
+            }
+    }
     // ---- online softmax (per query column)
     float mx = -INFINITY;
     for (int kb2 = 0; kb2 < 2; ++kb2)
@@ -157,7 +172,8 @@ LWM_DEVICE void fwd_tile(const AttnParams& p, const FwdCtx& cx, const bf16x8 (&q
     prio_lo();
 }
 
-LWM_KERNEL(kFwdThreads) void attn_fwd_kernel(AttnParams p) {
+template <bool INFER>
+LWM_DEVICE void attn_fwd_body(const AttnParams& p) {
     const lds_t lds = dyn_lds();
     const int tid = thread_idx();
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -167,7 +183,9 @@ LWM_KERNEL(kFwdThreads) void attn_fwd_kernel(AttnParams p) {
     // shared in that XCD's L2.
     const int nqt = (p.Sq + kFwdBQ - 1) / kFwdBQ;
     const int HB = p.H * p.B;
-    int lin = block_idx_x(), qt, hb;
+    const int nsplit = (INFER && p.k_splits > 1) ? p.k_splits : 1;
+    const int split = INFER ? block_idx_x() / (nqt * HB) : 0;
+    int lin = block_idx_x() - split * (nqt * HB), qt, hb;
     if ((HB & 7) == 0) {
         int xcd = lin & 7, i = lin >> 3;
         hb = xcd + 8 * (i / nqt);
@@ -209,6 +227,10 @@ LWM_KERNEL(kFwdThreads) void attn_fwd_kernel(AttnParams p) {
     cx.wq_min = p.q_start + qt * kFwdBQ + wave * 32;
     cx.wq_max = cx.wq_min + 31;
     cx.c = p.scale * kLog2e;
+    cx.wave_idle = INFER && wave_uniform(qt * kFwdBQ + wave * 32 >= p.Sq ? 1 : 0) != 0;
+    cx.mask_row = (INFER && p.dense_mask && q_ok)
+                      ? p.dense_mask + (int64_t)b * p.msk_sb + (int64_t)q_row * p.msk_sq
+                      : nullptr;
 
     // ---- kv tile range (causal: skip tiles wholly in the future of this q tile)
     const int nkt_all = (p.Sk + kFwdBK - 1) / kFwdBK;
@@ -232,22 +254,30 @@ LWM_KERNEL(kFwdThreads) void attn_fwd_kernel(AttnParams p) {
     // tile loop without passing the prologue's s_waitcnt (otherwise the Q-fragment
     // loads count as possibly pending at the loop's first MFMA and the compiler
     // drains vmcnt to 0 there every tile, serialising the staging loads).
-    if (nkt > 0) {
+    // split-K: this workgroup walks tiles [kt0, nkt) of its piece only
+    int kt0 = 0;
+    if (nsplit > 1) {
+        const int per = (nkt_all + nsplit - 1) / nsplit;
+        kt0 = split * per;
+        const int kt1 = kt0 + per;
+        nkt = nkt < kt1 ? nkt : kt1;
+    }
+    if (kt0 < nkt) {
         FwdStage stg;
-        fwd_stage_load(p, kb, vb, b, 0, tid, stg);
-        fwd_stage_write<0>(cx, stg, 0, p.Sk);
+        fwd_stage_load(p, kb, vb, b, kt0, tid, stg);
+        fwd_stage_write<0>(cx, stg, kt0, p.Sk);
         block_sync();
         // two tiles per trip so the LDS buffer index is a compile-time constant
-        for (int kt = 0; kt < nkt; kt += 2) {
+        for (int kt = kt0; kt < nkt; kt += 2) {
             const bool more1 = kt + 1 < nkt;
             if (more1) fwd_stage_load(p, kb, vb, b, kt + 1, tid, stg);
-            fwd_tile<0>(p, cx, qf, kt, m_run, l_run, acc);
+            fwd_tile<0, INFER>(p, cx, qf, kt, m_run, l_run, acc);
             if (more1) fwd_stage_write<1>(cx, stg, kt + 1, p.Sk);
             block_sync();
             if (!more1) break;
             const bool more2 = kt + 2 < nkt;
             if (more2) fwd_stage_load(p, kb, vb, b, kt + 2, tid, stg);
-            fwd_tile<1>(p, cx, qf, kt + 1, m_run, l_run, acc);
+            fwd_tile<1, INFER>(p, cx, qf, kt + 1, m_run, l_run, acc);
             if (more2) fwd_stage_write<0>(cx, stg, kt + 2, p.Sk);
             block_sync();
         }
@@ -261,7 +291,7 @@ LWM_KERNEL(kFwdThreads) void attn_fwd_kernel(AttnParams p) {
         lse_b = m_run * p.scale + logf(l_tot);
     }
     float w_a = 0.0f, w_b = 1.0f, lse_new = lse_b;
-    const int64_t lse_idx = ((int64_t)b * p.H + h) * p.Sq + q_row;
+    const int64_t lse_idx = ((int64_t)b * p.H + h) * p.Sq + q_row + (int64_t)split * p.B * p.H * p.Sq;
     if (p.carry_in && q_ok) {
         float lse_a = p.lse_acc[lse_idx];
         float mx = fmaxf(lse_a, lse_b);
@@ -280,7 +310,8 @@ LWM_KERNEL(kFwdThreads) void attn_fwd_kernel(AttnParams p) {
         const float sc = inv * w_b;
         const int64_t orow = (int64_t)b * p.o_sb + (int64_t)q_row * p.o_ss + (int64_t)h * p.o_sh;
         // the f32 carry is dense [B,Sq,H,D]
-        const int64_t arow = (((int64_t)b * p.Sq + q_row) * p.H + h) * kHeadDim;
+        const int64_t arow = (((int64_t)b * p.Sq + q_row) * p.H + h) * kHeadDim +
+                             (int64_t)split * p.B * p.Sq * p.H * kHeadDim;
         for (int db = 0; db < 4; ++db)
             for (int rq = 0; rq < 4; ++rq) {
                 int d0 = 32 * db + 8 * rq + 4 * hi;
@@ -305,5 +336,8 @@ LWM_KERNEL(kFwdThreads) void attn_fwd_kernel(AttnParams p) {
         }
     }
 }
+
+LWM_KERNEL(kFwdThreads) void attn_fwd_kernel(AttnParams p) { attn_fwd_body<false>(p); }
+LWM_KERNEL(kFwdThreads) void attn_fwd_infer_kernel(AttnParams p) { attn_fwd_body<true>(p); }
 
 }  // namespace lwm

@@ -65,12 +65,14 @@ def _base(q, k, v, *, q_start, k_start, causal, seg_q, seg_k, key_valid, scale):
 
 def attn_fwd_block(q, k, v, *, q_start=0, k_start=0, causal=True, seg_q=None, seg_k=None,
                    key_valid=None, scale=None, out=None, lse=None, out_acc=None, lse_acc=None,
-                   carry_in=False, final=True):
+                   carry_in=False, final=True, dense_mask=None):
     """One ring step of the forward (lwm_attn_fwd).  Returns (out, lse) when
-    `final`, else the updated (out_acc, lse_acc)."""
+    `final`, else the updated (out_acc, lse_acc).  dense_mask: optional u8
+    (B,Sq,Sk) view (last dim contiguous) ANDed with the other masks."""
     B, Sq, H, D = q.shape
     a = _base(q, k, v, q_start=q_start, k_start=k_start, causal=causal, seg_q=seg_q, seg_k=seg_k,
               key_valid=key_valid, scale=scale)
+    _set_dense_mask(a, dense_mask, B, Sq, k.shape[1])
     if final:
         if out is None:
             out = torch.empty((B, Sq, H, D), dtype=torch.bfloat16, device=q.device)
@@ -90,6 +92,70 @@ def attn_fwd_block(q, k, v, *, q_start=0, k_start=0, causal=True, seg_q=None, se
     L = lib()
     _capi.check(L, L.lwm_attn_fwd(C.byref(a), _stream_ptr()), "lwm_attn_fwd")
     return (out, lse) if final else (out_acc, lse_acc)
+
+
+def _set_dense_mask(a, dense_mask, B, Sq, Sk):
+    if dense_mask is None:
+        return
+    m = dense_mask
+    if not m.is_cuda or m.dtype != torch.uint8 or tuple(m.shape) != (B, Sq, Sk) or m.stride(2) != 1:
+        raise ValueError(f"dense_mask: expected a u8 device tensor of shape {(B, Sq, Sk)} with contiguous keys")
+    a.dense_mask, a.mask_stride_b, a.mask_stride_q = m.data_ptr(), m.stride(0), m.stride(1)
+
+
+def attn_fwd_splitk(q, k, v, *, k_splits, q_start=0, k_start=0, causal=False, seg_q=None, seg_k=None,
+                    key_valid=None, dense_mask=None, scale=None):
+    """Split-K forward for short query blocks (decode): returns normalised partials
+    (o_parts f32 [k_splits,B,Sq,H,D], lse_parts f32 [k_splits,B,H,Sq]) -- merge with
+    attn_combine."""
+    B, Sq, H, D = q.shape
+    a = _base(q, k, v, q_start=q_start, k_start=k_start, causal=causal, seg_q=seg_q, seg_k=seg_k,
+              key_valid=key_valid, scale=scale)
+    _set_dense_mask(a, dense_mask, B, Sq, k.shape[1])
+    k_splits = max(1, int(k_splits))
+    o_parts = torch.empty((k_splits, B, Sq, H, D), dtype=torch.float32, device=q.device)
+    lse_parts = torch.empty((k_splits, B, H, Sq), dtype=torch.float32, device=q.device)
+    a.out_acc, a.lse_acc = o_parts.data_ptr(), lse_parts.data_ptr()
+    a.carry_in, a.final_out, a.k_splits = 0, 0, k_splits
+    L = lib()
+    _capi.check(L, L.lwm_attn_fwd(C.byref(a), _stream_ptr()), "lwm_attn_fwd")
+    return o_parts, lse_parts
+
+
+def attn_combine(o_parts, lse_parts, *, out=None, out_f32=None, lse=None, want_bf16=True):
+    """Merge normalised partials (lwm_attn_combine).  Returns (out bf16 or f32, lse)."""
+    P, B, Sq, H, D = o_parts.shape
+    if lse is None:
+        lse = torch.empty((B, H, Sq), dtype=torch.float32, device=o_parts.device)
+    if want_bf16 and out is None:
+        out = torch.empty((B, Sq, H, D), dtype=torch.bfloat16, device=o_parts.device)
+    if not want_bf16 and out_f32 is None:
+        out_f32 = torch.empty((B, Sq, H, D), dtype=torch.float32, device=o_parts.device)
+    L = lib()
+    _capi.check(L, L.lwm_attn_combine(_f32(o_parts, "o_parts"), _f32(lse_parts, "lse_parts", (P, B, H, Sq)), P,
+                                      _t4(out, "out") if want_bf16 else _capi.LwmTensor4(None, 0, 0, 0),
+                                      None if want_bf16 else _f32(out_f32, "out_f32"),
+                                      _f32(lse, "lse", (B, H, Sq)), B, Sq, H, D, _stream_ptr()),
+                "lwm_attn_combine")
+    return (out if want_bf16 else out_f32), lse
+
+
+def kv_cache_write(cache, src, *, dst_row0, src_row0=0, nrows=None):
+    """cache[:, dst_row0:dst_row0+nrows] = src[:, src_row0:src_row0+nrows] for (B,S,H,D) bf16
+    tensors whose (S,H,D) block is contiguous (lwm_kv_cache_write)."""
+    for n, t in (("cache", cache), ("src", src)):
+        if not t.is_cuda or t.dtype != torch.bfloat16 or t.dim() != 4 or not t[0].is_contiguous():
+            raise ValueError(f"{n}: expected bf16 (B,S,H,D) device tensor with contiguous (S,H,D)")
+    B, _, H, D = cache.shape
+    if nrows is None:
+        nrows = src.shape[1] - src_row0
+    if dst_row0 < 0 or dst_row0 + nrows > cache.shape[1] or src_row0 + nrows > src.shape[1]:
+        raise ValueError("kv_cache_write: row range out of bounds")
+    L = lib()
+    _capi.check(L, L.lwm_kv_cache_write(cache.data_ptr(), src.data_ptr(), B, cache.stride(0), src.stride(0),
+                                        dst_row0, src_row0, nrows, H * D, _stream_ptr()),
+                "lwm_kv_cache_write")
+    return cache
 
 
 def attn_bwd_delta(out, dout, delta=None):

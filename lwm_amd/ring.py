@@ -100,11 +100,38 @@ class TorchRingComm:
         return _Handle(reqs, bufs)
 
 
+    def all_gather(self, t):
+        """-> (n, *t.shape), rank-major."""
+        out = torch.empty((self.size,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t.contiguous(), group=self.group) if t.is_cuda else \
+            dist.all_gather(list(out.unbind(0)), t.contiguous(), group=self.group)
+        return out
+
+    def exchange(self, sends, recvs):
+        """sends: [(peer, tensor)], recvs: [(peer, empty tensor)] -- one grouped P2P batch."""
+        ops_ = []
+        for peer, t in sends:
+            dst = dist.get_global_rank(self.group, peer) if self.group is not None else peer
+            ops_.append(dist.P2POp(dist.isend, t, dst, self.group))
+        for peer, t in recvs:
+            src = dist.get_global_rank(self.group, peer) if self.group is not None else peer
+            ops_.append(dist.P2POp(dist.irecv, t, src, self.group))
+        if ops_:
+            for r in dist.batch_isend_irecv(ops_):
+                r.wait()
+
+
 class SingleComm:
     rank, size = 0, 1
 
     def rotate(self, tensors):
         return _Handle([], list(tensors))
+
+    def all_gather(self, t):
+        return t.unsqueeze(0)
+
+    def exchange(self, sends, recvs):
+        assert not sends and not recvs
 
 
 # ----------------------------------------------------------------- block ops
@@ -116,6 +143,9 @@ class HipBlockOps:
     bwd_dq = staticmethod(_ops.attn_bwd_dq_block)
     bwd_dkdv = staticmethod(_ops.attn_bwd_dkdv_block)
     cast = staticmethod(_ops.cast_f32_to_bf16)
+    fwd_splitk = staticmethod(_ops.attn_fwd_splitk)
+    combine = staticmethod(_ops.attn_combine)
+    cache_write = staticmethod(_ops.kv_cache_write)
 
     @staticmethod
     def empty(shape, dtype, like):
@@ -328,3 +358,96 @@ def ring_attention(q, k, v, *, group=None, causal=True, segment_ids=None, key_va
     if key_valid is not None and key_valid.dtype != torch.uint8:
         key_valid = (key_valid != 0).to(torch.uint8)
     return _RingAttention.apply(q, k, v, segment_ids, key_valid, (block, comm, lay, causal, scale))
+
+
+# ----------------------------------------------------------------- inference (dense mask)
+def _pick_splits(B, Q, H, Sk):
+    """Enough workgroups to fill 256 CUs twice, at least 4 key tiles (256 keys) per piece."""
+    base = ((Q + 255) // 256) * H * B
+    want = max(1, -(-512 // base))
+    return max(1, min(want, max(1, Sk // 256)))
+
+
+def ring_inference(block, comm, q, k, v, mask, *, q_sharded, scale=None):
+    """ringattention_inference (lwm/llama.py:571-614).
+
+    q: (B,Q,H,D) replicated over the group when `q_sharded` is False (decode,
+    lwm/llama.py:599) else this rank's (B,Q/n,H,D) shard; k, v: this rank's
+    contiguous (B,K/n,H,D) shard of the cache; mask: u8 (B,Q_local,K_global).
+    MI355X-first: nothing rotates.  Decode computes each rank's normalised partial
+    over its own cache shard (split-K inside the launch) and all-gathers the tiny
+    (out, lse) partials; the short-prefill case all-gathers K/V (S <= chunk size)."""
+    n, r = comm.size, comm.rank
+    B, Q, H, D = q.shape
+    Kl = k.shape[1]
+    if mask.shape[-1] != Kl * n:
+        raise ValueError(f"attn_mask covers {mask.shape[-1]} keys but the cache has {Kl * n}")
+    if q_sharded and n > 1:
+        kf = comm.all_gather(k).transpose(0, 1).reshape(B, n * Kl, H, D).contiguous()
+        vf = comm.all_gather(v).transpose(0, 1).reshape(B, n * Kl, H, D).contiguous()
+        o_parts, l_parts = block.fwd_splitk(q, kf, vf, k_splits=_pick_splits(B, Q, H, n * Kl),
+                                            causal=False, dense_mask=mask, scale=scale)
+        return block.combine(o_parts, l_parts, want_bf16=True)[0]
+    local_mask = mask[:, :, r * Kl:(r + 1) * Kl]
+    o_parts, l_parts = block.fwd_splitk(q, k, v, k_splits=_pick_splits(B, Q, H, Kl), causal=False,
+                                        dense_mask=local_mask, scale=scale, k_start=r * Kl)
+    if n == 1:
+        return block.combine(o_parts, l_parts, want_bf16=True)[0]
+    o_loc, l_loc = block.combine(o_parts, l_parts, want_bf16=False)
+    return block.combine(comm.all_gather(o_loc), comm.all_gather(l_loc), want_bf16=True)[0]
+
+
+def cache_update(block, comm, cache_k, cache_v, key, value, cache_index, *, new_sharded):
+    """FlaxLLaMAAttention._concatenate_to_cache (lwm/llama.py:440-492) for a cache
+    sharded contiguously over the group: rank r holds global rows [r*c, (r+1)*c).
+
+    new_sharded False: key/value (B,P,H,D) are replicated (decode, P = 1:
+    only the owning shard writes, :454-467).  True: they are this rank's
+    (B,P/n,H,D) shard of a P-row update that lands at global rows
+    [cache_index, cache_index+P) (prefill, dynamic_update_slice :485-487) -- rows
+    that belong to another rank's shard are sent there.  Returns cache_index + P."""
+    n, r = comm.size, comm.rank
+    c = cache_k.shape[1]
+    p = key.shape[1]
+    P = p * n if new_sharded else p
+    if cache_index < 0 or cache_index + P > c * n:
+        raise ValueError("cache update out of range")
+    lo, hi = r * c, (r + 1) * c
+
+    def clip(a0, a1, b0, b1):
+        s, e = max(a0, b0), min(a1, b1)
+        return (s, e) if e > s else None
+
+    if not new_sharded:
+        rng = clip(cache_index, cache_index + P, lo, hi)
+        if rng is not None:
+            for cache, new in ((cache_k, key), (cache_v, value)):
+                block.cache_write(cache, new, dst_row0=rng[0] - lo, src_row0=rng[0] - cache_index,
+                                  nrows=rng[1] - rng[0])
+        return cache_index + P
+    # sharded update: my rows are global [cache_index + r*p, cache_index + (r+1)*p)
+    my0 = cache_index + r * p
+    sends, recvs, local = [], [], []
+    for peer in range(n):
+        out_rng = clip(my0, my0 + p, peer * c, (peer + 1) * c)          # my rows that peer owns
+        in_rng = clip(cache_index + peer * p, cache_index + (peer + 1) * p, lo, hi)  # peer's rows I own
+        if peer == r:
+            if out_rng is not None:
+                local.append(out_rng)
+            continue
+        if out_rng is not None:
+            sl = slice(out_rng[0] - my0, out_rng[1] - my0)
+            sends.append((peer, key[:, sl].contiguous()))
+            sends.append((peer, value[:, sl].contiguous()))
+        if in_rng is not None:
+            shape = (key.shape[0], in_rng[1] - in_rng[0]) + tuple(key.shape[2:])
+            bk, bv = block.empty(shape, key.dtype, key), block.empty(shape, key.dtype, key)
+            recvs.append((peer, bk, in_rng))
+            recvs.append((peer, bv, in_rng))
+    comm.exchange(sends, [(peer, t) for peer, t, _ in recvs])
+    for g0, g1 in local:
+        for cache, new in ((cache_k, key), (cache_v, value)):
+            block.cache_write(cache, new, dst_row0=g0 - lo, src_row0=g0 - my0, nrows=g1 - g0)
+    for i, (peer, buf, (g0, g1)) in enumerate(recvs):
+        block.cache_write(cache_k if i % 2 == 0 else cache_v, buf, dst_row0=g0 - lo, src_row0=0, nrows=g1 - g0)
+    return cache_index + P

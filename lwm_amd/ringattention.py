@@ -9,7 +9,8 @@ query/key_chunk_size only trade memory for speed and do not change results).
 """
 import torch
 
-from .ring import ring_attention
+from .ring import (HipBlockOps, SingleComm, TorchRingComm, cache_update, ring_attention,
+                   ring_inference)
 
 _SP_GROUP = {"group": None}
 
@@ -50,6 +51,43 @@ def ringattention(q, k, v, attn_bias, segment_ids, axis_name="sp", float32_logit
         key_valid = (attn_bias[:, 0, 0, :].float() > -1e30).to(torch.uint8).contiguous()
     return ring_attention(q, k, v, group=_resolve_axis(axis_name), causal=cbs == 1,
                           segment_ids=segment_ids, key_valid=key_valid, layout=layout)
+
+
+def _comm(group):
+    import torch.distributed as dist
+    if group is None and not (dist.is_available() and dist.is_initialized()):
+        return SingleComm()
+    if group is None and dist.get_world_size() == 1:
+        return SingleComm()
+    return TorchRingComm(group)
+
+
+def ringattention_inference(q, k, v, attn_mask, axis_name="sp", q_sharded=None, block_ops=None, comm=None):
+    """Dense-mask ring attention for S <= chunk size and for cached decoding
+    (call site lwm/llama.py:599-614).  q: (B,Q,H,D); k, v: this rank's (B,K/sp,H,D)
+    shard (the KV cache when decoding); attn_mask: boolean (B,1,Q,K_global) built at
+    lwm/llama.py:577-592.  As in the reference, q is replicated over "sp" when
+    Q == 1 and sharded otherwise (`q_sp_dim`, :599) unless `q_sharded` says so."""
+    if attn_mask.dim() != 4 or attn_mask.shape[1] != 1:
+        raise ValueError("attn_mask must be (B,1,Q,K) as built at lwm/llama.py:577-592")
+    if q_sharded is None:
+        q_sharded = q.shape[1] != 1
+    mask = (attn_mask[:, 0] != 0).to(torch.uint8).contiguous()
+    cm = comm if comm is not None else _comm(_resolve_axis(axis_name))
+    return ring_inference(block_ops or HipBlockOps, cm, q, k, v, mask, q_sharded=q_sharded)
+
+
+def concatenate_to_cache(cached_key, cached_value, key, value, cache_index, axis_name="sp",
+                         new_sharded=None, block_ops=None, comm=None):
+    """FlaxLLaMAAttention._concatenate_to_cache (lwm/llama.py:440-492) on this rank's
+    (B, max_length/sp, H, D) cache shards, in place.  Returns the new cache_index."""
+    if new_sharded is None:
+        new_sharded = key.shape[1] != 1            # decode keys are replicated (:468-471)
+    cm = comm if comm is not None else _comm(_resolve_axis(axis_name))
+    if cm.size == 1:
+        new_sharded = False
+    return cache_update(block_ops or HipBlockOps, cm, cached_key, cached_value, key, value, int(cache_index),
+                        new_sharded=new_sharded)
 
 
 def blockwise_feedforward(module, x, chunk_size, pre_remat=True):

@@ -39,7 +39,7 @@ NEG_INF = -np.inf
 
 
 def visible_mask(Sq, Sk, *, causal=True, q_start=0, k_start=0, seg_q=None, seg_k=None,
-                 key_valid=None, B=1):
+                 key_valid=None, B=1, dense_mask=None):
     """Boolean (B, Sq, Sk): the dense mask of lwm/llama.py:577-592 on global positions."""
     vis = np.ones((B, Sq, Sk), dtype=bool)
     if causal:
@@ -50,11 +50,13 @@ def visible_mask(Sq, Sk, *, causal=True, q_start=0, k_start=0, seg_q=None, seg_k
         vis &= (np.asarray(seg_q)[:, :, None] == np.asarray(seg_k)[:, None, :])
     if key_valid is not None:
         vis &= (np.asarray(key_valid)[:, None, :] != 0)
+    if dense_mask is not None:      # arbitrary (B,Sq,Sk) boolean mask: ringattention_inference,
+        vis &= (np.asarray(dense_mask) != 0)   # lwm/llama.py:577-614
     return vis
 
 
 def dense_attention(q, k, v, *, causal=True, q_start=0, k_start=0, seg_q=None, seg_k=None,
-                    key_valid=None, scale=None, dtype=np.float64):
+                    key_valid=None, scale=None, dtype=np.float64, dense_mask=None):
     """Dense masked softmax attention.  Returns (out (B,Sq,H,D), lse (B,H,Sq))."""
     q = np.asarray(q, dtype=dtype)
     k = np.asarray(k, dtype=dtype)
@@ -65,7 +67,7 @@ def dense_attention(q, k, v, *, causal=True, q_start=0, k_start=0, seg_q=None, s
         scale = 1.0 / np.sqrt(D)
     s = np.einsum("bqhd,bkhd->bhqk", q, k) * dtype(scale)
     vis = visible_mask(Sq, Sk, causal=causal, q_start=q_start, k_start=k_start, seg_q=seg_q,
-                       seg_k=seg_k, key_valid=key_valid, B=B)[:, None]
+                       seg_k=seg_k, key_valid=key_valid, B=B, dense_mask=dense_mask)[:, None]
     s = np.where(vis, s, NEG_INF)
     m = s.max(axis=-1, keepdims=True) if Sk > 0 else np.full(s.shape[:-1] + (1,), NEG_INF)
     m_safe = np.where(np.isfinite(m), m, 0.0)
@@ -105,6 +107,48 @@ def dense_attention_bwd(q, k, v, dout, *, causal=True, q_start=0, k_start=0, seg
     dq = np.einsum("bhqk,bkhd->bqhd", ds, k)
     dk = np.einsum("bhqk,bqhd->bkhd", ds, q)
     return dq, dk, dv
+
+
+def decode_mask(B, Q, K, cache_index, attention_mask=None):
+    """The mask the reference builds for cached decoding (lwm/llama.py:574-592):
+    key k visible to query i iff k <= i + cache_index, AND attention_mask[b,k]."""
+    m = (np.arange(K)[None, :] <= (np.arange(Q)[:, None] + cache_index))[None].repeat(B, 0)
+    if attention_mask is not None:
+        m = m & (np.asarray(attention_mask)[:, None, :] != 0)
+    return m
+
+
+def ring_inference(q, k, v, mask, *, ring=1, scale=None):
+    """ringattention_inference restated: the K/V cache is
+    sharded contiguously over `ring` devices, every device holds all queries, one
+    un-chunked online-softmax update per ring step with the boolean mask sliced to
+    the block; float32.  Returns out (B,Q,H,D)."""
+    q = np.asarray(q, np.float32)
+    k = np.asarray(k, np.float32)
+    v = np.asarray(v, np.float32)
+    B, Q, H, D = q.shape
+    K = k.shape[1]
+    c = K // ring
+    if scale is None:
+        scale = 1.0 / np.sqrt(D)
+    num = np.zeros((B, Q, H, D), np.float32)
+    den = np.zeros((B, H, Q), np.float32)
+    mx = np.full((B, H, Q), NEG_INF, np.float32)
+    fmin = np.finfo(np.float32).min
+    for t in range(ring):
+        sl = slice(t * c, (t + 1) * c)
+        s = np.einsum("bqhd,bkhd->bhqk", q, k[:, sl]) * np.float32(scale)
+        vis = (np.asarray(mask)[:, :, sl] != 0)[:, None]
+        s = np.where(vis, s, fmin)
+        m_new = np.maximum(mx, s.max(axis=-1))
+        p = np.where(vis, np.exp(s - m_new[..., None]), np.float32(0))
+        corr = np.where(np.isfinite(mx), np.exp(mx - m_new), np.float32(0))
+        num = num * np.transpose(corr, (0, 2, 1))[..., None] + np.einsum("bhqk,bkhd->bqhd", p, v[:, sl])
+        den = den * corr + p.sum(axis=-1)
+        mx = np.where(m_new <= fmin / 2, NEG_INF, m_new)
+    den_t = np.transpose(den, (0, 2, 1))[..., None]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.where(den_t > 0, num / np.where(den_t > 0, den_t, 1), 0)
 
 
 # --------------------------------------------------------------------------

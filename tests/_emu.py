@@ -217,3 +217,35 @@ def vq_gather(codebook, idx, z=None):
     _capi.check(L, L.lwm_vq_gather_f32(cb.ctypes.data, ia.ctypes.data, _ptr(zz), out.ctypes.data,
                                        ia.size, E, D, None), "lwm_vq_gather_f32")
     return out
+
+
+# ---------------------------------------------------------------- inference (dense mask, split-K)
+def attn_infer(q, k, v, mask, *, k_splits=1, scale=None):
+    """Split-K forward with a dense u8 mask (B,Sq,Sk) + combine; returns (out f32 from bf16, lse)."""
+    L = lib()
+    qb, kb, vb = bf16_array(q), bf16_array(k), bf16_array(v)
+    B, Sq, H, D = q.shape
+    Sk = k.shape[1]
+    a, keep = base_args(qb, kb, vb, causal=False, q_start=0, k_start=0, seg_q=None, seg_k=None,
+                        key_valid=None, scale=scale)
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    a.dense_mask, a.mask_stride_b, a.mask_stride_q = m.ctypes.data, m.strides[0], m.strides[1]
+    o_parts = aligned((k_splits, B, Sq, H, D), np.float32)
+    l_parts = aligned((k_splits, B, H, Sq), np.float32)
+    a.out_acc, a.lse_acc = o_parts.ctypes.data, l_parts.ctypes.data
+    a.k_splits = k_splits
+    _capi.check(L, L.lwm_attn_fwd(C.byref(a), None), "lwm_attn_fwd")
+    out = aligned((B, Sq, H, D), np.uint16)
+    lse = aligned((B, H, Sq), np.float32)
+    _capi.check(L, L.lwm_attn_combine(o_parts.ctypes.data, l_parts.ctypes.data, k_splits, _t4(out), None,
+                                      lse.ctypes.data, B, Sq, H, D, None), "lwm_attn_combine")
+    return from_bf16_bits(out), lse
+
+
+def kv_cache_write(cache_bits, src_bits, dst_row0, src_row0, nrows):
+    L = lib()
+    B, S, H, D = cache_bits.shape
+    _capi.check(L, L.lwm_kv_cache_write(cache_bits.ctypes.data, src_bits.ctypes.data, B,
+                                        cache_bits.strides[0] // 2, src_bits.strides[0] // 2, dst_row0,
+                                        src_row0, nrows, H * D, None), "lwm_kv_cache_write")
+    return cache_bits

@@ -121,3 +121,46 @@ class OracleBlockOps:
         dk_acc.copy_(rk.float())
         dv_acc.copy_(rv.float())
         return dk_acc, dv_acc
+
+    # ---- inference / cache (stand-ins for fwd_splitk, combine, cache_write)
+    @staticmethod
+    def fwd_splitk(q, k, v, *, k_splits, q_start=0, k_start=0, causal=False, seg_q=None, seg_k=None,
+                   key_valid=None, dense_mask=None, scale=None):
+        D = q.shape[-1]
+        scale = scale or 1.0 / math.sqrt(D)
+        Sk = k.shape[1]
+        per = -(-Sk // k_splits)
+        outs, lses = [], []
+        for s_ in range(k_splits):
+            sl = slice(s_ * per, min(Sk, (s_ + 1) * per))
+            kk, vv = k[:, sl].double(), v[:, sl].double()
+            sc = torch.einsum("bqhd,bkhd->bhqk", q.double(), kk) * scale
+            if dense_mask is not None:
+                sc = sc.masked_fill(~(dense_mask[:, None, :, sl] != 0), float("-inf"))
+            m = sc.amax(dim=-1, keepdim=True) if kk.shape[1] else torch.full(sc.shape[:-1] + (1,), float("-inf"))
+            m = torch.where(torch.isfinite(m), m, torch.zeros_like(m))
+            p = torch.exp(sc - m)
+            l = p.sum(dim=-1, keepdim=True)
+            outs.append(torch.einsum("bhqk,bkhd->bqhd", p / l.clamp_min(1e-300), vv).float())
+            lses.append(torch.where(l[..., 0] > 0, m[..., 0] + torch.log(l[..., 0].clamp_min(1e-300)),
+                                    torch.full_like(l[..., 0], float("-inf"))).float())
+        return torch.stack(outs), torch.stack(lses)
+
+    @staticmethod
+    def combine(o_parts, lse_parts, *, want_bf16=True, **_):
+        l = lse_parts.double()
+        mx = l.amax(dim=0)
+        w = torch.where(torch.isfinite(l), torch.exp(l - torch.where(torch.isfinite(mx), mx, torch.zeros_like(mx))),
+                        torch.zeros_like(l))
+        den = w.sum(dim=0)
+        wq = (w / den.clamp_min(1e-300)).permute(0, 1, 3, 2)[..., None]       # P,B,Sq,H,1
+        out = (o_parts.double() * wq).sum(dim=0)
+        lse = torch.where(den > 0, mx + torch.log(den.clamp_min(1e-300)), torch.full_like(den, float("-inf")))
+        return (out.to(torch.bfloat16) if want_bf16 else out.float()), lse.float()
+
+    @staticmethod
+    def cache_write(cache, src, *, dst_row0, src_row0=0, nrows=None):
+        if nrows is None:
+            nrows = src.shape[1] - src_row0
+        cache[:, dst_row0:dst_row0 + nrows] = src[:, src_row0:src_row0 + nrows]
+        return cache
