@@ -112,14 +112,24 @@ LWM_DEVICE void dq_tile(const AttnParams& p, const DqCtx& cx, const bf16x8 (&qf)
     constexpr uint32_t VB = (2 + BUF) * kDqTileBytes;
 
     f32x16 st = zero_f32x16(), dpt = zero_f32x16();
+    // fragment bases re-derived per tile (XOR form, see attn_common.h) and operand
+    // fragments requested kRing-1 steps ahead through a register ring, pinned by
+    // sched_fence (see dkv_tile)
+    const uint32_t ka0 = opaque(cx.ka.a[0]);
+    const uint32_t lo0 = opaque(cx.kta.lo[0]), up0 = opaque(cx.kta.up[0]);
+    constexpr int kRing = 3;
+    bf16x8 fa[kRing];
+    auto load1 = [&](int g) { fa[g % kRing] = lds_read_b128(row_frag_at(ka0, g & 7) + (g < 8 ? KB : VB)); };
     prio_hi();
-    for (int s = 0; s < 8; ++s) {
-        bf16x8 a = lds_read_b128(cx.ka.a[s] + KB);
-        st = mfma_32x32x16(a, qf[s], st);
-    }
-    for (int s = 0; s < 8; ++s) {
-        bf16x8 a = lds_read_b128(cx.ka.a[s] + VB);
-        dpt = mfma_32x32x16(a, dof[s], dpt);
+#pragma unroll
+    for (int g = 0; g < kRing - 1; ++g) load1(g);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        if (g + kRing - 1 < 16) load1(g + kRing - 1);
+        sched_fence();
+        if (g < 8) st = mfma_32x32x16(fa[g % kRing], qf[g], st);
+        else dpt = mfma_32x32x16(fa[g % kRing], dof[g - 8], dpt);
+        sched_fence();
     }
     prio_lo();
     const bool need_mask = cx.has_kmeta || (p.causal && k_pos0 + kDqBK - 1 > cx.wq_min);
@@ -142,13 +152,19 @@ LWM_DEVICE void dq_tile(const AttnParams& p, const DqCtx& cx, const bf16x8 (&qf)
         }
     }
     for (int r = 0; r < 16; ++r) st[r] = st[r] * (dpt[r] - cx.dlt);  // dS^T (unscaled)
+    bf16x8 dsb[2];
+    for (int t = 0; t < 2; ++t) dsb[t] = cvt_frag(st, 8 * t);
+    bf16x8 ft[kRing];
+    auto load_tr = [&](int h) { ft[h % kRing] = read_tr_frag_x(lo0, up0, h & 3, KB + 16 * (h >> 2) * kRowBytes); };
     prio_hi();
-    for (int t = 0; t < 2; ++t) {
-        bf16x8 dsb = cvt_frag(st, 8 * t);
-        for (int db = 0; db < 4; ++db) {
-            bf16x8 a = read_tr_frag(cx.kta, db, KB + 16 * t * kRowBytes);
-            acc[db] = mfma_32x32x16(a, dsb, acc[db]);
-        }
+#pragma unroll
+    for (int h = 0; h < kRing - 1; ++h) load_tr(h);
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+        if (h + kRing - 1 < 8) load_tr(h + kRing - 1);
+        sched_fence();
+        acc[h & 3] = mfma_32x32x16(ft[h % kRing], dsb[h >> 2], acc[h & 3]);
+        sched_fence();
     }
     prio_lo();
 }
@@ -313,19 +329,25 @@ struct DkvCtx {
 // applied to the SOURCE column: lane l writes physical slot l&15 of row
 // 4*piece + (l>>4) and therefore fetches logical slot (l&15) ^ swz(row).  Each
 // instruction still covers 4 whole 256-B rows of global memory.
-template <int NW, int NKB, int BUF>
+// SKEW: the DMA is issued by the second-dispatched half of the workgroup (waves
+// NW/2..NW-1, two pieces each) and the row statistics by wave NW/2.
+template <int NW, int NKB, int BUF, bool SKEW = false>
 LWM_DEVICE void dkv_stage_issue(const AttnParams& p, const DkvCtx<NKB>& cx, const bf16_t* qb,
                                 const bf16_t* dob, int b, int h, int qt, DkvStage& st) {
-    if (cx.tid < kDkvBQ) {
-        int qr = qt * kDkvBQ + cx.tid;
+    constexpr int T0 = SKEW ? NW * 32 : 0;          // first thread of the statistics loader
+    constexpr int NI = SKEW ? NW / 2 : NW;          // issuing waves
+    if (cx.tid >= T0 && cx.tid < T0 + kDkvBQ) {
+        const int tl = cx.tid - T0;
+        int qr = qt * kDkvBQ + tl;
         int qc = qr < p.Sq ? qr : p.Sq - 1;
         int64_t idx = ((int64_t)b * p.H + h) * p.Sq + qc;
         st.lse2 = p.lse[idx];
         st.delta = p.delta[idx];
         st.segq = p.seg_q ? p.seg_q[(int64_t)b * p.Sq + qc] : 0;
     }
-    for (int j = 0; j < 8 / NW; ++j) {
-        const int piece = cx.wave + NW * j;
+    if (SKEW && cx.wave < NW / 2) return;
+    for (int j = 0; j < 8 / NI; ++j) {
+        const int piece = (SKEW ? cx.wave - NW / 2 : cx.wave) + NI * j;
         const int r = 4 * piece + cx.lane_row;
         int qrow = qt * kDkvBQ + r;
         // rows past Sq re-read the last row; their lse2 is +inf so p = 0
@@ -337,10 +359,10 @@ LWM_DEVICE void dkv_stage_issue(const AttnParams& p, const DkvCtx<NKB>& cx, cons
     }
 }
 
-template <int NKB, int BUF>
+template <int NKB, int BUF, int T0 = 0>
 LWM_DEVICE void dkv_stage_finish(const DkvCtx<NKB>& cx, const DkvStage& st, int qt, int Sq) {
-    if (cx.tid < kDkvBQ) {
-        const bool ok = (qt * kDkvBQ + cx.tid < Sq) && st.lse2 != -INFINITY;
+    if (cx.tid >= T0 && cx.tid < T0 + kDkvBQ) {
+        const bool ok = (qt * kDkvBQ + (cx.tid - T0) < Sq) && st.lse2 != -INFINITY;
         lds_write_f32(cx.stat_w + BUF * kDkvStatBytes, ok ? st.lse2 * kLog2e : INFINITY);
         lds_write_f32(cx.stat_w + BUF * kDkvStatBytes + kDkvBQ * 4, st.delta);
         lds_write_i32(cx.stat_w + BUF * kDkvStatBytes + 2 * kDkvBQ * 4, st.segq);
@@ -362,17 +384,37 @@ LWM_DEVICE void dkv_tile(const AttnParams& p, const DkvCtx<NKB>& cx, const bf16x
         s[kb] = zero_f32x16();
         dp[kb] = zero_f32x16();
     }
-    prio_hi();
-    for (int st = 0; st < 8; ++st) {
-        bf16x8 a = lds_read_b128(cx.qa.a[st] + QB);
-        for (int kb = 0; kb < NKB; ++kb) s[kb] = mfma_32x32x16(a, kf[kb][st], s[kb]);
-    }
-    for (int st = 0; st < 8; ++st) {
-        bf16x8 a = lds_read_b128(cx.qa.a[st] + DB);
-        for (int kb = 0; kb < NKB; ++kb) {
-            bf16x8 vfr = lds_read_b128(cx.va.a[st] + kb * 32 * kRowBytes);
-            dp[kb] = mfma_32x32x16(a, vfr, dp[kb]);
+    // per-tile opaque copies of the fragment bases: the XOR-derived addresses are
+    // recomputed here instead of living in 24 registers across the whole launch
+    const uint32_t qa0 = opaque(cx.qa.a[0]), va0 = opaque(cx.va.a[0]);
+    const uint32_t lo0 = opaque(cx.qta.lo[0]), up0 = opaque(cx.qta.up[0]);
+    // S and dP: 16 steps (8 k-steps each); operand fragments go through a register
+    // ring and are requested kRing1-1 steps ahead, pinned by sched_fence (hipcc sinks
+    // every ds_read next to its use otherwise and the wave eats the LDS latency of
+    // each step).  pb/dsb are dead here, which pays for the ring.
+    constexpr int kRing1 = 3;
+    bf16x8 fa[kRing1], fv[kRing1][NKB];
+    auto load1 = [&](int g) {
+        if (g < 8) {
+            fa[g % kRing1] = lds_read_b128(row_frag_at(qa0, g) + QB);
+        } else {
+            fa[g % kRing1] = lds_read_b128(row_frag_at(qa0, g - 8) + DB);
+            for (int kb = 0; kb < NKB; ++kb)
+                fv[g % kRing1][kb] = lds_read_b128(row_frag_at(va0, g - 8) + kb * 32 * kRowBytes);
         }
+    };
+    prio_hi();
+#pragma unroll
+    for (int g = 0; g < kRing1 - 1; ++g) load1(g);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        if (g + kRing1 - 1 < 16) load1(g + kRing1 - 1);
+        sched_fence();
+        if (g < 8)
+            for (int kb = 0; kb < NKB; ++kb) s[kb] = mfma_32x32x16(fa[g % kRing1], kf[kb][g], s[kb]);
+        else
+            for (int kb = 0; kb < NKB; ++kb) dp[kb] = mfma_32x32x16(fa[g % kRing1], fv[g % kRing1][kb], dp[kb]);
+        sched_fence();
     }
     prio_lo();
     const bool need_mask = cx.has_meta || (p.causal && q_pos0 < cx.wk_max);
@@ -410,23 +452,41 @@ LWM_DEVICE void dkv_tile(const AttnParams& p, const DkvCtx<NKB>& cx, const bf16x
             pb[kb][t] = cvt_frag(s[kb], 8 * t);
             dsb[kb][t] = cvt_frag(dp[kb], 8 * t);
         }
+    // dV += P^T dO, dK += dS^T Q: 16 steps, each one transposed fragment (2 LDS
+    // reads) and NKB MFMAs.  The fragments go through a ring of kRing registers and
+    // are requested kRing-1 steps ahead (s and dp are dead here, so the ring is free).
+    constexpr int kRing = 3;
+    bf16x8 ft[kRing];
+    auto load_tr = [&](int h) {
+        const int t = (h & 7) >> 2, db = h & 3;
+        ft[h % kRing] = read_tr_frag_x(lo0, up0, db, (h < 8 ? DB : QB) + 16 * t * kRowBytes);
+    };
     prio_hi();
-    for (int t = 0; t < 2; ++t)
-        for (int db = 0; db < 4; ++db) {
-            bf16x8 a = read_tr_frag(cx.qta, db, DB + 16 * t * kRowBytes);
-            for (int kb = 0; kb < NKB; ++kb) dv[kb][db] = mfma_32x32x16(a, pb[kb][t], dv[kb][db]);
-        }
-    for (int t = 0; t < 2; ++t)
-        for (int db = 0; db < 4; ++db) {
-            bf16x8 a = read_tr_frag(cx.qta, db, QB + 16 * t * kRowBytes);
-            for (int kb = 0; kb < NKB; ++kb) dk[kb][db] = mfma_32x32x16(a, dsb[kb][t], dk[kb][db]);
-        }
+#pragma unroll
+    for (int h = 0; h < kRing - 1; ++h) load_tr(h);
+#pragma unroll
+    for (int h = 0; h < 16; ++h) {
+        if (h + kRing - 1 < 16) load_tr(h + kRing - 1);
+        sched_fence();   // hipcc otherwise sinks the request next to its use (one live fragment)
+        const int t = (h & 7) >> 2, db = h & 3;
+        if (h < 8)
+            for (int kb = 0; kb < NKB; ++kb) dv[kb][db] = mfma_32x32x16(ft[h % kRing], pb[kb][t], dv[kb][db]);
+        else
+            for (int kb = 0; kb < NKB; ++kb) dk[kb][db] = mfma_32x32x16(ft[h % kRing], dsb[kb][t], dk[kb][db]);
+        sched_fence();
+    }
     prio_lo();
 }
 
-template <int NW, int NKB>
+// SKEW >= 0: the second-dispatched half of the workgroup (the partner wave on every
+// SIMD) starts each tile late -- it alone issues the next tile's DMA and statistics
+// loads and then parks for SKEW*64 more cycles -- so that the two waves of a SIMD
+// are not in the same phase (matrix | VALU-only softmax | matrix) at the same time.
+template <int NW, int NKB, int SKEW = -1>
 LWM_DEVICE void attn_bwd_dkdv_body(const AttnParams& p) {
     static_assert(NW * NKB * 32 == kDkvBK, "workgroup covers 256 keys");
+    constexpr bool SK = SKEW >= 0;
+    constexpr int T0 = SK ? NW * 32 : 0;
     constexpr int NT = NW * 64;
     const lds_t lds = dyn_lds();
     const int tid = thread_idx();
@@ -483,7 +543,7 @@ LWM_DEVICE void attn_bwd_dkdv_body(const AttnParams& p) {
     cx.wave = wave_uniform(wave);
     cx.lane_row = lane >> 4;
     cx.lane_slot = lane & 15;
-    cx.stat_w = stats + tid * 4;
+    cx.stat_w = stats + (tid - T0) * 4;
     cx.stat_r = stats + 16 * hi;
     cx.has_meta =
         (p.seg_k != nullptr) || (p.key_valid != nullptr) || (kbi * kDkvBK + kDkvBK > p.Sk);
@@ -519,22 +579,25 @@ LWM_DEVICE void attn_bwd_dkdv_body(const AttnParams& p) {
     // (pipeline under `qt0 < nqt`: see attn_fwd_kernel)
     if (qt0 < nqt) {
         DkvStage stg;
-        dkv_stage_issue<NW, NKB, 0>(p, cx, qb, dob, b, h, qt0, stg);
-        dkv_stage_finish<NKB, 0>(cx, stg, qt0, p.Sq);
+        dkv_stage_issue<NW, NKB, 0, SK>(p, cx, qb, dob, b, h, qt0, stg);
+        dkv_stage_finish<NKB, 0, T0>(cx, stg, qt0, p.Sq);
         glds_wait_all();
         block_sync();
+        const bool late = SK && wave_uniform(wave >= NW / 2 ? 1 : 0) != 0;
         for (int qt = qt0; qt < nqt; qt += 2) {
             const bool more1 = qt + 1 < nqt;
-            if (more1) dkv_stage_issue<NW, NKB, 1>(p, cx, qb, dob, b, h, qt + 1, stg);
+            if (more1) dkv_stage_issue<NW, NKB, 1, SK>(p, cx, qb, dob, b, h, qt + 1, stg);
+            if constexpr (SKEW > 0) { if (late) sleep_cycles64<SKEW>(); }
             dkv_tile<NKB, 0>(p, cx, kf, qt, dk, dv);
-            if (more1) dkv_stage_finish<NKB, 1>(cx, stg, qt + 1, p.Sq);
+            if (more1) dkv_stage_finish<NKB, 1, T0>(cx, stg, qt + 1, p.Sq);
             glds_wait_all();
             block_sync();
             if (!more1) break;
             const bool more2 = qt + 2 < nqt;
-            if (more2) dkv_stage_issue<NW, NKB, 0>(p, cx, qb, dob, b, h, qt + 2, stg);
+            if (more2) dkv_stage_issue<NW, NKB, 0, SK>(p, cx, qb, dob, b, h, qt + 2, stg);
+            if constexpr (SKEW > 0) { if (late) sleep_cycles64<SKEW>(); }
             dkv_tile<NKB, 1>(p, cx, kf, qt + 1, dk, dv);
-            if (more2) dkv_stage_finish<NKB, 0>(cx, stg, qt + 2, p.Sq);
+            if (more2) dkv_stage_finish<NKB, 0, T0>(cx, stg, qt + 2, p.Sq);
             glds_wait_all();
             block_sync();
         }
@@ -579,6 +642,10 @@ LWM_DEVICE void attn_bwd_dkdv_body(const AttnParams& p) {
 }
 
 LWM_KERNEL(512) void attn_bwd_dkdv_kernel_w8(AttnParams p) { attn_bwd_dkdv_body<8, 1>(p); }
+LWM_KERNEL(512) void attn_bwd_dkdv_kernel_sk0(AttnParams p) { attn_bwd_dkdv_body<8, 1, 0>(p); }
+LWM_KERNEL(512) void attn_bwd_dkdv_kernel_sk4(AttnParams p) { attn_bwd_dkdv_body<8, 1, 4>(p); }
+LWM_KERNEL(512) void attn_bwd_dkdv_kernel_sk8(AttnParams p) { attn_bwd_dkdv_body<8, 1, 8>(p); }
+LWM_KERNEL(512) void attn_bwd_dkdv_kernel_sk12(AttnParams p) { attn_bwd_dkdv_body<8, 1, 12>(p); }
 LWM_KERNEL(256) void attn_bwd_dkdv_kernel_w4(AttnParams p) { attn_bwd_dkdv_body<4, 2>(p); }
 
 }  // namespace lwm

@@ -90,6 +90,20 @@ LWM_DEVICE RowFragAddr frag_rows_addr(lds_t base, int row_in_16x, int l31, int h
     return r;
 }
 
+// Compact form: k-step s of a row fragment differs from step 0 only in address
+// bits 5..7 (tile bases are 256-byte aligned, so the swizzled slot is an XOR on
+// the low byte): a[s] == a[0] ^ (s << 5); likewise lo/up[db] == lo/up[0] ^ (db << 6).
+// One register + one v_xor per read instead of 8 registers per fragment family.
+LWM_DEVICE uint32_t row_frag_at(uint32_t a0, int s) { return a0 ^ (uint32_t)(s << 5); }
+LWM_DEVICE bf16x8 read_tr_frag_x(uint32_t lo0, uint32_t up0, int db, uint32_t const_off) {
+    bf16x4 lo = lds_read_tr16((lo0 ^ (uint32_t)(db << 6)) + const_off);
+    bf16x4 up = lds_read_tr16((up0 ^ (uint32_t)(db << 6)) + const_off);
+    bf16x8 o;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+    o[4] = up[0]; o[5] = up[1]; o[6] = up[2]; o[7] = up[3];
+    return o;
+}
+
 // Transposed fragment (2 x ds_read_b64_tr_b16): the operand's non-contracted
 // index is d, the contracted index is the tile row.  Lane l (d = 32*db + (l&31))
 // gets, for j = 0..7, tile[row0 + 4*(l>>5) + (j&3) + 8*(j>>2)][d] -- exactly the

@@ -98,14 +98,29 @@ LWM_DEVICE void fwd_tile(const AttnParams& p, const FwdCtx& cx, const bf16x8 (&q
     constexpr uint32_t VB = BUF * kFwdTileBytes;  // va already points at V tile 0
 
     // ---- S^T = K Q^T  (rows = keys, cols = queries)
+    // Fragment bases are re-derived per tile (XOR form, attn_common.h) and the K / V
+    // fragments are requested kRing-1 steps ahead through a register ring, pinned by
+    // sched_fence: hipcc otherwise sinks each ds_read next to its MFMA and the wave
+    // pays the LDS latency at every step.
+    const uint32_t ka0 = opaque(cx.ka.a[0]);
+    const uint32_t lo0 = opaque(cx.va.lo[0]), up0 = opaque(cx.va.up[0]);
+    constexpr int kRing = 3;
     f32x16 st[2];
+    st[0] = zero_f32x16();
+    st[1] = zero_f32x16();
+    bf16x8 fa[kRing];
+    auto load1 = [&](int g) {
+        fa[g % kRing] = lds_read_b128(row_frag_at(ka0, g & 7) + KB + (g >> 3) * 32 * kRowBytes);
+    };
     prio_hi();
-    for (int kb2 = 0; kb2 < 2; ++kb2) {
-        st[kb2] = zero_f32x16();
-        for (int s = 0; s < 8; ++s) {
-            bf16x8 a = lds_read_b128(cx.ka.a[s] + KB + kb2 * 32 * kRowBytes);
-            st[kb2] = mfma_32x32x16(a, qf[s], st[kb2]);
-        }
+#pragma unroll
+    for (int g = 0; g < kRing - 1; ++g) load1(g);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        if (g + kRing - 1 < 16) load1(g + kRing - 1);
+        sched_fence();
+        st[g >> 3] = mfma_32x32x16(fa[g % kRing], qf[g & 7], st[g >> 3]);
+        sched_fence();
     }
     prio_lo();
     // ---- masks (lwm/llama.py:572-592): causal, same segment, key valid
@@ -162,13 +177,20 @@ LWM_DEVICE void fwd_tile(const AttnParams& p, const FwdCtx& cx, const bf16x8 (&q
     bf16x8 pb[2][2];
     for (int kb2 = 0; kb2 < 2; ++kb2)
         for (int t = 0; t < 2; ++t) pb[kb2][t] = cvt_frag(st[kb2], 8 * t);
+    bf16x8 ft[kRing];
+    auto load_tr = [&](int h) {   // h = (kb2, t, db)
+        ft[h % kRing] = read_tr_frag_x(lo0, up0, h & 3, VB + 16 * (h >> 2) * kRowBytes);
+    };
     prio_hi();
-    for (int kb2 = 0; kb2 < 2; ++kb2)
-        for (int t = 0; t < 2; ++t)
-            for (int db = 0; db < 4; ++db) {
-                bf16x8 a = read_tr_frag(cx.va, db, VB + (32 * kb2 + 16 * t) * kRowBytes);
-                acc[db] = mfma_32x32x16(a, pb[kb2][t], acc[db]);
-            }
+#pragma unroll
+    for (int h = 0; h < kRing - 1; ++h) load_tr(h);
+#pragma unroll
+    for (int h = 0; h < 16; ++h) {
+        if (h + kRing - 1 < 16) load_tr(h + kRing - 1);
+        sched_fence();
+        acc[h & 3] = mfma_32x32x16(ft[h % kRing], pb[h >> 3][(h >> 2) & 1], acc[h & 3]);
+        sched_fence();
+    }
     prio_lo();
 }
 

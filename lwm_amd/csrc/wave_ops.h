@@ -110,6 +110,26 @@ LWM_DEVICE void glds_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"
 // Make a value that IS the same in every lane provably uniform (SGPR).
 LWM_DEVICE int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
+// Make a value opaque to the optimiser at this point (no instruction is emitted):
+// address arithmetic derived from it cannot be hoisted out of the enclosing loop
+// (hipcc hoists such loop invariants and then spills them under register pressure).
+LWM_DEVICE uint32_t opaque(uint32_t x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+// Scheduler hint (LLVM sched_group_barrier): emit n_mfma MFMAs, then n_ds LDS reads,
+// at this point of the instruction stream.  Repeating it N times over a region that
+// holds N*n_mfma MFMAs and N*n_ds independent ds_reads yields the interleave
+// "MFMA, reads for a LATER step, MFMA, ..." -- i.e. software-pipelined fragment
+// loads -- without pinning anything else.
+template <int N_MFMA, int N_DS>
+LWM_DEVICE void sched_mfma_dsread() {
+    __builtin_amdgcn_sched_group_barrier(0x008, N_MFMA, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, N_DS, 0);
+}
+// s_sleep: park this wave for ~64*n cycles (n a compile-time constant 1..127).
+template <int N>
+LWM_DEVICE void sleep_cycles64() { __builtin_amdgcn_s_sleep(N); }
 // Scheduling fence: the compiler may not move instructions across it.
 LWM_DEVICE void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // Raise/lower this wave's issue priority around an MFMA cluster (T5).

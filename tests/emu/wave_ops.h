@@ -281,6 +281,11 @@ LWM_DEVICE void glds_load_b128(const void* g, lds_t wave_base) {
 LWM_DEVICE void glds_wait_all() {}
 LWM_DEVICE int wave_uniform(int x) { return x; }
 LWM_DEVICE void sched_fence() {}
+template <int A, int B>
+LWM_DEVICE void sched_mfma_dsread() {}
+template <int N>
+LWM_DEVICE void sleep_cycles64() {}
+LWM_DEVICE uint32_t opaque(uint32_t x) { return x; }
 LWM_DEVICE void prio_hi() {}
 LWM_DEVICE void prio_lo() {}
 
