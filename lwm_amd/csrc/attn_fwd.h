@@ -104,7 +104,7 @@ LWM_DEVICE void fwd_tile(const AttnParams& p, const FwdCtx& cx, const bf16x8 (&q
     // pays the LDS latency at every step.
     const uint32_t ka0 = opaque(cx.ka.a[0]);
     const uint32_t lo0 = opaque(cx.va.lo[0]), up0 = opaque(cx.va.up[0]);
-    constexpr int kRing = 3;
+    constexpr int kRing = 4;
     f32x16 st[2];
     st[0] = zero_f32x16();
     st[1] = zero_f32x16();

@@ -67,7 +67,11 @@ LWM_DEVICE f32x4 zero_f32x4() {
     return z;
 }
 
-template <int WM, int WN, int MB, int NB>
+// VEC: Cin % 4 == 0 and Cout % 4 == 0 (every layer but conv_in / the RGB output
+// conv): all staging loads are 16-byte and NOTHING in the staging path branches
+// at run time -- a load behind a runtime branch, even a uniform one, makes hipcc
+// wait vmcnt(0) before the next load (measured: 4.3k cycles per chunk).
+template <int WM, int WN, int MB, int NB, bool VEC>
 LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
     using Cfg = ConvCfg<WM, WN, MB, NB>;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, AP = Cfg::AP, BP = Cfg::BP;
@@ -106,60 +110,82 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
     const int b_col = (tid % (BN / 4)) * 4;
     const lds_t b_w = lds + Cfg::A_BYTES + (uint32_t)(b_row * BN + b_col) * 4;
     const int Hv = p.Hin << p.up_shift, Wv = p.Win << p.up_shift;
-    const bool cin_vec = (p.Cin & 3) == 0;
-    const bool cout_vec = (p.Cout & 3) == 0;
+    constexpr bool cin_vec = VEC, cout_vec = VEC;
 
     const int nch = (p.Cin + kConvKC - 1) / kConvKC;
     const int ntap = p.KH * p.KW;
     const int nit = ntap * nch;
 
     f32x4 sa[AP], sb[BP];
+    uint32_t s_ok = 0;  // bit ps: sa[ps] valid; bit 8+ps: sb[ps] valid (else the tile gets zeros)
 
-    auto stage_load = [&](int it) {
-        const int tap = it / nch, ch = it - tap * nch;
-        const int kh = tap / p.KW, kw = tap - kh * p.KW;
-        const int c0 = ch * kConvKC + a_slot * 4;
-        for (int ps = 0; ps < AP; ++ps) {
-            f32x4 v = zero_f32x4();
-            const int vy = a_oy[ps] + kh, vx = a_ox[ps] + kw;
-            if (a_base[ps] >= 0 && vy >= 0 && vy < Hv && vx >= 0 && vx < Wv && c0 < p.Cin) {
-                const float* src = p.x + a_base[ps] +
-                                   ((int64_t)(vy >> p.up_shift) * p.Win + (vx >> p.up_shift)) * p.Cin + c0;
-                if (cin_vec) {
-                    v = global_load_f32x4(src);
-                } else {
-                    for (int j = 0; j < 4; ++j)
-                        if (c0 + j < p.Cin) v[j] = src[j];
-                }
+    // Loads are UNCONDITIONAL (out-of-image taps / channels read a clamped, valid
+    // address) and the zero fill is a select at write time: a load behind a runtime
+    // branch makes hipcc wait vmcnt(0) at every join, which serialised the eight
+    // staging loads of a chunk (4.3k cycles per chunk, measured).
+    // One staging load (index l: 0..AP-1 = A passes, AP..AP+BP-1 = B passes) of chunk `it`.
+    // Measured alternatives: issuing them one per k-quad inside the MFMA loop
+    // instead of as a burst, or delaying co-resident workgroups against each other, do not
+    // help; without any staging the loop runs 125 TF/s, with it 100 TF/s.
+    int ld_kh = 0, ld_kw = 0, ld_ch = 0, ld_tap = 0;
+    auto stage_begin = [&](int it) {
+        ld_tap = it / nch;
+        ld_ch = it - ld_tap * nch;
+        ld_kh = ld_tap / p.KW;
+        ld_kw = ld_tap - ld_kh * p.KW;
+        s_ok = 0;
+    };
+    auto stage_load_one = [&](int l) {
+        if (l < AP) {
+            const int ps = l;
+            const int c0 = ld_ch * kConvKC + a_slot * 4;
+            const int vy = a_oy[ps] + ld_kh, vx = a_ox[ps] + ld_kw;
+            const bool ok = a_base[ps] >= 0 && vy >= 0 && vy < Hv && vx >= 0 && vx < Wv && c0 < p.Cin;
+            const int64_t off = ok ? a_base[ps] + ((int64_t)(vy >> p.up_shift) * p.Win + (vx >> p.up_shift)) * p.Cin + c0
+                                   : (int64_t)0;
+            const float* src = p.x + off;
+            if constexpr (cin_vec) {
+                sa[ps] = global_load_f32x4(src);
+            } else {  // Cin % 4 != 0 (conv_in): element loads, clamped inside the row
+                f32x4 v;
+                for (int j = 0; j < 4; ++j) v[j] = src[(ok && c0 + j < p.Cin) ? j : 0];
+                for (int j = 0; j < 4; ++j) v[j] = (c0 + j < p.Cin) ? v[j] : 0.0f;
+                sa[ps] = v;
             }
-            sa[ps] = v;
-        }
-        const float* wt = p.w + (int64_t)tap * p.Cin * p.Cout;
-        for (int ps = 0; ps < BP; ++ps) {
-            f32x4 v = zero_f32x4();
-            const int k = ch * kConvKC + ps * Cfg::BROWS + b_row;
+            s_ok |= ok ? (1u << ps) : 0u;
+        } else {
+            const int ps = l - AP;
+            const float* wt = p.w + (int64_t)ld_tap * p.Cin * p.Cout;
+            const int k = ld_ch * kConvKC + ps * Cfg::BROWS + b_row;
             const int col = n0 + b_col;
-            if (k < p.Cin && col < p.Cout) {
-                const float* src = wt + (int64_t)k * p.Cout + col;
-                if (cout_vec) {
-                    v = global_load_f32x4(src);
-                } else {
-                    for (int j = 0; j < 4; ++j)
-                        if (col + j < p.Cout) v[j] = src[j];
-                }
+            const bool ok = k < p.Cin && col < p.Cout;
+            const float* src = wt + (ok ? (int64_t)k * p.Cout + col : (int64_t)0);
+            if constexpr (cout_vec) {
+                sb[ps] = global_load_f32x4(src);
+            } else {
+                f32x4 v;
+                for (int j = 0; j < 4; ++j) v[j] = src[(ok && col + j < p.Cout) ? j : 0];
+                for (int j = 0; j < 4; ++j) v[j] = (col + j < p.Cout) ? v[j] : 0.0f;
+                sb[ps] = v;
             }
-            sb[ps] = v;
+            s_ok |= ok ? (1u << (8 + ps)) : 0u;
         }
+    };
+    auto stage_load = [&](int it) {
+        stage_begin(it);
+#pragma unroll
+        for (int l = 0; l < AP + BP; ++l) stage_load_one(l);
     };
     auto stage_write = [&](int buf) {
         const uint32_t bo = (uint32_t)buf * Cfg::BUF_BYTES;
         for (int ps = 0; ps < AP; ++ps) {
             const int px = ps * Cfg::APX + (tid >> 3);
             lds_write_f32x4(a_w + bo + (uint32_t)ps * Cfg::APX * 128 + ((a_slot ^ ((px >> 1) & 7)) << 4),
-                           sa[ps]);
+                            (s_ok >> ps) & 1 ? sa[ps] : zero_f32x4());
         }
         for (int ps = 0; ps < BP; ++ps)
-            lds_write_f32x4(b_w + bo + (uint32_t)ps * Cfg::BROWS * BN * 4, sb[ps]);
+            lds_write_f32x4(b_w + bo + (uint32_t)ps * Cfg::BROWS * BN * 4,
+                            (s_ok >> (8 + ps)) & 1 ? sb[ps] : zero_f32x4());
     };
 
     f32x16 acc[MB][NB], acc_tap[MB][NB];
@@ -241,9 +267,13 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
         }
 }
 
-LWM_KERNEL_OCC(256, 2) void conv_igemm_128x128(ConvParams p) { conv_igemm_body<2, 2, 2, 2>(p); }
-LWM_KERNEL(256) void conv_igemm_128x64(ConvParams p) { conv_igemm_body<4, 1, 1, 2>(p); }
-LWM_KERNEL(256) void conv_igemm_128x32(ConvParams p) { conv_igemm_body<4, 1, 1, 1>(p); }
-LWM_KERNEL(256) void conv_igemm_32x128(ConvParams p) { conv_igemm_body<1, 4, 1, 1>(p); }
+LWM_KERNEL_OCC(256, 2) void conv_igemm_128x128(ConvParams p) { conv_igemm_body<2, 2, 2, 2, true>(p); }
+LWM_KERNEL(256) void conv_igemm_128x64(ConvParams p) { conv_igemm_body<4, 1, 1, 2, true>(p); }
+LWM_KERNEL(256) void conv_igemm_32x128(ConvParams p) { conv_igemm_body<1, 4, 1, 1, true>(p); }
+// generic (scalar staging) forms: Cin or Cout not a multiple of 4
+LWM_KERNEL_OCC(256, 2) void conv_igemm_128x128_g(ConvParams p) { conv_igemm_body<2, 2, 2, 2, false>(p); }
+LWM_KERNEL(256) void conv_igemm_128x64_g(ConvParams p) { conv_igemm_body<4, 1, 1, 2, false>(p); }
+LWM_KERNEL(256) void conv_igemm_128x32_g(ConvParams p) { conv_igemm_body<4, 1, 1, 1, false>(p); }
+LWM_KERNEL(256) void conv_igemm_32x128_g(ConvParams p) { conv_igemm_body<1, 4, 1, 1, false>(p); }
 
 }  // namespace lwm
