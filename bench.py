@@ -170,7 +170,7 @@ def decode_leg(torch, K=131072):
     return {"workload": f"decode attention step, Q=1, cache K={K}, 32 heads x 128, bf16, k_splits={ns}",
             "us_per_layer_step": t * 1e6,
             "roofline": {"bound": "hbm", "unit": "GB/s", "achieved": nbytes / t / 1e9, "peak": 8000.0,
-                         "frac": nbytes / t / 1e9 / 8000.0, "kernel": "attn_fwd_infer_kernel + attn_combine_kernel"}}
+                         "frac": nbytes / t / 1e9 / 8000.0, "kernel": "attn_decode_kernel + attn_combine_kernel"}}
 
 
 class KernelTimer:

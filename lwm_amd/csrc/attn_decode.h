@@ -1,0 +1,114 @@
+// attn_decode.h -- cached-decode attention (one query per batch row) as a streaming
+// GEMV over the K/V cache.  Requires wave_ops.h + attn_common.h.
+//
+// Replaces ringattention_inference for q_len == 1 (lwm/llama.py:571-614: the decode
+// step reads the whole (B, max_len/sp, H, D) cache shard once).  HBM-bound: the
+// algorithmic traffic is the K and V shards read once, 2*Sk*H*D*2 bytes.
+//
+// The cache layout is the reference's (B, S, H, D): for one key ALL heads are
+// contiguous (H*256 B), so a workgroup streams whole key rows -- every wave load is
+// 1 KiB contiguous -- instead of striding through one head.  Workgroup = 8 waves; a
+// 16-lane group owns one head (lane i holds d = 8i..8i+7 of q, of the running output
+// and of each K/V row), a wave 4 heads, the workgroup 32 heads per pass.  The online
+// softmax state (m, l) is replicated in the 16 lanes of a group; scores are reduced
+// with 4 xor-shuffles.  Keys are processed 4 at a time (8 x 16-byte loads in flight
+// per lane).  Each workgroup handles one contiguous piece of the key range and
+// writes a normalised partial (out f32, lse) -- merged by attn_combine_kernel
+// exactly like the split-K pieces of the MFMA kernel.
+#pragma once
+
+namespace lwm {
+
+constexpr int kDecThreads = 512;
+constexpr int kDecUnroll = 4;
+
+LWM_DEVICE void unpack_bf16x8(u32x4 raw, float (&f)[8]) {
+    for (int j = 0; j < 4; ++j) {
+        f[2 * j] = __builtin_bit_cast(float, raw[j] << 16);
+        f[2 * j + 1] = __builtin_bit_cast(float, raw[j] & 0xffff0000u);
+    }
+}
+
+LWM_KERNEL(kDecThreads) void attn_decode_kernel(AttnParams p) {
+    const int tid = thread_idx();
+    const int grp = tid >> 4, li = tid & 15;       // 32 head slots per pass, 16 lanes each
+    const int nsplit = p.k_splits > 1 ? p.k_splits : 1;
+    const int b = block_idx_x() / nsplit, split = block_idx_x() % nsplit;
+    const int per = (p.Sk + nsplit - 1) / nsplit;
+    const int k0 = split * per;
+    const int k1 = k0 + per < p.Sk ? k0 + per : p.Sk;
+    const float c = p.scale * kLog2e;
+    const uint8_t* mrow = p.dense_mask ? p.dense_mask + (int64_t)b * p.msk_sb : nullptr;
+
+    for (int h0 = 0; h0 < p.H; h0 += 32) {
+        const int h = h0 + grp;
+        const bool h_ok = h < p.H;
+        const int hc = h_ok ? h : p.H - 1;         // clamped: loads stay in bounds
+        float qf[8], o[8];
+        unpack_bf16x8(global_load_b128(p.q + (int64_t)b * p.q_sb + (int64_t)hc * p.q_sh + li * 8), qf);
+        for (int j = 0; j < 8; ++j) {
+            qf[j] *= c;                            // scores directly in log2 units
+            o[j] = 0.0f;
+        }
+        float m = -INFINITY, l = 0.0f;
+        const bf16_t* kb = p.k + (int64_t)b * p.k_sb + (int64_t)hc * p.k_sh + li * 8;
+        const bf16_t* vb = p.v + (int64_t)b * p.v_sb + (int64_t)hc * p.v_sh + li * 8;
+        // Every piece starts at a different phase of its key range (softmax accumulation is
+        // order-free): pieces are a power-of-two number of bytes apart, and workgroups that
+        // walk them in lock step would otherwise camp on the same HBM channels.
+        const int nq = (k1 - k0 + kDecUnroll - 1) / kDecUnroll;   // groups of 4 keys
+        const int rot = nq > 0 ? (int)(((uint32_t)block_idx_x() * 2654435761u) >> 8) % nq : 0;
+        for (int g = 0; g < nq; ++g) {
+            const int gq = g + rot < nq ? g + rot : g + rot - nq;
+            const int j0 = k0 + gq * kDecUnroll;
+            u32x4 kr[kDecUnroll], vr[kDecUnroll];
+            bool vis[kDecUnroll];
+            for (int u = 0; u < kDecUnroll; ++u) {
+                const int j = j0 + u < k1 ? j0 + u : k1 - 1;
+                kr[u] = global_load_b128(kb + (int64_t)j * p.k_ss);
+                vr[u] = global_load_b128(vb + (int64_t)j * p.v_ss);
+                vis[u] = (j0 + u < k1) && (!mrow || mrow[j] != 0);
+            }
+            float s[kDecUnroll];
+            float mx = -INFINITY;
+            for (int u = 0; u < kDecUnroll; ++u) {
+                float kf[8];
+                unpack_bf16x8(kr[u], kf);
+                float a = 0.0f;
+                for (int j = 0; j < 8; ++j) a = fmaf(qf[j], kf[j], a);
+                a += shfl_xor_f(a, 1);
+                a += shfl_xor_f(a, 2);
+                a += shfl_xor_f(a, 4);
+                a += shfl_xor_f(a, 8);
+                s[u] = vis[u] ? a : -INFINITY;
+                mx = fmaxf(mx, s[u]);
+            }
+            const float m_new = fmaxf(m, mx);
+            const float m_safe = m_new == -INFINITY ? 0.0f : m_new;
+            const float alpha = fast_exp2(m - m_safe);
+            l *= alpha;
+            for (int j = 0; j < 8; ++j) o[j] *= alpha;
+            for (int u = 0; u < kDecUnroll; ++u) {
+                const float pu = fast_exp2(s[u] - m_safe);
+                l += pu;
+                float vf[8];
+                unpack_bf16x8(vr[u], vf);
+                for (int j = 0; j < 8; ++j) o[j] = fmaf(pu, vf[j], o[j]);
+            }
+            m = m_new;
+        }
+        if (h_ok) {
+            const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+            float* op = p.out_acc + (((int64_t)split * p.B + b) * p.H + h) * kHeadDim + li * 8;
+            f32x4 w0 = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
+            f32x4 w1 = {o[4] * inv, o[5] * inv, o[6] * inv, o[7] * inv};
+            global_store_f32x4(op, w0);
+            global_store_f32x4(op + 4, w1);
+            if (li == 0)   // m, l are in log2 units: lse = (m + log2 l) * ln 2
+                p.lse_acc[((int64_t)split * p.B + b) * p.H + h] =
+                    l > 0.0f ? (m + fast_log2(l)) * kLn2 : -INFINITY;
+        }
+    }
+}
+
+}  // namespace lwm

@@ -37,42 +37,66 @@ struct CombineParams {
     int32_t P, B, Sq, H, D;
 };
 
+// Workgroup = one (b, q, h) row: thread t owns d-quad t & 31 and partials
+// t >> 5, t >> 5 + 8, ... (8 subsets walked concurrently, each an online-softmax merge
+// in (m, l, acc) form), then the 8 subset states are merged through LDS.  A thread per
+// output element with a serial loop over P was latency-bound for decode (P ~ 1k pieces,
+// 1k threads in all).  D = 128.
 LWM_KERNEL(256) void attn_combine_kernel(CombineParams p) {
-    const int dq = p.D >> 2;
-    const int64_t total = (int64_t)p.B * p.Sq * p.H * dq;
+    const lds_t lds = dyn_lds();
+    const int tid = thread_idx();
+    const int dq = tid & 31, sub = tid >> 5;
     const int64_t part_o = (int64_t)p.B * p.Sq * p.H * p.D, part_l = (int64_t)p.B * p.H * p.Sq;
-    for (int64_t i = (int64_t)block_idx_x() * 256 + thread_idx(); i < total;
-         i += (int64_t)grid_dim_x() * 256) {
-        const int c = (int)(i % dq) * 4;
-        int64_t r = i / dq;
-        const int h = (int)(r % p.H);
-        r /= p.H;
-        const int q = (int)(r % p.Sq);
-        const int b = (int)(r / p.Sq);
+    for (int64_t row = block_idx_x(); row < (int64_t)p.B * p.Sq * p.H; row += grid_dim_x()) {
+        const int h = (int)(row % p.H);
+        const int q = (int)((row / p.H) % p.Sq);
+        const int b = (int)(row / ((int64_t)p.H * p.Sq));
         const int64_t li = ((int64_t)b * p.H + h) * p.Sq + q;
-        const int64_t oi = (((int64_t)b * p.Sq + q) * p.H + h) * p.D + c;
-        float mx = -INFINITY;
-        for (int s = 0; s < p.P; ++s) mx = fmaxf(mx, p.lse_parts[s * part_l + li]);
-        float den = 0.0f;
+        const int64_t oi = (((int64_t)b * p.Sq + q) * p.H + h) * p.D + dq * 4;
+        float m = -INFINITY, l = 0.0f;
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (mx != -INFINITY) {
-            for (int s = 0; s < p.P; ++s) {
-                const float l = p.lse_parts[s * part_l + li];
-                if (l == -INFINITY) continue;
-                const float w = expf(l - mx);
-                den += w;
-                f32x4 o = global_load_f32x4(p.o_parts + s * part_o + oi);
-                for (int j = 0; j < 4; ++j) acc[j] += w * o[j];
+        for (int s = sub; s < p.P; s += 8) {
+            const float ls = p.lse_parts[s * part_l + li];
+            if (ls == -INFINITY) continue;
+            f32x4 o = global_load_f32x4(p.o_parts + s * part_o + oi);
+            const float mn = fmaxf(m, ls);
+            const float wa = expf(m - mn), wb = expf(ls - mn);   // m = -inf: wa = 0
+            l = l * wa + wb;
+            for (int j = 0; j < 4; ++j) acc[j] = acc[j] * wa + o[j] * wb;
+            m = mn;
+        }
+        // merge the 8 subset states: [sub][dq] -> (m, l, acc[4]) = 24 B
+        const lds_t slot = lds + (uint32_t)(sub * 32 + dq) * 32;
+        lds_write_f32(slot, m);
+        lds_write_f32(slot + 4, l);
+        lds_write_f32x4(slot + 16, acc);
+        block_sync();
+        if (sub == 0) {
+            float mx = -INFINITY;
+            for (int s = 0; s < 8; ++s) mx = fmaxf(mx, lds_read_f32(lds + (uint32_t)(s * 32 + dq) * 32));
+            float den = 0.0f;
+            f32x4 r = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (mx != -INFINITY) {
+                for (int s = 0; s < 8; ++s) {
+                    const lds_t sl = lds + (uint32_t)(s * 32 + dq) * 32;
+                    const float ms = lds_read_f32(sl);
+                    if (ms == -INFINITY) continue;
+                    const float w = expf(ms - mx);
+                    den += w * lds_read_f32(sl + 4);
+                    f32x4 a = lds_read_f32x4(sl + 16);
+                    for (int j = 0; j < 4; ++j) r[j] += w * a[j];
+                }
+                const float inv = 1.0f / den;
+                for (int j = 0; j < 4; ++j) r[j] *= inv;
             }
-            const float inv = 1.0f / den;
-            for (int j = 0; j < 4; ++j) acc[j] *= inv;
+            if (p.out) {
+                u32x2 pk = {pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
+                global_store_b64(p.out + (int64_t)b * p.o_sb + (int64_t)q * p.o_ss + (int64_t)h * p.o_sh + dq * 4, pk);
+            }
+            if (p.out_f32) global_store_f32x4(p.out_f32 + oi, r);
+            if (p.lse && dq == 0) p.lse[li] = mx == -INFINITY ? -INFINITY : mx + logf(den);
         }
-        if (p.out) {
-            u32x2 pk = {pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3])};
-            global_store_b64(p.out + (int64_t)b * p.o_sb + (int64_t)q * p.o_ss + (int64_t)h * p.o_sh + c, pk);
-        }
-        if (p.out_f32) global_store_f32x4(p.out_f32 + oi, acc);
-        if (p.lse && c == 0) p.lse[li] = mx == -INFINITY ? -INFINITY : mx + logf(den);
+        block_sync();
     }
 }
 

@@ -362,7 +362,11 @@ def ring_attention(q, k, v, *, group=None, causal=True, segment_ids=None, key_va
 
 # ----------------------------------------------------------------- inference (dense mask)
 def _pick_splits(B, Q, H, Sk):
-    """Enough workgroups to fill 256 CUs twice, at least 4 key tiles (256 keys) per piece."""
+    """Enough workgroups to fill 256 CUs a few times over.  Q == 1 runs the streaming
+    decode kernel (one workgroup = all heads of a key range): ~512 workgroups of >= 128
+    keys; otherwise the MFMA kernel (one workgroup per head and piece), >= 256 keys each."""
+    if Q == 1:
+        return max(1, min(-(-512 // B), Sk // 128))
     base = ((Q + 255) // 256) * H * B
     want = max(1, -(-512 // base))
     return max(1, min(want, max(1, Sk // 256)))
