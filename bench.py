@@ -173,6 +173,40 @@ def decode_leg(torch, K=131072):
                          "frac": nbytes / t / 1e9 / 8000.0, "kernel": "attn_decode_kernel + attn_combine_kernel"}}
 
 
+def elementwise_leg(torch, S=32768):
+    """Secondary leg: RoPE (q and k) and RMSNorm fwd at LWM-7B shapes, HBM-bound.
+    Algorithmic bytes: RoPE 2 tensors x (read + write) x S*4096*2 B (+ the table);
+    RMSNorm read + write S*4096*2 B."""
+    from lwm_amd.llama_ops import RMSNorm, apply_rotary_emb, precompute_freqs_cis
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(1, S, N_HEADS, HEAD_DIM, generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+    tab = precompute_freqs_cis(HEAD_DIM, S, 1e7, device="cuda")
+    pos = torch.arange(S, device="cuda", dtype=torch.int32)[None].contiguous()
+    norm = RMSNorm(D_MODEL).cuda()
+    h = x.reshape(S, D_MODEL)
+
+    def timed(fn, reps=20):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    with torch.no_grad():
+        t_rope = timed(lambda: apply_rotary_emb(x, x, tab, pos))
+        t_norm = timed(lambda: norm(h))
+    n = S * D_MODEL * 2.0
+    return {"workload": f"RoPE(q,k) and RMSNorm forward, S={S}, d_model=4096, bf16",
+            "rope_GBps": (4 * n + S * 512.0) / t_rope / 1e9, "rmsnorm_GBps": 2 * n / t_norm / 1e9,
+            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0,
+                         "achieved": 2 * n / t_norm / 1e9, "frac": 2 * n / t_norm / 1e9 / 8000.0,
+                         "kernel": "rmsnorm_fwd_kernel"}}
+
+
 class KernelTimer:
     """HIP events (torch.cuda.Event on the stream the kernels are launched on)
     around every kernel launch of the timed region, aggregated per kernel."""
@@ -327,6 +361,7 @@ def main():
             if not args.no_vqgan:
                 res["vqgan"] = vqgan_leg(torch)
                 res["decode"] = decode_leg(torch)
+                res["elementwise"] = elementwise_leg(torch)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -114,6 +114,26 @@ int lwm_kv_cache_write(void* cache, const void* src, int32_t B, int64_t cache_st
 /* dst_bf16[n] = (bf16) src_f32[n] */
 int lwm_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 
+/* ------------------------------------------------------------------ RoPE, RMSNorm
+ * The HBM-bound steps either side of the attention op. */
+
+/* apply_rotary_emb (lwm/llama.py:353-375): y = x rotated, interleaved (even, odd) pairs as
+ * complex numbers times (cos, sin)[pos[b,s]][i]; f32 math, bf16 in/out; y may alias x.
+ * table: [max_pos][D/2][2] f32 built on the host as precompute_freqs_cis does
+ * (lwm/llama.py:344-350).  conj != 0 rotates by the negative angle (= backward). */
+int lwm_rope_bf16(LwmTensor4 x, LwmTensor4 y, const float* table, const int32_t* pos, int32_t B,
+                  int32_t S, int32_t H, int32_t D, int32_t max_pos, int32_t conj, void* stream);
+
+/* RMSNorm (lwm/llama.py:320-341) over rows of C bf16: y = bf16(bf16(x * rsqrt(mean(x^2)+eps)) * w).
+ * rstd [rows] f32 is written if non-NULL (needed by the backward). */
+int lwm_rmsnorm_fwd_bf16(const void* x, const void* w, void* y, float* rstd, int64_t rows, int32_t C,
+                         float eps, void* stream);
+/* dx [rows,C] bf16 and dw [C] bf16 from g = dL/dy; workspace of
+ * lwm_rmsnorm_bwd_workspace_bytes() bytes (f32 partial dW per workgroup). */
+int64_t lwm_rmsnorm_bwd_workspace_bytes(int64_t rows, int32_t C);
+int lwm_rmsnorm_bwd_bf16(const void* x, const void* w, const void* g, const float* rstd, void* dx,
+                         void* dw, void* workspace, int64_t rows, int32_t C, void* stream);
+
 /* ------------------------------------------------------------------ VQGAN
  * Primitives of the video tokeniser, lwm/vqgan.py.  All tensors are f32, NHWC,
  * dense; results are bit-exact with oracle/vqgan_ref.c (exact-f32 MFMA, fixed

@@ -11,4 +11,5 @@
 #include "attn_bwd.h"
 #include "attn_decode.h"
 #include "misc_kernels.h"
+#include "llama_elem.h"
 #include "api.inc"

@@ -1,0 +1,57 @@
+"""CPU oracle for RoPE and RMSNorm -- TEST INFRASTRUCTURE, NOT PRODUCT.
+
+Restates lwm/llama.py:320-375 in numpy.  PARITY UNPINNED (jax cannot be imported
+here, the reference ships no vectors); the restatement follows the in-tree source
+line by line, float32 where the reference computes in float32, and float64 variants
+are provided for gradient checks.
+"""
+import numpy as np
+
+from .attention_ref import round_bf16
+
+
+def precompute_freqs_cis(dim, max_pos, theta=10000.0, dtype=np.float32):
+    """lwm/llama.py:344-350, returning complex64."""
+    freqs = 1.0 / (theta ** (np.arange(0, dim, 2)[: (dim // 2)].astype(dtype) / dim))
+    t = np.arange(max_pos)
+    freqs = np.outer(t, freqs).astype(dtype)
+    return np.complex64(np.cos(freqs) + 1j * np.sin(freqs))
+
+
+def apply_rotary_emb(x, freqs_cis, position_ids, out_bf16=True):
+    """lwm/llama.py:353-375 for one tensor: x (B,S,H,D) -> f32 complex multiply on
+    interleaved pairs, result cast to the model dtype (bf16 when out_bf16)."""
+    x = np.asarray(x, np.float32)
+    fc = freqs_cis[np.asarray(position_ids)]            # jnp.take, lwm/llama.py:515
+    xr = x.reshape(x.shape[:-1] + (-1, 2))
+    xc = xr[..., 0] + 1j * xr[..., 1]
+    out = xc.astype(np.complex64) * fc[:, :, None, :]
+    y = np.stack((out.real, out.imag), axis=-1).reshape(x.shape).astype(np.float32)
+    return round_bf16(y) if out_bf16 else y
+
+
+def rope_bwd(g, freqs_cis, position_ids):
+    """Gradient of apply_rotary_emb w.r.t. x: multiply by the conjugate."""
+    return apply_rotary_emb(g, np.conj(freqs_cis), position_ids, out_bf16=False)
+
+
+def rmsnorm(x, weight, eps=1e-6, out_bf16=True):
+    """lwm/llama.py:335-341: f32 upcast, x*rsqrt(mean(x^2)+eps) cast to dtype, times weight (dtype)."""
+    x32 = np.asarray(x, np.float32)
+    r = 1.0 / np.sqrt(np.mean(np.square(x32.astype(np.float64)), axis=-1, keepdims=True) + eps)
+    y = (x32 * r).astype(np.float32)
+    if not out_bf16:
+        return y * np.asarray(weight, np.float32)
+    return round_bf16(round_bf16(y) * round_bf16(np.asarray(weight, np.float32)))
+
+
+def rmsnorm_bwd(x, weight, g, eps=1e-6):
+    """float64 gradients of out = (x * rsqrt(mean(x^2)+eps)) * w (casts treated as identity)."""
+    x, w, g = (np.asarray(a, np.float64) for a in (x, weight, g))
+    Cc = x.shape[-1]
+    r = 1.0 / np.sqrt(np.mean(x * x, axis=-1, keepdims=True) + eps)
+    xh = x * r
+    dy = g * w
+    dx = r * (dy - xh * np.sum(dy * xh, axis=-1, keepdims=True) / Cc)
+    dw = np.sum((g * xh).reshape(-1, Cc), axis=0)
+    return dx, dw

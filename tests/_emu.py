@@ -249,3 +249,45 @@ def kv_cache_write(cache_bits, src_bits, dst_row0, src_row0, nrows):
                                         cache_bits.strides[0] // 2, src_bits.strides[0] // 2, dst_row0,
                                         src_row0, nrows, H * D, None), "lwm_kv_cache_write")
     return cache_bits
+
+
+# ---------------------------------------------------------------- RoPE / RMSNorm
+def rope(x, table, pos, conj=False):
+    L = lib()
+    xb = bf16_array(x)
+    B, S, H, D = x.shape
+    y = aligned((B, S, H, D), np.uint16)
+    tab = aligned(table.shape, np.float32)
+    tab[...] = table
+    ps = np.ascontiguousarray(pos, dtype=np.int32)
+    _capi.check(L, L.lwm_rope_bf16(_t4(xb), _t4(y), tab.ctypes.data, ps.ctypes.data, B, S, H, D, table.shape[0],
+                                   int(conj), None), "lwm_rope_bf16")
+    return from_bf16_bits(y)
+
+
+def rmsnorm_fwd(x, w, eps=1e-6):
+    L = lib()
+    xb, wb = bf16_array(x), bf16_array(w)
+    Cc = x.shape[-1]
+    rows = x.size // Cc
+    y = aligned(x.shape, np.uint16)
+    rstd = aligned((rows,), np.float32)
+    _capi.check(L, L.lwm_rmsnorm_fwd_bf16(xb.ctypes.data, wb.ctypes.data, y.ctypes.data, rstd.ctypes.data, rows, Cc,
+                                          eps, None), "lwm_rmsnorm_fwd_bf16")
+    return from_bf16_bits(y), rstd
+
+
+def rmsnorm_bwd(x, w, g, rstd):
+    L = lib()
+    xb, wb, gb = bf16_array(x), bf16_array(w), bf16_array(g)
+    Cc = x.shape[-1]
+    rows = x.size // Cc
+    dx = aligned(x.shape, np.uint16)
+    dw = aligned((Cc,), np.uint16)
+    ws = aligned((max(L.lwm_rmsnorm_bwd_workspace_bytes(rows, Cc), 16) // 4,), np.float32)
+    r = aligned((rows,), np.float32)
+    r[...] = rstd
+    _capi.check(L, L.lwm_rmsnorm_bwd_bf16(xb.ctypes.data, wb.ctypes.data, gb.ctypes.data, r.ctypes.data,
+                                          dx.ctypes.data, dw.ctypes.data, ws.ctypes.data, rows, Cc, None),
+                "lwm_rmsnorm_bwd_bf16")
+    return from_bf16_bits(dx), from_bf16_bits(dw)

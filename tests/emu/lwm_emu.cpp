@@ -12,6 +12,7 @@
 #include "attn_bwd.h"
 #include "attn_decode.h"
 #include "misc_kernels.h"
+#include "llama_elem.h"
 #include "api.inc"
 #include "vqgan_conv.h"
 #include "vqgan_misc.h"

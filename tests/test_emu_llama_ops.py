@@ -1,0 +1,60 @@
+"""RoPE and RMSNorm kernels (lwm_amd/csrc/llama_elem.h) emulated on the host through
+the C ABI against the numpy oracle (oracle/llama_ops_ref.py)."""
+import numpy as np
+import pytest
+
+from lwm_amd.llama_ops import precompute_freqs_cis
+from oracle import llama_ops_ref as R
+from oracle.attention_ref import round_bf16
+from tests import _emu
+
+
+def _rnd(shape, seed, scale=1.0):
+    return round_bf16((np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32))
+
+
+@pytest.mark.parametrize("theta,max_pos", [(10000.0, 4096), (5e7, 1 << 20)])
+def test_rope_table_and_rotation(theta, max_pos):
+    B, S, H, D = 2, 37, 3, 128
+    x = _rnd((B, S, H, D), 1)
+    pos = np.random.default_rng(2).integers(0, max_pos, (B, S)).astype(np.int32)
+    pos[0, 0], pos[0, 1] = 0, max_pos - 1
+    fc = R.precompute_freqs_cis(D, max_pos, theta)
+    tab = precompute_freqs_cis(D, max_pos, theta).numpy()
+    # the product's host table is the reference's complex table, split into (cos, sin)
+    assert np.array_equal(tab[..., 0], fc.real) and np.array_equal(tab[..., 1], fc.imag)
+    got = _emu.rope(x, tab, pos)
+    ref = R.apply_rotary_emb(x, fc, pos)
+    assert np.abs(got - ref).max() <= 2 ** -7 * np.abs(ref).max()      # one bf16 ulp at most
+    assert np.mean(got != ref) < 1e-3                                  # (fma vs mul+sub rounding)
+    # backward = conjugate rotation; rotation is orthogonal: round trip restores x
+    back = _emu.rope(got, tab, pos, conj=True)
+    assert np.abs(back - x).max() <= 2e-2 * np.abs(x).max()
+    gref = R.rope_bwd(x, fc, pos)
+    assert np.abs(_emu.rope(x, tab, pos, conj=True) - gref).max() <= 2 ** -7 * np.abs(gref).max()
+
+
+@pytest.mark.parametrize("rows,C", [(5, 4096), (3, 256), (2, 8192), (7, 1000 // 8 * 8)])
+def test_rmsnorm_fwd_bwd(rows, C):
+    x = _rnd((rows, C), 3, 2.0)
+    w = round_bf16((1 + 0.1 * np.random.default_rng(4).standard_normal(C)).astype(np.float32))
+    g = _rnd((rows, C), 5)
+    y, rstd = _emu.rmsnorm_fwd(x, w)
+    ref = R.rmsnorm(x, w)
+    assert np.abs(y - ref).max() <= 2 ** -7 * np.abs(ref).max()
+    assert np.mean(y != ref) < 5e-3
+    r64 = 1.0 / np.sqrt(np.mean(x.astype(np.float64) ** 2, axis=-1) + 1e-6)
+    assert np.abs(rstd - r64).max() <= 1e-6 * r64.max()
+    dx, dw = _emu.rmsnorm_bwd(x, w, g, rstd)
+    rdx, rdw = R.rmsnorm_bwd(x, w, g)
+    assert np.abs(dx - rdx).max() <= 1e-2 * np.abs(rdx).max()
+    assert np.abs(dw - rdw).max() <= 1e-2 * max(np.abs(rdw).max(), 1e-6)
+
+
+def test_validation():
+    import ctypes as C
+    from lwm_amd import _capi
+    L = _emu.lib()
+    assert L.lwm_rmsnorm_fwd_bf16(16, 16, 16, None, 4, 100, 1e-6, None) == _capi.LWM_EUNSUPPORTED
+    t = _capi.LwmTensor4(None, 0, 0, 0)
+    assert L.lwm_rope_bf16(t, t, None, None, 1, 1, 1, 128, 16, 0, None) == _capi.LWM_EINVAL

@@ -1,0 +1,89 @@
+"""RoPE / RMSNorm HIP kernels on MI355X through the reference-named Python surface
+(lwm_amd.llama_ops), forward and backward, against the numpy oracle.
+Tolerance: bf16 outputs within one bf16 ulp (2^-7 relative) of the oracle's bf16 result;
+gradients within 1e-2 relative of the float64 gradients."""
+import numpy as np
+import pytest
+
+from oracle import llama_ops_ref as R
+from oracle.attention_ref import round_bf16
+
+pytestmark = pytest.mark.gpu
+
+
+def _rnd(shape, seed, scale=1.0):
+    return round_bf16((np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32))
+
+
+def _dev(a, dt=None):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t.to(dt) if dt is not None else t
+
+
+def _np(t):
+    return t.detach().float().cpu().numpy()
+
+
+@pytest.mark.parametrize("theta,max_pos,S", [(10000.0, 4096, 333), (5e7, 1 << 20, 1024)])
+def test_rope_fwd_bwd(theta, max_pos, S):
+    import torch
+    from lwm_amd.llama_ops import apply_rotary_emb, precompute_freqs_cis
+    B, H, D = 2, 4, 128
+    xq, xk, gq = _rnd((B, S, H, D), 1), _rnd((B, S, H, D), 2), _rnd((B, S, H, D), 3)
+    pos = np.random.default_rng(4).integers(0, max_pos, (B, S)).astype(np.int32)
+    tab = precompute_freqs_cis(D, max_pos, theta, device="cuda")
+    fc = R.precompute_freqs_cis(D, max_pos, theta)
+    q = _dev(xq, torch.bfloat16).requires_grad_(True)
+    k = _dev(xk, torch.bfloat16)
+    oq, ok = apply_rotary_emb(q, k, tab, _dev(pos))
+    rq, rk = R.apply_rotary_emb(xq, fc, pos), R.apply_rotary_emb(xk, fc, pos)
+    for got, ref in ((oq, rq), (ok, rk)):
+        assert np.abs(_np(got) - ref).max() <= 2 ** -7 * np.abs(ref).max()
+    oq.backward(_dev(gq, torch.bfloat16))
+    rg = R.rope_bwd(gq, fc, pos)
+    assert np.abs(_np(q.grad) - rg).max() <= 2 ** -7 * np.abs(rg).max()
+    # default positions = arange (lwm/llama.py:1081-1082)
+    o2, _ = apply_rotary_emb(k, k, tab)
+    r2 = R.apply_rotary_emb(xk, fc, np.tile(np.arange(S), (B, 1)))
+    assert np.abs(_np(o2) - r2).max() <= 2 ** -7 * np.abs(r2).max()
+
+
+@pytest.mark.parametrize("shape", [(2, 100, 4096), (1, 7, 256), (3, 8192)])
+def test_rmsnorm_module_fwd_bwd(shape):
+    import torch
+    from lwm_amd.llama_ops import RMSNorm
+    C = shape[-1]
+    x, g = _rnd(shape, 5, 2.0), _rnd(shape, 6)
+    w = (1 + 0.1 * np.random.default_rng(7).standard_normal(C)).astype(np.float32)
+    m = RMSNorm(C).cuda()
+    with torch.no_grad():
+        m.kernel.copy_(torch.from_numpy(w))
+    xd = _dev(x, torch.bfloat16).requires_grad_(True)
+    y = m(xd)
+    ref = R.rmsnorm(x, w)
+    assert np.abs(_np(y) - ref).max() <= 2 ** -7 * np.abs(ref).max()
+    y.backward(_dev(g, torch.bfloat16))
+    rdx, rdw = R.rmsnorm_bwd(x, round_bf16(w), g)
+    assert np.abs(_np(xd.grad) - rdx).max() <= 1e-2 * np.abs(rdx).max()
+    assert np.abs(_np(m.kernel.grad) - rdw).max() <= 1e-2 * np.abs(rdw).max()
+
+
+def test_full_size_bandwidth_and_properties():
+    """LWM-7B shapes at S = 32768: RoPE over (1,S,32,128), RMSNorm over (S,4096)."""
+    import torch
+    from lwm_amd.llama_ops import RMSNorm, apply_rotary_emb, precompute_freqs_cis
+    S = 32768
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(1, S, 32, 128, generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+    tab = precompute_freqs_cis(128, S, 1e7, device="cuda")
+    y, _ = apply_rotary_emb(x, x, tab)
+    # the rotation preserves the norm of every (even, odd) pair up to bf16 rounding
+    n0 = (x.float() ** 2).reshape(1, S, 32, 64, 2).sum(-1)
+    n1 = (y.float() ** 2).reshape(1, S, 32, 64, 2).sum(-1)
+    assert ((n0 - n1).abs() <= 2e-2 * n0 + 1e-6).all()
+    assert torch.equal(y[:, 0], x[:, 0])             # position 0: identity
+    h = x.reshape(S, 4096)
+    out = RMSNorm(4096).cuda()(h)
+    rms = out.float().pow(2).mean(-1).sqrt()
+    assert (rms - 1).abs().max().item() <= 1e-2      # weight = ones: unit RMS rows
