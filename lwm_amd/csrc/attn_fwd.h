@@ -23,6 +23,7 @@ namespace lwm {
 constexpr int kFwdBQ = 256;    // queries per workgroup
 constexpr int kFwdBK = 64;     // keys per LDS tile
 constexpr int kFwdThreads = 512;
+constexpr float kDeferLog2 = 8.0f;   // p stays below 2^8 between rescales of the running maximum
 constexpr int kFwdTileBytes = kFwdBK * kRowBytes;                  // 16 KiB
 constexpr int kFwdLdsBytes = 4 * kFwdTileBytes + 2 * kFwdBK * 4;  // K,V x2 + kseg x2
 
@@ -159,10 +160,21 @@ LWM_DEVICE void fwd_tile(const AttnParams& p, const FwdCtx& cx, const bf16x8 (&q
     for (int kb2 = 0; kb2 < 2; ++kb2)
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb2][r]);
     mx = fmaxf(mx, xhalf(mx));
-    const float m_new = fmaxf(m_run, mx);
-    const float m_safe = (m_new == -INFINITY) ? 0.0f : m_new;
-    const float alpha = fast_exp2((m_run - m_safe) * cx.c);
-    const float msc = m_safe * cx.c;
+    // Deferred rescale: the reference maximum m_run moves (and the 64 accumulator
+    // registers are rescaled) only when some row of this wave would otherwise produce
+    // p > 2^kDeferLog2; until then p = exp2((s - m_run)*c) is merely allowed to exceed 1.
+    // The decision precedes this tile's exponentials and the previous tile's P.V is
+    // complete, so everything at the old scale is rescaled exactly once.  The first
+    // visible tile always takes the branch (m_run = -inf).
+    if (wave_any((mx - m_run) * cx.c > kDeferLog2)) {
+        const float m_new = fmaxf(m_run, mx);
+        const float ms = (m_new == -INFINITY) ? 0.0f : m_new;
+        const float alpha = fast_exp2((m_run - ms) * cx.c);
+        l_run *= alpha;
+        for (int i = 0; i < 4; ++i) acc[i] *= alpha;
+        m_run = m_new;
+    }
+    const float msc = ((m_run == -INFINITY) ? 0.0f : m_run) * cx.c;
     float psum = 0.0f;
     for (int kb2 = 0; kb2 < 2; ++kb2)
         for (int r = 0; r < 16; ++r) {
@@ -170,9 +182,7 @@ LWM_DEVICE void fwd_tile(const AttnParams& p, const FwdCtx& cx, const bf16x8 (&q
             st[kb2][r] = pv;
             psum += pv;
         }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-    for (int i = 0; i < 4; ++i) acc[i] *= alpha;
+    l_run += psum;
     // ---- O^T += V^T P^T
     bf16x8 pb[2][2];
     for (int kb2 = 0; kb2 < 2; ++kb2)

@@ -135,6 +135,8 @@ LWM_DEVICE void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // Raise/lower this wave's issue priority around an MFMA cluster (T5).
 LWM_DEVICE void prio_hi() { __builtin_amdgcn_s_setprio(1); }
 LWM_DEVICE void prio_lo() { __builtin_amdgcn_s_setprio(0); }
+template <int N>
+LWM_DEVICE void set_prio() { __builtin_amdgcn_s_setprio(N); }
 
 // value held by lane (l ^ 32)
 LWM_DEVICE float xhalf(float x) {
@@ -142,6 +144,9 @@ LWM_DEVICE float xhalf(float x) {
 }
 LWM_DEVICE float shfl_xor_f(float x, int m) { return __shfl_xor(x, m, 64); }
 LWM_DEVICE int shfl_xor_i(int x, int m) { return __shfl_xor(x, m, 64); }
+
+// true if the predicate holds in ANY lane of the wave (wave-uniform result)
+LWM_DEVICE bool wave_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0; }
 
 LWM_DEVICE float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 LWM_DEVICE float fast_log2(float x) { return __builtin_amdgcn_logf(x); }

@@ -288,6 +288,8 @@ LWM_DEVICE void sleep_cycles64() {}
 LWM_DEVICE uint32_t opaque(uint32_t x) { return x; }
 LWM_DEVICE void prio_hi() {}
 LWM_DEVICE void prio_lo() {}
+template <int N>
+LWM_DEVICE void set_prio() {}
 
 LWM_DEVICE float shfl_xor_f(float x, int m) {
     emu::Wave& w = emu::g_blk->waves[emu::g_lane->tid >> 6];
@@ -308,6 +310,16 @@ LWM_DEVICE int shfl_xor_i(int x, int m) {
     return r;
 }
 LWM_DEVICE float xhalf(float x) { return shfl_xor_f(x, 32); }
+LWM_DEVICE bool wave_any(bool x) {
+    emu::Wave& w = emu::g_blk->waves[emu::g_lane->tid >> 6];
+    int l = emu::g_lane->tid & 63;
+    w.i[l] = x ? 1 : 0;
+    emu::wave_sync();
+    int r = 0;
+    for (int k = 0; k < 64; ++k) r |= w.i[k];
+    emu::wave_sync();
+    return r != 0;
+}
 
 LWM_DEVICE float fast_exp2(float x) { return exp2f(x); }
 LWM_DEVICE float fast_log2(float x) { return log2f(x); }
