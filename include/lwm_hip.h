@@ -183,6 +183,9 @@ int lwm_vq_gather_f32(const float* codebook, const int32_t* idx, const float* z,
 
 const char* lwm_last_error(void);
 int lwm_version(void);
+/* sizeof(LwmAttnArgs) (which = 0) / sizeof(LwmConvArgs) (1) as compiled into the library:
+ * lets a foreign-language binding verify its struct mirror at load time. */
+int lwm_sizeof(int which);
 
 #ifdef __cplusplus
 }

@@ -67,15 +67,21 @@ PROTOTYPES = {
     "lwm_vq_gather_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "lwm_last_error": (C.c_char_p, []),
     "lwm_version": (C.c_int, []),
+    "lwm_sizeof": (C.c_int, [C.c_int]),
 }
 
 
 def bind(lib):
-    """Attach restype/argtypes for every declared symbol; raises if one is missing."""
+    """Attach restype/argtypes for every declared symbol; raises if one is missing or if
+    the struct mirrors above do not have the library's layout."""
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    for which, cls in ((0, LwmAttnArgs), (1, LwmConvArgs)):
+        if lib.lwm_sizeof(which) != C.sizeof(cls):
+            raise ImportError(f"{cls.__name__}: ctypes mirror is {C.sizeof(cls)} bytes, library has "
+                              f"{lib.lwm_sizeof(which)} (include/lwm_hip.h and lwm_amd/_capi.py out of step)")
     return lib
 
 
