@@ -12,12 +12,13 @@ LWM_KERNEL(kCastThreads) void cast_f32_to_bf16_kernel(const float* src, bf16_t* 
     int64_t i = (int64_t)block_idx_x() * kCastThreads + thread_idx();
     const int64_t step = (int64_t)grid_dim_x() * kCastThreads;
     for (; i < nvec; i += step) {
-        u32x4 a = global_load_b128(src + i * 8);
-        u32x4 b = global_load_b128(src + i * 8 + 4);
-        u32x4 o = {pack_bf16x2(__builtin_bit_cast(float, a[0]), __builtin_bit_cast(float, a[1])),
-                   pack_bf16x2(__builtin_bit_cast(float, a[2]), __builtin_bit_cast(float, a[3])),
-                   pack_bf16x2(__builtin_bit_cast(float, b[0]), __builtin_bit_cast(float, b[1])),
-                   pack_bf16x2(__builtin_bit_cast(float, b[2]), __builtin_bit_cast(float, b[3]))};
+        // f32x4 loads: __builtin_bit_cast(float, v[k]) on an element of a u32 ext-vector
+        // reads element 0 for every k (host clang and hipcc alike) -- never bit-cast a
+        // vector ELEMENT lvalue; cast whole vectors or rvalue expressions.
+        f32x4 a = global_load_f32x4(src + i * 8);
+        f32x4 b = global_load_f32x4(src + i * 8 + 4);
+        u32x4 o = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]),
+                   pack_bf16x2(b[2], b[3])};
         global_store_b128(dst + i * 8, o);
     }
     // tail (n not a multiple of 8)

@@ -82,3 +82,15 @@ def test_emulated_future_block_is_fully_masked():
     q, k, v = (_rnd((B, S, H, 128), s) for s in (21, 22, 23))
     out, lse = _emu.attn_fwd(q, k, v, causal=True, q_start=0, k_start=4096)
     assert np.all(out == 0) and np.all(np.isneginf(lse))
+
+
+def test_emulated_cast_f32_to_bf16():
+    """lwm_cast_f32_to_bf16 (end of the backward ring): every element, ragged tail included."""
+    import ctypes as C
+    L = _emu.lib()
+    for n in (8, 2048 + 8, 100003):
+        x = _emu.aligned((n,), np.float32)
+        x[...] = np.random.default_rng(n).standard_normal(n)
+        y = _emu.aligned((n,), np.uint16)
+        assert L.lwm_cast_f32_to_bf16(x.ctypes.data, y.ctypes.data, n, None) == 0
+        assert np.array_equal(R.from_bf16_bits(y), R.round_bf16(x))

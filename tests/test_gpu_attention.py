@@ -121,6 +121,27 @@ def test_ring_carry_equals_single_shot():
     assert (lse - rlse).abs().max().item() <= 1e-4
 
 
+def test_cast_and_backward_carries():
+    """The n > 1 backward path: f32 carries (final=False) + lwm_cast_f32_to_bf16 must
+    reproduce the direct bf16 results of the single-block path."""
+    import torch
+    from lwm_amd import ops
+    q, k, v, do = (_rand((1, 512, 2, 128), s).cuda() for s in (41, 42, 43, 44))
+    x = torch.randn(1000, 129, device="cuda")[:, :128].contiguous()
+    assert torch.equal(ops.cast_f32_to_bf16(x), x.to(torch.bfloat16))
+    out, lse = ops.attn_fwd_block(q, k, v, causal=True)
+    delta = ops.attn_bwd_delta(out, do)
+    dq1 = ops.attn_bwd_dq_block(q, k, v, do, lse, delta, causal=True)
+    dk1, dv1 = ops.attn_bwd_dkdv_block(q, k, v, do, lse, delta, causal=True)
+    z = lambda: torch.zeros(1, 512, 2, 128, dtype=torch.float32, device="cuda")
+    dq2 = ops.cast_f32_to_bf16(ops.attn_bwd_dq_block(q, k, v, do, lse, delta, causal=True, dq_acc=z(),
+                                                     carry_in=True, final=False))
+    ka, va = ops.attn_bwd_dkdv_block(q, k, v, do, lse, delta, causal=True, dk_acc=z(), dv_acc=z(),
+                                     carry_in=True, final=False)
+    assert torch.equal(dq1, dq2)
+    assert torch.equal(dk1, ops.cast_f32_to_bf16(ka)) and torch.equal(dv1, ops.cast_f32_to_bf16(va))
+
+
 def test_autograd_ring1_matches_oracle():
     import torch
     from lwm_amd.ringattention import ringattention
