@@ -100,3 +100,86 @@ def test_ring_n_equals_ring_1_on_gpu(n, layout_kind, packed):
     for name, a, b in zip(("out", "dq", "dk", "dv"), got, (ro, rq, rk, rv)):
         err = np.abs(f(a) - b).max() / np.abs(b).max()
         assert err <= 2e-2, (name, err)
+
+
+class ThreadGroupComm(ThreadComm):
+    """adds all_gather / exchange (rank-major, barrier-synchronised) for the inference drivers."""
+
+    def __init__(self, rank, size, inboxes, shared, barrier):
+        super().__init__(rank, size, inboxes)
+        self.shared, self.barrier = shared, barrier
+
+    def all_gather(self, t):
+        import torch
+        self.shared[self.rank] = t.clone()
+        self.barrier.wait()
+        out = torch.stack([self.shared[r] for r in range(self.size)])
+        self.barrier.wait()
+        return out
+
+    def exchange(self, sends, recvs):
+        for peer, t in sends:
+            self.shared.setdefault(("x", self.rank, peer), []).append(t.clone())
+        self.barrier.wait()
+        cursor = {}
+        for peer, buf in recvs:
+            i = cursor.get(peer, 0)
+            buf.copy_(self.shared[("x", peer, self.rank)][i])
+            cursor[peer] = i + 1
+        self.barrier.wait()
+        for peer, _ in sends:
+            self.shared.pop(("x", self.rank, peer), None)
+        self.barrier.wait()
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_sharded_cache_and_decode_on_gpu(n):
+    """cache_update + ring_inference with the real kernels, n simulated ranks: prefill rows land
+    in the owning shards, then one decode step over the sharded cache equals dense attention."""
+    import torch
+    from lwm_amd.ring import HipBlockOps, cache_update, ring_inference
+    B, H, D, c, P, start = 2, 4, 128, 384, 64 * n, 100
+    max_len = c * n
+    g = torch.Generator().manual_seed(1)
+    mk = lambda s: torch.randn(B, s, H, D, generator=g).to(torch.bfloat16).cuda()
+    k_new, v_new, k_dec, v_dec, q_dec = mk(P), mk(P), mk(1), mk(1), mk(1)
+    am = torch.ones(B, max_len, dtype=torch.bool)
+    am[:, 130:140] = False
+    inboxes = [queue.Queue() for _ in range(n)]
+    shared, barrier = {}, threading.Barrier(n)
+    res, errs = [None] * n, []
+
+    def worker(r):
+        try:
+            comm = ThreadGroupComm(r, n, inboxes, shared, barrier)
+            ck = torch.zeros(B, c, H, D, dtype=torch.bfloat16, device="cuda")
+            cv = torch.zeros_like(ck)
+            p = P // n
+            idx = cache_update(HipBlockOps, comm, ck, cv, k_new[:, r * p:(r + 1) * p].contiguous(),
+                               v_new[:, r * p:(r + 1) * p].contiguous(), start, new_sharded=True)
+            idx = cache_update(HipBlockOps, comm, ck, cv, k_dec, v_dec, idx, new_sharded=False)
+            mask = ((torch.arange(max_len)[None, None, :] <= idx - 1) & am[:, None, :]).to(torch.uint8).cuda()
+            out = ring_inference(HipBlockOps, comm, q_dec, ck, cv, mask, q_sharded=False)
+            torch.cuda.synchronize()
+            res[r] = (idx, ck.cpu(), cv.cpu(), out.float().cpu())
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+            barrier.abort()
+
+    ths = [threading.Thread(target=worker, args=(r,)) for r in range(n)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    assert not errs, errs
+    ck = torch.zeros(B, max_len, H, D)
+    cv = torch.zeros(B, max_len, H, D)
+    ck[:, start:start + P], cv[:, start:start + P] = k_new.float().cpu(), v_new.float().cpu()
+    ck[:, start + P], cv[:, start + P] = k_dec[:, 0].float().cpu(), v_dec[:, 0].float().cpu()
+    assert all(r[0] == start + P + 1 for r in res)
+    assert torch.equal(torch.cat([r[1] for r in res], 1).float(), ck)
+    assert torch.equal(torch.cat([r[2] for r in res], 1).float(), cv)
+    rmask = R.decode_mask(B, 1, max_len, start + P, am.numpy())
+    ro, _ = R.dense_attention(q_dec.float().cpu().numpy(), ck.numpy(), cv.numpy(), causal=False, dense_mask=rmask)
+    for r in res:
+        assert np.abs(r[3].numpy() - ro).max() / np.abs(ro).max() <= 2e-2
