@@ -245,6 +245,9 @@ def main():
     ap.add_argument("--layout", default="zigzag", choices=["zigzag", "contiguous"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vqgan", action="store_true", help="skip the secondary VQGAN leg")
+    ap.add_argument("--packed", action="store_true",
+                    help="masked sequence packing (BASELINE config #5 style): documents log-uniform in "
+                         "[S/256, S/4]; FLOPs are counted over visible pairs only")
     args = ap.parse_args()
 
     import torch
@@ -277,6 +280,20 @@ def main():
                              dtype=torch.float32).to(torch.bfloat16)
     q, k, v, do = mk(), mk(), mk(), mk()
     timer = KernelTimer(torch)
+    segment_ids, doc_sq = None, None
+    if args.packed:
+        import numpy as np
+        rng = np.random.default_rng(0)
+        seg = np.zeros((1, S), np.int32)
+        pos, d, lens = 0, 0, []
+        while pos < S:
+            ln = int(np.exp(rng.uniform(np.log(S / 256), np.log(S / 4))))
+            ln = min(ln, S - pos)
+            seg[:, pos:pos + ln] = d
+            lens.append(ln)
+            pos, d = pos + ln, d + 1
+        segment_ids = torch.from_numpy(seg).to(dev)
+        doc_sq = float(sum(l * l for l in lens))
 
     class TimedOps(HipBlockOps):
         fwd = staticmethod(lambda *a, **kw: timer.run("attn_fwd_kernel", ops.attn_fwd_block, *a, **kw))
@@ -286,8 +303,9 @@ def main():
 
     def step():
         for _ in range(args.layers):
-            out, lses = ring_forward(TimedOps, comm, q, k, v, layout=layout, causal=True)
-            ring_backward(TimedOps, comm, q, k, v, out, lses, do, layout=layout, causal=True)
+            out, lses = ring_forward(TimedOps, comm, q, k, v, layout=layout, causal=True, segment_ids=segment_ids)
+            ring_backward(TimedOps, comm, q, k, v, out, lses, do, layout=layout, causal=True,
+                          segment_ids=segment_ids)
 
     def barrier():
         if world > 1:
@@ -311,7 +329,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         tokens_per_s = S * args.steps / elapsed
-        unit = gemm_unit_flops(S)
+        unit = gemm_unit_flops(S) if doc_sq is None else doc_sq * D_MODEL   # visible pairs only when packed
         algo_flops_step = 7.0 * unit * args.layers
         res = {
             "metric": "tokens/sec fwd+bwd, LWM-7B RingAttention hot path (32 layers x 32 heads x 128)",
@@ -327,7 +345,8 @@ def main():
             "config": {
                 "workload": (f"LWM-7B attention fwd+bwd, {args.layers} layers, B=1, S={S}, H=32, D=128, "
                              f"causal, ring={world}" + (f", layout={layout.kind}" if world > 1 else "")
-                             + (" [BASELINE configs[1]]" if world == 1 and S == 32768 else "")
+                             + (f", masked packing ({len(lens)} documents)" if args.packed else "")
+                             + (" [BASELINE configs[1]]" if world == 1 and S == 32768 and not args.packed else "")
                              + (" [BASELINE configs[2] problem]" if world > 1 and S == 131072 else "")),
                 "seq_len": S, "ring": world, "layers": args.layers,
             },

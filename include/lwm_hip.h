@@ -85,12 +85,26 @@ typedef struct LwmAttnArgs {
      * out_acc + s*B*Sq*H*D and lse_acc + s*B*H*Sq (requires final_out = 0,
      * carry_in = 0); merge with lwm_attn_combine.  0 or 1 = no split. */
     int32_t k_splits;
+    /* Optional: block-sparsity hints for packed sequences.  seg_blocks_q [B][ceil(Sq/32)][2]
+     * and seg_blocks_k [B][ceil(Sk/32)][2] hold the (min, max) segment id of every 32-row
+     * block (filled by lwm_attn_segment_blocks; padded keys excluded).  When both are given
+     * a workgroup only walks the tiles of the other operand whose segment range meets its
+     * own -- whole documents of a packed batch are skipped instead of computed and masked.
+     * Results are unchanged (the per-element mask is still applied).  NULL = no skipping. */
+    const int32_t* seg_blocks_q;
+    const int32_t* seg_blocks_k;
 } LwmAttnArgs;
 
 int lwm_attn_fwd(const LwmAttnArgs* args, void* stream);
 int lwm_attn_bwd_delta(const LwmAttnArgs* args, void* stream);
 int lwm_attn_bwd_dq(const LwmAttnArgs* args, void* stream);
 int lwm_attn_bwd_dkdv(const LwmAttnArgs* args, void* stream);
+
+/* (min, max) of segment_ids over each block of 32 rows, excluding rows whose valid[] is 0
+ * (valid may be NULL); an all-invalid block gets (INT32_MAX, INT32_MIN).
+ * blocks: [B][ceil(S/32)][2] int32. */
+int lwm_attn_segment_blocks(const int32_t* segment_ids, const uint8_t* valid, int32_t* blocks,
+                            int32_t B, int32_t S, void* stream);
 
 /* Merge P normalised partial attention results (split-K pieces of one launch, or
  * the per-rank partials of a sequence-sharded K/V cache, lwm/llama.py:599-614):

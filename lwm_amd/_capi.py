@@ -32,6 +32,7 @@ class LwmAttnArgs(C.Structure):
         ("causal", C.c_int32), ("carry_in", C.c_int32), ("final_out", C.c_int32),
         ("dense_mask", C.c_void_p), ("mask_stride_b", C.c_int64), ("mask_stride_q", C.c_int64),
         ("k_splits", C.c_int32),
+        ("seg_blocks_q", C.c_void_p), ("seg_blocks_k", C.c_void_p),
     ]
 
 
@@ -48,6 +49,7 @@ PROTOTYPES = {
     "lwm_attn_bwd_delta": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
     "lwm_attn_bwd_dq": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
     "lwm_attn_bwd_dkdv": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
+    "lwm_attn_segment_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "lwm_attn_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, LwmTensor4, C.c_void_p, C.c_void_p,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "lwm_kv_cache_write": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64,

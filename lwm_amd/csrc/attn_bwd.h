@@ -244,13 +244,23 @@ LWM_KERNEL(kDqThreads) void attn_bwd_dq_kernel(AttnParams p) {
     f32x16 acc[4];
     for (int i = 0; i < 4; ++i) acc[i] = zero_f32x16();
 
-    // (pipeline under `nkt > 0`: see attn_fwd_kernel)
-    if (nkt > 0) {
+    int kt0 = 0;
+    if (p.segb_q && p.segb_k && nkt > 0) {   // packed sequences: skip other documents' key tiles
+        const int nbq = (p.Sq + 31) >> 5, nbk = (p.Sk + 31) >> 5;
+        int smin, smax, lo, hi;
+        seg_own_range(p.segb_q + (int64_t)b * nbq * 2, nbq, qt * (kDqBQ / 32), kDqBQ / 32, smin, smax);
+        seg_narrow<kDqThreads>(p.segb_k + (int64_t)b * nbk * 2, nbk, kDqBK / 32, 0, nkt, smin, smax,
+                               lds + 4 * kDqTileBytes, tid, lo, hi);
+        kt0 = lo;
+        nkt = hi;
+    }
+    // (pipeline under `kt0 < nkt`: see attn_fwd_kernel)
+    if (kt0 < nkt) {
         DqStage stg;
-        dq_stage_load(p, kb, vb, b, 0, tid, stg);
-        dq_stage_write<0>(cx, stg, 0, p.Sk);
+        dq_stage_load(p, kb, vb, b, kt0, tid, stg);
+        dq_stage_write<0>(cx, stg, kt0, p.Sk);
         block_sync();
-        for (int kt = 0; kt < nkt; kt += 2) {
+        for (int kt = kt0; kt < nkt; kt += 2) {
             const bool more1 = kt + 1 < nkt;
             if (more1) dq_stage_load(p, kb, vb, b, kt + 1, tid, stg);
             dq_tile<0>(p, cx, qf, dof, kt, acc);
@@ -562,11 +572,19 @@ LWM_DEVICE void attn_bwd_dkdv_body(const AttnParams& p) {
     }
 
     // ---- q tile range (causal: skip q tiles wholly before this key block)
-    const int nqt = (p.Sq + kDkvBQ - 1) / kDkvBQ;
+    int nqt = (p.Sq + kDkvBQ - 1) / kDkvBQ;
     int qt0 = 0;
     if (p.causal) {
         int64_t d = p.k_start + (int64_t)kbi * kDkvBK - p.q_start;  // first q row that can see key 0
         if (d > 0) qt0 = (int)(d / kDkvBQ < nqt ? d / kDkvBQ : nqt);
+    }
+    if (p.segb_q && p.segb_k && qt0 < nqt) {   // packed sequences: skip other documents' query tiles
+        const int nbq = (p.Sq + 31) >> 5, nbk = (p.Sk + 31) >> 5;
+        int smin, smax, lo, hi;
+        seg_own_range(p.segb_k + (int64_t)b * nbk * 2, nbk, kbi * (kDkvBK / 32), kDkvBK / 32, smin, smax);
+        seg_narrow<NT>(p.segb_q + (int64_t)b * nbq * 2, nbq, kDkvBQ / 32, qt0, nqt, smin, smax, stats, tid, lo, hi);
+        qt0 = lo;
+        nqt = hi;
     }
 
     f32x16 dk[NKB][4], dv[NKB][4];

@@ -66,6 +66,9 @@ struct AttnParams {
     const uint8_t* dense_mask;
     int64_t msk_sb, msk_sq;
     int32_t k_splits;
+    // block-sparsity hints (packed sequences), see include/lwm_hip.h
+    const int32_t* segb_q;
+    const int32_t* segb_k;
 };
 
 LWM_DEVICE int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -152,6 +155,65 @@ LWM_DEVICE bf16x8 cvt_frag(const f32x16& x, int base) {
     bf16x8 o;
     for (int j = 0; j < 8; ++j) o[j] = (bf16_t)x[base + j];
     return o;
+}
+
+// ---- packed sequences: narrow a tile loop to the tiles whose segment range can meet
+// the workgroup's own.  `blk` = (min,max) per 32-row block of the OTHER operand (one batch
+// row), a tile = `per` consecutive blocks; the workgroup's own range is [smin, smax].
+// All NT threads scan [t0, t1) cooperatively; returns the smallest enclosing [lo, hi).
+// Tiles inside [lo, hi) may still be fully masked (non-monotone segment ids): the
+// per-element mask stays authoritative, this only removes work that cannot contribute.
+template <int NT>
+LWM_DEVICE void seg_narrow(const int32_t* blk, int nblk, int per, int t0, int t1, int smin, int smax,
+                           lds_t scratch, int tid, int& lo, int& hi) {
+    int mylo = 0x7fffffff, myhi = -1;
+    for (int t = t0 + tid; t < t1; t += NT) {
+        int kmin = 0x7fffffff, kmax = (int)0x80000000;
+        for (int j = 0; j < per; ++j) {
+            const int bi = t * per + j;
+            if (bi < nblk) {
+                const int a = blk[2 * bi], b = blk[2 * bi + 1];
+                kmin = a < kmin ? a : kmin;
+                kmax = b > kmax ? b : kmax;
+            }
+        }
+        if (kmax >= smin && kmin <= smax) {
+            mylo = t < mylo ? t : mylo;
+            myhi = t > myhi ? t : myhi;
+        }
+    }
+    for (int m = 1; m < 64; m <<= 1) {
+        const int a = shfl_xor_i(mylo, m), b = shfl_xor_i(myhi, m);
+        mylo = a < mylo ? a : mylo;
+        myhi = b > myhi ? b : myhi;
+    }
+    if ((tid & 63) == 0) {
+        lds_write_i32(scratch + (tid >> 6) * 8, mylo);
+        lds_write_i32(scratch + (tid >> 6) * 8 + 4, myhi);
+    }
+    block_sync();
+    lo = 0x7fffffff;
+    hi = -1;
+    for (int w = 0; w < NT / 64; ++w) {
+        const int a = lds_read_i32(scratch + w * 8), b = lds_read_i32(scratch + w * 8 + 4);
+        lo = a < lo ? a : lo;
+        hi = b > hi ? b : hi;
+    }
+    block_sync();
+    hi = hi + 1;            // exclusive; lo > hi-1 means "nothing"
+    if (lo >= hi) { lo = t0; hi = t0; }
+}
+
+// (min, max) over blocks [b0, b0+n) of a (min,max) block table
+LWM_DEVICE void seg_own_range(const int32_t* blk, int nblk, int b0, int n, int& smin, int& smax) {
+    smin = 0x7fffffff;
+    smax = (int)0x80000000;
+    for (int j = 0; j < n; ++j)
+        if (b0 + j < nblk) {
+            const int a = blk[2 * (b0 + j)], b = blk[2 * (b0 + j) + 1];
+            smin = a < smin ? a : smin;
+            smax = b > smax ? b : smax;
+        }
 }
 
 constexpr float kLog2e = 1.4426950408889634f;

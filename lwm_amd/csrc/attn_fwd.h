@@ -127,21 +127,27 @@ LWM_DEVICE void fwd_tile(const AttnParams& p, const FwdCtx& cx, const bf16x8 (&q
     // ---- masks (lwm/llama.py:572-592): causal, same segment, key valid
     const bool need_mask = cx.has_kmeta || (p.causal && k_pos0 + kFwdBK - 1 > cx.wq_min);
     if (need_mask) {
-        // key kl of this tile is causally visible iff kl <= rel
+        // key kl of this tile is causally visible iff kl <= rel.  (Every loop here is fully
+        // unrolled: a rolled loop indexes the score registers dynamically -- s_set_gpr_idx --
+        // which made every masked tile ~4x slower than an unmasked one.)
         int64_t rel64 = p.causal ? (cx.q_pos - k_pos0) : (int64_t)kFwdBK;
         const int rel = rel64 > kFwdBK ? kFwdBK : (rel64 < -1 ? -1 : (int)rel64);
+        const int relh = rel - 4 * cx.hi;   // kl = 32*kb2 + 8*g + 4*hi + j <= rel
+#pragma unroll
         for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int kl0 = 32 * kb2 + 8 * g + 4 * cx.hi;
                 if (cx.has_kmeta) {
                     u32x4 sg = lds_read_u32x4(cx.kseg_r + BUF * kFwdBK * 4 + (32 * kb2 + 8 * g) * 4);
+#pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        bool vis = ((int32_t)sg[j] == cx.seg_q) && (kl0 + j <= rel);
+                        bool vis = ((int32_t)sg[j] == cx.seg_q) && (32 * kb2 + 8 * g + j <= relh);
                         st[kb2][4 * g + j] = vis ? st[kb2][4 * g + j] : -INFINITY;
                     }
                 } else {
+#pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        st[kb2][4 * g + j] = (kl0 + j <= rel) ? st[kb2][4 * g + j] : -INFINITY;
+                        st[kb2][4 * g + j] = (32 * kb2 + 8 * g + j <= relh) ? st[kb2][4 * g + j] : -INFINITY;
                 }
             }
     }
@@ -286,13 +292,23 @@ LWM_DEVICE void attn_fwd_body(const AttnParams& p) {
     // tile loop without passing the prologue's s_waitcnt (otherwise the Q-fragment
     // loads count as possibly pending at the loop's first MFMA and the compiler
     // drains vmcnt to 0 there every tile, serialising the staging loads).
-    // split-K: this workgroup walks tiles [kt0, nkt) of its piece only
     int kt0 = 0;
+    // packed sequences: skip key tiles that belong to other documents
+    if (p.segb_q && p.segb_k && nkt > 0) {
+        const int nbq = (p.Sq + 31) >> 5, nbk = (p.Sk + 31) >> 5;
+        int smin, smax, lo, hi;
+        seg_own_range(p.segb_q + (int64_t)b * nbq * 2, nbq, qt * (kFwdBQ / 32), kFwdBQ / 32, smin, smax);
+        seg_narrow<kFwdThreads>(p.segb_k + (int64_t)b * nbk * 2, nbk, kFwdBK / 32, 0, nkt, smin, smax,
+                                lds + 4 * kFwdTileBytes, tid, lo, hi);
+        kt0 = lo;
+        nkt = hi;
+    }
+    // split-K: this workgroup walks tiles [kt0, nkt) of its piece only
     if (nsplit > 1) {
         const int per = (nkt_all + nsplit - 1) / nsplit;
-        kt0 = split * per;
-        const int kt1 = kt0 + per;
-        nkt = nkt < kt1 ? nkt : kt1;
+        const int s0 = split * per, s1 = s0 + per;
+        kt0 = kt0 > s0 ? kt0 : s0;
+        nkt = nkt < s1 ? nkt : s1;
     }
     if (kt0 < nkt) {
         FwdStage stg;

@@ -26,6 +26,25 @@ LWM_KERNEL(kCastThreads) void cast_f32_to_bf16_kernel(const float* src, bf16_t* 
         for (int64_t j = nvec << 3; j < n; ++j) dst[j] = (bf16_t)src[j];
 }
 
+// (min, max) segment id per block of 32 rows (include/lwm_hip.h, lwm_attn_segment_blocks).
+LWM_KERNEL(256) void seg_blocks_kernel(const int32_t* seg, const uint8_t* valid, int32_t* out, int B, int S) {
+    const int nblk = (S + 31) >> 5;
+    const int64_t i = (int64_t)block_idx_x() * 256 + thread_idx();
+    if (i >= (int64_t)B * nblk) return;
+    const int b = (int)(i / nblk), blk = (int)(i % nblk);
+    int mn = 0x7fffffff, mx = (int)0x80000000;
+    for (int r = 0; r < 32; ++r) {
+        const int row = blk * 32 + r;
+        if (row < S && (!valid || valid[(int64_t)b * S + row] != 0)) {
+            const int v = seg[(int64_t)b * S + row];
+            mn = v < mn ? v : mn;
+            mx = v > mx ? v : mx;
+        }
+    }
+    out[2 * i] = mn;
+    out[2 * i + 1] = mx;
+}
+
 // Merge P normalised partial attention results (include/lwm_hip.h, lwm_attn_combine).
 // One thread per (b, q, h, 4 consecutive d); HBM-bound.
 struct CombineParams {

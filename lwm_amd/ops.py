@@ -60,7 +60,25 @@ def _base(q, k, v, *, q_start, k_start, causal, seg_q, seg_k, key_valid, scale):
                 tuple(key_valid.shape) != (B, Sk) or not key_valid.is_cuda:
             raise ValueError(f"key_valid: expected contiguous uint8 device tensor of shape {(B, Sk)}")
         a.key_valid = key_valid.data_ptr()
+    if seg_q is not None and SEGMENT_SKIP:
+        # block-sparsity hints: whole documents of a packed batch are skipped in-kernel
+        bq, bk = segment_blocks(seg_q), segment_blocks(seg_k, key_valid)
+        a.seg_blocks_q, a.seg_blocks_k = bq.data_ptr(), bk.data_ptr()
+        a._keep = (bq, bk)
     return a
+
+
+SEGMENT_SKIP = True   # set False to A/B the in-kernel document skipping
+
+
+def segment_blocks(seg, valid=None):
+    """(min, max) segment id per block of 32 rows -> int32 (B, ceil(S/32), 2) (lwm_attn_segment_blocks)."""
+    B, S = seg.shape
+    out = torch.empty((B, (S + 31) // 32, 2), dtype=torch.int32, device=seg.device)
+    L = lib()
+    _capi.check(L, L.lwm_attn_segment_blocks(seg.data_ptr(), None if valid is None else valid.data_ptr(),
+                                             out.data_ptr(), B, S, _stream_ptr()), "lwm_attn_segment_blocks")
+    return out
 
 
 def attn_fwd_block(q, k, v, *, q_start=0, k_start=0, causal=True, seg_q=None, seg_k=None,

@@ -83,11 +83,23 @@ def base_args(q, k, v, *, causal, q_start, k_start, seg_q, seg_k, key_valid, sca
         sk = np.ascontiguousarray(seg_k, dtype=np.int32)
         a.segment_ids_q, a.segment_ids_k = sq.ctypes.data, sk.ctypes.data
         keep += [sq, sk]
+    kv = None
     if key_valid is not None:
         kv = np.ascontiguousarray(key_valid, dtype=np.uint8)
         a.key_valid = kv.ctypes.data
         keep.append(kv)
+    if seg_q is not None and SEGMENT_SKIP:
+        L = lib()
+        bq = aligned((B, (Sq + 31) // 32, 2), np.int32)
+        bk = aligned((B, (Sk + 31) // 32, 2), np.int32)
+        _capi.check(L, L.lwm_attn_segment_blocks(sq.ctypes.data, None, bq.ctypes.data, B, Sq, None), "seg_blocks")
+        _capi.check(L, L.lwm_attn_segment_blocks(sk.ctypes.data, _ptr(kv), bk.ctypes.data, B, Sk, None), "seg_blocks")
+        a.seg_blocks_q, a.seg_blocks_k = bq.ctypes.data, bk.ctypes.data
+        keep += [bq, bk]
     return a, keep
+
+
+SEGMENT_SKIP = True
 
 
 def attn_fwd(q, k, v, *, causal=True, q_start=0, k_start=0, seg_q=None, seg_k=None,

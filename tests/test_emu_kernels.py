@@ -94,3 +94,48 @@ def test_emulated_cast_f32_to_bf16():
         y = _emu.aligned((n,), np.uint16)
         assert L.lwm_cast_f32_to_bf16(x.ctypes.data, y.ctypes.data, n, None) == 0
         assert np.array_equal(R.from_bf16_bits(y), R.round_bf16(x))
+
+
+@pytest.mark.parametrize("monotone", [True, False])
+def test_emulated_packed_documents_are_skipped_not_changed(monotone):
+    """Packed batch of several documents spanning many tiles: with the segment-block hints the
+    kernels walk only their own documents' tiles; results equal the oracle and the hint-free run."""
+    B, S, H = 1, 1536, 1
+    q, k, v, do = (_rnd((B, S, H, 128), s) for s in (31, 32, 33, 34))
+    seg = np.zeros((B, S), np.int32)
+    for i, c in enumerate((200, 700, 705, 1290)):
+        seg[:, c:] = i + 1
+    if not monotone:                       # ids are only compared for equality (lwm/llama.py:582-584)
+        seg = np.array([7, 3, 9, 3, 1], np.int32)[seg]     # document 1 and 3 share an id
+    kv = np.ones((B, S), np.uint8)
+    kv[:, 690:720] = 0
+    kw = dict(causal=True, seg_q=seg, seg_k=seg, key_valid=kv)
+    ro, rl = R.dense_attention(q, k, v, **kw)
+    rq, rk, rv = R.dense_attention_bwd(q, k, v, do, **kw)
+    outs = {}
+    for skip in (True, False):
+        _emu.SEGMENT_SKIP = skip
+        try:
+            out, lse = _emu.attn_fwd(q, k, v, **kw)
+            dq, dk, dv = _emu.attn_bwd(q, k, v, out, lse, do, **kw)
+        finally:
+            _emu.SEGMENT_SKIP = True
+        outs[skip] = (out, lse, dq, dk, dv)
+        assert _rel(out, ro) < 1e-2 and _rel(dq, rq) < 1e-2 and _rel(dk, rk) < 1e-2 and _rel(dv, rv) < 1e-2
+        fin = np.isfinite(rl)
+        assert np.array_equal(np.isfinite(lse), fin) and np.abs(lse[fin] - rl[fin]).max() < 1e-4
+    for a, b in zip(outs[True], outs[False]):
+        assert np.array_equal(a, b)        # skipping removes only tiles that contribute exact zeros
+
+
+def test_segment_block_table():
+    import ctypes as C
+    L = _emu.lib()
+    seg = np.repeat(np.arange(5, dtype=np.int32), 30)[None]            # (1, 150)
+    valid = np.ones((1, 150), np.uint8)
+    valid[:, 64:128] = 0
+    out = _emu.aligned((1, 5, 2), np.int32)
+    assert L.lwm_attn_segment_blocks(seg.ctypes.data, valid.ctypes.data, out.ctypes.data, 1, 150, None) == 0
+    assert out[0, 0].tolist() == [0, 1] and out[0, 1].tolist() == [1, 2]
+    assert out[0, 2].tolist() == [2 ** 31 - 1, -2 ** 31] and out[0, 3].tolist() == out[0, 2].tolist()
+    assert out[0, 4].tolist() == [4, 4]
