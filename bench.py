@@ -143,6 +143,44 @@ def pmc_traffic(kernel, S):
     return best
 
 
+def packed_leg(torch, S=32768, layers=4):
+    """Secondary leg: masked sequence packing (BASELINE config #5 style) on one GPU --
+    the same S = 32768 batch cut into documents (log-uniform lengths in [S/256, S/4], seed 0),
+    segment_ids driving the in-kernel document skipping.  FLOPs counted over visible pairs."""
+    import numpy as np
+    from lwm_amd.ring import HipBlockOps, SeqLayout, SingleComm, ring_backward, ring_forward
+    rng = np.random.default_rng(0)
+    seg = np.zeros((1, S), np.int32)
+    pos, d, lens = 0, 0, []
+    while pos < S:
+        ln = min(int(np.exp(rng.uniform(np.log(S / 256), np.log(S / 4)))), S - pos)
+        seg[:, pos:pos + ln] = d
+        lens.append(ln)
+        pos, d = pos + ln, d + 1
+    segd = torch.from_numpy(seg).cuda()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    mk = lambda: torch.randn(1, S, N_HEADS, HEAD_DIM, generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+    q, k, v, do = mk(), mk(), mk(), mk()
+    lay, comm = SeqLayout("contiguous", 1, S), SingleComm()
+
+    def step():
+        for _ in range(layers):
+            out, lses = ring_forward(HipBlockOps, comm, q, k, v, layout=lay, causal=True, segment_ids=segd)
+            ring_backward(HipBlockOps, comm, q, k, v, out, lses, do, layout=lay, causal=True, segment_ids=segd)
+
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / layers
+    flops = 7.0 * sum(l * l for l in lens) * D_MODEL
+    return {"workload": f"attention fwd+bwd, S={S}, {len(lens)} packed documents (lengths {min(lens)}..{max(lens)}), "
+                        f"per layer", "ms_per_layer": dt * 1e3, "tokens_per_s_32_layers": S / (dt * N_LAYERS),
+            "algorithmic_tflops": flops / dt / 1e12,
+            "dense_equivalent_speedup": "see kernels above: the same S unpacked takes ~36 ms per layer"}
+
+
 def decode_leg(torch, K=131072):
     """Secondary leg: one cached-decode attention step of LWM-7B (Q = 1, 32 heads)
     over a K-token KV cache resident in HBM -- ringattention_inference's path
@@ -379,6 +417,7 @@ def main():
                 res["cpu_baseline"] = cpu_baseline(S)
             if not args.no_vqgan:
                 res["vqgan"] = vqgan_leg(torch)
+                res["packed"] = packed_leg(torch)
                 res["decode"] = decode_leg(torch)
                 res["elementwise"] = elementwise_leg(torch)
         print(json.dumps(res), flush=True)
