@@ -148,6 +148,14 @@ int64_t lwm_rmsnorm_bwd_workspace_bytes(int64_t rows, int32_t C);
 int lwm_rmsnorm_bwd_bf16(const void* x, const void* w, const void* g, const float* rstd, void* dx,
                          void* dw, void* workspace, int64_t rows, int32_t C, void* stream);
 
+/* tux.cross_entropy_loss_and_accuracy as used at lwm/train.py:177-181, :192-201, per row of
+ * bf16 logits [rows, V] (V % 8 == 0, V <= 32768): nll[r] = logsumexp(row) - row[target[r]] in
+ * f32; correct[r] = (first argmax == target[r]) (may be NULL); and, if dlogits != NULL, the
+ * fused gradient dlogits[r] = (softmax(row) - onehot(target[r])) * weight[r] (weight NULL = 1).
+ * dlogits may alias logits. */
+int lwm_softmax_ce_bf16(const void* logits, const int32_t* target, const float* weight, float* nll,
+                        int32_t* correct, void* dlogits, int64_t rows, int32_t V, void* stream);
+
 /* ------------------------------------------------------------------ VQGAN
  * Primitives of the video tokeniser, lwm/vqgan.py.  All tensors are f32, NHWC,
  * dense; results are bit-exact with oracle/vqgan_ref.c (exact-f32 MFMA, fixed

@@ -72,6 +72,22 @@ struct RmsParams {
     float eps;
 };
 
+template <int NT>
+LWM_DEVICE float block_sum(float v, lds_t scratch, int tid) {
+    v += shfl_xor_f(v, 1);
+    v += shfl_xor_f(v, 2);
+    v += shfl_xor_f(v, 4);
+    v += shfl_xor_f(v, 8);
+    v += shfl_xor_f(v, 16);
+    v += shfl_xor_f(v, 32);
+    if ((tid & 63) == 0) lds_write_f32(scratch + (tid >> 6) * 4, v);
+    block_sync();
+    float t = 0.0f;
+    for (int w = 0; w < NT / 64; ++w) t += lds_read_f32(scratch + w * 4);
+    block_sync();
+    return t;
+}
+
 LWM_DEVICE float block_sum_256(float v, lds_t scratch, int tid) {
     v += shfl_xor_f(v, 1);
     v += shfl_xor_f(v, 2);
@@ -196,6 +212,112 @@ LWM_KERNEL(256) void rmsnorm_dw_reduce_kernel(const float* part, bf16_t* dw, int
     float s = 0.0f;
     for (int i = 0; i < nblk; ++i) s += part[(int64_t)i * C + c];
     dw[c] = (bf16_t)s;
+}
+
+// ---------------------------------------------------------------- softmax cross-entropy
+// tux.cross_entropy_loss_and_accuracy as called at lwm/train.py:177-181, :192-201: f32
+// log-softmax over the vocabulary, the target's log-probability, argmax == target, and (fused,
+// same pass) the logits gradient (softmax - onehot) * w[row].  One workgroup per row; the row
+// (V <= 32768 bf16) is read from HBM ONCE into registers.  HBM-bound: V*2 B read (+ V*2 B
+// gradient write) per row.
+struct CeParams {
+    const bf16_t* logits;   // [rows, V]
+    const int32_t* target;  // [rows]
+    const float* weight;    // [rows] gradient weight (valid / normaliser) or null (= 1)
+    float* nll;             // [rows]  -log p(target)
+    int32_t* correct;       // [rows]  argmax == target (first maximum), or null
+    bf16_t* dlogits;        // [rows, V] or null
+    int64_t rows;
+    int32_t V;
+};
+
+constexpr int kCeThreads = 512;   // 8 vectors of 8 logits per thread: V <= 32768
+LWM_KERNEL(kCeThreads) void softmax_ce_kernel(CeParams p) {
+    const lds_t lds = dyn_lds();
+    const int tid = thread_idx();
+    const int nv = p.V >> 3;
+    for (int64_t row = block_idx_x(); row < p.rows; row += grid_dim_x()) {
+        const bf16_t* lr = p.logits + row * p.V;
+        float x[8][8];
+        float mx = -INFINITY;
+        int amax = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int v = tid + kCeThreads * k;
+            if (v < nv) {
+                u32x4 raw = global_load_b128(lr + v * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    x[k][2 * j] = __builtin_bit_cast(float, raw[j] << 16);
+                    x[k][2 * j + 1] = __builtin_bit_cast(float, raw[j] & 0xffff0000u);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (x[k][j] > mx) {          // strict: keeps the first maximum of this thread
+                        mx = x[k][j];
+                        amax = v * 8 + j;
+                    }
+            }
+        }
+        // block argmax: larger value wins, ties -> smaller index
+        for (int m = 1; m < 64; m <<= 1) {
+            const float om = shfl_xor_f(mx, m);
+            const int oi = shfl_xor_i(amax, m);
+            if (om > mx || (om == mx && oi < amax)) {
+                mx = om;
+                amax = oi;
+            }
+        }
+        if ((tid & 63) == 0) {
+            lds_write_f32(lds + (tid >> 6) * 8, mx);
+            lds_write_i32(lds + (tid >> 6) * 8 + 4, amax);
+        }
+        block_sync();
+        for (int w = 0; w < kCeThreads / 64; ++w) {
+            const float om = lds_read_f32(lds + w * 8);
+            const int oi = lds_read_i32(lds + w * 8 + 4);
+            if (om > mx || (om == mx && oi < amax)) {
+                mx = om;
+                amax = oi;
+            }
+        }
+        block_sync();
+        float se = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (tid + kCeThreads * k < nv)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    x[k][j] = fast_exp2((x[k][j] - mx) * 1.4426950408889634f);
+                    se += x[k][j];
+                }
+        const float tot = block_sum<kCeThreads>(se, lds + 64, tid);
+        const int tg = p.target[row];
+        const float wgt = p.weight ? p.weight[row] : 1.0f;
+        if (tid == 0) {
+            const float lt = (tg >= 0 && tg < p.V) ? (float)lr[tg] : 0.0f;
+            p.nll[row] = (mx + logf(tot)) - lt;
+            if (p.correct) p.correct[row] = (amax == tg) ? 1 : 0;
+        }
+        if (p.dlogits) {
+            const float s = wgt / tot;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int v = tid + kCeThreads * k;
+                if (v < nv) {
+                    u32x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i0 = v * 8 + 2 * j;
+                        const float g0 = x[k][2 * j] * s - (i0 == tg ? wgt : 0.0f);
+                        const float g1 = x[k][2 * j + 1] * s - (i0 + 1 == tg ? wgt : 0.0f);
+                        o[j] = pack_bf16x2(g0, g1);
+                    }
+                    global_store_b128(p.dlogits + row * p.V + v * 8, o);
+                }
+            }
+        }
+    }
 }
 
 }  // namespace lwm

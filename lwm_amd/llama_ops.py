@@ -116,3 +116,111 @@ class RMSNorm(torch.nn.Module):
 
     def forward(self, x):
         return _RmsNorm.apply(x.to(self.dtype), self.kernel, self.eps)
+
+
+# ---------------------------------------------------------------- loss (lwm/train.py:177-202)
+def _softmax_ce(logits2d, target, weight, want_grad):
+    rows, V = logits2d.shape
+    if not logits2d.is_cuda or logits2d.dtype != torch.bfloat16 or not logits2d.is_contiguous():
+        raise ValueError("cross entropy: expected contiguous bf16 ROCm logits")
+    nll = torch.empty(rows, dtype=torch.float32, device=logits2d.device)
+    correct = torch.empty(rows, dtype=torch.int32, device=logits2d.device)
+    dl = torch.empty_like(logits2d) if want_grad else None
+    L = lib()
+    _capi.check(L, L.lwm_softmax_ce_bf16(logits2d.data_ptr(), target.data_ptr(),
+                                         None if weight is None else weight.data_ptr(), nll.data_ptr(),
+                                         correct.data_ptr(), None if dl is None else dl.data_ptr(), rows, V,
+                                         _stream_ptr()), "lwm_softmax_ce_bf16")
+    return nll, correct, dl
+
+
+def _row_weights(valid, B, S, device):
+    """valid (B,S) or None -> (valid f32, per-row gradient weight valid / (max(sum_s valid, 1e-10) * B))."""
+    v = torch.ones(B, S, dtype=torch.float32, device=device) if valid is None else valid.to(torch.float32)
+    denom = v.sum(dim=-1, keepdim=True).clamp_min(1e-10) * B
+    return v, (v / denom).contiguous()
+
+
+class _CrossEntropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, tokens, valid):
+        B, S, V = logits.shape
+        v, w = _row_weights(valid, B, S, logits.device)
+        nll, correct, dl = _softmax_ce(logits.reshape(B * S, V), tokens.reshape(-1).to(torch.int32).contiguous(),
+                                       w.reshape(-1), logits.requires_grad)
+        loss = (nll.reshape(B, S) * w).sum()
+        acc = (correct.reshape(B, S).to(torch.float32) * w).sum()
+        ctx.save_for_backward(dl)
+        ctx.shape = (B, S, V)
+        ctx.mark_non_differentiable(acc)
+        return loss, acc
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_acc):
+        (dl,) = ctx.saved_tensors
+        return (dl.reshape(ctx.shape) * g_loss.to(dl.dtype)), None, None
+
+
+def cross_entropy_loss_and_accuracy(logits, tokens, valid=None):
+    """tux.cross_entropy_loss_and_accuracy (call sites lwm/train.py:177-181, :192-201):
+    loss = -mean_b( sum_s valid*log p(token) / max(sum_s valid, 1e-10) ), accuracy likewise
+    with argmax == token.  logits (B,S,V) bf16 (upcast to f32 in the kernel), tokens (B,S) int."""
+    return _CrossEntropy.apply(logits, tokens, valid)
+
+
+class _ChunkedHeadLoss(torch.autograd.Function):
+    """lm_head + cross entropy over sequence chunks: the (B,S,V) logits of a 1M-token batch
+    (128 GB in f32) are never materialised -- each chunk's logits live only between its GEMM
+    (hipBLASLt through torch.matmul: a plain library GEMM) and the fused loss/gradient kernel."""
+
+    @staticmethod
+    def forward(ctx, hidden, kernel, tokens, valid, chunk):
+        B, S, Dm = hidden.shape
+        V = kernel.shape[1]
+        v, w = _row_weights(valid, B, S, hidden.device)
+        tok = tokens.to(torch.int32)
+        need = hidden.requires_grad or kernel.requires_grad
+        loss = torch.zeros((), dtype=torch.float32, device=hidden.device)
+        acc = torch.zeros((), dtype=torch.float32, device=hidden.device)
+        dh = torch.empty_like(hidden) if need else None
+        dk = torch.zeros(kernel.shape, dtype=torch.float32, device=hidden.device) if need else None
+        kb = kernel.to(torch.bfloat16)
+        for s0 in range(0, S, chunk):
+            s1 = min(S, s0 + chunk)
+            h = hidden[:, s0:s1].reshape(-1, Dm)
+            logits = (h @ kb).contiguous()
+            nll, correct, dl = _softmax_ce(logits, tok[:, s0:s1].reshape(-1).contiguous(),
+                                           w[:, s0:s1].reshape(-1).contiguous(), need)
+            wc = w[:, s0:s1].reshape(-1)
+            loss += (nll * wc).sum()
+            acc += (correct.to(torch.float32) * wc).sum()
+            if need:
+                dh[:, s0:s1] = (dl @ kb.t()).reshape(B, s1 - s0, Dm)
+                dk += (h.t() @ dl).to(torch.float32)
+        ctx.save_for_backward(dh, dk)
+        ctx.kdtype = kernel.dtype
+        ctx.mark_non_differentiable(acc)
+        return loss, acc
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_acc):
+        dh, dk = ctx.saved_tensors
+        return dh * g_loss.to(dh.dtype), (dk * g_loss).to(ctx.kdtype), None, None, None
+
+
+def chunked_lm_head_loss(hidden, lm_head_kernel, tokens, valid=None, chunk=8192):
+    """logits = hidden @ kernel (lwm/llama.py:1101, flax Dense kernel (d_model, vocab)) followed by
+    cross_entropy_loss_and_accuracy, chunked over the sequence.  Returns (loss, accuracy)."""
+    return _ChunkedHeadLoss.apply(hidden, lm_head_kernel, tokens, valid, int(chunk))
+
+
+def vision_text_loss(vision_logits, text_logits, target_tokens, loss_masks, target_vision_masks):
+    """lwm/train.py:192-202: 0.5 * (vision CE + text CE) with the two masked target sets."""
+    tvm = target_vision_masks.to(torch.bool)
+    lm = loss_masks.to(torch.float32)
+    zeros = torch.zeros_like(target_tokens)
+    v_loss, v_acc = cross_entropy_loss_and_accuracy(vision_logits, torch.where(tvm, target_tokens, zeros),
+                                                    lm * tvm.to(torch.float32))
+    t_loss, t_acc = cross_entropy_loss_and_accuracy(text_logits, torch.where(tvm, zeros, target_tokens),
+                                                    lm * (1.0 - tvm.to(torch.float32)))
+    return 0.5 * (v_loss + t_loss), dict(vision_loss=v_loss, vision_acc=v_acc, text_loss=t_loss, text_acc=t_acc)

@@ -55,3 +55,25 @@ def rmsnorm_bwd(x, weight, g, eps=1e-6):
     dx = r * (dy - xh * np.sum(dy * xh, axis=-1, keepdims=True) / Cc)
     dw = np.sum((g * xh).reshape(-1, Cc), axis=0)
     return dx, dw
+
+
+def cross_entropy_loss_and_accuracy(logits, tokens, valid=None):
+    """tux.cross_entropy_loss_and_accuracy [upstream package, restated from its published source;
+    call sites lwm/train.py:177-181, :192-201], float64.  Returns (loss, accuracy, dloss/dlogits)."""
+    x = np.asarray(logits, np.float64)
+    B, S, V = x.shape
+    tokens = np.asarray(tokens)
+    valid = np.ones((B, S)) if valid is None else np.asarray(valid, np.float64)
+    length = np.maximum(valid.sum(axis=-1), 1e-10)
+    m = x.max(axis=-1, keepdims=True)
+    lse = m[..., 0] + np.log(np.exp(x - m).sum(axis=-1))
+    logp_t = np.take_along_axis(x, tokens[..., None], axis=-1)[..., 0] - lse
+    logp_t = np.where(valid > 0, logp_t, 0.0)
+    loss = -np.mean(np.sum(logp_t, axis=-1) / length)
+    correct = np.where(valid > 0, x.argmax(axis=-1) == tokens, False)
+    acc = np.mean(np.sum(correct, axis=-1) / length)
+    p = np.exp(x - lse[..., None])
+    onehot = np.zeros_like(p)
+    np.put_along_axis(onehot, tokens[..., None], 1.0, axis=-1)
+    w = np.where(valid > 0, 1.0, 0.0) / (length[:, None] * B)
+    return loss, acc, (p - onehot) * w[..., None]

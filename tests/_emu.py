@@ -303,3 +303,17 @@ def rmsnorm_bwd(x, w, g, rstd):
                                           dx.ctypes.data, dw.ctypes.data, ws.ctypes.data, rows, Cc, None),
                 "lwm_rmsnorm_bwd_bf16")
     return from_bf16_bits(dx), from_bf16_bits(dw)
+
+
+def softmax_ce(logits, target, weight=None, want_grad=True):
+    L = lib()
+    lb = bf16_array(logits)
+    rows, V = logits.shape
+    tg = np.ascontiguousarray(target, dtype=np.int32)
+    w = None if weight is None else _af32(weight)
+    nll = aligned((rows,), np.float32)
+    cor = aligned((rows,), np.int32)
+    dl = aligned((rows, V), np.uint16) if want_grad else None
+    _capi.check(L, L.lwm_softmax_ce_bf16(lb.ctypes.data, tg.ctypes.data, _ptr(w), nll.ctypes.data, cor.ctypes.data,
+                                         _ptr(dl), rows, V, None), "lwm_softmax_ce_bf16")
+    return nll, cor, (None if dl is None else from_bf16_bits(dl))

@@ -58,3 +58,20 @@ def test_validation():
     assert L.lwm_rmsnorm_fwd_bf16(16, 16, 16, None, 4, 100, 1e-6, None) == _capi.LWM_EUNSUPPORTED
     t = _capi.LwmTensor4(None, 0, 0, 0)
     assert L.lwm_rope_bf16(t, t, None, None, 1, 1, 1, 128, 16, 0, None) == _capi.LWM_EINVAL
+
+
+@pytest.mark.parametrize("B,S,V", [(2, 5, 32000), (1, 3, 8448), (2, 4, 64)])
+def test_softmax_cross_entropy(B, S, V):
+    g = np.random.default_rng(9)
+    logits = round_bf16((g.standard_normal((B, S, V)) * 3).astype(np.float32))
+    tokens = g.integers(0, V, (B, S))
+    tokens[0, 0] = int(logits[0, 0].argmax())              # one guaranteed-correct prediction
+    valid = (g.random((B, S)) > 0.3).astype(np.float32)
+    valid[0, 0] = 1
+    loss, acc, dref = R.cross_entropy_loss_and_accuracy(logits, tokens, valid)
+    w = valid / (np.maximum(valid.sum(-1, keepdims=True), 1e-10) * B)
+    nll, cor, dl = _emu.softmax_ce(logits.reshape(-1, V), tokens.reshape(-1), w.reshape(-1))
+    assert abs(float((nll * w.reshape(-1)).sum()) - loss) <= 1e-5 * max(1.0, abs(loss))
+    assert abs(float((cor * w.reshape(-1)).sum()) - acc) <= 1e-6
+    assert cor[0] == 1
+    assert np.abs(dl.reshape(B, S, V) - dref).max() <= 2 ** -8 * np.abs(dref).max() + 1e-9

@@ -87,3 +87,52 @@ def test_full_size_bandwidth_and_properties():
     out = RMSNorm(4096).cuda()(h)
     rms = out.float().pow(2).mean(-1).sqrt()
     assert (rms - 1).abs().max().item() <= 1e-2      # weight = ones: unit RMS rows
+
+
+def test_cross_entropy_and_chunked_head():
+    """tux.cross_entropy_loss_and_accuracy semantics (lwm/train.py:177-181) + the chunked lm_head:
+    loss / accuracy / gradients against the float64 oracle; chunked == unchunked."""
+    import torch
+    from lwm_amd.llama_ops import chunked_lm_head_loss, cross_entropy_loss_and_accuracy
+    B, S, Dm, V = 2, 96, 256, 32000
+    g = np.random.default_rng(11)
+    h = round_bf16((g.standard_normal((B, S, Dm))).astype(np.float32))
+    W = round_bf16((g.standard_normal((Dm, V)) * 0.05).astype(np.float32))
+    tokens = g.integers(0, V, (B, S))
+    valid = (g.random((B, S)) > 0.25).astype(np.float32)
+    hd = _dev(h, torch.bfloat16).requires_grad_(True)
+    Wd = _dev(W, torch.bfloat16).requires_grad_(True)
+    logits = hd @ Wd                                   # bf16 logits, as the model's lm_head gives
+    lg = logits.detach().clone().requires_grad_(True)
+    loss, acc = cross_entropy_loss_and_accuracy(lg, _dev(tokens), _dev(valid))
+    loss.backward()
+    rl, ra, rd = R.cross_entropy_loss_and_accuracy(_np(logits), tokens, valid)
+    assert abs(loss.item() - rl) <= 1e-4 * abs(rl) and abs(acc.item() - ra) <= 1e-6
+    assert np.abs(_np(lg.grad) - rd).max() <= 2 ** -7 * np.abs(rd).max() + 1e-9
+    # chunked head: same loss, gradients of hidden and kernel vs float64 chain rule
+    l2, a2 = chunked_lm_head_loss(hd, Wd, _dev(tokens), _dev(valid), chunk=32)
+    l2.backward()
+    assert abs(l2.item() - rl) <= 1e-4 * abs(rl) and abs(a2.item() - ra) <= 1e-6
+    dh_ref = rd @ W.astype(np.float64).T
+    dW_ref = np.einsum("bsd,bsv->dv", h.astype(np.float64), rd)
+    assert np.abs(_np(hd.grad) - dh_ref).max() <= 2e-2 * np.abs(dh_ref).max()
+    assert np.abs(_np(Wd.grad) - dW_ref).max() <= 2e-2 * np.abs(dW_ref).max()
+    l3, _ = chunked_lm_head_loss(hd.detach(), Wd.detach(), _dev(tokens), _dev(valid), chunk=96)
+    assert abs(l3.item() - l2.item()) <= 1e-6 * abs(l2.item())
+
+
+def test_vision_text_loss_combination():
+    import torch
+    from lwm_amd.llama_ops import vision_text_loss
+    B, S = 1, 64
+    g = np.random.default_rng(12)
+    vl = round_bf16(g.standard_normal((B, S, 8448)).astype(np.float32))
+    tl = round_bf16(g.standard_normal((B, S, 32000)).astype(np.float32))
+    tvm = g.random((B, S)) > 0.5
+    tgt = np.where(tvm, g.integers(0, 8448, (B, S)), g.integers(0, 32000, (B, S)))
+    lm = (g.random((B, S)) > 0.1).astype(np.float32)
+    loss, m = vision_text_loss(_dev(vl, torch.bfloat16), _dev(tl, torch.bfloat16), _dev(tgt), _dev(lm), _dev(tvm))
+    rv, _, _ = R.cross_entropy_loss_and_accuracy(vl, np.where(tvm, tgt, 0), lm * tvm)
+    rt, _, _ = R.cross_entropy_loss_and_accuracy(tl, np.where(tvm, 0, tgt), lm * (1.0 - tvm))
+    assert abs(loss.item() - 0.5 * (rv + rt)) <= 1e-4 * abs(0.5 * (rv + rt))
+    assert abs(m["vision_loss"].item() - rv) <= 1e-4 * abs(rv)
