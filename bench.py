@@ -181,6 +181,32 @@ def packed_leg(torch, S=32768, layers=4):
             "dense_equivalent_speedup": "see kernels above: the same S unpacked takes ~36 ms per layer"}
 
 
+def model_slice_leg(torch, S=32768):
+    """Secondary leg: the 2-layer slice of LWM-7B (BASELINE config #1's model) at S = 32768, one
+    forward+backward through the harness (lwm_amd/llama.py): HIP RMSNorm / RoPE / RingAttention /
+    SwiGLU gate / chunked loss + hipBLASLt projections.  Shows the hot path in position."""
+    from lwm_amd.llama import LLaMAConfig, LLaMAForCausalLM
+    cfg = LLaMAConfig.load_config("7b", num_hidden_layers=2, max_sequence_length=S, theta=1e7)
+    torch.manual_seed(0)
+    model = LLaMAForCausalLM(cfg).cuda()
+    tok = torch.randint(0, cfg.vocab_size, (1, S + 1), device="cuda")
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        loss, _ = model.loss(tok[:, :-1], tok[:, 1:], chunk=8192)
+        loss.backward()
+        return loss
+
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"workload": f"LWM-7B 2-layer slice + lm_head, B=1, S={S}, bf16, fwd+bwd", "ms": dt * 1e3,
+            "tokens_per_s": S / dt, "loss": float(loss)}
+
+
 def decode_leg(torch, K=131072):
     """Secondary leg: one cached-decode attention step of LWM-7B (Q = 1, 32 heads)
     over a K-token KV cache resident in HBM -- ringattention_inference's path
@@ -418,6 +444,7 @@ def main():
             if not args.no_vqgan:
                 res["vqgan"] = vqgan_leg(torch)
                 res["packed"] = packed_leg(torch)
+                res["model_slice"] = model_slice_leg(torch)
                 res["decode"] = decode_leg(torch)
                 res["elementwise"] = elementwise_leg(torch)
         print(json.dumps(res), flush=True)

@@ -148,6 +148,12 @@ int64_t lwm_rmsnorm_bwd_workspace_bytes(int64_t rows, int32_t C);
 int lwm_rmsnorm_bwd_bf16(const void* x, const void* w, const void* g, const float* rstd, void* dx,
                          void* dw, void* workspace, int64_t rows, int32_t C, void* stream);
 
+/* The SwiGLU gate of FlaxLLaMAMLP (lwm/llama.py:659): y = silu(a) * b and its backward
+ * (da, db from g = dL/dy); bf16, n % 8 == 0, all pointers 16-byte aligned. */
+int lwm_swiglu_fwd_bf16(const void* a, const void* b, void* y, int64_t n, void* stream);
+int lwm_swiglu_bwd_bf16(const void* a, const void* b, const void* g, void* da, void* db, int64_t n,
+                        void* stream);
+
 /* tux.cross_entropy_loss_and_accuracy as used at lwm/train.py:177-181, :192-201, per row of
  * bf16 logits [rows, V] (V % 8 == 0, V <= 32768): nll[r] = logsumexp(row) - row[target[r]] in
  * f32; correct[r] = (first argmax == target[r]) (may be NULL); and, if dlogits != NULL, the

@@ -1,0 +1,148 @@
+"""Model HARNESS: the LLaMA transformer of lwm/llama.py assembled from this package's
+operators, so that the hot path can be validated and timed in its real position
+(BASELINE config #1: 2-layer slice of LWM-7B, S = 4096).  It is not a product subsystem of
+its own: every projection is a plain library GEMM (hipBLASLt through torch.matmul), the
+embedding a gather; what is hand-written HIP is what sits between them -- RMSNorm, RoPE,
+RingAttention, the SwiGLU gate, the chunked lm_head loss.
+
+Names, parameter layouts and config knobs follow the reference: flax Dense kernels are
+(in, out) (lwm/llama.py:390-421, :631-655); `wte`, `h.<i>.attention.{wq,wk,wv,wo}`,
+`h.<i>.feed_forward.{w1,w2,w3}`, `h.<i>.{attention_norm,ffn_norm}.kernel`, `ln_f.kernel`,
+`lm_head.kernel` (lwm/llama.py:664-744, :982-1106).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .llama_ops import (LLaMAMLP, RMSNorm, apply_rotary_emb, chunked_lm_head_loss,
+                        precompute_freqs_cis)
+from .ringattention import blockwise_feedforward, ringattention
+
+# lwm/llama.py:33-130 (the entries this harness is exercised with)
+LLAMA_STANDARD_CONFIGS = {
+    "7b": dict(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32,
+               num_attention_heads=32, max_sequence_length=4096, initializer_range=0.02, rms_norm_eps=1e-6),
+    "1b": dict(vocab_size=32000, hidden_size=2048, intermediate_size=5504, num_hidden_layers=22,
+               num_attention_heads=16, max_sequence_length=2048, initializer_range=0.02, rms_norm_eps=1e-6),
+}
+
+
+class LLaMAConfig:
+    """lwm/llama.py:133-199: same field names and defaults (dropout fields are 0 and unused)."""
+
+    def __init__(self, vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32,
+                 num_attention_heads=32, max_sequence_length=4096, rms_norm_eps=1e-6, initializer_range=0.02,
+                 scan_attention=True, scan_mlp=True, scan_query_chunk_size=1024, scan_key_chunk_size=1024,
+                 scan_mlp_chunk_size=1024, theta=10000, **kwargs):
+        self.vocab_size, self.hidden_size, self.intermediate_size = vocab_size, hidden_size, intermediate_size
+        self.num_hidden_layers, self.num_attention_heads = num_hidden_layers, num_attention_heads
+        self.max_sequence_length, self.rms_norm_eps = max_sequence_length, rms_norm_eps
+        self.initializer_range = initializer_range
+        self.scan_attention, self.scan_mlp = scan_attention, scan_mlp
+        self.scan_query_chunk_size, self.scan_key_chunk_size = scan_query_chunk_size, scan_key_chunk_size
+        self.scan_mlp_chunk_size, self.theta = scan_mlp_chunk_size, theta
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    @classmethod
+    def load_config(cls, name, **updates):
+        cfg = dict(LLAMA_STANDARD_CONFIGS[name])
+        cfg.update(updates)
+        return cls(**cfg)
+
+
+def _dense(i, o, std, dtype):
+    return torch.nn.Parameter(torch.randn(i, o, dtype=torch.float32).mul_(std).to(dtype))
+
+
+class LLaMAAttention(torch.nn.Module):
+    """FlaxLLaMAAttention.__call__, training branch (lwm/llama.py:494-570, :616-617)."""
+
+    def __init__(self, cfg: LLaMAConfig, dtype=torch.bfloat16):
+        super().__init__()
+        self.cfg, self.dtype = cfg, dtype
+        d = cfg.hidden_size
+        self.num_heads, self.head_dim = cfg.num_attention_heads, d // cfg.num_attention_heads
+        self.wq, self.wk, self.wv, self.wo = (_dense(d, d, cfg.initializer_range, dtype) for _ in range(4))
+
+    def forward(self, x, freqs_cis, attention_mask=None, segment_ids=None, position_ids=None):
+        B, S, d = x.shape
+        split = lambda t: t.reshape(B, S, self.num_heads, self.head_dim)      # reshape, no transpose (:434-438)
+        xq, xk, xv = split(x @ self.wq), split(x @ self.wk), split(x @ self.wv)
+        xq, xk = apply_rotary_emb(xq, xk, freqs_cis, position_ids)
+        bias = None
+        if attention_mask is not None:                                        # (:527-537)
+            m = attention_mask.reshape(B, 1, 1, S)
+            bias = torch.where(m > 0, 0.0, torch.finfo(torch.float32).min)
+        out = ringattention(xq, xk, xv.contiguous(), bias, segment_ids, axis_name="sp", float32_logits=True,
+                            cache_idx=None,
+                            blockwise_kwargs=dict(causal_block_size=1, deterministic=True, attn_pdrop=0.0,
+                                                  query_chunk_size=self.cfg.scan_query_chunk_size,
+                                                  key_chunk_size=self.cfg.scan_key_chunk_size))
+        return out.reshape(B, S, d) @ self.wo
+
+
+class LLaMABlock(torch.nn.Module):
+    """FlaxLLaMABlock (lwm/llama.py:664-744): pre-norm residual block, blockwise FFN."""
+
+    def __init__(self, cfg: LLaMAConfig, dtype=torch.bfloat16):
+        super().__init__()
+        self.cfg = cfg
+        self.attention_norm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, dtype)
+        self.attention = LLaMAAttention(cfg, dtype)
+        self.ffn_norm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, dtype)
+        self.feed_forward = LLaMAMLP(cfg.hidden_size, cfg.intermediate_size, dtype, cfg.initializer_range)
+
+    def forward(self, x, freqs_cis, attention_mask=None, segment_ids=None, position_ids=None):
+        x = x + self.attention(self.attention_norm(x), freqs_cis, attention_mask, segment_ids, position_ids)
+        h = self.ffn_norm(x)
+        if self.cfg.scan_mlp and h.shape[1] >= self.cfg.scan_mlp_chunk_size:      # (:728-734)
+            ff = blockwise_feedforward(self.feed_forward, h, self.cfg.scan_mlp_chunk_size)
+        else:
+            ff = self.feed_forward(h)
+        return x + ff
+
+
+class LLaMAForCausalLM(torch.nn.Module):
+    """FlaxLLaMAModule + lm_head (lwm/llama.py:982-1106), loss of lwm/train.py:171-181."""
+
+    def __init__(self, cfg: LLaMAConfig, dtype=torch.bfloat16):
+        super().__init__()
+        self.cfg, self.dtype = cfg, dtype
+        self.wte = torch.nn.Parameter(torch.randn(cfg.vocab_size, cfg.hidden_size).mul_(cfg.initializer_range).to(dtype))
+        self.h = torch.nn.ModuleList(LLaMABlock(cfg, dtype) for _ in range(cfg.num_hidden_layers))
+        self.ln_f = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, dtype)
+        self.lm_head = _dense(cfg.hidden_size, cfg.vocab_size, cfg.initializer_range, dtype)
+        self._freqs = None
+
+    def _table(self, device):
+        if self._freqs is None or self._freqs.device != device:
+            head_dim = self.cfg.hidden_size // self.cfg.num_attention_heads
+            self._freqs = precompute_freqs_cis(head_dim, self.cfg.max_sequence_length, self.cfg.theta, device=device)
+        return self._freqs
+
+    def hidden_states(self, input_ids, attention_mask=None, segment_ids=None, position_ids=None):
+        x = torch.nn.functional.embedding(input_ids.long(), self.wte)
+        fc = self._table(x.device)
+        for blk in self.h:
+            x = blk(x, fc, attention_mask, segment_ids, position_ids)
+        return self.ln_f(x)
+
+    def loss(self, input_tokens, target_tokens, loss_masks=None, attention_mask=None, segment_ids=None,
+             position_ids=None, chunk=8192):
+        h = self.hidden_states(input_tokens, attention_mask, segment_ids, position_ids)
+        return chunked_lm_head_loss(h, self.lm_head, target_tokens, loss_masks, chunk)
+
+
+def hf_rotary_to_interleaved(w_out_in, num_heads):
+    """HF-PyTorch LLaMA checkpoints (README.md:74, scripts/sample_pyt.py:8) store wq/wk for the
+    rotate_half RoPE convention; the reference rotates interleaved (even, odd) pairs
+    (lwm/llama.py:360-364).  w_out_in: torch Linear weight (out, in).  Returns the flax-layout
+    kernel (in, out) whose head dims are re-ordered [0, d/2, 1, d/2+1, ...] so that interleaved
+    RoPE on it equals rotate_half RoPE on the original."""
+    out_f, in_f = w_out_in.shape
+    hd = out_f // num_heads
+    w = w_out_in.reshape(num_heads, 2, hd // 2, in_f).transpose(1, 2).reshape(out_f, in_f)
+    return w.t().contiguous()

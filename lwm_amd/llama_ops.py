@@ -224,3 +224,47 @@ def vision_text_loss(vision_logits, text_logits, target_tokens, loss_masks, targ
     t_loss, t_acc = cross_entropy_loss_and_accuracy(text_logits, torch.where(tvm, zeros, target_tokens),
                                                     lm * (1.0 - tvm.to(torch.float32)))
     return 0.5 * (v_loss + t_loss), dict(vision_loss=v_loss, vision_acc=v_acc, text_loss=t_loss, text_acc=t_acc)
+
+
+# ---------------------------------------------------------------- SwiGLU MLP (lwm/llama.py:623-661)
+class _SwiGLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        for t in (a, b):
+            if not t.is_cuda or t.dtype != torch.bfloat16 or not t.is_contiguous():
+                raise ValueError("swiglu: expected contiguous bf16 ROCm tensors")
+        y = torch.empty_like(a)
+        L = lib()
+        _capi.check(L, L.lwm_swiglu_fwd_bf16(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream_ptr()),
+                    "lwm_swiglu_fwd_bf16")
+        ctx.save_for_backward(a, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        L = lib()
+        _capi.check(L, L.lwm_swiglu_bwd_bf16(a.data_ptr(), b.data_ptr(), g.data_ptr(), da.data_ptr(), db.data_ptr(),
+                                             a.numel(), _stream_ptr()), "lwm_swiglu_bwd_bf16")
+        return da, db
+
+
+def swiglu(a, b):
+    """silu(a) * b (the gate of FlaxLLaMAMLP, lwm/llama.py:659)."""
+    return _SwiGLU.apply(a, b)
+
+
+class LLaMAMLP(torch.nn.Module):
+    """FlaxLLaMAMLP (lwm/llama.py:623-661): w2(silu(w1 x) * w3 x), flax Dense kernels
+    (in, out), no bias.  The three GEMMs are library GEMMs (hipBLASLt via torch.matmul)."""
+
+    def __init__(self, hidden_size, intermediate_size, dtype=torch.bfloat16, initializer_range=0.02):
+        super().__init__()
+        mk = lambda i, o: torch.nn.Parameter(torch.randn(i, o, dtype=dtype) * initializer_range)
+        self.w1, self.w2, self.w3 = mk(hidden_size, intermediate_size), mk(intermediate_size, hidden_size), \
+            mk(hidden_size, intermediate_size)
+
+    def forward(self, x):
+        return swiglu((x @ self.w1).contiguous(), (x @ self.w3).contiguous()) @ self.w2

@@ -1,0 +1,64 @@
+"""CPU float32 reference of the LLaMA harness (lwm/llama.py restated with plain PyTorch-CPU
+ops: dense masked attention, interleaved RoPE, RMSNorm, SwiGLU, tux cross entropy) --
+TEST INFRASTRUCTURE, NOT PRODUCT.  BASELINE config #1 (2-layer slice, S = 4096, fp32 on CPU).
+PARITY UNPINNED (see oracle/attention_ref.py): this follows the in-tree source line by line."""
+import math
+
+import numpy as np
+import torch
+
+
+def _rmsnorm(x, w, eps):
+    x32 = x.float()
+    return (x32 * torch.rsqrt(x32.pow(2).mean(-1, keepdim=True) + eps)) * w.float()
+
+
+def _rope(x, fc, pos):
+    B, S, H, D = x.shape
+    xr = x.float().reshape(B, S, H, D // 2, 2)
+    c, s = fc[pos][..., 0][:, :, None, :], fc[pos][..., 1][:, :, None, :]
+    return torch.stack((xr[..., 0] * c - xr[..., 1] * s, xr[..., 0] * s + xr[..., 1] * c), dim=-1).reshape(B, S, H, D)
+
+
+def forward_loss(state, cfg, input_tokens, target_tokens, loss_masks=None, attention_mask=None,
+                 segment_ids=None):
+    """state: dict name -> float32 CPU tensor (requires_grad as wanted), names as lwm_amd.llama."""
+    B, S = input_tokens.shape
+    H = cfg.num_attention_heads
+    D = cfg.hidden_size // H
+    freqs = 1.0 / (cfg.theta ** (np.arange(0, D, 2)[: D // 2].astype(np.float32) / D))
+    ang = np.outer(np.arange(cfg.max_sequence_length), freqs).astype(np.float32)
+    fc = torch.from_numpy(np.stack((np.cos(ang), np.sin(ang)), -1))
+    pos = torch.arange(S)[None].expand(B, S)
+    x = state["wte"][input_tokens.long()]
+    vis = torch.tril(torch.ones(S, S, dtype=torch.bool))[None, None]
+    if segment_ids is not None:
+        vis = vis & (segment_ids[:, None, :, None] == segment_ids[:, None, None, :])
+    if attention_mask is not None:
+        vis = vis & (attention_mask[:, None, None, :] > 0)
+    for i in range(cfg.num_hidden_layers):
+        p = f"h.{i}."
+        hn = _rmsnorm(x, state[p + "attention_norm.kernel"], cfg.rms_norm_eps)
+        q = (hn @ state[p + "attention.wq"]).reshape(B, S, H, D)
+        k = (hn @ state[p + "attention.wk"]).reshape(B, S, H, D)
+        v = (hn @ state[p + "attention.wv"]).reshape(B, S, H, D)
+        q, k = _rope(q, fc, pos), _rope(k, fc, pos)
+        s = torch.einsum("bqhd,bkhd->bhqk", q, k) / math.sqrt(D)
+        s = s.masked_fill(~vis, float("-inf"))
+        a = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, dim=-1), v).reshape(B, S, H * D)
+        x = x + a @ state[p + "attention.wo"]
+        hn = _rmsnorm(x, state[p + "ffn_norm.kernel"], cfg.rms_norm_eps)
+        ff = (torch.nn.functional.silu(hn @ state[p + "feed_forward.w1"]) * (hn @ state[p + "feed_forward.w3"])) \
+            @ state[p + "feed_forward.w2"]
+        x = x + ff
+    h = _rmsnorm(x, state["ln_f.kernel"], cfg.rms_norm_eps)
+    logits = h @ state["lm_head"]
+    valid = torch.ones(B, S) if loss_masks is None else loss_masks.float()
+    logp = torch.log_softmax(logits.float(), dim=-1)
+    tok_lp = torch.gather(logp, -1, target_tokens.long()[..., None])[..., 0]
+    tok_lp = torch.where(valid > 0, tok_lp, torch.zeros_like(tok_lp))
+    length = valid.sum(-1).clamp_min(1e-10)
+    loss = -(tok_lp.sum(-1) / length).mean()
+    correct = torch.where(valid > 0, logits.argmax(-1) == target_tokens.long(), torch.zeros_like(valid, dtype=torch.bool))
+    acc = (correct.float().sum(-1) / length).mean()
+    return loss, acc

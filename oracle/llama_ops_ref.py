@@ -77,3 +77,15 @@ def cross_entropy_loss_and_accuracy(logits, tokens, valid=None):
     np.put_along_axis(onehot, tokens[..., None], 1.0, axis=-1)
     w = np.where(valid > 0, 1.0, 0.0) / (length[:, None] * B)
     return loss, acc, (p - onehot) * w[..., None]
+
+
+def swiglu(a, b):
+    """silu(a) * b in float64 (lwm/llama.py:659) and its gradients given g."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return a / (1.0 + np.exp(-a)) * b
+
+
+def swiglu_bwd(a, b, g):
+    a, b, g = (np.asarray(t, np.float64) for t in (a, b, g))
+    sg = 1.0 / (1.0 + np.exp(-a))
+    return g * b * sg * (1.0 + a * (1.0 - sg)), g * a * sg

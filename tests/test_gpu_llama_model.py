@@ -1,0 +1,88 @@
+"""BASELINE config #1: LWM-7B 2-layer slice, S = 4096, bs = 1 -- the harness built from the HIP
+operators (bf16) against the float32 CPU reference of the same model (oracle/llama_model_ref.py):
+loss, accuracy and parameter gradients.  Tolerance: bf16 weights/activations vs fp32:
+loss within 1e-2 relative, gradient cosine >= 0.99 per parameter."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _state_fp32(model):
+    import torch
+    st = {}
+    for n, p in model.named_parameters():
+        st[n] = p.detach().float().cpu().clone().requires_grad_(True)
+    return st
+
+
+def _run(cfg, S, packed, seed):
+    import torch
+    from lwm_amd.llama import LLaMAForCausalLM
+    from oracle import llama_model_ref as M
+    torch.manual_seed(seed)
+    model = LLaMAForCausalLM(cfg).cuda()
+    g = torch.Generator().manual_seed(seed + 1)
+    tokens = torch.randint(0, cfg.vocab_size, (1, S + 1), generator=g)
+    inp, tgt = tokens[:, :-1].contiguous(), tokens[:, 1:].contiguous()
+    lm = (torch.rand(1, S, generator=g) > 0.1).float()
+    seg = am = None
+    if packed:
+        seg = torch.zeros(1, S, dtype=torch.int32)
+        seg[:, S // 3:] = 1
+        seg[:, (3 * S) // 4:] = 2
+        am = torch.ones(1, S, dtype=torch.int32)
+        am[:, 5:9] = 0
+    loss, acc = model.loss(inp.cuda(), tgt.cuda(), lm.cuda(), None if am is None else am.cuda(),
+                           None if seg is None else seg.cuda(), chunk=1024)
+    loss.backward()
+    st = _state_fp32(model)
+    rl, ra = M.forward_loss(st, cfg, inp, tgt, lm, am, seg)
+    rl.backward()
+    return model, st, loss.item(), acc.item(), rl.item(), ra.item()
+
+
+def _check(model, st, loss, acc, rl, ra):
+    assert abs(loss - rl) <= 1e-2 * abs(rl), (loss, rl)
+    assert abs(acc - ra) <= 2e-3
+    for n, p in model.named_parameters():
+        a = p.grad.float().cpu().flatten().double()
+        b = st[n].grad.flatten().double()
+        cos = float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-30))
+        assert cos >= 0.99, (n, cos)
+        assert abs(float(a.norm() / b.norm().clamp_min(1e-30)) - 1) <= 5e-2, n
+
+
+def test_small_slice_packed():
+    from lwm_amd.llama import LLaMAConfig
+    cfg = LLaMAConfig(vocab_size=4096, hidden_size=512, intermediate_size=1408, num_hidden_layers=2,
+                      num_attention_heads=4, max_sequence_length=2048, scan_mlp_chunk_size=256)
+    _check(*_run(cfg, 1536, True, 0))
+
+
+def test_config1_7b_two_layer_slice_4k():
+    from lwm_amd.llama import LLaMAConfig
+    cfg = LLaMAConfig.load_config("7b", num_hidden_layers=2)
+    _check(*_run(cfg, 4096, False, 1))
+
+
+def test_hf_rotary_permutation():
+    """interleaved RoPE on the permuted projection == rotate_half RoPE on the original."""
+    import torch
+    from lwm_amd.llama import hf_rotary_to_interleaved
+    from oracle import llama_ops_ref as R
+    H, D, d_in, S = 2, 128, 64, 16
+    g = torch.Generator().manual_seed(0)
+    W = torch.randn(H * D, d_in, generator=g)
+    x = torch.randn(1, S, d_in, generator=g)
+    q_hf = (x @ W.t()).reshape(1, S, H, D)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))
+    ang = torch.outer(torch.arange(S).float(), inv)
+    cos, sin = torch.cat((ang.cos(), ang.cos()), -1)[None, :, None], torch.cat((ang.sin(), ang.sin()), -1)[None, :, None]
+    rot = torch.cat((-q_hf[..., D // 2:], q_hf[..., :D // 2]), -1)
+    ref = q_hf * cos + rot * sin                                        # HF rotate_half convention
+    q_il = (x @ hf_rotary_to_interleaved(W, H)).reshape(1, S, H, D)
+    fc = R.precompute_freqs_cis(D, S, 10000.0)
+    got = R.apply_rotary_emb(q_il.numpy(), fc, np.arange(S)[None], out_bf16=False)
+    got = torch.from_numpy(got).reshape(1, S, H, D // 2, 2).transpose(3, 4).reshape(1, S, H, D)   # back to halves
+    assert (got - ref).abs().max().item() <= 1e-4

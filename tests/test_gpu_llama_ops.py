@@ -136,3 +136,17 @@ def test_vision_text_loss_combination():
     rt, _, _ = R.cross_entropy_loss_and_accuracy(tl, np.where(tvm, 0, tgt), lm * (1.0 - tvm))
     assert abs(loss.item() - 0.5 * (rv + rt)) <= 1e-4 * abs(0.5 * (rv + rt))
     assert abs(m["vision_loss"].item() - rv) <= 1e-4 * abs(rv)
+
+
+def test_swiglu_fwd_bwd():
+    import torch
+    from lwm_amd.llama_ops import swiglu
+    a, b, g = _rnd((3, 700, 88), 21, 2.0), _rnd((3, 700, 88), 22), _rnd((3, 700, 88), 23)
+    ad, bd = _dev(a, torch.bfloat16).requires_grad_(True), _dev(b, torch.bfloat16).requires_grad_(True)
+    y = swiglu(ad, bd)
+    ref = R.swiglu(a, b)
+    assert np.abs(_np(y) - ref).max() <= 2 ** -7 * np.abs(ref).max()
+    y.backward(_dev(g, torch.bfloat16))
+    da, db = R.swiglu_bwd(a, b, g)
+    assert np.abs(_np(ad.grad) - da).max() <= 2 ** -7 * np.abs(da).max() + 1e-6
+    assert np.abs(_np(bd.grad) - db).max() <= 2 ** -7 * np.abs(db).max() + 1e-6
