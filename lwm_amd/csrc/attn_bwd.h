@@ -381,7 +381,9 @@ LWM_DEVICE void dkv_stage_finish(const DkvCtx<NKB>& cx, const DkvStage& st, int 
 
 template <int NKB, int BUF>
 LWM_DEVICE void dkv_tile(const AttnParams& p, const DkvCtx<NKB>& cx, const bf16x8 (&kf)[NKB][8],
-                         int qt, f32x16 (&dk)[NKB][4], f32x16 (&dv)[NKB][4]) {
+                         int qt, f32x16 (&dk)[NKB][4], f32x16 (&dv)[NKB][4], ProfAcc& pa) {
+    PROF_DECL(4);
+    PROF_T(0);
     const int64_t q_pos0 = p.q_start + (int64_t)qt * kDkvBQ;
     if (p.causal && q_pos0 + kDkvBQ - 1 < cx.wk_min) return;  // all queries before this wave's keys
     constexpr uint32_t QB = BUF * kDkvQTileBytes;
@@ -427,6 +429,8 @@ LWM_DEVICE void dkv_tile(const AttnParams& p, const DkvCtx<NKB>& cx, const bf16x
         sched_fence();
     }
     prio_lo();
+    PROF_KEEP(dp[0][15]);
+    PROF_T(1);
     const bool need_mask = cx.has_meta || (p.causal && q_pos0 < cx.wk_max);
     // row statistics of the 16 query rows this lane's C/D registers hold
     for (int g = 0; g < 4; ++g) {
@@ -462,6 +466,8 @@ LWM_DEVICE void dkv_tile(const AttnParams& p, const DkvCtx<NKB>& cx, const bf16x
             pb[kb][t] = cvt_frag(s[kb], 8 * t);
             dsb[kb][t] = cvt_frag(dp[kb], 8 * t);
         }
+    PROF_KEEP(dsb[0][1]);
+    PROF_T(2);
     // dV += P^T dO, dK += dS^T Q: 16 steps, each one transposed fragment (2 LDS
     // reads) and NKB MFMAs.  The fragments go through a ring of kRing registers and
     // are requested kRing-1 steps ahead (s and dp are dead here, so the ring is free).
@@ -486,6 +492,14 @@ LWM_DEVICE void dkv_tile(const AttnParams& p, const DkvCtx<NKB>& cx, const bf16x
         sched_fence();
     }
     prio_lo();
+    PROF_KEEP(dk[0][3][0]);
+    PROF_T(3);
+    PROF_ADD(pa, 0, 0, 1);   // S, dP MFMAs
+    PROF_ADD(pa, 1, 1, 2);   // exp / mask / dS
+    PROF_ADD(pa, 2, 2, 3);   // dV, dK MFMAs
+#ifdef LWM_PROF
+    pa.v[5] += 1;
+#endif
 }
 
 // SKEW >= 0: the second-dispatched half of the workgroup (the partner wave on every
@@ -595,6 +609,11 @@ LWM_DEVICE void attn_bwd_dkdv_body(const AttnParams& p) {
         }
 
     // (pipeline under `qt0 < nqt`: see attn_fwd_kernel)
+    ProfAcc pa = {};
+    PROF_DECL(3);
+#ifdef LWM_PROF
+    const unsigned long long prof_k0 = __builtin_amdgcn_s_memtime();
+#endif
     if (qt0 < nqt) {
         DkvStage stg;
         dkv_stage_issue<NW, NKB, 0, SK>(p, cx, qb, dob, b, h, qt0, stg);
@@ -606,21 +625,32 @@ LWM_DEVICE void attn_bwd_dkdv_body(const AttnParams& p) {
             const bool more1 = qt + 1 < nqt;
             if (more1) dkv_stage_issue<NW, NKB, 1, SK>(p, cx, qb, dob, b, h, qt + 1, stg);
             if constexpr (SKEW > 0) { if (late) sleep_cycles64<SKEW>(); }
-            dkv_tile<NKB, 0>(p, cx, kf, qt, dk, dv);
+            dkv_tile<NKB, 0>(p, cx, kf, qt, dk, dv, pa);
+            PROF_T(0);
             if (more1) dkv_stage_finish<NKB, 1, T0>(cx, stg, qt + 1, p.Sq);
             glds_wait_all();
+            PROF_T(1);
             block_sync();
+            PROF_T(2);
+            PROF_ADD(pa, 3, 0, 1);   // statistics write + DMA wait (every second tile is sampled)
+            PROF_ADD(pa, 4, 1, 2);   // barrier wait
             if (!more1) break;
             const bool more2 = qt + 2 < nqt;
             if (more2) dkv_stage_issue<NW, NKB, 0, SK>(p, cx, qb, dob, b, h, qt + 2, stg);
             if constexpr (SKEW > 0) { if (late) sleep_cycles64<SKEW>(); }
-            dkv_tile<NKB, 1>(p, cx, kf, qt + 1, dk, dv);
+            dkv_tile<NKB, 1>(p, cx, kf, qt + 1, dk, dv, pa);
             if (more2) dkv_stage_finish<NKB, 0, T0>(cx, stg, qt + 2, p.Sq);
             glds_wait_all();
             block_sync();
         }
     }
 
+#ifdef LWM_PROF
+    if (hb == 0 && kbi == 0 && lane == 0 && p.out_acc) {   // the longest key block of head 0
+        pa.v[6] = __builtin_amdgcn_s_memtime() - prof_k0;
+        *((ProfAcc*)p.out_acc + wave) = pa;
+    }
+#endif
 #pragma unroll
     for (int kbk = 0; kbk < NKB; ++kbk) {
         const int k_row = kbi * kDkvBK + wave_row0 + 32 * kbk + l31;

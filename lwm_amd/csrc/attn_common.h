@@ -216,6 +216,25 @@ LWM_DEVICE void seg_own_range(const int32_t* blk, int nblk, int b0, int n, int& 
         }
 }
 
+// ---- per-phase cycle accounting (only in -DLWM_PROF builds: scripts/build_prof.sh).
+// PROF_T(i) stamps s_memtime into slot i; PROF_ADD(dst, a, b) accumulates t[b]-t[a].  Lane 0 of
+// every wave of ONE chosen workgroup writes its sums to AttnParams::out_acc (unused by the
+// instrumented launch).  s_memtime drains lgkmcnt, so the stamps perturb the schedule by
+// ~10 %; the numbers rank phases, they are not a clock.
+#ifdef LWM_PROF
+struct ProfAcc { unsigned long long v[8]; };
+#define PROF_DECL(n) unsigned long long prof_t[n]
+#define PROF_T(i) prof_t[i] = __builtin_amdgcn_s_memtime()
+#define PROF_ADD(acc, slot, a, b) (acc).v[slot] += prof_t[b] - prof_t[a]
+#define PROF_KEEP(x) asm volatile("" ::"v"(x))
+#else
+struct ProfAcc {};
+#define PROF_DECL(n)
+#define PROF_T(i)
+#define PROF_ADD(acc, slot, a, b)
+#define PROF_KEEP(x)
+#endif
+
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 constexpr int32_t kSegInvalid = (int32_t)0x80000000;

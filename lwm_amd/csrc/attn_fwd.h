@@ -91,7 +91,9 @@ LWM_DEVICE void fwd_stage_write(const FwdCtx& cx, const FwdStage& st, int kt, in
 // kernel is compiled without that code.
 template <int BUF, bool INFER>
 LWM_DEVICE void fwd_tile(const AttnParams& p, const FwdCtx& cx, const bf16x8 (&qf)[8], int kt,
-                         float& m_run, float& l_run, f32x16 (&acc)[4]) {
+                         float& m_run, float& l_run, f32x16 (&acc)[4], ProfAcc& pa) {
+    PROF_DECL(4);
+    PROF_T(0);
     const int64_t k_pos0 = p.k_start + (int64_t)kt * kFwdBK;
     if (INFER && cx.wave_idle) return;           // staging only (short query blocks)
     if (p.causal && k_pos0 > cx.wq_max) return;  // wholly in this wave's future
@@ -124,6 +126,8 @@ LWM_DEVICE void fwd_tile(const AttnParams& p, const FwdCtx& cx, const bf16x8 (&q
         sched_fence();
     }
     prio_lo();
+    PROF_KEEP(st[1][15]);
+    PROF_T(1);
     // ---- masks (lwm/llama.py:572-592): causal, same segment, key valid
     const bool need_mask = cx.has_kmeta || (p.causal && k_pos0 + kFwdBK - 1 > cx.wq_min);
     if (need_mask) {
@@ -193,6 +197,8 @@ LWM_DEVICE void fwd_tile(const AttnParams& p, const FwdCtx& cx, const bf16x8 (&q
     bf16x8 pb[2][2];
     for (int kb2 = 0; kb2 < 2; ++kb2)
         for (int t = 0; t < 2; ++t) pb[kb2][t] = cvt_frag(st[kb2], 8 * t);
+    PROF_KEEP(pb[1][1]);
+    PROF_T(2);
     bf16x8 ft[kRing];
     auto load_tr = [&](int h) {   // h = (kb2, t, db)
         ft[h % kRing] = read_tr_frag_x(lo0, up0, h & 3, VB + 16 * (h >> 2) * kRowBytes);
@@ -208,6 +214,14 @@ LWM_DEVICE void fwd_tile(const AttnParams& p, const FwdCtx& cx, const bf16x8 (&q
         sched_fence();
     }
     prio_lo();
+    PROF_KEEP(acc[3][0]);
+    PROF_T(3);
+    PROF_ADD(pa, 0, 0, 1);   // S = K Q^T
+    PROF_ADD(pa, 1, 1, 2);   // masks + softmax
+    PROF_ADD(pa, 2, 2, 3);   // O += V^T P^T
+#ifdef LWM_PROF
+    pa.v[5] += 1;
+#endif
 }
 
 template <bool INFER>
@@ -283,6 +297,11 @@ LWM_DEVICE void attn_fwd_body(const AttnParams& p) {
         }
     }
 
+    ProfAcc pa = {};
+    PROF_DECL(3);
+#ifdef LWM_PROF
+    const unsigned long long prof_k0 = __builtin_amdgcn_s_memtime();
+#endif
     float m_run = -INFINITY;  // running max of raw scores (q.k, unscaled)
     float l_run = 0.0f;       // this half-wave's partial row sum
     f32x16 acc[4];
@@ -319,18 +338,29 @@ LWM_DEVICE void attn_fwd_body(const AttnParams& p) {
         for (int kt = kt0; kt < nkt; kt += 2) {
             const bool more1 = kt + 1 < nkt;
             if (more1) fwd_stage_load(p, kb, vb, b, kt + 1, tid, stg);
-            fwd_tile<0, INFER>(p, cx, qf, kt, m_run, l_run, acc);
+            fwd_tile<0, INFER>(p, cx, qf, kt, m_run, l_run, acc, pa);
+            PROF_T(0);
             if (more1) fwd_stage_write<1>(cx, stg, kt + 1, p.Sk);
+            PROF_T(1);
             block_sync();
+            PROF_T(2);
+            PROF_ADD(pa, 3, 0, 1);   // staging ds_writes (every second tile is sampled)
+            PROF_ADD(pa, 4, 1, 2);   // barrier wait
             if (!more1) break;
             const bool more2 = kt + 2 < nkt;
             if (more2) fwd_stage_load(p, kb, vb, b, kt + 2, tid, stg);
-            fwd_tile<1, INFER>(p, cx, qf, kt + 1, m_run, l_run, acc);
+            fwd_tile<1, INFER>(p, cx, qf, kt + 1, m_run, l_run, acc, pa);
             if (more2) fwd_stage_write<0>(cx, stg, kt + 2, p.Sk);
             block_sync();
         }
     }
 
+#ifdef LWM_PROF
+    if (!INFER && hb == 0 && qt == nqt - 1 && lane == 0 && p.out_acc) {   // the longest q tile of head 0
+        pa.v[6] = __builtin_amdgcn_s_memtime() - prof_k0;
+        *((ProfAcc*)p.out_acc + wave) = pa;
+    }
+#endif
     // ---- epilogue: normalise, merge with the ring carry, store
     const float l_tot = l_run + xhalf(l_run);
     float inv = 0.0f, lse_b = -INFINITY;
