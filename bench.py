@@ -271,6 +271,66 @@ def elementwise_leg(torch, S=32768):
                          "kernel": "rmsnorm_fwd_kernel"}}
 
 
+class NullComm:
+    """Same rank/size/schedule as the real communicator, but nothing moves: rotate() hands the
+    local tensors back and exchange_async() leaves the receive buffers as allocated.  Used once,
+    after the timed region, to price the exchange (bench `exchange` object)."""
+
+    def __init__(self, real):
+        self.rank, self.size, self.schedule = real.rank, real.size, real.schedule
+
+    class _H:
+        def __init__(self, bufs):
+            self.bufs = bufs
+
+        def wait(self):
+            return self.bufs
+
+    def rotate(self, tensors):
+        return NullComm._H(list(tensors))
+
+    def exchange_async(self, sends, recvs):
+        return NullComm._H([t for _, t in recvs])
+
+
+def HostStagedComm(torch, dist, Base, schedule):
+    """--backend gloo (dry run): gloo moves host memory, so every message is staged device -> host
+    -> peer -> device.  Only the control flow of the N > 1 path is being exercised."""
+
+    class _H:
+        def __init__(self, reqs, pairs):
+            self.reqs, self.pairs = reqs, pairs
+
+        def wait(self):
+            for r in self.reqs:
+                r.wait()
+            self.reqs = []
+            for dst, host in self.pairs:
+                dst.copy_(host)
+            self.pairs = []
+            return getattr(self, "bufs", None)
+
+    class Staged(Base):
+        def exchange_async(self, sends, recvs):
+            ops_ = [dist.P2POp(dist.isend, t.cpu(), peer) for peer, t in sends]
+            pairs = []
+            for peer, buf in recvs:
+                host = torch.empty(buf.shape, dtype=buf.dtype)
+                pairs.append((buf, host))
+                ops_.append(dist.P2POp(dist.irecv, host, peer))
+            h = _H(dist.batch_isend_irecv(ops_) if ops_ else [], pairs)
+            h.bufs = [b for _, b in recvs]
+            h.keep = [op.tensor for op in ops_]     # host copies stay alive until wait()
+            return h
+
+        def rotate(self, tensors):
+            bufs = [torch.empty_like(t) for t in tensors]
+            return self.exchange_async([((self.rank + 1) % self.size, t) for t in tensors],
+                                       [((self.rank - 1) % self.size, b) for b in bufs])
+
+    return Staged(None, schedule=schedule)
+
+
 class KernelTimer:
     """HIP events (torch.cuda.Event on the stream the kernels are launched on)
     around every kernel launch of the timed region, aggregated per kernel."""
@@ -309,6 +369,11 @@ def main():
     ap.add_argument("--layout", default="zigzag", choices=["zigzag", "contiguous"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vqgan", action="store_true", help="skip the secondary VQGAN leg")
+    ap.add_argument("--schedule", default=None, choices=["ring", "mesh"],
+                    help="K/V exchange schedule for N > 1 (default: mesh for N > 2; lwm_amd/ring.py)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = DRY RUN of the N > 1 code path on a box with fewer than N GPUs: the ranks "
+                         "share the visible devices and stage every message through host memory")
     ap.add_argument("--packed", action="store_true",
                     help="masked sequence packing (BASELINE config #5 style): documents log-uniform in "
                          "[S/256, S/4]; FLOPs are counted over visible pairs only")
@@ -326,13 +391,19 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
                          f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dry = args.backend == "gloo"
+    dev_index = local_rank % torch.cuda.device_count() if dry else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
-        comm = TorchRingComm(None)
+        if dry:
+            dist.init_process_group("gloo")
+            comm = HostStagedComm(torch, dist, TorchRingComm, args.schedule)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+            comm = TorchRingComm(None, schedule=args.schedule)
     else:
         comm = SingleComm()
 
@@ -372,9 +443,17 @@ def main():
                           segment_ids=segment_ids)
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if dry else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     for _ in range(args.warmup):
         step()
@@ -384,11 +463,23 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+
+    exchange = None
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # the same launches with the exchange removed (buffers left as allocated): what the step
+        # would cost if every transfer were free.  exposed = what the xGMI traffic adds on top.
+        real_comm, comm = comm, NullComm(comm)
+        step()
+        barrier()
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        compute_only = max_over_ranks(time.perf_counter() - t0)
+        comm = real_comm
+        exchange = {"schedule": comm.schedule, "compute_only_ms_per_step": compute_only * 1e3,
+                    "exposed_ms_per_step": (elapsed / args.steps - compute_only) * 1e3,
+                    "overlap_efficiency": compute_only / (elapsed / args.steps)}
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -413,8 +504,11 @@ def main():
                              + (" [BASELINE configs[1]]" if world == 1 and S == 32768 and not args.packed else "")
                              + (" [BASELINE configs[2] problem]" if world > 1 and S == 131072 else "")),
                 "seq_len": S, "ring": world, "layers": args.layers,
+                "exchange_schedule": getattr(comm, "schedule", None) if world > 1 else None,
             },
             "tokens_per_s_per_gpu": tokens_per_s / world,
+            "exchange": exchange,
+            "dry_run": "ranks share devices, messages staged through host memory; timings are not xGMI" if dry else None,
             "path_algorithmic_tflops_per_gpu": algo_flops_step / (ms_per_step * 1e-3) / 1e12 / world,
         }
         if world == 1:

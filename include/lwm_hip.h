@@ -127,6 +127,12 @@ int lwm_kv_cache_write(void* cache, const void* src, int32_t B, int64_t cache_st
 /* Elementwise helpers of the ring driver (HBM-bound). */
 /* dst_bf16[n] = (bf16) src_f32[n] */
 int lwm_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* dst_bf16[n] = (bf16) (((srcs[0] + srcs[1]) + srcs[2]) + ...), f32 adds in argument order.
+ * `srcs` is a HOST array of n_src (1..16) device pointers.  Replaces the f32 dk/dv carry
+ * that the reference's backward scan ppermutes around the ring:
+ * under the mesh schedule every rank returns its partial straight to the block's owner,
+ * which reduces them here. */
+int lwm_sum_f32_to_bf16(const float* const* srcs, int32_t n_src, void* dst, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------ RoPE, RMSNorm
  * The HBM-bound steps either side of the attention op. */

@@ -26,6 +26,34 @@ LWM_KERNEL(kCastThreads) void cast_f32_to_bf16_kernel(const float* src, bf16_t* 
         for (int64_t j = nvec << 3; j < n; ++j) dst[j] = (bf16_t)src[j];
 }
 
+// dst[i] = bf16(((src0[i] + src1[i]) + src2[i]) + ...): the owner-side reduction of the
+// dK/dV partials that the other ranks return under the mesh schedule (lwm_amd/ring.py).
+// The order is the argument order, so a rank's result does not depend on arrival times.
+constexpr int kSumMaxSrc = 16;
+struct SumSrcs { const float* p[kSumMaxSrc]; };
+LWM_KERNEL(kCastThreads) void sum_f32_to_bf16_kernel(SumSrcs srcs, int n_src, bf16_t* dst, int64_t n) {
+    const int64_t nvec = n >> 3;
+    int64_t i = (int64_t)block_idx_x() * kCastThreads + thread_idx();
+    const int64_t step = (int64_t)grid_dim_x() * kCastThreads;
+    for (; i < nvec; i += step) {
+        f32x4 a = global_load_f32x4(srcs.p[0] + i * 8);
+        f32x4 b = global_load_f32x4(srcs.p[0] + i * 8 + 4);
+        for (int s = 1; s < n_src; ++s) {
+            a += global_load_f32x4(srcs.p[s] + i * 8);
+            b += global_load_f32x4(srcs.p[s] + i * 8 + 4);
+        }
+        u32x4 o = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]),
+                   pack_bf16x2(b[2], b[3])};
+        global_store_b128(dst + i * 8, o);
+    }
+    if (block_idx_x() == 0 && thread_idx() == 0)
+        for (int64_t j = nvec << 3; j < n; ++j) {
+            float t = srcs.p[0][j];
+            for (int s = 1; s < n_src; ++s) t += srcs.p[s][j];
+            dst[j] = (bf16_t)t;
+        }
+}
+
 // (min, max) segment id per block of 32 rows (include/lwm_hip.h, lwm_attn_segment_blocks).
 LWM_KERNEL(256) void seg_blocks_kernel(const int32_t* seg, const uint8_t* valid, int32_t* out, int B, int S) {
     const int nblk = (S + 31) >> 5;

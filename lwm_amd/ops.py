@@ -258,6 +258,23 @@ def cast_f32_to_bf16(src, dst=None):
     return dst
 
 
+def sum_f32_to_bf16(srcs, dst=None):
+    """bf16(((srcs[0] + srcs[1]) + ...)) -- the owner-side reduction of returned dK/dV partials."""
+    srcs = list(srcs)
+    for s in srcs:
+        if not s.is_cuda or s.dtype != torch.float32 or not s.is_contiguous() or s.shape != srcs[0].shape:
+            raise ValueError("sum_f32_to_bf16: expected same-shaped contiguous f32 device tensors")
+    if dst is None:
+        dst = torch.empty(srcs[0].shape, dtype=torch.bfloat16, device=srcs[0].device)
+    elif not dst.is_contiguous() or dst.dtype != torch.bfloat16 or dst.numel() != srcs[0].numel():
+        raise ValueError("sum_f32_to_bf16: dst must be a contiguous bf16 tensor of the same size")
+    ptrs = (C.c_void_p * len(srcs))(*[s.data_ptr() for s in srcs])
+    L = lib()
+    _capi.check(L, L.lwm_sum_f32_to_bf16(ptrs, len(srcs), dst.data_ptr(), srcs[0].numel(), _stream_ptr()),
+                "lwm_sum_f32_to_bf16")
+    return dst
+
+
 # ---------------------------------------------------------------- VQGAN primitives
 def _f32c(t, name):
     if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():

@@ -15,13 +15,28 @@ MI355X-first differences (results identical):
     balances causal work across ranks; ownership is a property of the layout
     object, the kernels only ever see (q_start, k_start) global offsets.
 
+Two exchange schedules produce the same results:
+  * "ring"  -- the reference's: K/V (and, in the backward, the f32 dK/dV carries) hop
+    i -> i+1 once per step; every byte crosses ONE xGMI link per step, serially.
+  * "mesh"  -- MI355X's xGMI is a full mesh (a direct link to each of the 7 peers), so
+    nothing needs forwarding: every rank posts, up front and in one grouped launch, the
+    direct transfer of exactly those K/V segments each peer's queries can see (all links
+    busy at once, ~1/4 fewer bytes under zigzag+causal), works through the blocks as in
+    the ring, returns each block's f32 dK/dV PARTIAL straight to its owner while the
+    next block is computed, and the owner reduces the partials in fixed rank order
+    (lwm_sum_f32_to_bf16).  Default for n > 2; LWM_RING_SCHEDULE=ring|mesh overrides.
+
 The driver is written against two small interfaces so the schedule can be
 exercised on CPU (gloo) in tests with a stand-in block backend:
   block ops : fwd / bwd_delta / bwd_dq / bwd_dkdv / cast / zeros / empty
-  comm      : rank, size, rotate(list[tensor]) -> handle.wait() -> list[tensor]
+  block ops (mesh) : + sum_cast
+  comm      : rank, size, schedule, rotate(list[tensor]) -> handle.wait() -> list[tensor],
+              exchange_async([(peer, tensor)], [(peer, buffer)]) -> handle
 The product block ops (`HipBlockOps`) call liblwm_hip.so and nothing else.
 """
 from __future__ import annotations
+
+import os
 
 import torch
 import torch.distributed as dist
@@ -68,12 +83,13 @@ def pair_visible(qseg, kseg, causal: bool) -> bool:
 
 # ----------------------------------------------------------------- comm
 class _Handle:
-    def __init__(self, reqs, bufs):
-        self.reqs, self.bufs = reqs, bufs
+    def __init__(self, reqs, bufs, keep=None):
+        self.reqs, self.bufs, self.keep = reqs, bufs, keep
 
     def wait(self):
         for r in self.reqs:
             r.wait()
+        self.reqs = []
         return self.bufs
 
 
@@ -81,10 +97,13 @@ class TorchRingComm:
     """send to (rank+1)%n, receive from (rank-1)%n -- RCCL (backend "nccl") on
     GPUs, gloo in the CPU tests."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, schedule=None):
         self.group = group
         self.rank = dist.get_rank(group)
         self.size = dist.get_world_size(group)
+        self.schedule = schedule or os.environ.get("LWM_RING_SCHEDULE") or ("mesh" if self.size > 2 else "ring")
+        if self.schedule not in ("ring", "mesh"):
+            raise ValueError(f"unknown exchange schedule {self.schedule!r}")
         self._dst = dist.get_global_rank(group, (self.rank + 1) % self.size) if group is not None \
             else (self.rank + 1) % self.size
         self._src = dist.get_global_rank(group, (self.rank - 1) % self.size) if group is not None \
@@ -107,8 +126,11 @@ class TorchRingComm:
             dist.all_gather(list(out.unbind(0)), t.contiguous(), group=self.group)
         return out
 
-    def exchange(self, sends, recvs):
-        """sends: [(peer, tensor)], recvs: [(peer, empty tensor)] -- one grouped P2P batch."""
+    def exchange_async(self, sends, recvs):
+        """sends: [(peer, tensor)], recvs: [(peer, empty tensor)] -- ONE grouped P2P launch
+        (on RCCL the transfers of a group run concurrently, one xGMI link per peer).
+        Messages between one pair of ranks match in list order.  -> handle; the sent
+        tensors are kept alive by it."""
         ops_ = []
         for peer, t in sends:
             dst = dist.get_global_rank(self.group, peer) if self.group is not None else peer
@@ -116,19 +138,26 @@ class TorchRingComm:
         for peer, t in recvs:
             src = dist.get_global_rank(self.group, peer) if self.group is not None else peer
             ops_.append(dist.P2POp(dist.irecv, t, src, self.group))
-        if ops_:
-            for r in dist.batch_isend_irecv(ops_):
-                r.wait()
+        reqs = dist.batch_isend_irecv(ops_) if ops_ else []
+        return _Handle(reqs, [t for _, t in recvs], keep=[t for _, t in sends])
+
+    def exchange(self, sends, recvs):
+        self.exchange_async(sends, recvs).wait()
 
 
 class SingleComm:
     rank, size = 0, 1
+    schedule = "ring"
 
     def rotate(self, tensors):
         return _Handle([], list(tensors))
 
     def all_gather(self, t):
         return t.unsqueeze(0)
+
+    def exchange_async(self, sends, recvs):
+        assert not sends and not recvs
+        return _Handle([], [])
 
     def exchange(self, sends, recvs):
         assert not sends and not recvs
@@ -143,6 +172,7 @@ class HipBlockOps:
     bwd_dq = staticmethod(_ops.attn_bwd_dq_block)
     bwd_dkdv = staticmethod(_ops.attn_bwd_dkdv_block)
     cast = staticmethod(_ops.cast_f32_to_bf16)
+    sum_cast = staticmethod(_ops.sum_f32_to_bf16)
     fwd_splitk = staticmethod(_ops.attn_fwd_splitk)
     combine = staticmethod(_ops.attn_combine)
     cache_write = staticmethod(_ops.kv_cache_write)
@@ -187,6 +217,59 @@ def _fwd_plan(layout, rank, n, causal):
     return plan
 
 
+def _needed_ksegs(layout, q_rank, k_rank, causal):
+    """Indices of k_rank's segments that at least one query segment of q_rank can see."""
+    qs_, ks_ = layout.segments(q_rank), layout.segments(k_rank)
+    return [ki for ki, ks in enumerate(ks_) if any(pair_visible(qs, ks, causal) for qs in qs_)]
+
+
+def _is_mesh(comm):
+    return comm.size > 1 and getattr(comm, "schedule", "ring") == "mesh"
+
+
+class _MeshBlocks:
+    """Direct fetch of every peer's visible K/V segments (the mesh schedule's transport).
+
+    All transfers are posted at construction, `wave` distances per grouped launch (default:
+    all of them in one, i.e. every xGMI link of this GPU busy at once).  get(t) -> {ki: [k_seg,
+    v_seg]} of rank (r - t) mod n, waiting for that wave only."""
+
+    def __init__(self, comm, layout, tensors, causal, wave=None):
+        n, r = comm.size, comm.rank
+        own = layout.segments(r)
+        B = tensors[0].shape[0]
+        self.local = {ki: [_rows(x, s) for x in tensors] for ki, s in enumerate(own)}
+        self.remote, self.handles = {}, {}
+        wave = wave or int(os.environ.get("LWM_MESH_WAVE", "0")) or (n - 1)
+        ts = list(range(1, n))
+        for w0 in range(0, len(ts), wave):
+            sends, recvs = [], []
+            for t in ts[w0:w0 + wave]:
+                dst, src = (r + t) % n, (r - t) % n
+                for ki in _needed_ksegs(layout, dst, r, causal):
+                    sends += [(dst, _rows(x, own[ki]).contiguous()) for x in tensors]
+                segs = layout.segments(src)
+                got = {}
+                for ki in _needed_ksegs(layout, r, src, causal):
+                    got[ki] = [torch.empty((B, segs[ki][1]) + tuple(x.shape[2:]), dtype=x.dtype,
+                                           device=x.device) for x in tensors]
+                    recvs += [(src, b) for b in got[ki]]
+                self.remote[t] = got
+            h = comm.exchange_async(sends, recvs)
+            for t in ts[w0:w0 + wave]:
+                self.handles[t] = h
+
+    def get(self, t):
+        if t == 0:
+            return self.local
+        self.handles[t].wait()
+        return self.remote[t]
+
+    def finish(self):
+        for h in self.handles.values():
+            h.wait()
+
+
 # ----------------------------------------------------------------- forward
 def ring_forward(block, comm, q, k, v, *, layout, causal=True, segment_ids=None, key_valid=None,
                  scale=None):
@@ -214,17 +297,24 @@ def ring_forward(block, comm, q, k, v, *, layout, causal=True, segment_ids=None,
 
     k_cur = k if k.is_contiguous() else k.contiguous()
     v_cur = v if v.is_contiguous() else v.contiguous()
+    mesh = _MeshBlocks(comm, layout, [k_cur, v_cur], causal) if _is_mesh(comm) else None
     keep = []
     idx = 0
     for t in range(n):
-        handle = comm.rotate([k_cur, v_cur]) if t < n - 1 else None
+        handle = comm.rotate([k_cur, v_cur]) if (mesh is None and t < n - 1) else None
         ksegs = layout.segments((r - t) % n)
+        held = None
         while idx < len(plan) and plan[idx][0] == t:
             _, qi, ki = plan[idx]
             qs, ks = qsegs[qi], ksegs[ki]
             sq, sk, kv = _mask_slices(segment_ids, key_valid, qs, ks)
             fin = idx == last[qi]
-            block.fwd(_rows(q, qs), _rows(k_cur, ks), _rows(v_cur, ks), q_start=qs[2], k_start=ks[2],
+            if mesh is not None:
+                held = held if held is not None else mesh.get(t)
+                k_blk, v_blk = held[ki]
+            else:
+                k_blk, v_blk = _rows(k_cur, ks), _rows(v_cur, ks)
+            block.fwd(_rows(q, qs), k_blk, v_blk, q_start=qs[2], k_start=ks[2],
                       causal=causal, seg_q=sq, seg_k=sk, key_valid=kv, scale=scale,
                       out=_rows(out, qs) if fin else None, lse=lses[qi] if fin else None,
                       out_acc=acc_o[qi], lse_acc=acc_l[qi], carry_in=idx != first[qi], final=fin)
@@ -232,6 +322,8 @@ def ring_forward(block, comm, q, k, v, *, layout, causal=True, segment_ids=None,
         if handle is not None:
             keep.append((k_cur, v_cur))
             k_cur, v_cur = handle.wait()
+    if mesh is not None:
+        mesh.finish()   # our sends must have left before k/v may be reused by the caller
     return out, lses
 
 
@@ -255,6 +347,10 @@ def ring_backward(block, comm, q, k, v, out, lses, dout, *, layout, causal=True,
         dk, dv = block.bwd_dkdv(q, k, v, dout, lses[0], deltas[0], final=True, **kw)
         dq = block.bwd_dq(q, k, v, dout, lses[0], deltas[0], final=True, **kw)
         return dq, dk, dv
+
+    if _is_mesh(comm):
+        return _mesh_backward(block, comm, q, k, v, lses, dout, deltas, layout=layout, causal=causal,
+                              segment_ids=segment_ids, key_valid=key_valid, scale=scale)
 
     dq_acc = [block.zeros((B, ln, H, D), torch.float32, q) for _, ln, _ in qsegs]
     # f32 dk/dv accumulators of the block currently held; they travel with it
@@ -309,6 +405,102 @@ def ring_backward(block, comm, q, k, v, out, lses, dout, *, layout, causal=True,
             dq[:, off:off + ln].copy_(block.cast(dq_acc[i]))
             dk[:, off:off + ln].copy_(block.cast(dk_acc[i]))
             dv[:, off:off + ln].copy_(block.cast(dv_acc[i]))
+    return dq, dk, dv
+
+
+def _mesh_backward(block, comm, q, k, v, lses, dout, deltas, *, layout, causal, segment_ids, key_valid,
+                   scale):
+    """Backward under the mesh schedule (module docstring).  Order on the compute stream:
+    dq(local) | for each remote block: dq, dk/dv partial -> posted to its owner | dk/dv(local),
+    so the first arrivals are covered by local work and the last partial's flight by the
+    local dK/dV launch."""
+    n, r = comm.size, comm.rank
+    B, c, H, D = q.shape
+    qsegs = layout.segments(r)
+    k_c = k if k.is_contiguous() else k.contiguous()
+    v_c = v if v.is_contiguous() else v.contiguous()
+    mesh = _MeshBlocks(comm, layout, [k_c, v_c], causal)
+    dq = block.empty((B, c, H, D), q.dtype, q)
+    dk = block.empty((B, c, H, D), q.dtype, q)
+    dv = block.empty((B, c, H, D), q.dtype, q)
+
+    def pairs_at(t):
+        ksegs = layout.segments((r - t) % n)
+        return ksegs, [(qi, ki) for qi, qs in enumerate(qsegs) for ki, ks in enumerate(ksegs)
+                       if pair_visible(qs, ks, causal)]
+
+    # dq: chained through an f32 carry per q segment; the last contribution writes bf16
+    n_dq = [0] * len(qsegs)
+    for t in range(n):
+        for qi, _ in pairs_at(t)[1]:
+            n_dq[qi] += 1
+    dq_acc = [block.empty((B, ln, H, D), torch.float32, q) if n_dq[qi] > 1 else None
+              for qi, (_, ln, _) in enumerate(qsegs)]
+    done_dq = [0] * len(qsegs)
+    for qi, (off, ln, _) in enumerate(qsegs):
+        if n_dq[qi] == 0:
+            dq[:, off:off + ln].zero_()
+
+    def run_dq(t, held):
+        ksegs, pairs = pairs_at(t)
+        for qi, ki in pairs:
+            qs, ks = qsegs[qi], ksegs[ki]
+            sq, sk, kv = _mask_slices(segment_ids, key_valid, qs, ks)
+            done_dq[qi] += 1
+            fin = done_dq[qi] == n_dq[qi]
+            block.bwd_dq(_rows(q, qs), held[ki][0], held[ki][1], _rows(dout, qs), lses[qi], deltas[qi],
+                         q_start=qs[2], k_start=ks[2], causal=causal, seg_q=sq, seg_k=sk, key_valid=kv,
+                         scale=scale, dq=_rows(dq, qs) if fin else None, dq_acc=dq_acc[qi],
+                         carry_in=done_dq[qi] > 1, final=fin)
+
+    def run_dkdv(t, held):
+        """-> {ki: (dk_part, dv_part)} f32, for the key segments that got a contribution."""
+        ksegs, pairs = pairs_at(t)
+        part = {}
+        for qi, ki in pairs:
+            qs, ks = qsegs[qi], ksegs[ki]
+            sq, sk, kv = _mask_slices(segment_ids, key_valid, qs, ks)
+            first = ki not in part
+            if first:
+                part[ki] = (block.empty((B, ks[1], H, D), torch.float32, q),
+                            block.empty((B, ks[1], H, D), torch.float32, q))
+            block.bwd_dkdv(_rows(q, qs), held[ki][0], held[ki][1], _rows(dout, qs), lses[qi], deltas[qi],
+                           q_start=qs[2], k_start=ks[2], causal=causal, seg_q=sq, seg_k=sk, key_valid=kv,
+                           scale=scale, dk_acc=part[ki][0], dv_acc=part[ki][1], carry_in=not first,
+                           final=False)
+        return part
+
+    own = layout.segments(r)
+    run_dq(0, mesh.get(0))
+    returned = {}     # t -> ({ki: (dk, dv)} received from rank r+t for MY segments, handle)
+    for t in range(1, n):
+        held = mesh.get(t)
+        run_dq(t, held)
+        part = run_dkdv(t, held)
+        owner, giver = (r - t) % n, (r + t) % n
+        sends = []
+        for ki in _needed_ksegs(layout, r, owner, causal):   # == sorted(part)
+            sends += [(owner, part[ki][0]), (owner, part[ki][1])]
+        got, recvs = {}, []
+        for ki in _needed_ksegs(layout, giver, r, causal):
+            ln = own[ki][1]
+            got[ki] = (block.empty((B, ln, H, D), torch.float32, q), block.empty((B, ln, H, D), torch.float32, q))
+            recvs += [(giver, got[ki][0]), (giver, got[ki][1])]
+        returned[t] = (got, comm.exchange_async(sends, recvs))
+    local = run_dkdv(0, mesh.get(0))
+    mesh.finish()
+    for t in returned:
+        returned[t][1].wait()
+    for ki, (off, ln, _) in enumerate(own):
+        for which, dst in ((0, dk), (1, dv)):
+            srcs = ([local[ki][which]] if ki in local else []) + \
+                   [returned[t][0][ki][which] for t in sorted(returned) if ki in returned[t][0]]
+            if not srcs:
+                dst[:, off:off + ln].zero_()
+            elif len(own) == 1 or B == 1:
+                block.sum_cast(srcs, dst[:, off:off + ln] if len(own) > 1 else dst)
+            else:
+                dst[:, off:off + ln].copy_(block.sum_cast(srcs))
     return dq, dk, dv
 
 

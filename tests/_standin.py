@@ -35,6 +35,16 @@ class OracleBlockOps:
         return dst
 
     @staticmethod
+    def sum_cast(srcs, dst=None):
+        acc = srcs[0].clone()
+        for x in srcs[1:]:
+            acc = acc + x            # f32 adds in argument order, as the kernel
+        if dst is None:
+            return acc.to(torch.bfloat16)
+        dst.copy_(acc.to(dst.dtype).reshape(dst.shape))
+        return dst
+
+    @staticmethod
     def fwd(q, k, v, *, q_start=0, k_start=0, causal=True, seg_q=None, seg_k=None, key_valid=None,
             scale=None, out=None, lse=None, out_acc=None, lse_acc=None, carry_in=False, final=True):
         D = q.shape[-1]

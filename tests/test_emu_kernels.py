@@ -96,6 +96,28 @@ def test_emulated_cast_f32_to_bf16():
         assert np.array_equal(R.from_bf16_bits(y), R.round_bf16(x))
 
 
+def test_emulated_sum_f32_to_bf16():
+    """lwm_sum_f32_to_bf16 (owner-side reduction of returned dK/dV partials): f32 adds in
+    argument order, one rounding to bf16, ragged tail included."""
+    import ctypes as C
+    L = _emu.lib()
+    L.lwm_sum_f32_to_bf16.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
+    for n, k in ((8, 1), (2048 + 8, 3), (100003, 8)):
+        xs = []
+        for i in range(k):
+            x = _emu.aligned((n,), np.float32)
+            x[...] = np.random.default_rng(n + i).standard_normal(n) * 10.0 ** (i % 3)
+            xs.append(x)
+        y = _emu.aligned((n,), np.uint16)
+        ptrs = (C.c_void_p * k)(*[x.ctypes.data for x in xs])
+        assert L.lwm_sum_f32_to_bf16(ptrs, k, y.ctypes.data, n, None) == 0
+        ref = xs[0].copy()
+        for x in xs[1:]:
+            ref = (ref + x).astype(np.float32)
+        assert np.array_equal(R.from_bf16_bits(y), R.round_bf16(ref))
+    assert L.lwm_sum_f32_to_bf16(ptrs, 17, y.ctypes.data, 8, None) != 0
+
+
 @pytest.mark.parametrize("monotone", [True, False])
 def test_emulated_packed_documents_are_skipped_not_changed(monotone):
     """Packed batch of several documents spanning many tiles: with the segment-block hints the

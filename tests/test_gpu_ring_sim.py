@@ -24,18 +24,39 @@ class _Handle:
         return self.q.get(timeout=60)
 
 
-class ThreadComm:
-    """rank r puts into rank (r+1)%n's inbox, takes from its own."""
+class _PairHandle:
+    def __init__(self, links, me, recvs):
+        self.links, self.me, self.recvs = links, me, recvs
 
-    def __init__(self, rank, size, inboxes):
+    def wait(self):
+        for peer, buf in self.recvs:
+            buf.copy_(self.links[(peer, self.me)].get(timeout=60))
+        self.recvs = []
+
+
+class ThreadComm:
+    """rank r puts into rank (r+1)%n's inbox, takes from its own; exchange_async (the mesh
+    schedule's transport) uses one FIFO per ordered (src, dst) pair -- messages between a pair
+    match in posting order, as grouped RCCL send/recv do."""
+
+    def __init__(self, rank, size, inboxes, schedule="ring", links=None):
         self.rank, self.size, self.inboxes = rank, size, inboxes
+        self.schedule, self.links = schedule, links
+        self.sent_bytes = 0
 
     def rotate(self, tensors):
+        self.sent_bytes += sum(t.numel() * t.element_size() for t in tensors)
         self.inboxes[(self.rank + 1) % self.size].put([t.clone() for t in tensors])
         return _Handle(self.inboxes[self.rank], len(tensors))
 
+    def exchange_async(self, sends, recvs):
+        for peer, t in sends:
+            self.sent_bytes += t.numel() * t.element_size()
+            self.links[(self.rank, peer)].put(t.clone())
+        return _PairHandle(self.links, self.rank, list(recvs))
 
-def _run_ring(n, layout_kind, S, H, packed):
+
+def _run_ring(n, layout_kind, S, H, packed, schedule="ring"):
     import torch
     from lwm_amd.ring import HipBlockOps, SeqLayout, ring_attention, ring_backward, ring_forward
     g = torch.Generator().manual_seed(0)
@@ -49,19 +70,21 @@ def _run_ring(n, layout_kind, S, H, packed):
         seg = seg.cuda()
     lay = SeqLayout(layout_kind, n, S)
     inboxes = [queue.Queue() for _ in range(n)]
-    res, errs = [None] * n, []
+    links = {(a, b): queue.Queue() for a in range(n) for b in range(n)}
+    res, errs, sent = [None] * n, [], [0] * n
 
     def worker(r):
         try:
             idx = lay.global_index(r).cuda()
             ql, kl, vl, dol = (t[:, idx].clone() for t in (q, k, v, do))
-            comm = ThreadComm(r, n, inboxes)
+            comm = ThreadComm(r, n, inboxes, schedule, links)
             # the driver functions directly: torch runs every backward() of a device on ONE
             # autograd thread, which would serialise (deadlock) the n simulated ranks
             out, lses = ring_forward(HipBlockOps, comm, ql, kl, vl, layout=lay, causal=True, segment_ids=seg)
             dq, dk, dv = ring_backward(HipBlockOps, comm, ql, kl, vl, out, lses, dol, layout=lay, causal=True,
                                        segment_ids=seg)
             torch.cuda.synchronize()
+            sent[r] = comm.sent_bytes
             res[r] = (idx.cpu(), out, dq, dk, dv)
         except Exception as e:  # pragma: no cover
             errs.append(e)
@@ -80,14 +103,17 @@ def _run_ring(n, layout_kind, S, H, packed):
     for idx, o, gq, gk, gv in res:
         for dst, src in zip(full, (o, gq, gk, gv)):
             dst[:, idx.cuda()] = src
+    _run_ring.sent_bytes = sum(sent)
     return full, (o1.detach(), q1.grad, k1.grad, v1.grad), (q, k, v, do, seg)
 
 
-@pytest.mark.parametrize("n,layout_kind,packed", [(2, "contiguous", False), (2, "zigzag", True),
-                                                  (4, "zigzag", False), (8, "zigzag", True)])
-def test_ring_n_equals_ring_1_on_gpu(n, layout_kind, packed):
+@pytest.mark.parametrize("n,layout_kind,packed,schedule", [
+    (2, "contiguous", False, "ring"), (2, "zigzag", True, "ring"), (4, "zigzag", False, "ring"),
+    (8, "zigzag", True, "ring"),
+    (2, "zigzag", True, "mesh"), (4, "contiguous", False, "mesh"), (8, "zigzag", True, "mesh")])
+def test_ring_n_equals_ring_1_on_gpu(n, layout_kind, packed, schedule):
     S, H = 256 * n, 2
-    got, ref, (q, k, v, do, seg) = _run_ring(n, layout_kind, S, H, packed)
+    got, ref, (q, k, v, do, seg) = _run_ring(n, layout_kind, S, H, packed, schedule)
     for name, a, b in zip(("out", "dq", "dk", "dv"), got, ref):
         a, b = a.float(), b.float()
         err = ((a - b).abs().max() / b.abs().max()).item()
@@ -100,6 +126,18 @@ def test_ring_n_equals_ring_1_on_gpu(n, layout_kind, packed):
     for name, a, b in zip(("out", "dq", "dk", "dv"), got, (ro, rq, rk, rv)):
         err = np.abs(f(a) - b).max() / np.abs(b).max()
         assert err <= 2e-2, (name, err)
+
+
+def test_mesh_schedule_moves_fewer_bytes_than_the_ring():
+    """zigzag + causal: a rank's early half-chunk is invisible to every earlier rank's queries and
+    its late half-chunk to every later rank's early queries, so the direct fetch ships ~3/4 of
+    the K/V bytes the rotating ring does, and no f32 carry is forwarded through bystanders."""
+    n, S, H = 8, 2048, 2
+    _run_ring(n, "zigzag", S, H, False, "ring")
+    ring_bytes = _run_ring.sent_bytes
+    _run_ring(n, "zigzag", S, H, False, "mesh")
+    mesh_bytes = _run_ring.sent_bytes
+    assert mesh_bytes < 0.8 * ring_bytes, (mesh_bytes, ring_bytes)
 
 
 class ThreadGroupComm(ThreadComm):

@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, layout_kind, causal, packed, q_out):
+def _worker(rank, world, port, layout_kind, causal, packed, schedule, q_out):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -43,7 +43,7 @@ def _worker(rank, world, port, layout_kind, causal, packed, q_out):
         idx = lay.global_index(rank)
         ql, kl, vl = (t[:, idx].clone().requires_grad_(True) for t in (q, k, v))
         out = ring_attention(ql, kl, vl, causal=causal, segment_ids=seg, key_valid=kv, layout=lay,
-                             block_ops=OracleBlockOps, comm=TorchRingComm(None))
+                             block_ops=OracleBlockOps, comm=TorchRingComm(None, schedule=schedule))
         out.backward(do[:, idx])
         q_out.put((rank, idx.numpy(), out.detach().float().numpy(), ql.grad.float().numpy(),
                    kl.grad.float().numpy(), vl.grad.float().numpy()))
@@ -52,18 +52,23 @@ def _worker(rank, world, port, layout_kind, causal, packed, q_out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,layout_kind,causal,packed", [
-    (2, "contiguous", True, False),
-    (2, "zigzag", True, True),
-    (2, "contiguous", False, True),
-    (4, "zigzag", True, False),
+@pytest.mark.parametrize("world,layout_kind,causal,packed,schedule", [
+    (2, "contiguous", True, False, "ring"),
+    (2, "zigzag", True, True, "ring"),
+    (2, "contiguous", False, True, "ring"),
+    (4, "zigzag", True, False, "ring"),
+    # the mesh schedule: direct fetch of the visible K/V segments, partial dK/dV returned to the owner
+    (2, "zigzag", True, True, "mesh"),
+    (4, "zigzag", True, True, "mesh"),
+    (4, "contiguous", True, False, "mesh"),
+    (3, "contiguous", False, True, "mesh"),
 ])
-def test_ring_equals_single_device(world, layout_kind, causal, packed):
+def test_ring_equals_single_device(world, layout_kind, causal, packed, schedule):
     from oracle import attention_ref as R
     ctx = mp.get_context("spawn")
     qout = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, layout_kind, causal, packed, qout))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, layout_kind, causal, packed, schedule, qout))
              for r in range(world)]
     for p in procs:
         p.start()
