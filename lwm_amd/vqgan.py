@@ -143,8 +143,8 @@ class VQGAN:
         independent, so multi-GPU use is one VQGAN per process ("replicas only")."""
         if params is None:
             assert vqgan_checkpoint != ""
-            with open(vqgan_checkpoint, "rb") as f:
-                params = pickle.load(f)
+            from .weights import load_pickle_tree      # also reads pickles written from jax arrays
+            params = load_pickle_tree(vqgan_checkpoint)
         if not torch.cuda.is_available():
             raise RuntimeError("lwm_amd.VQGAN needs a ROCm device (there is no CPU path)")
         self.replicate = replicate

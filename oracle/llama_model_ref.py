@@ -23,6 +23,12 @@ def _rope(x, fc, pos):
 def forward_loss(state, cfg, input_tokens, target_tokens, loss_masks=None, attention_mask=None,
                  segment_ids=None):
     """state: dict name -> float32 CPU tensor (requires_grad as wanted), names as lwm_amd.llama."""
+    return _loss(forward_logits(state, cfg, input_tokens, attention_mask, segment_ids), target_tokens, loss_masks)
+
+
+def forward_logits(state, cfg, input_tokens, attention_mask=None, segment_ids=None):
+    """(B, S, vocab) float32 logits (lwm/llama.py:982-1106).  Pinned against HF transformers'
+    LlamaForCausalLM by tests/test_weights.py (tests/golden/hf_llama_tiny.npz)."""
     B, S = input_tokens.shape
     H = cfg.num_attention_heads
     D = cfg.hidden_size // H
@@ -52,7 +58,12 @@ def forward_loss(state, cfg, input_tokens, target_tokens, loss_masks=None, atten
             @ state[p + "feed_forward.w2"]
         x = x + ff
     h = _rmsnorm(x, state["ln_f.kernel"], cfg.rms_norm_eps)
-    logits = h @ state["lm_head"]
+    return h @ state["lm_head"]
+
+
+def _loss(logits, target_tokens, loss_masks=None):
+    """tux.cross_entropy_loss_and_accuracy as called at lwm/train.py:177-181."""
+    B, S = target_tokens.shape
     valid = torch.ones(B, S) if loss_masks is None else loss_masks.float()
     logp = torch.log_softmax(logits.float(), dim=-1)
     tok_lp = torch.gather(logp, -1, target_tokens.long()[..., None])[..., 0]

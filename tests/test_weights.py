@@ -1,0 +1,150 @@
+"""Weight I/O (lwm_amd/weights.py) and the HF-transformers anchor.
+
+tests/golden/hf_llama_tiny.npz holds logits / loss / gradients of HF `LlamaForCausalLM` (the
+PyTorch implementation the reference points at, scripts/sample_pyt.py:8) for a tiny model whose
+weights are a function of a seed (tests/golden/hf_fixture.py).  Here, on CPU: the checkpoint
+converter (layout transposes + the rotate_half -> interleaved q/k re-ordering) feeding the fp32
+oracle model must reproduce them, which pins oracle/llama_model_ref.py -- and through it RoPE,
+RMSNorm, causal attention, SwiGLU and the loss -- against code that is not ours."""
+import io
+import os
+import pickle
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import hf_fixture as F  # noqa: E402
+
+from lwm_amd import weights as W  # noqa: E402
+from lwm_amd.llama import hf_rotary_to_interleaved  # noqa: E402
+from oracle import llama_model_ref as M  # noqa: E402
+
+GOLD = np.load(os.path.join(HERE, "golden", "hf_llama_tiny.npz"))
+
+
+def _oracle_state(requires_grad=False):
+    cfg = W.config_from_hf(F.HF_CONFIG)
+    st = W.hf_to_lwm(F.state_dict(), cfg.num_attention_heads)
+    st = {k: v.clone().requires_grad_(requires_grad) for k, v in st.items()}
+    return cfg, st
+
+
+def test_oracle_model_reproduces_hf_transformers_logits_and_loss():
+    cfg, st = _oracle_state()
+    ids = F.token_ids()
+    logits = M.forward_logits(st, cfg, ids[:, :-1])
+    ref = torch.from_numpy(GOLD["logits"])
+    assert (logits - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
+    loss, acc = M.forward_loss(st, cfg, ids[:, :-1], ids[:, 1:])
+    assert abs(loss.item() - float(GOLD["loss"])) <= 1e-5 * float(GOLD["loss"])
+    assert abs(acc.item() - float(GOLD["accuracy"])) < 1e-6
+
+
+def test_oracle_model_reproduces_hf_transformers_gradients():
+    cfg, st = _oracle_state(requires_grad=True)
+    ids = F.token_ids()
+    loss, _ = M.forward_loss(st, cfg, ids[:, :-1], ids[:, 1:])
+    loss.backward()
+    nh = cfg.num_attention_heads
+    for hf_name, ours, kind in (("grad_q_proj_0", "h.0.attention.wq", "rotary"),
+                                ("grad_k_proj_1", "h.1.attention.wk", "rotary"),
+                                ("grad_v_proj_0", "h.0.attention.wv", "linear")):
+        g = torch.from_numpy(GOLD[hf_name])
+        g = hf_rotary_to_interleaved(g, nh) if kind == "rotary" else g.t()
+        got = st[ours].grad
+        assert (got - g).abs().max().item() <= 2e-4 * g.abs().max().item(), hf_name
+
+
+def test_hf_checkpoint_directory_round_trip(tmp_path):
+    import json
+    from safetensors.torch import save_file
+    sd = {k: v.to(torch.bfloat16) for k, v in F.state_dict().items()}
+    save_file(sd, str(tmp_path / "model.safetensors"))
+    (tmp_path / "config.json").write_text(json.dumps(F.HF_CONFIG))
+    got, cfg = W.read_hf_checkpoint(str(tmp_path))
+    assert cfg["rope_theta"] == 10000.0 and set(got) == set(sd)
+    lw = W.hf_to_lwm(got, cfg["num_attention_heads"])
+    assert lw["h.1.feed_forward.w2"].shape == (512, 256) and lw["lm_head"].shape == (256, 384)
+    assert torch.equal(lw["h.0.attention.wv"], sd["model.layers.0.self_attn.v_proj.weight"].t())
+    with pytest.raises(KeyError):
+        W.hf_to_lwm({"model.layers.0.self_attn.qkv.weight": torch.zeros(2, 2)}, 2)
+    with pytest.raises(ValueError):
+        W.config_from_hf(dict(F.HF_CONFIG, num_key_value_heads=1))
+
+
+def test_flax_msgpack_stream_round_trip():
+    """tux StreamingCheckpointer layout: records (key tuple, flax to_bytes(leaf)); bf16 leaves keep
+    their bits; the harness names come out of the flax names."""
+    g = torch.Generator().manual_seed(0)
+    flat = {
+        "params/transformer/wte/embedding": torch.randn(16, 8, generator=g).to(torch.bfloat16),
+        "params/transformer/h/0/attention/wq/kernel": torch.randn(8, 8, generator=g),
+        "params/transformer/h/0/attention_norm/kernel": np.ones(8, np.float32),
+        "params/transformer/ln_f/kernel": np.arange(8, dtype=np.float32),
+        "params/lm_head/kernel": torch.randn(8, 16, generator=g),
+        "step": np.int32(7),
+    }
+    flat["step"] = np.asarray(flat["step"])
+    buf = io.BytesIO()
+    W.write_flax_stream(buf, flat)
+    buf.seek(0)
+    back = W.read_flax_stream(buf)
+    assert set(back) == set(flat)
+    assert back["params/transformer/wte/embedding"].dtype == torch.bfloat16
+    assert torch.equal(back["params/transformer/wte/embedding"], flat["params/transformer/wte/embedding"])
+    assert np.array_equal(back["params/transformer/ln_f/kernel"], flat["params/transformer/ln_f/kernel"])
+    names = W.flax_llama_to_lwm(back)
+    assert set(names) == {"wte", "h.0.attention.wq", "h.0.attention_norm.kernel", "ln_f.kernel", "lm_head"}
+    # a leaf flax would have split into chunks
+    import msgpack
+    part = lambda a: msgpack.ExtType(1, msgpack.packb((list(a.shape), a.dtype.name, a.tobytes()), use_bin_type=True))
+    a = np.arange(12, dtype=np.float32)
+    blob = msgpack.packb({"__msgpack_chunks__": 2, "shape": [3, 4], "chunks": {"0": part(a[:6]), "1": part(a[6:])}},
+                         use_bin_type=True)
+    assert np.array_equal(W.flax_from_bytes(blob), a.reshape(3, 4))
+
+
+def test_vqgan_pickle_written_from_jax_arrays_loads_without_jax():
+    """A pickle that names jax._src.array._reconstruct_array and flax's FrozenDict (what
+    pickle.dump of a flax param tree of jax arrays produces) must load as numpy / dict."""
+    assert "jax" not in sys.modules
+    arr = np.arange(6, dtype=np.float32).reshape(2, 3)
+    mods = {}
+    for name in ("jax", "jax._src", "jax._src.array", "flax", "flax.core", "flax.core.frozen_dict"):
+        mods[name] = types.ModuleType(name)
+
+    def _reconstruct_array(fun, args, arr_state, aval_state):   # stand-in so that pickling can name it
+        raise AssertionError("must not be called")
+    _reconstruct_array.__module__, _reconstruct_array.__qualname__ = "jax._src.array", "_reconstruct_array"
+    mods["jax._src.array"]._reconstruct_array = _reconstruct_array
+
+    class FakeJaxArray:
+        def __init__(self, a):
+            self.a = a
+
+        def __reduce__(self):
+            fun, args, state = self.a.__reduce__()
+            return _reconstruct_array, (fun, args, state, {"weak_type": False})
+
+    class FrozenDict(dict):
+        def __reduce__(self):
+            return FrozenDict, (), {"_dict": dict(self)}
+    FrozenDict.__module__, FrozenDict.__qualname__ = "flax.core.frozen_dict", "FrozenDict"
+    mods["flax.core.frozen_dict"].FrozenDict = FrozenDict
+
+    sys.modules.update(mods)
+    try:
+        blob = pickle.dumps(FrozenDict(encoder=FrozenDict(conv_in={"kernel": FakeJaxArray(arr)}),
+                                       quantize={"embeddings": arr * 2}))
+    finally:
+        for name in mods:
+            sys.modules.pop(name, None)
+    tree = W.load_pickle_tree(blob)
+    assert type(tree) is dict and type(tree["encoder"]) is dict
+    assert np.array_equal(tree["encoder"]["conv_in"]["kernel"], arr)
+    assert np.array_equal(tree["quantize"]["embeddings"], arr * 2)
