@@ -22,6 +22,11 @@ cannot be executed to generate fixtures.  This module therefore restates
       custom-VJP backward (recompute p from the saved statistics, rotate
       k,v,dk,dv) -- SURVEY.md Appendix A.1,
 
+(an independent executable anchor exists one level up: HF transformers' LlamaForCausalLM --
+the PyTorch route the reference documents, scripts/sample_pyt.py:8 -- is reproduced by the
+oracle MODEL, whose attention is checked against dense_attention() below; tests/test_weights.py.
+That pins the dense semantics, not the JAX package's blockwise order of operations)
+
 and anchors parity on the structural identities the reference's own code
 implies: blockwise == dense branch, ring n == ring 1, packed == per-segment.
 

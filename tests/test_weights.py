@@ -60,6 +60,30 @@ def test_oracle_model_reproduces_hf_transformers_gradients():
         assert (got - g).abs().max().item() <= 2e-4 * g.abs().max().item(), hf_name
 
 
+def test_attention_oracle_equals_the_attention_inside_the_hf_anchored_model():
+    """Closes the chain HF transformers == oracle model == oracle/attention_ref.dense_attention
+    (== blockwise / ring oracle == HIP kernels, tests/test_oracle.py and the -m gpu tests): the
+    softmax-attention expression of oracle/llama_model_ref.py, which the HF vectors pin, against
+    the fp64 attention oracle on the same q, k, v, packed segments and padding included."""
+    import math
+    from oracle import attention_ref as R
+    g = torch.Generator().manual_seed(3)
+    B, S, H, D = 1, 80, 2, 128
+    q, k, v = (torch.randn(B, S, H, D, generator=g) for _ in range(3))
+    seg = torch.zeros(B, S, dtype=torch.int32)
+    seg[:, 30:] = 1
+    am = torch.ones(B, S, dtype=torch.int32)
+    am[:, 4:7] = 0
+    vis = torch.tril(torch.ones(S, S, dtype=torch.bool))[None, None]
+    vis = vis & (seg[:, None, :, None] == seg[:, None, None, :]) & (am[:, None, None, :] > 0)
+    s_ = (torch.einsum("bqhd,bkhd->bhqk", q, k) / math.sqrt(D)).masked_fill(~vis, float("-inf"))
+    a = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s_, dim=-1), v)
+    out, _ = R.dense_attention(q.numpy(), k.numpy(), v.numpy(), causal=True, seg_q=seg.numpy(),
+                               seg_k=seg.numpy(), key_valid=am.numpy().astype(np.uint8))
+    rows = (vis.any(-1)[0, 0]).numpy()              # rows with no visible key are defined as 0 by the oracle
+    assert np.abs(a.numpy()[:, rows] - out[:, rows]).max() <= 2e-6
+
+
 def test_hf_checkpoint_directory_round_trip(tmp_path):
     import json
     from safetensors.torch import save_file
