@@ -20,13 +20,40 @@ from .llama_ops import (LLaMAMLP, RMSNorm, apply_rotary_emb, chunked_lm_head_los
                         precompute_freqs_cis)
 from .ringattention import blockwise_feedforward, ringattention
 
-# lwm/llama.py:33-130 (the entries this harness is exercised with)
+# The model sizes of lwm/llama.py:33-130:
+# name: (hidden, intermediate, layers, heads, max_sequence_length, rms_norm_eps)
+_SIZES = {"200m": (1024, 2048, 14, 8, 2048, 1e-6), "1b": (2048, 5504, 22, 16, 2048, 1e-6),
+          "3b": (3200, 8640, 26, 32, 2048, 1e-6), "7b": (4096, 11008, 32, 32, 4096, 1e-6),
+          "13b": (5120, 13824, 40, 40, 2048, 1e-6), "30b": (6656, 17920, 60, 52, 2048, 1e-6),
+          "65b": (8192, 22016, 80, 64, 2048, 1e-5), "debug": (256, 256, 2, 2, 2048, 1e-6)}
 LLAMA_STANDARD_CONFIGS = {
-    "7b": dict(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32,
-               num_attention_heads=32, max_sequence_length=4096, initializer_range=0.02, rms_norm_eps=1e-6),
-    "1b": dict(vocab_size=32000, hidden_size=2048, intermediate_size=5504, num_hidden_layers=22,
-               num_attention_heads=16, max_sequence_length=2048, initializer_range=0.02, rms_norm_eps=1e-6),
-}
+    name: dict(vocab_size=32000, hidden_size=d, intermediate_size=f, num_hidden_layers=L, num_attention_heads=h,
+               max_sequence_length=s, initializer_range=0.02, rms_norm_eps=eps, use_cache=True,
+               tie_word_embeddings=False)
+    for name, (d, f, L, h, s, eps) in _SIZES.items()}
+
+
+def parse_config_updates(text):
+    """`--update_llama_config` (lwm/train.py:120-121, scripts/run_*.sh): a string such as
+    "dict(theta=10000000,max_sequence_length=131072,scan_attention=True)" or a dict literal.
+    The reference eval()s it; here only `dict(name=literal, ...)` / `{...}` of Python literals is
+    accepted."""
+    import ast
+    text = text.strip()
+    if not text:
+        return {}
+    node = ast.parse(text, mode="eval").body
+    if isinstance(node, ast.Call) and isinstance(node.func, ast.Name) and node.func.id == "dict" and not node.args:
+        out = {}
+        for kw in node.keywords:
+            if kw.arg is None:
+                raise ValueError("update_llama_config: **expansion is not accepted")
+            out[kw.arg] = ast.literal_eval(kw.value)
+        return out
+    val = ast.literal_eval(node)
+    if not isinstance(val, dict):
+        raise ValueError("update_llama_config must be dict(...) or a dict literal")
+    return val
 
 
 class LLaMAConfig:
@@ -46,9 +73,41 @@ class LLaMAConfig:
         for k, v in kwargs.items():
             setattr(self, k, v)
 
+    def update(self, updates):
+        """ConfigDict-style in-place update; a string is parsed like --update_llama_config."""
+        if isinstance(updates, str):
+            updates = parse_config_updates(updates)
+        for k, v in dict(updates).items():
+            setattr(self, k, v)
+        return self
+
+    def to_dict(self):
+        return {k: v for k, v in vars(self).items() if not k.startswith("_")}
+
     @classmethod
-    def load_config(cls, name, **updates):
-        cfg = dict(LLAMA_STANDARD_CONFIGS[name])
+    def from_dict(cls, d):
+        return cls(**dict(d))
+
+    @classmethod
+    def load_config(cls, path, **updates):
+        """lwm/llama.py:300-312: a standard size name, 'json::<file>' or 'pickle::<file>' (the latter
+        holds {'llama_config': {...}})."""
+        if path in LLAMA_STANDARD_CONFIGS:
+            cfg = dict(LLAMA_STANDARD_CONFIGS[path])
+        else:
+            if "::" not in path:
+                raise ValueError(f"unknown model size {path!r}; expected one of {sorted(LLAMA_STANDARD_CONFIGS)} "
+                                 "or json::<file> / pickle::<file>")
+            load_type, load_path = path.split("::", 1)
+            if load_type == "json":
+                import json
+                with open(load_path) as f:
+                    cfg = json.load(f)
+            elif load_type == "pickle":
+                from .weights import load_pickle_tree
+                cfg = dict(load_pickle_tree(load_path)["llama_config"])
+            else:
+                raise ValueError(f"Unsupported load config type: {load_type}")
         cfg.update(updates)
         return cls(**cfg)
 

@@ -172,3 +172,25 @@ def test_vqgan_pickle_written_from_jax_arrays_loads_without_jax():
     assert type(tree) is dict and type(tree["encoder"]) is dict
     assert np.array_equal(tree["encoder"]["conv_in"]["kernel"], arr)
     assert np.array_equal(tree["quantize"]["embeddings"], arr * 2)
+
+
+def test_config_tables_and_update_string(tmp_path):
+    """LLaMAConfig.load_config / --update_llama_config (lwm/llama.py:300-312, lwm/train.py:120-121)."""
+    import json
+    from lwm_amd.llama import LLaMAConfig, parse_config_updates
+    c = LLaMAConfig.load_config("7b")
+    assert (c.hidden_size, c.intermediate_size, c.num_hidden_layers, c.num_attention_heads) == (4096, 11008, 32, 32)
+    assert LLaMAConfig.load_config("65b").rms_norm_eps == 1e-5
+    # the string of scripts/run_eval_needle.sh:19
+    c.update("dict(theta=10000000,max_sequence_length=131072,scan_attention=True,scan_query_chunk_size=1024,"
+             "scan_key_chunk_size=1024,scan_mlp=True,scan_mlp_chunk_size=1024,scan_layers=True)")
+    assert c.theta == 10000000 and c.max_sequence_length == 131072 and c.scan_layers is True
+    assert parse_config_updates("dict(sample_mode='vision',theta=50000000)") == dict(sample_mode="vision", theta=50000000)
+    assert parse_config_updates("{'theta': 1e7}") == {"theta": 1e7}
+    for bad in ("__import__('os').system('true')", "dict(a=open('x'))", "dict(**{'a': 1})", "[1, 2]"):
+        with pytest.raises((ValueError, SyntaxError)):
+            parse_config_updates(bad)
+    (tmp_path / "c.json").write_text(json.dumps(dict(LLaMAConfig.load_config("debug").to_dict(), theta=5e7)))
+    assert LLaMAConfig.load_config(f"json::{tmp_path / 'c.json'}").theta == 5e7
+    with pytest.raises(ValueError):
+        LLaMAConfig.load_config("yaml::x")
