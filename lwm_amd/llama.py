@@ -18,7 +18,8 @@ import torch
 
 from .llama_ops import (LLaMAMLP, RMSNorm, apply_rotary_emb, chunked_lm_head_loss,
                         precompute_freqs_cis)
-from .ringattention import blockwise_feedforward, ringattention
+from .ringattention import (blockwise_feedforward, concatenate_to_cache, ringattention,
+                            ringattention_inference)
 
 # The model sizes of lwm/llama.py:33-130:
 # name: (hidden, intermediate, layers, heads, max_sequence_length, rms_norm_eps)
@@ -126,11 +127,13 @@ class LLaMAAttention(torch.nn.Module):
         self.num_heads, self.head_dim = cfg.num_attention_heads, d // cfg.num_attention_heads
         self.wq, self.wk, self.wv, self.wo = (_dense(d, d, cfg.initializer_range, dtype) for _ in range(4))
 
-    def forward(self, x, freqs_cis, attention_mask=None, segment_ids=None, position_ids=None):
+    def forward(self, x, freqs_cis, attention_mask=None, segment_ids=None, position_ids=None, cache=None):
         B, S, d = x.shape
         split = lambda t: t.reshape(B, S, self.num_heads, self.head_dim)      # reshape, no transpose (:434-438)
         xq, xk, xv = split(x @ self.wq), split(x @ self.wk), split(x @ self.wv)
         xq, xk = apply_rotary_emb(xq, xk, freqs_cis, position_ids)
+        if cache is not None:
+            return self._cached(xq, xk, xv.contiguous(), attention_mask, cache).reshape(B, S, d) @ self.wo
         bias = None
         if attention_mask is not None:                                        # (:527-537)
             m = attention_mask.reshape(B, 1, 1, S)
@@ -141,6 +144,22 @@ class LLaMAAttention(torch.nn.Module):
                                                   query_chunk_size=self.cfg.scan_query_chunk_size,
                                                   key_chunk_size=self.cfg.scan_key_chunk_size))
         return out.reshape(B, S, d) @ self.wo
+
+    def _cached(self, xq, xk, xv, attention_mask, cache):
+        """The inference branch (lwm/llama.py:571-614): mask = key j visible to query i iff
+        j <= cache_index + i and attention_mask[j] (:577-592); the new keys/values are written into
+        the cache at cache_index (:440-492); attention runs over the WHOLE cache (kv_len =
+        max_length != q_len).  `cache`: dict(cached_key, cached_value (B, max_length, H, D),
+        cache_index int); `attention_mask`: (B, max_length), ones beyond the prompt (:1121-1124)."""
+        B, Q = xq.shape[:2]
+        ck, cv = cache["cached_key"], cache["cached_value"]
+        max_len, idx = ck.shape[1], int(cache["cache_index"])
+        ar = torch.arange(max_len, device=xq.device)
+        mask = (ar[None, :] <= (torch.arange(Q, device=xq.device) + idx)[:, None])[None, None].expand(B, 1, Q, max_len)
+        if attention_mask is not None:
+            mask = mask & (attention_mask[:, None, None, :max_len] > 0)
+        cache["cache_index"] = concatenate_to_cache(ck, cv, xk.contiguous(), xv, idx, axis_name="sp")
+        return ringattention_inference(xq.contiguous(), ck, cv, mask, axis_name="sp")
 
 
 class LLaMABlock(torch.nn.Module):
@@ -154,8 +173,8 @@ class LLaMABlock(torch.nn.Module):
         self.ffn_norm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, dtype)
         self.feed_forward = LLaMAMLP(cfg.hidden_size, cfg.intermediate_size, dtype, cfg.initializer_range)
 
-    def forward(self, x, freqs_cis, attention_mask=None, segment_ids=None, position_ids=None):
-        x = x + self.attention(self.attention_norm(x), freqs_cis, attention_mask, segment_ids, position_ids)
+    def forward(self, x, freqs_cis, attention_mask=None, segment_ids=None, position_ids=None, cache=None):
+        x = x + self.attention(self.attention_norm(x), freqs_cis, attention_mask, segment_ids, position_ids, cache)
         h = self.ffn_norm(x)
         if self.cfg.scan_mlp and h.shape[1] >= self.cfg.scan_mlp_chunk_size:      # (:728-734)
             ff = blockwise_feedforward(self.feed_forward, h, self.cfg.scan_mlp_chunk_size)
@@ -182,12 +201,49 @@ class LLaMAForCausalLM(torch.nn.Module):
             self._freqs = precompute_freqs_cis(head_dim, self.cfg.max_sequence_length, self.cfg.theta, device=device)
         return self._freqs
 
-    def hidden_states(self, input_ids, attention_mask=None, segment_ids=None, position_ids=None):
+    def hidden_states(self, input_ids, attention_mask=None, segment_ids=None, position_ids=None, cache=None):
         x = torch.nn.functional.embedding(input_ids.long(), self.wte)
         fc = self._table(x.device)
-        for blk in self.h:
-            x = blk(x, fc, attention_mask, segment_ids, position_ids)
+        for i, blk in enumerate(self.h):
+            x = blk(x, fc, attention_mask, segment_ids, position_ids, None if cache is None else cache[i])
         return self.ln_f(x)
+
+    def init_cache(self, batch_size, max_length, device=None):
+        """FlaxLLaMAPreTrainedModel.init_cache (lwm/llama.py:810-825): per layer, zeroed
+        (B, max_length, H, D) key/value caches and cache_index = 0."""
+        device = device or self.wte.device
+        H = self.cfg.num_attention_heads
+        D = self.cfg.hidden_size // H
+        z = lambda: torch.zeros(batch_size, max_length, H, D, dtype=self.dtype, device=device)
+        return [dict(cached_key=z(), cached_value=z(), cache_index=0) for _ in self.h]
+
+    @torch.no_grad()
+    def generate(self, input_ids, attention_mask=None, max_new_tokens=16, max_length=None, return_logits=False):
+        """Greedy decoding through the KV cache: prepare_inputs_for_generation /
+        update_inputs_for_generation of the reference (lwm/llama.py:1113-1137) + argmax.
+        Prefill writes the prompt's keys/values at cache_index 0 and attends over the whole
+        (B, max_length) cache under the dense mask; every further step feeds one token."""
+        B, S = input_ids.shape
+        max_length = max_length or (S + max_new_tokens)
+        cache = self.init_cache(B, max_length, input_ids.device)
+        ext = torch.ones(B, max_length, dtype=torch.int32, device=input_ids.device)
+        if attention_mask is not None:
+            pos = attention_mask.to(torch.int32).cumsum(-1) - 1
+            ext[:, :S] = attention_mask.to(torch.int32)
+        else:
+            pos = torch.arange(S, dtype=torch.int32, device=input_ids.device)[None].expand(B, S)
+        pos = pos.clamp_min(0).contiguous()
+        tokens, logits_out = input_ids, []
+        step_in = input_ids
+        for _ in range(max_new_tokens):
+            h = self.hidden_states(step_in, ext, None, pos, cache)
+            logits = h[:, -1].float() @ self.lm_head.float()
+            if return_logits:
+                logits_out.append(logits)
+            nxt = logits.argmax(-1, keepdim=True).to(input_ids.dtype)
+            tokens = torch.cat([tokens, nxt], dim=1)
+            step_in, pos = nxt, (pos[:, -1:] + 1).contiguous()
+        return (tokens, torch.stack(logits_out, 1)) if return_logits else tokens
 
     def loss(self, input_tokens, target_tokens, loss_masks=None, attention_mask=None, segment_ids=None,
              position_ids=None, chunk=8192):

@@ -32,6 +32,14 @@ def main():
     loss = -torch.gather(logp, -1, ids[:, 1:, None])[..., 0].mean()          # lwm/train.py:171-181
     loss.backward()
     acc = (logits.argmax(-1) == ids[:, 1:]).float().mean()
+    # greedy generation through HF's KV cache from a left-padded prompt (positions = cumsum(mask) - 1)
+    PL, NEW = 43, 12       # the prompt length whose greedy top-2 margins are all > 0.1
+    gmask = torch.ones(1, PL, dtype=torch.long)
+    gmask[:, :5] = 0
+    with torch.no_grad():
+        gen = model.generate(input_ids=ids[:, :PL], attention_mask=gmask, max_new_tokens=NEW, do_sample=False,
+                             output_scores=True, return_dict_in_generate=True, pad_token_id=0)
+    gen_scores = torch.stack(gen.scores, 1).float()          # (1, NEW, vocab): raw logits under greedy
     p = dict(model.named_parameters())
     np.savez_compressed(
         os.path.join(HERE, "hf_llama_tiny.npz"),
@@ -39,6 +47,8 @@ def main():
         grad_q_proj_0=p["model.layers.0.self_attn.q_proj.weight"].grad.numpy(),
         grad_k_proj_1=p["model.layers.1.self_attn.k_proj.weight"].grad.numpy(),
         grad_v_proj_0=p["model.layers.0.self_attn.v_proj.weight"].grad.numpy(),
+        gen_mask=gmask.numpy().astype(np.int32), gen_tokens=gen.sequences.numpy().astype(np.int64),
+        gen_scores=gen_scores.numpy(),
         transformers_version=np.array(transformers.__version__), torch_version=np.array(torch.__version__))
     print("loss", loss.item(), "acc", acc.item(), "logits |max|", logits.abs().max().item())
 

@@ -59,3 +59,33 @@ def test_harness_loss_and_gradients_match_hf_transformers():
         cos = float(got @ g / (got.norm() * g.norm()))
         assert cos >= 0.995, (hf_name, cos)
         assert abs(float(got.norm() / g.norm()) - 1) <= 3e-2, hf_name
+
+
+def test_cached_greedy_generation_matches_hf_transformers():
+    """Prefill into the KV cache + one-token decode steps (lwm/llama.py:440-492, :571-614, :1113-1137)
+    from a LEFT-PADDED prompt, against HF `generate(do_sample=False)`: per-step logits under teacher
+    forcing within 3e-2 * max|ref|, and the greedy tokens themselves (HF's top-2 margins here are all
+    > 0.1, several times the bf16 logit error)."""
+    import torch
+    F, cfg, model = _model()
+    gold = np.load(os.path.join(HERE, "golden", "hf_llama_tiny.npz"))
+    seq = torch.from_numpy(gold["gen_tokens"]).cuda()
+    mask = torch.from_numpy(gold["gen_mask"]).cuda()
+    scores = torch.from_numpy(gold["gen_scores"])
+    PL, NEW = mask.shape[1], scores.shape[1]
+    toks, logits = model.generate(seq[:, :PL], attention_mask=mask, max_new_tokens=NEW, return_logits=True)
+    # teacher forcing: same loop, HF's tokens fed back
+    cache = model.init_cache(1, PL + NEW)
+    ext = torch.ones(1, PL + NEW, dtype=torch.int32, device="cuda")
+    ext[:, :PL] = mask
+    pos = (mask.cumsum(-1) - 1).clamp_min(0).to(torch.int32).contiguous()
+    step_in, worst = seq[:, :PL], 0.0
+    with torch.no_grad():
+        for t in range(NEW):
+            h = model.hidden_states(step_in, ext, None, pos, cache)
+            lg = (h[:, -1].float() @ model.lm_head.float()).cpu()
+            worst = max(worst, (lg - scores[:, t]).abs().max().item())
+            step_in, pos = seq[:, PL + t:PL + t + 1], (pos[:, -1:] + 1).contiguous()
+    assert worst <= 3e-2 * scores.abs().max().item(), worst
+    assert torch.equal(toks.cpu(), seq.cpu()), (toks.cpu()[0, PL:], seq.cpu()[0, PL:])
+    assert all(c["cache_index"] == PL + NEW - 1 for c in cache)    # prefill + (NEW - 1) fed-back tokens
