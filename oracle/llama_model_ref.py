@@ -29,6 +29,25 @@ def forward_loss(state, cfg, input_tokens, target_tokens, loss_masks=None, atten
 def forward_logits(state, cfg, input_tokens, attention_mask=None, segment_ids=None):
     """(B, S, vocab) float32 logits (lwm/llama.py:982-1106).  Pinned against HF transformers'
     LlamaForCausalLM by tests/test_weights.py (tests/golden/hf_llama_tiny.npz)."""
+    return forward_hidden(state, cfg, input_tokens, attention_mask, segment_ids) @ state["lm_head"]
+
+
+def vision_text_loss(state, cfg, input_tokens, input_vision_masks, target_tokens, target_vision_masks,
+                     loss_masks=None, attention_mask=None, segment_ids=None):
+    """lwm/vision_llama.py:307-311 (mixed embedding), :411-415 (two heads), lwm/train.py:183-202."""
+    vm = input_vision_masks.bool()
+    ids = input_tokens.long()
+    emb = torch.where(vm[..., None], state["vte"][torch.where(vm, ids, 0)], state["wte"][torch.where(vm, 0, ids)])
+    h = forward_hidden(state, cfg, input_tokens, attention_mask, segment_ids, input_embeds=emb)
+    tvm = target_vision_masks.bool()
+    lm = torch.ones(input_tokens.shape) if loss_masks is None else loss_masks.float()
+    v_loss, v_acc = _loss(h @ state["vision_head"], torch.where(tvm, target_tokens, 0), lm * tvm.float())
+    t_loss, t_acc = _loss(h @ state["lm_head"], torch.where(tvm, 0, target_tokens), lm * (~tvm).float())
+    return 0.5 * (v_loss + t_loss), dict(vision_loss=v_loss, vision_acc=v_acc, text_loss=t_loss, text_acc=t_acc)
+
+
+def forward_hidden(state, cfg, input_tokens, attention_mask=None, segment_ids=None, input_embeds=None):
+    """(B, S, d) float32 final hidden states (after ln_f)."""
     B, S = input_tokens.shape
     H = cfg.num_attention_heads
     D = cfg.hidden_size // H
@@ -36,7 +55,7 @@ def forward_logits(state, cfg, input_tokens, attention_mask=None, segment_ids=No
     ang = np.outer(np.arange(cfg.max_sequence_length), freqs).astype(np.float32)
     fc = torch.from_numpy(np.stack((np.cos(ang), np.sin(ang)), -1))
     pos = torch.arange(S)[None].expand(B, S)
-    x = state["wte"][input_tokens.long()]
+    x = state["wte"][input_tokens.long()] if input_embeds is None else input_embeds
     vis = torch.tril(torch.ones(S, S, dtype=torch.bool))[None, None]
     if segment_ids is not None:
         vis = vis & (segment_ids[:, None, :, None] == segment_ids[:, None, None, :])
@@ -57,8 +76,7 @@ def forward_logits(state, cfg, input_tokens, attention_mask=None, segment_ids=No
         ff = (torch.nn.functional.silu(hn @ state[p + "feed_forward.w1"]) * (hn @ state[p + "feed_forward.w3"])) \
             @ state[p + "feed_forward.w2"]
         x = x + ff
-    h = _rmsnorm(x, state["ln_f.kernel"], cfg.rms_norm_eps)
-    return h @ state["lm_head"]
+    return _rmsnorm(x, state["ln_f.kernel"], cfg.rms_norm_eps)
 
 
 def _loss(logits, target_tokens, loss_masks=None):
