@@ -9,7 +9,8 @@ import os
 from . import _capi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblwm_hip.so")
+# LWM_HIP_LIB: another build of the same ABI (kernel A/B measurements, scripts/ab_build.sh)
+LIB_PATH = os.environ.get("LWM_HIP_LIB") or os.path.join(_HERE, "liblwm_hip.so")
 _lib = None
 
 

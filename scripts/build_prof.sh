@@ -4,5 +4,5 @@
 set -e
 cd "$(dirname "$0")/.."
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -mcode-object-version=5 -shared -fPIC \
-    -DLWM_PROF -I include -I lwm_amd/csrc lwm_amd/csrc/lwm_hip.hip -o scripts/liblwm_prof.so
+    -fno-slp-vectorize -DLWM_PROF -I include -I lwm_amd/csrc lwm_amd/csrc/lwm_hip.hip -o scripts/liblwm_prof.so
 echo "built scripts/liblwm_prof.so"
