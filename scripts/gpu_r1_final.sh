@@ -6,14 +6,10 @@ cd $R
 (timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3) > gpurun_out/smoke.log
 (timeout 900 python bench.py --steps 3 --warmup 1 2>&1 | tail -1) > gpurun_out/bench.log
 cd /tmp && export TMPDIR=/tmp
-rm -rf $R/gpurun_out/prof $R/gpurun_out/pmc
-(timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o r01d -- python $R/bench.py --steps 1 --warmup 0 --layers 4 --no-cpu-baseline 2>&1 | tail -2) > $R/gpurun_out/prof.log
-B="python $R/bench.py --steps 1 --warmup 0 --layers 1 --no-cpu-baseline --no-vqgan"
-i=1
-for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16"; do
-  (timeout 300 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/pmc -o pass$i -- $B 2>&1 | tail -2) > $R/gpurun_out/pmc_pass$i.log
-  i=$((i+1))
-done
+rm -rf $R/gpurun_out/prof
+(timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o r01e -- python $R/bench.py --steps 1 --warmup 0 --layers 4 --no-cpu-baseline 2>&1 | tail -2) > $R/gpurun_out/prof.log
+bash $R/scripts/gpu_pmc_attention.sh
 cd $R
 for f in tests smoke bench; do echo "=== $f"; cat gpurun_out/$f.log; done
 head -12 $(find gpurun_out/prof -name "*kernel_stats.csv" | head -1) | cut -c1-160
+(timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 2 --steps 1 --warmup 1 --layers 2 --seq 16384 --backend gloo 2>&1 | tail -1 | cut -c1-400) > gpurun_out/dry2.log; echo "=== dry-run N=2"; cat gpurun_out/dry2.log
