@@ -133,8 +133,17 @@ LWM_DEVICE void sleep_cycles64() { __builtin_amdgcn_s_sleep(N); }
 // Scheduling fence: the compiler may not move instructions across it.
 LWM_DEVICE void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // Raise/lower this wave's issue priority around an MFMA cluster (T5).
-LWM_DEVICE void prio_hi() { __builtin_amdgcn_s_setprio(1); }
-LWM_DEVICE void prio_lo() { __builtin_amdgcn_s_setprio(0); }
+#ifndef LWM_PRIO_MODE
+#define LWM_PRIO_MODE 1      // 1: matrix phases at priority 1; 0: no priorities; 2: vector phases at priority 1
+#endif
+LWM_DEVICE void prio_hi() {
+    if (LWM_PRIO_MODE == 1) __builtin_amdgcn_s_setprio(1);
+    if (LWM_PRIO_MODE == 2) __builtin_amdgcn_s_setprio(0);
+}
+LWM_DEVICE void prio_lo() {
+    if (LWM_PRIO_MODE == 1) __builtin_amdgcn_s_setprio(0);
+    if (LWM_PRIO_MODE == 2) __builtin_amdgcn_s_setprio(1);
+}
 template <int N>
 LWM_DEVICE void set_prio() { __builtin_amdgcn_s_setprio(N); }
 
