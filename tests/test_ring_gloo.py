@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, layout_kind, causal, packed, schedule, q_out):
+def _worker(rank, world, port, layout_kind, causal, packed, schedule, q_out, B=1):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -30,7 +30,7 @@ def _worker(rank, world, port, layout_kind, causal, packed, schedule, q_out):
         from lwm_amd.ring import SeqLayout, TorchRingComm, ring_attention
         from tests._standin import OracleBlockOps
         torch.manual_seed(0)
-        B, S, H, D = 1, 64 * world, 2, 16
+        S, H, D = 64 * world, 2, 16
         q, k, v, do = (torch.randn(B, S, H, D).to(torch.bfloat16) for _ in range(4))
         seg = kv = None
         if packed:
@@ -52,23 +52,25 @@ def _worker(rank, world, port, layout_kind, causal, packed, schedule, q_out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,layout_kind,causal,packed,schedule", [
-    (2, "contiguous", True, False, "ring"),
-    (2, "zigzag", True, True, "ring"),
-    (2, "contiguous", False, True, "ring"),
-    (4, "zigzag", True, False, "ring"),
+@pytest.mark.parametrize("world,layout_kind,causal,packed,schedule,B", [
+    (2, "contiguous", True, False, "ring", 1),
+    (2, "zigzag", True, True, "ring", 1),
+    (2, "contiguous", False, True, "ring", 1),
+    (4, "zigzag", True, False, "ring", 1),
     # the mesh schedule: direct fetch of the visible K/V segments, partial dK/dV returned to the owner
-    (2, "zigzag", True, True, "mesh"),
-    (4, "zigzag", True, True, "mesh"),
-    (4, "contiguous", True, False, "mesh"),
-    (3, "contiguous", False, True, "mesh"),
+    (2, "zigzag", True, True, "mesh", 1),
+    (4, "zigzag", True, True, "mesh", 1),
+    (4, "contiguous", True, False, "mesh", 1),
+    (3, "contiguous", False, True, "mesh", 1),
+    (2, "zigzag", True, False, "mesh", 2),          # batch 2: strided segment views of the outputs
+    (2, "zigzag", True, False, "ring", 2),
 ])
-def test_ring_equals_single_device(world, layout_kind, causal, packed, schedule):
+def test_ring_equals_single_device(world, layout_kind, causal, packed, schedule, B):
     from oracle import attention_ref as R
     ctx = mp.get_context("spawn")
     qout = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, layout_kind, causal, packed, schedule, qout))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, layout_kind, causal, packed, schedule, qout, B))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -77,7 +79,7 @@ def test_ring_equals_single_device(world, layout_kind, causal, packed, schedule)
         p.join(timeout=60)
         assert p.exitcode == 0
     torch.manual_seed(0)
-    B, S, H, D = 1, 64 * world, 2, 16
+    S, H, D = 64 * world, 2, 16
     q, k, v, do = (torch.randn(B, S, H, D).to(torch.bfloat16).float().numpy() for _ in range(4))
     seg = kv = None
     if packed:
