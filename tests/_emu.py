@@ -29,8 +29,9 @@ def build():
         t = os.path.getmtime(EMU_SO)
         if all(os.path.getmtime(s) <= t for s in _sources()):
             return EMU_SO
+    # LWM_EMU_CFLAGS: extra -D switches, to run the emulated tests against a kernel variant
     cmd = [CLANG, "-O2", "-std=c++17", "-mavx2", "-mfma", "-ffp-contract=off", "-shared", "-fPIC",
-           "-I", "tests", "-I", "lwm_amd/csrc",
+           *os.environ.get("LWM_EMU_CFLAGS", "").split(), "-I", "tests", "-I", "lwm_amd/csrc",
            "-I", "include", "tests/emu/lwm_emu.cpp", "-o", EMU_SO, "-lpthread"]
     subprocess.run(cmd, cwd=ROOT, check=True)
     return EMU_SO
