@@ -54,6 +54,11 @@ def test_validation_errors(lib):
     assert lib.lwm_attn_bwd_dq(C.byref(a), None) == _capi.LWM_EINVAL
     assert lib.lwm_cast_f32_to_bf16(None, None, 8, None) == _capi.LWM_EINVAL
     assert lib.lwm_cast_f32_to_bf16(None, None, 0, None) == _capi.LWM_OK
+    import ctypes as _C
+    one = (_C.c_void_p * 1)(None)
+    assert lib.lwm_sum_f32_to_bf16(one, 0, None, 8, None) == _capi.LWM_EINVAL      # n_src out of range
+    assert lib.lwm_sum_f32_to_bf16(one, 1, None, 8, None) == _capi.LWM_EINVAL      # null pointers
+    assert lib.lwm_sum_f32_to_bf16(one, 1, None, 0, None) == _capi.LWM_OK
 
 
 def test_product_has_no_cpu_fallback():
