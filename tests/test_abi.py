@@ -74,3 +74,46 @@ def test_product_has_no_cpu_fallback():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+(oracle|tests)\b", src, re.M), f
                 assert "emu/" not in src or f in ("wave_ops.h", "api.inc", "vqgan_api.inc"), f
+
+
+def test_header_is_plain_c_and_links_from_a_c_program(tmp_path):
+    """The boundary is a C ABI: include/lwm_hip.h must compile as C99 (no C++ in the signatures) and a
+    plain C program linked against the shared library must see the same struct sizes the library was
+    built with, get error codes (not exceptions) for bad arguments, and read the error string."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    if not os.path.exists(SO):
+        import __graft_entry__ as g
+        g.build()
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "lwm_hip.h"
+int main(void) {
+    LwmAttnArgs a;
+    LwmConvArgs c;
+    memset(&a, 0, sizeof a);
+    memset(&c, 0, sizeof c);
+    if (lwm_version() < 111) return 1;
+    if (lwm_sizeof(0) != (int)sizeof(LwmAttnArgs)) return 2;
+    if (lwm_sizeof(1) != (int)sizeof(LwmConvArgs)) return 3;
+    if (lwm_attn_fwd(NULL, NULL) >= 0) return 4;
+    a.D = 64; a.B = 1; a.H = 1; a.Sq = 16; a.Sk = 16;
+    if (lwm_attn_fwd(&a, NULL) >= 0) return 5;
+    if (strstr(lwm_last_error(), "head_dim") == NULL) return 6;
+    if (lwm_conv2d_nhwc_f32(&c, NULL) >= 0) return 7;
+    printf("ok %d\n", lwm_version());
+    return 0;
+}
+''')
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                    str(src), "-o", str(exe), SO, f"-Wl,-rpath,{os.path.dirname(SO)}"], check=True)
+    env = dict(os.environ)
+    import torch
+    env["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(torch.__file__), "lib") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), (r.returncode, r.stdout, r.stderr)
