@@ -237,6 +237,37 @@ def decode_leg(torch, K=131072):
                          "frac": nbytes / t / 1e9 / 8000.0, "kernel": "attn_decode_kernel + attn_combine_kernel"}}
 
 
+def generate_leg(torch, layers=4, prompt=2048, new=34, max_length=32768):
+    """Secondary leg: greedy decoding through the KV cache on a `layers`-layer slice of LWM-7B (d_model 4096,
+    32 heads, FFN 11008, vocab 32000): milliseconds per generated token with the one-token step issued
+    kernel by kernel, and with the same step captured once in a hipGraph and replayed
+    (LLaMAForCausalLM.generate(graph=True)).  The prefill and the first two tokens are outside the timing."""
+    import time as _t
+    from lwm_amd.llama import LLaMAConfig, LLaMAForCausalLM
+    cfg = LLaMAConfig.load_config("7b", num_hidden_layers=layers, max_sequence_length=max_length, theta=1e7)
+    with torch.device("cuda"):
+        model = LLaMAForCausalLM(cfg)
+    ids = torch.randint(0, cfg.vocab_size, (1, prompt), device="cuda", generator=torch.Generator(device="cuda").manual_seed(0))
+    out = {}
+    for name, graph in (("eager", False), ("hipgraph", True)):
+        def run(n):
+            torch.cuda.synchronize()
+            t0 = _t.perf_counter()
+            toks = model.generate(ids, max_new_tokens=n, max_length=max_length, graph=graph)
+            torch.cuda.synchronize()
+            return _t.perf_counter() - t0, toks
+        run(3)                                   # warm
+        t_short, _ = run(2)
+        t_long, toks = run(new)
+        out[name + "_ms_per_token"] = (t_long - t_short) / (new - 2) * 1e3
+        out[name + "_tokens"] = toks[0, prompt:prompt + 8].tolist()
+    out["same_tokens"] = out.pop("eager_tokens") == out.pop("hipgraph_tokens")
+    out["workload"] = (f"greedy decode, {layers}-layer slice of LWM-7B, prompt {prompt}, cache max_length {max_length} "
+                       f"(attention runs over the whole cache, lwm/llama.py:571-614), B=1, bf16")
+    out["speedup"] = out["eager_ms_per_token"] / out["hipgraph_ms_per_token"]
+    return out
+
+
 def elementwise_leg(torch, S=32768):
     """Secondary leg: RoPE (q and k) and RMSNorm fwd at LWM-7B shapes, HBM-bound.
     Algorithmic bytes: RoPE 2 tensors x (read + write) x S*4096*2 B (+ the table);
@@ -572,6 +603,7 @@ def main():
                 res["packed"] = packed_leg(torch)
                 res["model_slice"] = model_slice_leg(torch)
                 res["decode"] = decode_leg(torch)
+                res["generate"] = generate_leg(torch)
                 res["elementwise"] = elementwise_leg(torch)
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -124,6 +124,15 @@ int lwm_kv_cache_write(void* cache, const void* src, int32_t B, int64_t cache_st
                        int64_t src_stride_b, int64_t dst_row0, int64_t src_row0, int64_t nrows,
                        int32_t row_elems, void* stream);
 
+/* The same with the destination row read from DEVICE memory: row = *dst_row0_dev + row_offset + i;
+ * rows outside [0, cache_rows) are skipped, which is the decode rule "only the owning sp shard
+ * writes" (lwm/llama.py:454-467) with row_offset = -rank * cache_rows.  No host value changes from
+ * one decode step to the next, so a step can be captured in a hipGraph and replayed. */
+int lwm_kv_cache_write_at(void* cache, const void* src, int32_t B, int64_t cache_stride_b,
+                          int64_t src_stride_b, const int32_t* dst_row0_dev, int64_t row_offset,
+                          int64_t cache_rows, int64_t src_row0, int64_t nrows, int32_t row_elems,
+                          void* stream);
+
 /* Elementwise helpers of the ring driver (HBM-bound). */
 /* dst_bf16[n] = (bf16) src_f32[n] */
 int lwm_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);

@@ -54,6 +54,8 @@ PROTOTYPES = {
                                   C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "lwm_kv_cache_write": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64,
                                     C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
+    "lwm_kv_cache_write_at": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
+                                        C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
     "lwm_rope_bf16": (C.c_int, [LwmTensor4, LwmTensor4, C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]),
     "lwm_rmsnorm_fwd_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                       C.c_float, C.c_void_p]),

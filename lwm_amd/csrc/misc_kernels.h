@@ -164,4 +164,27 @@ LWM_KERNEL(256) void kv_cache_write_kernel(bf16_t* cache, const bf16_t* src, int
     }
 }
 
+// The same copy with the destination row taken from DEVICE memory: dst row = *row0_dev + row_offset + i,
+// rows outside [0, cache_rows) are skipped ("only the owning shard writes", lwm/llama.py:454-467).
+// Nothing about the step depends on a host value, so a decode step can be captured in a hipGraph and
+// replayed while the index advances on the device.
+LWM_KERNEL(256) void kv_cache_write_at_kernel(bf16_t* cache, const bf16_t* src, int B, int64_t cache_sb,
+                                              int64_t src_sb, const int32_t* row0_dev, int64_t row_offset,
+                                              int64_t cache_rows, int64_t src_row0, int64_t nrows,
+                                              int row_elems) {
+    const int vec = row_elems >> 3;
+    const int64_t total = (int64_t)B * nrows * vec;
+    const int64_t dst_row0 = (int64_t)row0_dev[0] + row_offset;
+    for (int64_t i = (int64_t)block_idx_x() * 256 + thread_idx(); i < total;
+         i += (int64_t)grid_dim_x() * 256) {
+        const int c = (int)(i % vec) * 8;
+        const int64_t r = (i / vec) % nrows;
+        const int64_t b = i / ((int64_t)vec * nrows);
+        const int64_t dr = dst_row0 + r;
+        if (dr < 0 || dr >= cache_rows) continue;
+        u32x4 v = global_load_b128(src + b * src_sb + (src_row0 + r) * row_elems + c);
+        global_store_b128(cache + b * cache_sb + dr * row_elems + c, v);
+    }
+}
+
 }  // namespace lwm

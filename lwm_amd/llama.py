@@ -16,6 +16,7 @@ import math
 
 import torch
 
+from . import ops as _ops
 from .llama_ops import (LLaMAMLP, RMSNorm, apply_rotary_emb, chunked_lm_head_loss,
                         precompute_freqs_cis)
 from .ringattention import (blockwise_feedforward, concatenate_to_cache, ringattention,
@@ -153,6 +154,13 @@ class LLaMAAttention(torch.nn.Module):
         cache_index int); `attention_mask`: (B, max_length), ones beyond the prompt (:1121-1124)."""
         B, Q = xq.shape[:2]
         ck, cv = cache["cached_key"], cache["cached_value"]
+        if "index_dev" in cache:
+            # hipGraph-capturable decode step: cache_index lives on the device (one int32 shared by all
+            # layers), the mask was built from it once for this step, and the new row is written by
+            # lwm_kv_cache_write_at -- no host value changes between replays.
+            _ops.kv_cache_write_at(ck, xk.contiguous(), cache["index_dev"])
+            _ops.kv_cache_write_at(cv, xv, cache["index_dev"])
+            return ringattention_inference(xq.contiguous(), ck, cv, cache["mask_dev"], axis_name="sp")
         max_len, idx = ck.shape[1], int(cache["cache_index"])
         ar = torch.arange(max_len, device=xq.device)
         mask = (ar[None, :] <= (torch.arange(Q, device=xq.device) + idx)[:, None])[None, None].expand(B, 1, Q, max_len)
@@ -218,38 +226,85 @@ class LLaMAForCausalLM(torch.nn.Module):
         return [dict(cached_key=z(), cached_value=z(), cache_index=0) for _ in self.h]
 
     @torch.no_grad()
-    def generate(self, input_ids, attention_mask=None, max_new_tokens=16, max_length=None, return_logits=False):
+    def generate(self, input_ids, attention_mask=None, max_new_tokens=16, max_length=None, return_logits=False,
+                 graph=False):
         """Greedy decoding through the KV cache: prepare_inputs_for_generation /
         update_inputs_for_generation of the reference (lwm/llama.py:1113-1137) + argmax.
         Prefill writes the prompt's keys/values at cache_index 0 and attends over the whole
-        (B, max_length) cache under the dense mask; every further step feeds one token."""
+        (B, max_length) cache under the dense mask; every further step feeds one token.
+
+        graph=True: the one-token step (every layer's RMSNorm, projections, RoPE, cache write, decode
+        attention, MLP, and the head) is captured ONCE in a hipGraph and replayed per token; the
+        cache index, position and current token advance on the device inside the graph.  A decode
+        step is some 15 launches per layer of a few microseconds of work each -- launch-bound when
+        issued one by one.  Single-rank only (the cross-rank combine is not captured)."""
         B, S = input_ids.shape
         max_length = max_length or (S + max_new_tokens)
-        cache = self.init_cache(B, max_length, input_ids.device)
-        ext = torch.ones(B, max_length, dtype=torch.int32, device=input_ids.device)
+        dev = input_ids.device
+        cache = self.init_cache(B, max_length, dev)
+        ext = torch.ones(B, max_length, dtype=torch.int32, device=dev)
         if attention_mask is not None:
             pos = attention_mask.to(torch.int32).cumsum(-1) - 1
             ext[:, :S] = attention_mask.to(torch.int32)
         else:
-            pos = torch.arange(S, dtype=torch.int32, device=input_ids.device)[None].expand(B, S)
-        pos = pos.clamp_min(0).contiguous()
-        tokens, logits_out = input_ids, []
-        step_in = input_ids
-        for _ in range(max_new_tokens):
-            h = self.hidden_states(step_in, ext, None, pos, cache)
-            logits = h[:, -1].float() @ self.lm_head.float()
+            pos = torch.arange(S, dtype=torch.int32, device=dev)[None].expand(B, S)
+        pos = pos.clamp_min(0).to(torch.int32).contiguous()
+        head = self.lm_head.float()
+        tokens, logits_out = [input_ids], []
+
+        def emit(logits):
             if return_logits:
-                logits_out.append(logits)
+                logits_out.append(logits.clone())
             nxt = logits.argmax(-1, keepdim=True).to(input_ids.dtype)
-            tokens = torch.cat([tokens, nxt], dim=1)
-            step_in, pos = nxt, (pos[:, -1:] + 1).contiguous()
-        return (tokens, torch.stack(logits_out, 1)) if return_logits else tokens
+            tokens.append(nxt.clone())
+            return nxt
+
+        # prefill (and, without graph, every later step): host-side cache_index
+        step_in = input_ids
+        n_eager = max_new_tokens if not graph else min(1, max_new_tokens)
+        for _ in range(n_eager):
+            h = self.hidden_states(step_in, ext, None, pos, cache)
+            step_in = emit(h[:, -1].float() @ head)
+            pos = (pos[:, -1:] + 1).contiguous()
+        if graph and max_new_tokens > 1:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                raise NotImplementedError("generate(graph=True) is single-rank")
+            idx = torch.tensor([int(cache[0]["cache_index"])], dtype=torch.int32, device=dev)
+            ar = torch.arange(max_length, device=dev, dtype=torch.int32)
+            tok, posd = step_in.clone(), pos.clone()
+            dcache = [dict(cached_key=c["cached_key"], cached_value=c["cached_value"], index_dev=idx) for c in cache]
+
+            def step():
+                mask = ((ar[None, :] <= idx) & (ext > 0))[:, None, None, :]
+                for c in dcache:
+                    c["mask_dev"] = mask
+                logits = self.hidden_states(tok, ext, None, posd, dcache)[:, -1].float() @ head
+                tok.copy_(logits.argmax(-1, keepdim=True).to(tok.dtype))
+                posd.add_(1)
+                idx.add_(1)
+                return logits
+
+            # one eager step on a side stream (library handles, first-call state), then capture
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                emit(step())
+            torch.cuda.current_stream(dev).wait_stream(side)
+            if max_new_tokens > 2:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    static_logits = step()
+                for _ in range(max_new_tokens - 2):
+                    g.replay()
+                    emit(static_logits)
+        out = torch.cat(tokens, dim=1)
+        return (out, torch.stack(logits_out, 1)) if return_logits else out
 
     def loss(self, input_tokens, target_tokens, loss_masks=None, attention_mask=None, segment_ids=None,
              position_ids=None, chunk=8192):
         h = self.hidden_states(input_tokens, attention_mask, segment_ids, position_ids)
         return chunked_lm_head_loss(h, self.lm_head, target_tokens, loss_masks, chunk)
-
 
 def hf_rotary_to_interleaved(w_out_in, num_heads):
     """HF-PyTorch LLaMA checkpoints (README.md:74, scripts/sample_pyt.py:8) store wq/wk for the

@@ -176,6 +176,26 @@ def kv_cache_write(cache, src, *, dst_row0, src_row0=0, nrows=None):
     return cache
 
 
+def kv_cache_write_at(cache, src, index_dev, *, row_offset=0, src_row0=0, nrows=None):
+    """cache[:, index + row_offset + i] = src[:, src_row0 + i] with `index` an int32 DEVICE tensor
+    (lwm_kv_cache_write_at); rows that fall outside the cache are skipped."""
+    for n, t in (("cache", cache), ("src", src)):
+        if not t.is_cuda or t.dtype != torch.bfloat16 or t.dim() != 4 or not t[0].is_contiguous():
+            raise ValueError(f"{n}: expected bf16 (B,S,H,D) device tensor with contiguous (S,H,D)")
+    if not index_dev.is_cuda or index_dev.dtype != torch.int32 or index_dev.numel() != 1:
+        raise ValueError("index_dev: expected a one-element int32 device tensor")
+    B, rows, H, D = cache.shape
+    if nrows is None:
+        nrows = src.shape[1] - src_row0
+    if src_row0 < 0 or src_row0 + nrows > src.shape[1]:
+        raise ValueError("kv_cache_write_at: source row range out of bounds")
+    L = lib()
+    _capi.check(L, L.lwm_kv_cache_write_at(cache.data_ptr(), src.data_ptr(), B, cache.stride(0), src.stride(0),
+                                           index_dev.data_ptr(), row_offset, rows, src_row0, nrows, H * D,
+                                           _stream_ptr()), "lwm_kv_cache_write_at")
+    return cache
+
+
 def attn_bwd_delta(out, dout, delta=None):
     """delta[b,h,q] = sum_d dout*out (lwm_attn_bwd_delta)."""
     B, Sq, H, D = out.shape

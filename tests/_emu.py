@@ -318,3 +318,15 @@ def softmax_ce(logits, target, weight=None, want_grad=True):
     _capi.check(L, L.lwm_softmax_ce_bf16(lb.ctypes.data, tg.ctypes.data, _ptr(w), nll.ctypes.data, cor.ctypes.data,
                                          _ptr(dl), rows, V, None), "lwm_softmax_ce_bf16")
     return nll, cor, (None if dl is None else from_bf16_bits(dl))
+
+
+def kv_cache_write_at(cache_bits, src_bits, index, row_offset, src_row0, nrows):
+    L = lib()
+    B, S, H, D = cache_bits.shape
+    idx = aligned((4,), np.int32)
+    idx[0] = index
+    _capi.check(L, L.lwm_kv_cache_write_at(cache_bits.ctypes.data, src_bits.ctypes.data, B,
+                                           cache_bits.strides[0] // 2, src_bits.strides[0] // 2,
+                                           idx.ctypes.data, row_offset, S, src_row0, nrows, H * D, None),
+                "lwm_kv_cache_write_at")
+    return cache_bits

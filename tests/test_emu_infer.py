@@ -50,3 +50,23 @@ def test_kv_cache_write():
     _emu.kv_cache_write(cache, new, dst_row0=30, src_row0=2, nrows=5)
     assert np.array_equal(cache[:, 30:35], new[:, 2:7])
     assert not cache[:, :30].any() and not cache[:, 35:].any()
+
+
+def test_kv_cache_write_at_device_index():
+    """lwm_kv_cache_write_at: the row comes from (device) memory; rows outside the shard are skipped --
+    the decode rule of lwm/llama.py:454-467 (shard r of a cache sharded in blocks of S rows)."""
+    B, S, H, D = 2, 40, 2, 128
+    new = _emu.bf16_array(_rnd((B, 3, H, D), 11))
+    cache = _emu.bf16_array(np.zeros((B, S, H, D), np.float32))
+    _emu.kv_cache_write_at(cache, new, index=17, row_offset=0, src_row0=0, nrows=3)
+    assert np.array_equal(cache[:, 17:20], new) and not cache[:, :17].any() and not cache[:, 20:].any()
+    # global row 41 on shard 1 (rows 40..79): local row 1; on shard 0 nothing is written
+    c0 = _emu.bf16_array(np.zeros((B, S, H, D), np.float32))
+    c1 = _emu.bf16_array(np.zeros((B, S, H, D), np.float32))
+    _emu.kv_cache_write_at(c0, new, index=41, row_offset=0, src_row0=0, nrows=1)
+    _emu.kv_cache_write_at(c1, new, index=41, row_offset=-S, src_row0=0, nrows=1)
+    assert not c0.any() and np.array_equal(c1[:, 1:2], new[:, :1]) and not c1[:, 2:].any()
+    # a 3-row write that straddles the end of the shard keeps only the rows inside
+    c2 = _emu.bf16_array(np.zeros((B, S, H, D), np.float32))
+    _emu.kv_cache_write_at(c2, new, index=S - 2, row_offset=0, src_row0=0, nrows=3)
+    assert np.array_equal(c2[:, S - 2:], new[:, :2])

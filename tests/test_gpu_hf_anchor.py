@@ -89,3 +89,18 @@ def test_cached_greedy_generation_matches_hf_transformers():
     assert worst <= 3e-2 * scores.abs().max().item(), worst
     assert torch.equal(toks.cpu(), seq.cpu()), (toks.cpu()[0, PL:], seq.cpu()[0, PL:])
     assert all(c["cache_index"] == PL + NEW - 1 for c in cache)    # prefill + (NEW - 1) fed-back tokens
+
+
+def test_graph_captured_decode_matches_hf_and_eager():
+    """generate(graph=True): the one-token step captured in a hipGraph (device-side cache index,
+    lwm_kv_cache_write_at) must produce the same tokens as the eager loop and as HF transformers."""
+    import torch
+    F, cfg, model = _model()
+    gold = np.load(os.path.join(HERE, "golden", "hf_llama_tiny.npz"))
+    seq = torch.from_numpy(gold["gen_tokens"]).cuda()
+    mask = torch.from_numpy(gold["gen_mask"]).cuda()
+    PL, NEW = mask.shape[1], gold["gen_scores"].shape[1]
+    eager, le = model.generate(seq[:, :PL], attention_mask=mask, max_new_tokens=NEW, return_logits=True)
+    graph, lg = model.generate(seq[:, :PL], attention_mask=mask, max_new_tokens=NEW, return_logits=True, graph=True)
+    assert torch.equal(graph, eager) and torch.equal(graph.cpu(), seq.cpu())
+    assert (lg - le).abs().max().item() <= 1e-3 * le.abs().max().item()
