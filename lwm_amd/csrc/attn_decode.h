@@ -40,6 +40,39 @@ LWM_KERNEL(kDecThreads) void attn_decode_kernel(AttnParams p) {
     const float c = p.scale * kLog2e;
     const uint8_t* mrow = p.dense_mask ? p.dense_mask + (int64_t)b * p.msk_sb : nullptr;
 
+    // Visible key range of this piece.  The reference attends over the WHOLE cache under the mask
+    // (kv_len = max_length, lwm/llama.py:571-614); the keys beyond cache_index (and padding at either
+    // end) are masked, so the piece first scans its mask bytes -- 1 B per key against 8 KiB of K/V per
+    // key -- and streams only [ka, kz).  A generation that has filled 2K of a 32K cache then moves
+    // 1/16 of the bytes; a piece with no visible key writes (0, -inf) without touching K or V.
+    int ka = k0, kz = k1;
+    if (mrow) {
+        int first = 0x7fffffff, last = -1;
+        for (int j = k0 + tid; j < k1; j += kDecThreads)
+            if (mrow[j] != 0) {
+                first = j < first ? j : first;
+                last = j > last ? j : last;
+            }
+        for (int msk = 1; msk < 64; msk <<= 1) {
+            const int of = shfl_xor_i(first, msk), ol = shfl_xor_i(last, msk);
+            first = of < first ? of : first;
+            last = ol > last ? ol : last;
+        }
+        const lds_t scan = dyn_lds();
+        if ((tid & 63) == 0) {
+            lds_write_i32(scan + (tid >> 6) * 8, first);
+            lds_write_i32(scan + (tid >> 6) * 8 + 4, last);
+        }
+        block_sync();
+        for (int w = 0; w < kDecThreads / 64; ++w) {
+            const int of = lds_read_i32(scan + w * 8), ol = lds_read_i32(scan + w * 8 + 4);
+            first = of < first ? of : first;
+            last = ol > last ? ol : last;
+        }
+        ka = last >= 0 ? first : k0;
+        kz = last >= 0 ? last + 1 : k0;          // empty range when nothing is visible
+    }
+
     for (int h0 = 0; h0 < p.H; h0 += 32) {
         const int h = h0 + grp;
         const bool h_ok = h < p.H;
@@ -56,18 +89,18 @@ LWM_KERNEL(kDecThreads) void attn_decode_kernel(AttnParams p) {
         // Every piece starts at a different phase of its key range (softmax accumulation is
         // order-free): pieces are a power-of-two number of bytes apart, and workgroups that
         // walk them in lock step would otherwise camp on the same HBM channels.
-        const int nq = (k1 - k0 + kDecUnroll - 1) / kDecUnroll;   // groups of 4 keys
+        const int nq = (kz - ka + kDecUnroll - 1) / kDecUnroll;   // groups of 4 keys
         const int rot = nq > 0 ? (int)(((uint32_t)block_idx_x() * 2654435761u) >> 8) % nq : 0;
         for (int g = 0; g < nq; ++g) {
             const int gq = g + rot < nq ? g + rot : g + rot - nq;
-            const int j0 = k0 + gq * kDecUnroll;
+            const int j0 = ka + gq * kDecUnroll;
             u32x4 kr[kDecUnroll], vr[kDecUnroll];
             bool vis[kDecUnroll];
             for (int u = 0; u < kDecUnroll; ++u) {
-                const int j = j0 + u < k1 ? j0 + u : k1 - 1;
+                const int j = j0 + u < kz ? j0 + u : kz - 1;
                 kr[u] = global_load_b128(kb + (int64_t)j * p.k_ss);
                 vr[u] = global_load_b128(vb + (int64_t)j * p.v_ss);
-                vis[u] = (j0 + u < k1) && (!mrow || mrow[j] != 0);
+                vis[u] = (j0 + u < kz) && (!mrow || mrow[j] != 0);
             }
             float s[kDecUnroll];
             float mx = -INFINITY;

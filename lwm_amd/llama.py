@@ -114,6 +114,11 @@ class LLaMAConfig:
         return cls(**cfg)
 
 
+def _multi_rank():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 def _dense(i, o, std, dtype):
     return torch.nn.Parameter(torch.randn(i, o, dtype=torch.float32).mul_(std).to(dtype))
 
@@ -162,6 +167,13 @@ class LLaMAAttention(torch.nn.Module):
             _ops.kv_cache_write_at(cv, xv, cache["index_dev"])
             return ringattention_inference(xq.contiguous(), ck, cv, cache["mask_dev"], axis_name="sp")
         max_len, idx = ck.shape[1], int(cache["cache_index"])
+        if Q > 1 and not _multi_rank():
+            # prefill into the cache: the same mask, handed over as its structure (see
+            # ringattention_inference) -- key tiles past cache_index + Q are never read
+            cache["cache_index"] = concatenate_to_cache(ck, cv, xk.contiguous(), xv, idx, axis_name="sp")
+            kvld = None if attention_mask is None else attention_mask[:, :max_len]
+            return ringattention_inference(xq.contiguous(), ck, cv, None, axis_name="sp", causal_offset=idx,
+                                           key_valid=kvld)
         ar = torch.arange(max_len, device=xq.device)
         mask = (ar[None, :] <= (torch.arange(Q, device=xq.device) + idx)[:, None])[None, None].expand(B, 1, Q, max_len)
         if attention_mask is not None:

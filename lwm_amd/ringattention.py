@@ -62,18 +62,32 @@ def _comm(group):
     return TorchRingComm(group)
 
 
-def ringattention_inference(q, k, v, attn_mask, axis_name="sp", q_sharded=None, block_ops=None, comm=None):
+def ringattention_inference(q, k, v, attn_mask, axis_name="sp", q_sharded=None, block_ops=None, comm=None, *,
+                            causal_offset=None, key_valid=None):
     """Dense-mask ring attention for S <= chunk size and for cached decoding
     (call site lwm/llama.py:599-614).  q: (B,Q,H,D); k, v: this rank's (B,K/sp,H,D)
     shard (the KV cache when decoding); attn_mask: boolean (B,1,Q,K_global) built at
     lwm/llama.py:577-592.  As in the reference, q is replicated over "sp" when
-    Q == 1 and sharded otherwise (`q_sp_dim`, :599) unless `q_sharded` says so."""
+    Q == 1 and sharded otherwise (`q_sp_dim`, :599) unless `q_sharded` says so.
+
+    Extension (keyword-only, single rank): with a KV cache present the mask of :577-592 is always
+    `key <= cache_index + query  AND  attention_mask[key]` (segment_mask is None, :582).  Passing that
+    structure -- causal_offset = cache_index, key_valid = attention_mask -- instead of the dense
+    (B,1,Q,K) tensor runs the causal kernel with q_start = cache_index: key tiles beyond the diagonal are
+    never read and no Q x K mask is materialised (prefill of a long prompt into a longer cache)."""
+    cm = comm if comm is not None else _comm(_resolve_axis(axis_name))
+    if causal_offset is not None and cm.size == 1:
+        kv = None if key_valid is None else (key_valid != 0).to(torch.uint8).contiguous()
+        out, _ = (block_ops or HipBlockOps).fwd(q, k, v, q_start=int(causal_offset), k_start=0, causal=True,
+                                               key_valid=kv)
+        return out
+    if attn_mask is None:
+        raise ValueError("attn_mask is required (the structured form is single-rank only)")
     if attn_mask.dim() != 4 or attn_mask.shape[1] != 1:
         raise ValueError("attn_mask must be (B,1,Q,K) as built at lwm/llama.py:577-592")
     if q_sharded is None:
         q_sharded = q.shape[1] != 1
     mask = (attn_mask[:, 0] != 0).to(torch.uint8).contiguous()
-    cm = comm if comm is not None else _comm(_resolve_axis(axis_name))
     return ring_inference(block_ops or HipBlockOps, cm, q, k, v, mask, q_sharded=q_sharded)
 
 

@@ -30,6 +30,28 @@ def test_decode_mask_splitk(B, Q, K, H, splits, cache_index):
     assert np.abs(R.ring_inference(q, k, v, mask, ring=1) - ro).max() < 1e-5
 
 
+def test_decode_streams_only_the_visible_range():
+    """Left padding + a mostly empty cache: the decode kernel scans its mask piece and reads K/V only in
+    [first visible, last visible]; pieces before / after / inside the range must still combine exactly."""
+    B, Q, K, H = 2, 1, 1000, 2
+    q, k, v = _rnd((B, Q, H, 128), 21), _rnd((B, K, H, 128), 22), _rnd((B, K, H, 128), 23)
+    am = np.ones((B, K), np.uint8)
+    am[0, :130] = 0                      # left-padded prompt in row 0
+    am[1, 37] = 0                        # a hole in row 1
+    mask = R.decode_mask(B, Q, K, 333, am)
+    for splits in (1, 7, 16):
+        out, lse = _emu.attn_infer(q, k, v, mask, k_splits=splits)
+        ro, rl = R.dense_attention(q, k, v, causal=False, dense_mask=mask)
+        assert np.abs(out - ro).max() / np.abs(ro).max() < 1e-2, splits
+        assert np.abs(lse - rl).max() < 1e-4, splits
+    # poison everything outside the visible range: the result must not change (nothing is read there)
+    k2, v2 = k.copy(), v.copy()
+    k2[0, :130], v2[0, :130], k2[:, 334:], v2[:, 334:] = 1e30, 1e30, 1e30, 1e30
+    out2, _ = _emu.attn_infer(q, R.round_bf16(k2), R.round_bf16(v2), mask, k_splits=7)
+    out1, _ = _emu.attn_infer(q, k, v, mask, k_splits=7)
+    assert np.array_equal(out1, out2)
+
+
 def test_fully_masked_rows_and_arbitrary_mask():
     B, Q, K, H = 1, 4, 128, 1
     q, k, v = _rnd((B, Q, H, 128), 5), _rnd((B, K, H, 128), 6), _rnd((B, K, H, 128), 7)

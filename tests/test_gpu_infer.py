@@ -63,6 +63,33 @@ def test_ringattention_inference_api_and_cache():
     assert np.abs(_np(out) - ro).max() / np.abs(ro).max() <= 2e-2
 
 
+def test_structured_prefill_mask_equals_the_dense_mask():
+    """ringattention_inference(causal_offset=, key_valid=) -- the cache-present mask of lwm/llama.py:577-592
+    handed over as its structure -- against the dense (B,1,Q,K) mask of the reference signature and the
+    oracle: a 700-token block prefilled at cache_index 300 of a 4096-row cache, padded keys included."""
+    import torch
+    from lwm_amd.ringattention import ringattention_inference
+    B, Q, K, H, idx = 2, 700, 4096, 4, 300
+    q, k, v = _rand((B, Q, H, 128), 11).cuda(), _rand((B, K, H, 128), 12).cuda(), _rand((B, K, H, 128), 13).cuda()
+    am = torch.ones(B, K, dtype=torch.int32, device="cuda")
+    am[0, :17] = 0
+    am[1, 450:460] = 0
+    dense = ((torch.arange(K, device="cuda")[None, :] <= (torch.arange(Q, device="cuda") + idx)[:, None])[None, None]
+             & (am[:, None, None, :] > 0))
+    o_dense = ringattention_inference(q, k, v, dense)
+    o_struct = ringattention_inference(q, k, v, None, causal_offset=idx, key_valid=am)
+    ro, _ = R.dense_attention(_np(q), _np(k), _np(v), causal=False, dense_mask=_np(dense[:, 0]).astype(np.uint8))
+    for o in (o_dense, o_struct):
+        assert np.abs(_np(o) - ro).max() / np.abs(ro).max() <= 2e-2
+    assert (o_dense.float() - o_struct.float()).abs().max().item() <= 1.6e-2 * np.abs(ro).max()
+    # no key tile beyond the diagonal's own is read: poison the cache from the next 64-key tile on
+    k2, v2 = k.clone(), v.clone()
+    tail = -(-(idx + Q) // 64) * 64
+    k2[:, tail:], v2[:, tail:] = float("nan"), float("nan")
+    o2 = ringattention_inference(q, k2, v2, None, causal_offset=idx, key_valid=am)
+    assert torch.equal(o2, o_struct)
+
+
 def test_decode_full_size_cache_properties():
     """LWM-7B decode shapes: 32 heads, 131072-token cache shard (1 GiB of K+V per
     batch row): V = ones -> output exactly ones; masked tail has no influence."""
