@@ -53,6 +53,30 @@ def test_emulated_fwd_bwd(B, Sq, Sk, H, causal, seg, kv):
     assert _rel(dq, rq) < 1e-2 and _rel(dk, rk) < 1e-2 and _rel(dv, rv) < 1e-2
 
 
+@pytest.mark.parametrize("Sq,Sk", [(0, 64), (64, 0), (1, 1), (33, 1), (257, 3)])
+def test_emulated_empty_and_degenerate_shapes(Sq, Sk):
+    """Empty query / key blocks (a rank whose shard sees nothing yet, an empty cache) and one-row
+    blocks: no out-of-bounds access, out = 0 and lse = -inf where no key exists, zero gradients."""
+    B, H = 1, 2
+    q, k, v, do = _rnd((B, Sq, H, 128), 1), _rnd((B, Sk, H, 128), 2), _rnd((B, Sk, H, 128), 3), _rnd((B, Sq, H, 128), 4)
+    out, lse = _emu.attn_fwd(q, k, v, causal=False)
+    assert out.shape == (B, Sq, H, 128) and lse.shape == (B, H, Sq)
+    if Sk == 0:
+        assert not out.any() and np.isneginf(lse).all()
+    elif Sq:
+        ro, rl = R.dense_attention(q, k, v, causal=False)
+        assert _rel(out, ro) < 1e-2 and np.abs(lse - rl).max() < 1e-4
+    dq, dk, dv = _emu.attn_bwd(q, k, v, out, lse, do, causal=False)
+    assert dq.shape == q.shape and dk.shape == k.shape and dv.shape == v.shape
+    if Sq == 0 or Sk == 0:
+        assert not dq.any() and not dk.any() and not dv.any()
+    else:
+        rq, rk, rv = R.dense_attention_bwd(q, k, v, do, causal=False)
+        # with one key p == 1 and dS == 0 exactly: dq, dk are pure rounding noise around a zero reference
+        near = lambda a, b: np.abs(a - b).max() <= 1e-2 * max(np.abs(b).max(), 1.0)
+        assert near(dq, rq) and near(dk, rk) and near(dv, rv)
+
+
 def test_emulated_ring_carries():
     """two kv blocks with f32 carries (a 2-step ring on one q block) == one shot,
     forward and backward, with global position offsets."""
