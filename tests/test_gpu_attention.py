@@ -281,3 +281,31 @@ def test_full_size_properties(full):
     rq, rk, rv = R.dense_attention_bwd(_np(q[:, sl, h:h + 1]), _np(k[:, sl, h:h + 1]), _np(v[:, sl, h:h + 1]),
                                        _np(do[:, sl, h:h + 1]), causal=True)
     _check("dq window", _np(dq[:, r0:r0 + w, h:h + 1]), rq[:, r0:r0 + w])
+
+
+def test_addressing_beyond_4g_elements_at_1m_tokens():
+    """Maximum size: B=1, S=1,048,576, H=32, D=128 is 4.29e9 elements (8 GiB) per tensor, past 32-bit
+    element offsets.  Size-independent property: a head's result depends only on that head's data, so the
+    LAST head (highest addresses) of the 32-head launch must equal, bit for bit, the same data run as a
+    1-head problem -- forward and backward.  Packed 4096-token documents keep the arithmetic small."""
+    import torch
+    from lwm_amd.ring import ring_attention
+    S, H, doc = 1 << 20, 32, 4096
+    g = torch.Generator(device="cuda").manual_seed(5)
+    mk = lambda: torch.randn(1, S, H, 128, generator=g, device="cuda", dtype=torch.bfloat16)
+    seg = (torch.arange(S, device="cuda", dtype=torch.int32) // doc)[None]
+    q, k, v, do = mk(), mk(), mk(), mk()
+    q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
+    out = ring_attention(q, k, v, causal=True, segment_ids=seg)
+    out.backward(do)
+    h = H - 1
+    q1, k1, v1 = (t.detach()[:, :, h:h + 1].contiguous().requires_grad_(True) for t in (q, k, v))
+    out1 = ring_attention(q1, k1, v1, causal=True, segment_ids=seg)
+    out1.backward(do[:, :, h:h + 1].contiguous())
+    assert torch.equal(out.detach()[:, :, h:h + 1], out1.detach())
+    for a, b in ((q.grad, q1.grad), (k.grad, k1.grad), (v.grad, v1.grad)):
+        assert torch.equal(a[:, :, h:h + 1], b)
+    # and the last rows of the last head are really attention over their own document
+    f = lambda t: t.detach()[0, S - doc:, h].float().cpu().numpy()[None, :, None]
+    ro, _ = R.dense_attention(f(q), f(k), f(v), causal=True)
+    _check("out tail", f(out), ro)
