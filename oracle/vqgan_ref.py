@@ -202,6 +202,29 @@ def encode(params, pixel_values, cfg=None):
     return zq, idx
 
 
+def index_mismatch_report(params, pixel_values, got_idx, cfg=None):
+    """when code indices differ from the oracle's, say how many and how close the
+    call was -- for every mismatching position the oracle's best and second-best squared distances and the
+    distance of the index the device chose.  -> (n_mismatch, n_total, report string)."""
+    cfg = cfg or DEFAULT_CONFIG
+    x = _c(pixel_values)
+    if x.ndim == 5:
+        x = x.reshape((-1,) + x.shape[2:])
+    h = _conv(params["quant_conv"], encoder(params["encoder"], x, cfg))
+    cb = np.asarray(params["quantize"]["embeddings"], np.float32)
+    ref = vq_argmin(h, cb).reshape(-1)
+    got = np.asarray(got_idx).reshape(-1)
+    z = h.reshape(-1, h.shape[-1]).astype(np.float64)
+    bad = np.nonzero(ref != got)[0]
+    lines = []
+    for i in bad[:8]:
+        d = ((z[i][None] - cb.astype(np.float64)) ** 2).sum(-1)
+        o = np.argsort(d)
+        lines.append(f"pos {i}: oracle {ref[i]} (d={d[ref[i]]:.9g}), device {got[i]} (d={d[got[i]]:.9g}), "
+                     f"top-2 margin {d[o[1]] - d[o[0]]:.3g}")
+    return len(bad), len(ref), f"{len(bad)}/{len(ref)} code indices differ; " + "; ".join(lines)
+
+
 def decode(params, encoding, cfg=None, is_codebook_indices=True):
     """VQGANModel.decode (lwm/vqgan.py:130-141)."""
     cfg = cfg or DEFAULT_CONFIG

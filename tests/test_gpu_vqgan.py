@@ -119,7 +119,8 @@ def test_model_encode_decode_small():
     px = np.random.default_rng(12).uniform(-1, 1, (2, 64, 64, 3)).astype(np.float32)
     zq, idx = vq.encode(px)
     rzq, ridx = R.encode(params, px, cfg.as_dict())
-    assert np.array_equal(idx.cpu().numpy(), ridx)            # code indices: identical
+    if not np.array_equal(idx.cpu().numpy(), ridx):           # code indices: identical
+        raise AssertionError(R.index_mismatch_report(params, px, idx.cpu().numpy(), cfg.as_dict())[2])
     assert np.array_equal(zq.cpu().numpy(), rzq)
     rec = vq.decode(idx)
     rrec = R.decode(params, ridx, cfg.as_dict())
@@ -139,7 +140,8 @@ def test_model_full_resolution_frame():
     zq, idx = vq.encode(px)
     rzq, ridx = R.encode(params, px, cfg.as_dict())
     assert tuple(idx.shape) == (1, 16, 16)
-    assert np.array_equal(idx.cpu().numpy(), ridx)
+    if not np.array_equal(idx.cpu().numpy(), ridx):           # say how close the calls were (top-2 margins)
+        raise AssertionError(R.index_mismatch_report(params, px, idx.cpu().numpy(), cfg.as_dict())[2])
     assert np.array_equal(zq.cpu().numpy(), rzq)
     rec = vq.decode(idx).cpu().numpy()
     rrec = R.decode(params, ridx, cfg.as_dict())

@@ -147,3 +147,19 @@ def test_video_5d_folds_time_into_batch(params):
     assert idx5.shape == (1, 2) + idx4.shape[1:] and np.array_equal(idx5[0], idx4)
     assert np.array_equal(zq5[0], zq4)
     assert R.decode(params, idx5, cfg).shape == px.shape
+
+
+def test_index_mismatch_report_names_margins():
+    """a code-index mismatch is reported with its top-2 margin."""
+    import numpy as np
+    from lwm_amd.vqgan import VQGANConfig, random_params
+    from oracle import vqgan_ref as V
+    cfg = VQGANConfig.get_default_config(dict(resolution=32, channel_mult=(1, 2, 4), num_embeddings=1024))
+    params = random_params(cfg, seed=5)
+    px = np.random.default_rng(6).uniform(-1, 1, (1, 32, 32, 3)).astype(np.float32)
+    _, idx = V.encode(params, px, cfg.as_dict())
+    assert V.index_mismatch_report(params, px, idx, cfg.as_dict())[:2] == (0, idx.size)
+    bad = idx.copy()
+    bad.reshape(-1)[3] = (bad.reshape(-1)[3] + 1) % 1024
+    n, total, text = V.index_mismatch_report(params, px, bad, cfg.as_dict())
+    assert (n, total) == (1, idx.size) and "top-2 margin" in text and "pos 3" in text
