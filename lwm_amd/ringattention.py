@@ -105,11 +105,20 @@ def concatenate_to_cache(cached_key, cached_value, key, value, cache_index, axis
 
 
 def blockwise_feedforward(module, x, chunk_size, pre_remat=True):
-    """lwm/llama.py:729-734: apply a position-wise module over sequence chunks
-    (identical result to module(x); bounds peak activation memory)."""
+    """lwm/llama.py:729-734: apply a position-wise module over sequence chunks (identical result to
+    module(x)).  `pre_remat` (the reference wraps the MLP in remat with policy nothing_saveable,
+    lwm/llama.py:673-678): each chunk's activations inside `module` are recomputed in the backward
+    instead of stored -- at 1M tokens the two (S, 11008) SwiGLU intermediates are 44 GB per layer."""
     S = x.shape[1]
+
+    def run(c):
+        if pre_remat and torch.is_grad_enabled() and c.requires_grad:
+            from torch.utils.checkpoint import checkpoint
+            return checkpoint(module, c, use_reentrant=False)
+        return module(c)
+
     if chunk_size is None or S <= chunk_size:
-        return module(x)
+        return run(x)
     if S % chunk_size:
         raise ValueError(f"sequence length {S} is not a multiple of chunk_size {chunk_size}")
-    return torch.cat([module(c) for c in x.split(chunk_size, dim=1)], dim=1)
+    return torch.cat([run(c) for c in x.split(chunk_size, dim=1)], dim=1)

@@ -56,3 +56,27 @@ def test_sp_groups_on_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == {0: (2, 1.0), 1: (2, 1.0), 2: (2, 5.0), 3: (2, 5.0)}
+
+
+def test_blockwise_feedforward_remat_is_transparent():
+    """blockwise_feedforward (lwm/llama.py:729-734): chunked == whole, and pre_remat (recompute the module in
+    the backward, lwm/llama.py:673-678) changes neither values nor gradients."""
+    import torch
+    from lwm_amd.ringattention import blockwise_feedforward
+    torch.manual_seed(0)
+    mlp = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.SiLU(), torch.nn.Linear(64, 16))
+    x = torch.randn(2, 96, 16, requires_grad=True)
+    outs = {}
+    for name, kw in (("whole", dict(chunk_size=None, pre_remat=False)), ("chunked", dict(chunk_size=32, pre_remat=False)),
+                     ("remat", dict(chunk_size=32, pre_remat=True))):
+        for p in mlp.parameters():
+            p.grad = None
+        x.grad = None
+        y = blockwise_feedforward(mlp, x, **kw)
+        y.square().sum().backward()
+        outs[name] = (y.detach().clone(), x.grad.clone(), mlp[0].weight.grad.clone())
+    for name in ("chunked", "remat"):
+        for a, b in zip(outs[name], outs["whole"]):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-5), name
+    with pytest.raises(ValueError):
+        blockwise_feedforward(mlp, x, chunk_size=40)
