@@ -40,15 +40,31 @@ LWM_KERNEL(kDecThreads) void attn_decode_kernel(AttnParams p) {
     const float c = p.scale * kLog2e;
     const uint8_t* mrow = p.dense_mask ? p.dense_mask + (int64_t)b * p.msk_sb : nullptr;
 
-    // Visible key range of this piece.  The reference attends over the WHOLE cache under the mask
-    // (kv_len = max_length, lwm/llama.py:571-614); the keys beyond cache_index (and padding at either
-    // end) are masked, so the piece first scans its mask bytes -- 1 B per key against 8 KiB of K/V per
-    // key -- and streams only [ka, kz).  A generation that has filled 2K of a 32K cache then moves
-    // 1/16 of the bytes; a piece with no visible key writes (0, -inf) without touching K or V.
+    // Visible key range.  The reference attends over the WHOLE cache under the mask (kv_len = max_length,
+    // lwm/llama.py:571-614); the keys beyond cache_index (and padding at either end) are masked.  Every
+    // workgroup scans the mask row -- 1 B per key, L2-resident, against 8 KiB of K/V per key -- finds
+    // [first, last] visible, and the k_splits pieces partition THAT range instead of [0, Sk): a generation
+    // that has filled 2K of a 32K cache moves 1/16 of the bytes and still spreads them over every
+    // workgroup (a piece's keys are a serial chain of HBM round trips, so few long pieces are slow).
+    // Holes inside the range are handled per key below.  Nothing visible -> every piece writes (0, -inf).
     int ka = k0, kz = k1;
     if (mrow) {
         int first = 0x7fffffff, last = -1;
-        for (int j = k0 + tid; j < k1; j += kDecThreads)
+        // 16 mask bytes per load where the row allows it (a byte-wise scan of a 131072-key row by all 512
+        // pieces cost ~100 us); lowest / highest nonzero byte of a word from its lowest / highest set bit
+        const int nvec = (((uintptr_t)mrow & 15) == 0) ? (p.Sk >> 4) : 0;
+        for (int i = tid; i < nvec; i += kDecThreads) {
+            const u32x4 w = global_load_b128(mrow + 16 * i);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (w[c] != 0u) {
+                    const int lo = 16 * i + 4 * c + (__builtin_ctz(w[c]) >> 3);
+                    const int hi = 16 * i + 4 * c + ((31 - __builtin_clz(w[c])) >> 3);
+                    first = lo < first ? lo : first;
+                    last = hi > last ? hi : last;
+                }
+        }
+        for (int j = 16 * nvec + tid; j < p.Sk; j += kDecThreads)
             if (mrow[j] != 0) {
                 first = j < first ? j : first;
                 last = j > last ? j : last;
@@ -69,8 +85,15 @@ LWM_KERNEL(kDecThreads) void attn_decode_kernel(AttnParams p) {
             first = of < first ? of : first;
             last = ol > last ? ol : last;
         }
-        ka = last >= 0 ? first : k0;
-        kz = last >= 0 ? last + 1 : k0;          // empty range when nothing is visible
+        if (last < 0) {
+            ka = kz = 0;
+        } else {
+            const int nv = last - first + 1;
+            const int pv = (nv + nsplit - 1) / nsplit;
+            ka = first + split * pv;
+            kz = ka + pv < last + 1 ? ka + pv : last + 1;
+            if (ka > kz) ka = kz;
+        }
     }
 
     for (int h0 = 0; h0 < p.H; h0 += 32) {
