@@ -69,11 +69,13 @@ VQGAN_ENC_GFLOP, VQGAN_DEC_GFLOP = 216.6, 477.4   # per 256x256 frame, SURVEY.md
 MFMA_F32_PEAK_TFLOPS = 157.3                      # exact-f32 MFMA, MI355X_MICROARCH.md
 
 
-def vqgan_leg(torch, frames=8, reps=3):
+def vqgan_leg(torch, frames=32, reps=3):
     """Secondary leg (not part of `value`): VQGAN encode/decode of synthetic
     256x256 frames U(-1,1), random weights of the default VQGANConfig
     (lwm/vqgan.py:62-77), frames resident in HBM; plus the C oracle on the host
-    cores for one frame (cpu_baseline of this leg)."""
+    cores for one frame (cpu_baseline of this leg).  32 frames per call: frames are independent
+    (BASELINE configs[3] tokenises 1020 of them) and the late-encoder / early-decoder layers have
+    only 256-4096 output pixels per frame (8 frames: 330 / 170 frames/s, 32: 377 / 184)."""
     import numpy as np
     from lwm_amd.vqgan import VQGAN, VQGANConfig, random_params
     cfg = VQGANConfig.get_default_config()
