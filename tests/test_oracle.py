@@ -104,3 +104,41 @@ def test_bf16_helpers_round_to_nearest_even():
     rng = np.random.default_rng(0)
     y = rng.standard_normal(10000).astype(np.float32) * 100
     assert np.array_equal(R.round_bf16(y), torch.from_numpy(y).to(torch.bfloat16).float().numpy())
+
+
+# ---- property tests (hypothesis): random shapes, chunkings, ring sizes, packings
+from hypothesis import given, settings, strategies as st  # noqa: E402
+
+
+@settings(max_examples=25, deadline=None)
+@given(ring=st.sampled_from([1, 2, 4]), chunks=st.integers(1, 4), qc=st.sampled_from([8, 16, 32]),
+       kc=st.sampled_from([8, 16, 32]), causal=st.booleans(), nseg=st.integers(1, 4), pad=st.booleans(),
+       seed=st.integers(0, 2 ** 16))
+def test_property_blockwise_ring_equals_dense(ring, chunks, qc, kc, causal, nseg, pad, seed):
+    """For any ring size, chunking, document packing and key padding: the blockwise/ring restatement
+    (forward AND backward) equals dense masked attention, and a packed batch equals its documents run
+    one by one."""
+    S = ring * chunks * 32
+    rng = np.random.default_rng(seed)
+    q, k, v, do = (rng.standard_normal((1, S, 1, 8)).astype(np.float32) for _ in range(4))
+    cuts = np.sort(rng.choice(np.arange(1, S), size=nseg - 1, replace=False)) if nseg > 1 else np.array([], int)
+    seg = np.searchsorted(cuts, np.arange(S), side="right").astype(np.int32)[None]
+    kv = np.ones((1, S), np.uint8)
+    if pad:
+        kv[0, rng.choice(S, size=S // 8, replace=False)] = 0
+    kw = dict(causal=causal, seg_q=seg, seg_k=seg, key_valid=kv)
+    ref, _ = R.dense_attention(q, k, v, **kw)
+    bkw = dict(causal=causal, segment_ids=seg, key_valid=kv)
+    out = R.blockwise_ring_attention(q, k, v, ring=ring, q_chunk=qc, k_chunk=kc, **bkw)
+    assert np.abs(out - ref).max() < 5e-5
+    rq, rk, rv = R.dense_attention_bwd(q, k, v, do, **kw)
+    bq, bk, bv = R.blockwise_ring_attention_bwd(q, k, v, do, ring=ring, q_chunk=qc, k_chunk=kc, **bkw)
+    for a, b in ((bq, rq), (bk, rk), (bv, rv)):
+        assert np.abs(a - b).max() < 2e-4 * max(1.0, np.abs(b).max())
+    # packed == per document
+    bounds = [0, *cuts.tolist(), S]
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        sl = slice(a, b)
+        one, _ = R.dense_attention(q[:, sl], k[:, sl], v[:, sl], causal=causal, key_valid=kv[:, sl])
+        rows = kv[0, sl].astype(bool) if not causal else np.ones(b - a, bool)
+        assert np.abs(one - ref[:, sl])[:, rows].max() < 1e-9
