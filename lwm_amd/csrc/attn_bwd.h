@@ -620,20 +620,25 @@ LWM_DEVICE void attn_bwd_dkdv_body(const AttnParams& p) {
     // block's own diagonal put the 32 streams at 32 different places (measured: 20.6 GB fetched
     // per launch for 0.5 GB of Q + dO per head set).
     const int q_top = nqt - 1 + qt0;             // loop index i  ->  tile q_top - i
+#ifdef LWM_DKDV_WALK_UP
+#define LWM_QT(i) (i)
+#else
+#define LWM_QT(i) (q_top - (i))
+#endif
     if (qt0 < nqt) {
         DkvStage stg;
-        dkv_stage_issue<NW, NKB, 0, SK>(p, cx, qb, dob, b, h, q_top - qt0, stg);
-        dkv_stage_finish<NKB, 0, T0>(cx, stg, q_top - qt0, p.Sq);
+        dkv_stage_issue<NW, NKB, 0, SK>(p, cx, qb, dob, b, h, LWM_QT(qt0), stg);
+        dkv_stage_finish<NKB, 0, T0>(cx, stg, LWM_QT(qt0), p.Sq);
         glds_wait_all();
         block_sync();
         const bool late = SK && wave_uniform(wave >= NW / 2 ? 1 : 0) != 0;
         for (int qt = qt0; qt < nqt; qt += 2) {
             const bool more1 = qt + 1 < nqt;
-            if (more1) dkv_stage_issue<NW, NKB, 1, SK>(p, cx, qb, dob, b, h, q_top - (qt + 1), stg);
+            if (more1) dkv_stage_issue<NW, NKB, 1, SK>(p, cx, qb, dob, b, h, LWM_QT(qt + 1), stg);
             if constexpr (SKEW > 0) { if (late) sleep_cycles64<SKEW>(); }
-            dkv_tile<NKB, 0>(p, cx, kf, q_top - qt, dk, dv, pa);
+            dkv_tile<NKB, 0>(p, cx, kf, LWM_QT(qt), dk, dv, pa);
             PROF_T(0);
-            if (more1) dkv_stage_finish<NKB, 1, T0>(cx, stg, q_top - (qt + 1), p.Sq);
+            if (more1) dkv_stage_finish<NKB, 1, T0>(cx, stg, LWM_QT(qt + 1), p.Sq);
             glds_wait_all();
             PROF_T(1);
             block_sync();
@@ -642,10 +647,10 @@ LWM_DEVICE void attn_bwd_dkdv_body(const AttnParams& p) {
             PROF_ADD(pa, 4, 1, 2);   // barrier wait
             if (!more1) break;
             const bool more2 = qt + 2 < nqt;
-            if (more2) dkv_stage_issue<NW, NKB, 0, SK>(p, cx, qb, dob, b, h, q_top - (qt + 2), stg);
+            if (more2) dkv_stage_issue<NW, NKB, 0, SK>(p, cx, qb, dob, b, h, LWM_QT(qt + 2), stg);
             if constexpr (SKEW > 0) { if (late) sleep_cycles64<SKEW>(); }
-            dkv_tile<NKB, 1>(p, cx, kf, q_top - (qt + 1), dk, dv, pa);
-            if (more2) dkv_stage_finish<NKB, 0, T0>(cx, stg, q_top - (qt + 2), p.Sq);
+            dkv_tile<NKB, 1>(p, cx, kf, LWM_QT(qt + 1), dk, dv, pa);
+            if (more2) dkv_stage_finish<NKB, 0, T0>(cx, stg, LWM_QT(qt + 2), p.Sq);
             glds_wait_all();
             block_sync();
         }
