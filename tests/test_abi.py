@@ -117,3 +117,18 @@ int main(void) {
     env["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(torch.__file__), "lib") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
     r = subprocess.run([str(exe)], capture_output=True, text=True, env=env)
     assert r.returncode == 0 and r.stdout.startswith("ok"), (r.returncode, r.stdout, r.stderr)
+
+
+def test_c_example_builds():
+    """examples/attn_fwd_from_c.c -- the hot path called from plain C with only the HIP runtime -- compiles and
+    links against the header and the library (it needs a GPU to run: tests/test_gpu_probe.py runs it)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("no gcc / ROCm headers")
+    exe = os.path.join(ROOT, "examples", "attn_fwd_from_c")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
+                    "-I", "/opt/rocm/include", os.path.join(ROOT, "examples", "attn_fwd_from_c.c"), SO,
+                    "-L", "/opt/rocm/lib", "-lamdhip64", "-lm", f"-Wl,-rpath,{os.path.dirname(SO)}", "-o", exe],
+                   check=True)
+    assert os.path.exists(exe)

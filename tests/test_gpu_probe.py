@@ -85,3 +85,21 @@ def test_mfma_f32_is_ordered_fma_chain(probe):
             ref[i, j] = c
     got = out.cpu().numpy()
     assert np.array_equal(got, ref), f"max diff {np.abs(got - ref).max()}"
+
+
+def test_plain_c_program_runs_the_forward():
+    """examples/attn_fwd_from_c.c: C99 + HIP runtime + liblwm_hip.so, no Python in the call path."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "attn_fwd_from_c")
+    if not os.path.exists(exe):
+        so = os.path.join(root, "lwm_amd", "liblwm_hip.so")
+        subprocess.run(["gcc", "-std=c99", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(root, "include"), "-I",
+                        "/opt/rocm/include", os.path.join(root, "examples", "attn_fwd_from_c.c"), so, "-L",
+                        "/opt/rocm/lib", "-lamdhip64", "-lm", f"-Wl,-rpath,{os.path.dirname(so)}", "-o", exe], check=True)
+    import torch
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(torch.__file__), "lib") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), (r.returncode, r.stdout, r.stderr)
