@@ -270,6 +270,45 @@ def generate_leg(torch, layers=4, prompt=2048, new=34, max_length=32768):
     return out
 
 
+def ring_model_leg(torch, n=8, S=131072, schedule="mesh"):
+    """What the compute side of BASELINE configs[2] (S=131072, ring 8) costs, measured on ONE GPU: every
+    rank's launches of the n-rank zigzag ring (same shapes, offsets and masks; the exchange replaced by a
+    communicator that moves nothing) are run in turn for one layer.  The slowest rank bounds the job:
+    tokens/s <= S / (max_r ms_per_layer * 32 layers).  What the 8-GPU run adds on top is exchange time that
+    is not hidden (bench `exchange.exposed_ms_per_step` at N > 1)."""
+    from lwm_amd.ring import HipBlockOps, SeqLayout, ring_backward, ring_forward
+    lay = SeqLayout("zigzag", n, S)
+    c = lay.local_len
+    g = torch.Generator(device="cuda").manual_seed(4321)
+    mk = lambda: torch.randn(1, c, N_HEADS, HEAD_DIM, generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+    q, k, v, do = mk(), mk(), mk(), mk()
+    per_rank = []
+    for r in range(n):
+        comm = NullComm(rank=r, size=n, schedule=schedule)
+
+        def layer():
+            out, lses = ring_forward(HipBlockOps, comm, q, k, v, layout=lay, causal=True)
+            ring_backward(HipBlockOps, comm, q, k, v, out, lses, do, layout=lay, causal=True)
+
+        layer()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        layer()
+        layer()
+        e1.record()
+        torch.cuda.synchronize()
+        per_rank.append(e0.elapsed_time(e1) / 2)
+    worst = max(per_rank)
+    flops_layer = 7.0 * gemm_unit_flops(S)
+    return {"workload": f"compute side of an {n}-rank zigzag ring at S={S} ({schedule} schedule), each rank's launches "
+                        f"run on this GPU, 1 layer, no exchange",
+            "per_rank_ms_per_layer": [round(x, 3) for x in per_rank],
+            "imbalance_max_over_mean": worst / (sum(per_rank) / n),
+            "compute_bound_tokens_per_s": S / (worst * 1e-3 * N_LAYERS),
+            "compute_bound_tflops_per_gpu": flops_layer / n / (worst * 1e-3) / 1e12}
+
+
 def elementwise_leg(torch, S=32768):
     """Secondary leg: RoPE (q and k) and RMSNorm fwd at LWM-7B shapes, HBM-bound.
     Algorithmic bytes: RoPE 2 tensors x (read + write) x S*4096*2 B (+ the table);
@@ -307,10 +346,13 @@ def elementwise_leg(torch, S=32768):
 class NullComm:
     """Same rank/size/schedule as the real communicator, but nothing moves: rotate() hands the
     local tensors back and exchange_async() leaves the receive buffers as allocated.  Used once,
-    after the timed region, to price the exchange (bench `exchange` object)."""
+    after the timed region, to price the exchange (bench `exchange` object), and by ring_model_leg
+    to run any rank's launches of an N-rank ring on one GPU."""
 
-    def __init__(self, real):
-        self.rank, self.size, self.schedule = real.rank, real.size, real.schedule
+    def __init__(self, real=None, *, rank=0, size=1, schedule="mesh"):
+        if real is not None:
+            rank, size, schedule = real.rank, real.size, real.schedule
+        self.rank, self.size, self.schedule = rank, size, schedule
 
     class _H:
         def __init__(self, bufs):
@@ -606,6 +648,7 @@ def main():
                 res["model_slice"] = model_slice_leg(torch)
                 res["decode"] = decode_leg(torch)
                 res["generate"] = generate_leg(torch)
+                res["ring8_compute_model"] = ring_model_leg(torch)
                 res["elementwise"] = elementwise_leg(torch)
         print(json.dumps(res), flush=True)
     if world > 1:
