@@ -445,7 +445,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vqgan", action="store_true", help="skip the secondary VQGAN leg")
     ap.add_argument("--schedule", default=None, choices=["ring", "mesh"],
-                    help="K/V exchange schedule for N > 1 (default: mesh for N > 2; lwm_amd/ring.py)")
+                    help="K/V exchange schedule for N > 1 (default: mesh; lwm_amd/ring.py)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = DRY RUN of the N > 1 code path on a box with fewer than N GPUs: the ranks "
                          "share the visible devices and stage every message through host memory")

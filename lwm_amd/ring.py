@@ -24,7 +24,7 @@ Two exchange schedules produce the same results:
     busy at once, ~1/4 fewer bytes under zigzag+causal), works through the blocks as in
     the ring, returns each block's f32 dK/dV PARTIAL straight to its owner while the
     next block is computed, and the owner reduces the partials in fixed rank order
-    (lwm_sum_f32_to_bf16).  Default for n > 2; LWM_RING_SCHEDULE=ring|mesh overrides.
+    (lwm_sum_f32_to_bf16).  Default; LWM_RING_SCHEDULE=ring|mesh overrides.
 
 The driver is written against two small interfaces so the schedule can be
 exercised on CPU (gloo) in tests with a stand-in block backend:
@@ -101,7 +101,7 @@ class TorchRingComm:
         self.group = group
         self.rank = dist.get_rank(group)
         self.size = dist.get_world_size(group)
-        self.schedule = schedule or os.environ.get("LWM_RING_SCHEDULE") or ("mesh" if self.size > 2 else "ring")
+        self.schedule = schedule or os.environ.get("LWM_RING_SCHEDULE") or "mesh"
         if self.schedule not in ("ring", "mesh"):
             raise ValueError(f"unknown exchange schedule {self.schedule!r}")
         self._dst = dist.get_global_rank(group, (self.rank + 1) % self.size) if group is not None \
