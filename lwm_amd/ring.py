@@ -352,11 +352,14 @@ def ring_backward(block, comm, q, k, v, out, lses, dout, *, layout, causal=True,
         return _mesh_backward(block, comm, q, k, v, lses, dout, deltas, layout=layout, causal=causal,
                               segment_ids=segment_ids, key_valid=key_valid, scale=scale)
 
-    dq_acc = [block.zeros((B, ln, H, D), torch.float32, q) for _, ln, _ in qsegs]
-    # f32 dk/dv accumulators of the block currently held; they travel with it
+    # f32 carries.  None is zeroed: the first contribution to a carry is written, not accumulated
+    # (every key segment has one at step 0 -- its own diagonal -- and every query segment likewise).
+    dq_acc = [block.empty((B, ln, H, D), torch.float32, q) for _, ln, _ in qsegs]
+    dq_seen = [False] * len(qsegs)
+    # dk/dv accumulators of the block currently held; they travel with it
     ksegs0 = layout.segments(r)
-    dk_acc = [block.zeros((B, ln, H, D), torch.float32, q) for _, ln, _ in ksegs0]
-    dv_acc = [block.zeros((B, ln, H, D), torch.float32, q) for _, ln, _ in ksegs0]
+    dk_acc = [block.empty((B, ln, H, D), torch.float32, q) for _, ln, _ in ksegs0]
+    dv_acc = [block.empty((B, ln, H, D), torch.float32, q) for _, ln, _ in ksegs0]
     nks = len(ksegs0)
 
     k_cur = k if k.is_contiguous() else k.contiguous()
@@ -374,17 +377,21 @@ def ring_backward(block, comm, q, k, v, out, lses, dout, *, layout, causal=True,
             sq, sk, kv = _mask_slices(segment_ids, key_valid, qs, ks)
             block.bwd_dq(_rows(q, qs), _rows(k_cur, ks), _rows(v_cur, ks), _rows(dout, qs), lses[qi],
                          deltas[qi], q_start=qs[2], k_start=ks[2], causal=causal, seg_q=sq, seg_k=sk,
-                         key_valid=kv, scale=scale, dq_acc=dq_acc[qi], carry_in=True, final=False)
+                         key_valid=kv, scale=scale, dq_acc=dq_acc[qi], carry_in=dq_seen[qi], final=False)
+            dq_seen[qi] = True
         if dkv_handle is not None:
             got = dkv_handle.wait()
             dk_acc, dv_acc = got[:nks], got[nks:]
+        fresh = set(range(nks)) if t == 0 else set()     # at step 0 the carries hold nothing yet
         for qi, ki in pairs:
             qs, ks = qsegs[qi], ksegs[ki]
             sq, sk, kv = _mask_slices(segment_ids, key_valid, qs, ks)
             block.bwd_dkdv(_rows(q, qs), _rows(k_cur, ks), _rows(v_cur, ks), _rows(dout, qs), lses[qi],
                            deltas[qi], q_start=qs[2], k_start=ks[2], causal=causal, seg_q=sq,
                            seg_k=sk, key_valid=kv, scale=scale, dk_acc=dk_acc[ki], dv_acc=dv_acc[ki],
-                           carry_in=True, final=False)
+                           carry_in=ki not in fresh, final=False)
+            fresh.discard(ki)
+        assert not fresh, "a key segment without a step-0 contribution"
         keep.append((dk_acc, dv_acc))
         dkv_handle = comm.rotate(list(dk_acc) + list(dv_acc))  # n rotations bring them home
         if kv_handle is not None:
