@@ -8,9 +8,15 @@ N(0,1) bf16 already resident in HBM when the timed region starts.
 
   N=1 : BASELINE.json configs[1]  (S=32768, ring=1, no send/recv)
   N>1 : BASELINE.json configs[2]'s problem (S=131072) ring-sharded over N GPUs
-        (zigzag ownership for causal balance), K/V (+dK/dV) rotated with RCCL.
+        (zigzag ownership for causal balance), K/V and dK/dV exchanged over RCCL
+        (mesh schedule by default, --schedule ring for the reference's pattern).
+        Also reported at N>1 (object `exchange`): the step re-run with a communicator
+        that moves nothing (what the exchange costs on top of the launches) and one
+        layer of the SAME problem on a single GPU (like-for-like strong scaling).
 
 Prints ONE JSON line (rank 0).  `value` = whole-job tokens/s = S*steps/time.
+At N=1 the line also carries `roofline`, `cpu_baseline` and secondary legs that are never
+part of `value`: vqgan, packed, model_slice, decode, generate, ring8_compute_model, elementwise.
 """
 import argparse
 import json
