@@ -17,10 +17,19 @@ inline int launch(const char* name, void (*kernel)(KArgs...), long grid, int thr
                   size_t lds_bytes, void* stream, Args... args) {
     if (grid <= 0) return 0;
     if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds_bytes);
-        if (e != hipSuccess) return fail(-3, "%s: hipFuncSetAttribute(LDS=%ld): %ld", name, (long)lds_bytes, (long)e);
+        // once per kernel and host thread: the attribute is sticky, the call is not free
+        static thread_local const void* raised[16];
+        static thread_local int n_raised = 0;
+        bool done = false;
+        for (int i = 0; i < n_raised; ++i) done |= raised[i] == (const void*)kernel;
+        if (!done) {
+            hipError_t e = hipFuncSetAttribute((const void*)kernel,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)lds_bytes);
+            if (e != hipSuccess)
+                return fail(-3, "%s: hipFuncSetAttribute(LDS=%ld): %ld", name, (long)lds_bytes, (long)e);
+            if (n_raised < 16) raised[n_raised++] = (const void*)kernel;
+        }
     }
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3((unsigned)threads), lds_bytes,
                        (hipStream_t)stream, args...);
