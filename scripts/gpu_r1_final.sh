@@ -7,7 +7,7 @@ cd $R
 (timeout 900 python bench.py --steps 3 --warmup 1 2>&1 | tail -1) > gpurun_out/bench.log
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof
-(timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o r01h -- python $R/bench.py --steps 1 --warmup 0 --layers 4 --no-cpu-baseline 2>&1 | tail -2) > $R/gpurun_out/prof.log
+(timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o r01i -- python $R/bench.py --steps 1 --warmup 0 --layers 4 --no-cpu-baseline 2>&1 | tail -2) > $R/gpurun_out/prof.log
 bash $R/scripts/gpu_pmc_attention.sh
 cd $R
 for f in tests smoke bench; do echo "=== $f"; cat gpurun_out/$f.log; done
