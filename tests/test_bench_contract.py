@@ -1,0 +1,51 @@
+"""The bench line the driver consumes: the newest committed profiles/*_bench.json (written by
+`python bench.py --steps 3 --warmup 1` on an MI355X, scripts/gpu_r1_final.sh) must carry every field of the
+contract, with the metric and workload BASELINE.json names, a roofline object for the dominant kernel and a
+CPU baseline from the same run -- and bench.py must keep the command-line contract."""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _latest():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench.json")))
+    assert files, "no committed bench line under profiles/"
+    return json.loads(open(files[-1]).read().strip().splitlines()[-1])
+
+
+def test_committed_bench_line_follows_the_contract():
+    d = _latest()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "tokens/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and "synthetic" in d["data"]
+    assert "S=32768" in d["config"]["workload"] and "configs[1]" in d["config"]["workload"]
+    assert "model" not in d["config"]
+    assert abs(d["value"] - 32768 * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
+    assert r["traffic"] is None or r["traffic"] > 1e9          # HBM bytes per launch of the dominant kernel
+    # achieved = algorithmic FLOPs per launch / measured launch duration (dK/dV carries 4/7 of the 5 backward units)
+    unit = 2.0 * 32768 ** 2 * 4096 / 2
+    assert abs(r["achieved"] - (5.0 * 4 / 7) * unit / (r["avg_launch_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+
+
+def test_bench_cli_contract_without_a_gpu():
+    """--gpus N must match WORLD_SIZE (the driver launches N > 1 under torch.distributed.run)."""
+    env = dict(os.environ, WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+    h = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in h.stdout
