@@ -382,6 +382,7 @@ LWM_DEVICE void dkv_stage_finish(const DkvCtx<NKB>& cx, const DkvStage& st, int 
 template <int NKB, int BUF>
 LWM_DEVICE void dkv_tile(const AttnParams& p, const DkvCtx<NKB>& cx, const bf16x8 (&kf)[NKB][8],
                          int qt, f32x16 (&dk)[NKB][4], f32x16 (&dv)[NKB][4], ProfAcc& pa) {
+    (void)pa;
     PROF_DECL(4);
     PROF_T(0);
     const int64_t q_pos0 = p.q_start + (int64_t)qt * kDkvBQ;

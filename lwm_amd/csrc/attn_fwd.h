@@ -283,6 +283,7 @@ LWM_DEVICE bool fwd_wave_skips(const AttnParams& p, const FwdCtx& cx, int kt, bo
 template <int BUF, bool INFER>
 LWM_DEVICE void fwd_tile(const AttnParams& p, const FwdCtx& cx, const bf16x8 (&qf)[8], int kt,
                          float& m_run, float& l_run, f32x16 (&acc)[4], ProfAcc& pa) {
+    (void)pa;
     PROF_DECL(4);
     PROF_T(0);
     if (fwd_wave_skips(p, cx, kt, INFER)) return;
