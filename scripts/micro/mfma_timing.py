@@ -1,4 +1,9 @@
-"""Runs scripts/micro/mfma_timing.hip on the GPU box:  cycles per MFMA for one or two waves per SIMD."""
+"""Runs scripts/micro/mfma_timing.hip on the GPU box:  cycles per MFMA for one or two waves per SIMD.
+
+Build first (here):
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -mcode-object-version=5 -shared -fPIC -I lwm_amd/csrc \
+        scripts/micro/mfma_timing.hip -o build/ab/libmfma_timing.so
+"""
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 so = os.path.join(ROOT, "build", "ab", "libmfma_timing.so")
