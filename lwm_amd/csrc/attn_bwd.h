@@ -303,10 +303,7 @@ LWM_KERNEL(kDqThreads) void attn_bwd_dq_kernel(AttnParams p) {
 // Workgroup = NW waves; wave w owns NKB blocks of 32 keys (keys
 // [w*NKB*32, (w+1)*NKB*32) of the workgroup's 256-key block) and keeps their
 // K fragments and f32 dK^T/dV^T accumulators in registers for the whole launch.
-// Two shapes are instantiated:
-//   <NW=8, NKB=1>  2 waves/SIMD, 256 registers each
-//   <NW=4, NKB=2>  1 wave/SIMD, the whole 512-register file; every Q/dO fragment
-//                  read from LDS feeds two MFMAs (half the LDS traffic per FLOP)
+// Instantiated as <NW=8, NKB=1>: 2 waves/SIMD, 256 registers each.
 // LDS map: V (resident, 64 KiB) | Q tile 0 | Q tile 1 | dO tile 0 | dO tile 1
 //          (8 KiB each) | stats 0 | stats 1 (lse2[32], delta[32], seg_q[32])
 constexpr int kDkvBK = 256;   // keys per workgroup
@@ -339,25 +336,19 @@ struct DkvCtx {
 // applied to the SOURCE column: lane l writes physical slot l&15 of row
 // 4*piece + (l>>4) and therefore fetches logical slot (l&15) ^ swz(row).  Each
 // instruction still covers 4 whole 256-B rows of global memory.
-// SKEW: the DMA is issued by the second-dispatched half of the workgroup (waves
-// NW/2..NW-1, two pieces each) and the row statistics by wave NW/2.
-template <int NW, int NKB, int BUF, bool SKEW = false>
+template <int NW, int NKB, int BUF>
 LWM_DEVICE void dkv_stage_issue(const AttnParams& p, const DkvCtx<NKB>& cx, const bf16_t* qb,
                                 const bf16_t* dob, int b, int h, int qt, DkvStage& st) {
-    constexpr int T0 = SKEW ? NW * 32 : 0;          // first thread of the statistics loader
-    constexpr int NI = SKEW ? NW / 2 : NW;          // issuing waves
-    if (cx.tid >= T0 && cx.tid < T0 + kDkvBQ) {
-        const int tl = cx.tid - T0;
-        int qr = qt * kDkvBQ + tl;
+    if (cx.tid < kDkvBQ) {
+        int qr = qt * kDkvBQ + cx.tid;
         int qc = qr < p.Sq ? qr : p.Sq - 1;
         int64_t idx = ((int64_t)b * p.H + h) * p.Sq + qc;
         st.lse2 = p.lse[idx];
         st.delta = p.delta[idx];
         st.segq = p.seg_q ? p.seg_q[(int64_t)b * p.Sq + qc] : 0;
     }
-    if (SKEW && cx.wave < NW / 2) return;
-    for (int j = 0; j < 8 / NI; ++j) {
-        const int piece = (SKEW ? cx.wave - NW / 2 : cx.wave) + NI * j;
+    for (int j = 0; j < 8 / NW; ++j) {
+        const int piece = cx.wave + NW * j;
         const int r = 4 * piece + cx.lane_row;
         int qrow = qt * kDkvBQ + r;
         // rows past Sq re-read the last row; their lse2 is +inf so p = 0
@@ -369,10 +360,10 @@ LWM_DEVICE void dkv_stage_issue(const AttnParams& p, const DkvCtx<NKB>& cx, cons
     }
 }
 
-template <int NKB, int BUF, int T0 = 0>
+template <int NKB, int BUF>
 LWM_DEVICE void dkv_stage_finish(const DkvCtx<NKB>& cx, const DkvStage& st, int qt, int Sq) {
-    if (cx.tid >= T0 && cx.tid < T0 + kDkvBQ) {
-        const bool ok = (qt * kDkvBQ + (cx.tid - T0) < Sq) && st.lse2 != -INFINITY;
+    if (cx.tid < kDkvBQ) {
+        const bool ok = (qt * kDkvBQ + cx.tid < Sq) && st.lse2 != -INFINITY;
         lds_write_f32(cx.stat_w + BUF * kDkvStatBytes, ok ? st.lse2 * kLog2e : INFINITY);
         lds_write_f32(cx.stat_w + BUF * kDkvStatBytes + kDkvBQ * 4, st.delta);
         lds_write_i32(cx.stat_w + BUF * kDkvStatBytes + 2 * kDkvBQ * 4, st.segq);
@@ -503,15 +494,9 @@ LWM_DEVICE void dkv_tile(const AttnParams& p, const DkvCtx<NKB>& cx, const bf16x
 #endif
 }
 
-// SKEW >= 0: the second-dispatched half of the workgroup (the partner wave on every
-// SIMD) starts each tile late -- it alone issues the next tile's DMA and statistics
-// loads and then parks for SKEW*64 more cycles -- so that the two waves of a SIMD
-// are not in the same phase (matrix | VALU-only softmax | matrix) at the same time.
-template <int NW, int NKB, int SKEW = -1>
+template <int NW, int NKB>
 LWM_DEVICE void attn_bwd_dkdv_body(const AttnParams& p) {
     static_assert(NW * NKB * 32 == kDkvBK, "workgroup covers 256 keys");
-    constexpr bool SK = SKEW >= 0;
-    constexpr int T0 = SK ? NW * 32 : 0;
     constexpr int NT = NW * 64;
     const lds_t lds = dyn_lds();
     const int tid = thread_idx();
@@ -568,7 +553,7 @@ LWM_DEVICE void attn_bwd_dkdv_body(const AttnParams& p) {
     cx.wave = wave_uniform(wave);
     cx.lane_row = lane >> 4;
     cx.lane_slot = lane & 15;
-    cx.stat_w = stats + (tid - T0) * 4;
+    cx.stat_w = stats + tid * 4;
     cx.stat_r = stats + 16 * hi;
     cx.has_meta =
         (p.seg_k != nullptr) || (p.key_valid != nullptr) || (kbi * kDkvBK + kDkvBK > p.Sk);
@@ -621,25 +606,19 @@ LWM_DEVICE void attn_bwd_dkdv_body(const AttnParams& p) {
     // block's own diagonal put the 32 streams at 32 different places (measured: 20.6 GB fetched
     // per launch for 0.5 GB of Q + dO per head set).
     const int q_top = nqt - 1 + qt0;             // loop index i  ->  tile q_top - i
-#ifdef LWM_DKDV_WALK_UP
-#define LWM_QT(i) (i)
-#else
 #define LWM_QT(i) (q_top - (i))
-#endif
     if (qt0 < nqt) {
         DkvStage stg;
-        dkv_stage_issue<NW, NKB, 0, SK>(p, cx, qb, dob, b, h, LWM_QT(qt0), stg);
-        dkv_stage_finish<NKB, 0, T0>(cx, stg, LWM_QT(qt0), p.Sq);
+        dkv_stage_issue<NW, NKB, 0>(p, cx, qb, dob, b, h, LWM_QT(qt0), stg);
+        dkv_stage_finish<NKB, 0>(cx, stg, LWM_QT(qt0), p.Sq);
         glds_wait_all();
         block_sync();
-        const bool late = SK && wave_uniform(wave >= NW / 2 ? 1 : 0) != 0;
         for (int qt = qt0; qt < nqt; qt += 2) {
             const bool more1 = qt + 1 < nqt;
-            if (more1) dkv_stage_issue<NW, NKB, 1, SK>(p, cx, qb, dob, b, h, LWM_QT(qt + 1), stg);
-            if constexpr (SKEW > 0) { if (late) sleep_cycles64<SKEW>(); }
+            if (more1) dkv_stage_issue<NW, NKB, 1>(p, cx, qb, dob, b, h, LWM_QT(qt + 1), stg);
             dkv_tile<NKB, 0>(p, cx, kf, LWM_QT(qt), dk, dv, pa);
             PROF_T(0);
-            if (more1) dkv_stage_finish<NKB, 1, T0>(cx, stg, LWM_QT(qt + 1), p.Sq);
+            if (more1) dkv_stage_finish<NKB, 1>(cx, stg, LWM_QT(qt + 1), p.Sq);
             glds_wait_all();
             PROF_T(1);
             block_sync();
@@ -648,10 +627,9 @@ LWM_DEVICE void attn_bwd_dkdv_body(const AttnParams& p) {
             PROF_ADD(pa, 4, 1, 2);   // barrier wait
             if (!more1) break;
             const bool more2 = qt + 2 < nqt;
-            if (more2) dkv_stage_issue<NW, NKB, 0, SK>(p, cx, qb, dob, b, h, LWM_QT(qt + 2), stg);
-            if constexpr (SKEW > 0) { if (late) sleep_cycles64<SKEW>(); }
+            if (more2) dkv_stage_issue<NW, NKB, 0>(p, cx, qb, dob, b, h, LWM_QT(qt + 2), stg);
             dkv_tile<NKB, 1>(p, cx, kf, LWM_QT(qt + 1), dk, dv, pa);
-            if (more2) dkv_stage_finish<NKB, 0, T0>(cx, stg, LWM_QT(qt + 2), p.Sq);
+            if (more2) dkv_stage_finish<NKB, 0>(cx, stg, LWM_QT(qt + 2), p.Sq);
             glds_wait_all();
             block_sync();
         }
@@ -702,10 +680,5 @@ LWM_DEVICE void attn_bwd_dkdv_body(const AttnParams& p) {
 }
 
 LWM_KERNEL(512) void attn_bwd_dkdv_kernel_w8(AttnParams p) { attn_bwd_dkdv_body<8, 1>(p); }
-LWM_KERNEL(512) void attn_bwd_dkdv_kernel_sk0(AttnParams p) { attn_bwd_dkdv_body<8, 1, 0>(p); }
-LWM_KERNEL(512) void attn_bwd_dkdv_kernel_sk4(AttnParams p) { attn_bwd_dkdv_body<8, 1, 4>(p); }
-LWM_KERNEL(512) void attn_bwd_dkdv_kernel_sk8(AttnParams p) { attn_bwd_dkdv_body<8, 1, 8>(p); }
-LWM_KERNEL(512) void attn_bwd_dkdv_kernel_sk12(AttnParams p) { attn_bwd_dkdv_body<8, 1, 12>(p); }
-LWM_KERNEL(256) void attn_bwd_dkdv_kernel_w4(AttnParams p) { attn_bwd_dkdv_body<4, 2>(p); }
 
 }  // namespace lwm

@@ -23,10 +23,6 @@ namespace lwm {
 constexpr int kFwdBQ = 256;    // queries per workgroup
 constexpr int kFwdBK = 64;     // keys per LDS tile
 constexpr int kFwdThreads = 512;
-#ifndef LWM_PP_RING
-#define LWM_PP_RING 8
-#endif
-constexpr int kPpRing = LWM_PP_RING;   // fragment look-ahead of the ping-pong schedule (one MFMA wave per SIMD)
 constexpr float kDeferLog2 = 8.0f;   // p stays below 2^8 between rescales of the running maximum
 constexpr int kFwdTileBytes = kFwdBK * kRowBytes;                  // 16 KiB
 constexpr int kFwdLdsBytes = 4 * kFwdTileBytes + 2 * kFwdBK * 4;  // K,V x2 + kseg x2
@@ -87,55 +83,6 @@ LWM_DEVICE void fwd_stage_write(const FwdCtx& cx, const FwdStage& st, int kt, in
     if (cx.tid < kFwdBK) {
         const bool ok = (kt * kFwdBK + cx.tid < Sk) && st.kvalid != 0;
         lds_write_i32(cx.kseg_w + BUF * kFwdBK * 4, ok ? st.kseg : kSegInvalid);
-    }
-}
-
-// ---- staging of the ping-pong schedule: the K tile of one key tile and the V tile of another
-// travel together (see attn_fwd_body<.., PP = true>).  Tile indices are clamped instead of
-// branched on: a conditional global load makes hipcc drain vmcnt to 0 at the next use.
-struct FwdMeta {
-    int32_t kseg;
-    uint8_t kvalid;
-};
-
-LWM_DEVICE void pp_load_kv(const AttnParams& p, const bf16_t* kb, const bf16_t* vb, int kt_k, int kt_v,
-                           int tid, FwdStage& st) {
-    for (int i = 0; i < 2; ++i) {
-        int c = tid + kFwdThreads * i;
-        int row = c >> 4, slot = c & 15;
-        int kr = kt_k * kFwdBK + row, vr = kt_v * kFwdBK + row;
-        kr = kr < p.Sk ? kr : p.Sk - 1;       // rows past Sk re-read the last row (masked via key meta)
-        vr = vr < p.Sk ? vr : p.Sk - 1;
-        st.k[i] = global_load_b128(kb + (int64_t)kr * p.k_ss + slot * 8);
-        st.v[i] = global_load_b128(vb + (int64_t)vr * p.v_ss + slot * 8);
-    }
-}
-
-LWM_DEVICE void pp_load_meta(const AttnParams& p, int b, int kt, int tid, FwdMeta& m) {
-    if (tid < kFwdBK) {
-        int krow = kt * kFwdBK + tid;
-        int kr = krow < p.Sk ? krow : p.Sk - 1;
-        m.kvalid = p.key_valid ? p.key_valid[(int64_t)b * p.Sk + kr] : (uint8_t)1;
-        m.kseg = p.seg_k ? p.seg_k[(int64_t)b * p.Sk + kr] : 0;
-    }
-}
-
-template <int KBUF>
-LWM_DEVICE void pp_write_k(const FwdCtx& cx, const FwdStage& st) {
-    for (int i = 0; i < 2; ++i) lds_write_b128(cx.stage_w + KBUF * kFwdTileBytes + i * 32 * kRowBytes, st.k[i]);
-}
-
-template <int VBUF>
-LWM_DEVICE void pp_write_v(const FwdCtx& cx, const FwdStage& st) {
-    for (int i = 0; i < 2; ++i)
-        lds_write_b128(cx.stage_w + (2 + VBUF) * kFwdTileBytes + i * 32 * kRowBytes, st.v[i]);
-}
-
-template <int BUF>
-LWM_DEVICE void pp_write_meta(const FwdCtx& cx, const FwdMeta& m, int kt, int Sk) {
-    if (cx.tid < kFwdBK) {
-        const bool ok = (kt * kFwdBK + cx.tid < Sk) && m.kvalid != 0;
-        lds_write_i32(cx.kseg_w + BUF * kFwdBK * 4, ok ? m.kseg : kSegInvalid);
     }
 }
 
@@ -279,7 +226,7 @@ LWM_DEVICE bool fwd_wave_skips(const AttnParams& p, const FwdCtx& cx, int kt, bo
     return p.causal && p.k_start + (int64_t)kt * kFwdBK > cx.wq_max;   // wholly in this wave's future
 }
 
-// One 64-key tile held in LDS buffer BUF, the three phases back to back (lockstep schedule).
+// One 64-key tile held in LDS buffer BUF, the three phases back to back.
 template <int BUF, bool INFER>
 LWM_DEVICE void fwd_tile(const AttnParams& p, const FwdCtx& cx, const bf16x8 (&qf)[8], int kt,
                          float& m_run, float& l_run, f32x16 (&acc)[4], ProfAcc& pa) {
@@ -306,7 +253,7 @@ LWM_DEVICE void fwd_tile(const AttnParams& p, const FwdCtx& cx, const bf16x8 (&q
 #endif
 }
 
-template <bool INFER, bool PP = false>
+template <bool INFER>
 LWM_DEVICE void attn_fwd_body(const AttnParams& p) {
     const lds_t lds = dyn_lds();
     const int tid = thread_idx();
@@ -411,102 +358,6 @@ LWM_DEVICE void attn_fwd_body(const AttnParams& p) {
         kt0 = kt0 > s0 ? kt0 : s0;
         nkt = nkt < s1 ? nkt : s1;
     }
-    if constexpr (PP) {
-        // ---- ping-pong schedule.  The two waves that share a SIMD (w and w+4) run the same
-        // program ONE PHASE APART, so that one is in a matrix phase while the other is in its
-        // vector phase; in lockstep they contend for the MFMA pipe and then for the VALU and the
-        // SIMD does the two back to back (measured: 4.1k cycles per tile pair against 2 x 1.0k
-        // of MFMA).  Per wave, tile u = 0..n-1:
-        //     X_u = [P.V of tile u-1] [S of tile u] [stage: K(u+1), V(u) -> LDS; issue loads of K(u+2), V(u+1)]
-        //     Y_u = [mask + softmax of tile u]      [key meta of tile u+1 -> LDS; load meta of u+2]
-        // with a workgroup barrier after every phase; group B (waves 4-7) takes one extra barrier
-        // first and group A one last, so in barrier interval i group A executes its phase i and
-        // group B its phase i-1.  LDS hazards: K/V tiles are read and written only by the group
-        // that is in an X phase; buffer (u+1)&1 of K held tile u-1, last read in B's X_{u-1}
-        // (interval 2u-1) before A's X_u (interval 2u) overwrites it, and becomes visible to A's
-        // X_{u+1} (interval 2u+2) after B's X_u (interval 2u+1) has written its share.  Same for V
-        // one tile behind, and for the key meta in the Y phases.
-        if (kt0 < nkt) {
-            const int n = nkt - kt0;
-            const bool grp_b = wave_uniform(wave >> 2) != 0;
-            const int kt_last = nkt_all - 1;
-            auto clampt = [&](int t) { return t < kt_last ? t : kt_last; };
-            FwdStage stg;
-            FwdMeta mreg;
-            pp_load_kv(p, kb, vb, kt0, kt0, tid, stg);
-            pp_load_meta(p, b, kt0, tid, mreg);
-            pp_write_k<0>(cx, stg);
-            pp_write_meta<0>(cx, mreg, kt0, p.Sk);
-            pp_load_kv(p, kb, vb, clampt(kt0 + 1), kt0, tid, stg);     // Z_0 = {K(1), V(0)}
-            pp_load_meta(p, b, clampt(kt0 + 1), tid, mreg);
-            block_sync();
-            f32x16 st[2];
-            bf16x8 pb[2][2];
-            bool act_prev = false, act = false;
-            if (grp_b) block_sync();
-            int u = 0;
-            for (;;) {
-                // ---- X_u, u even
-                PROF_T(0);
-#ifndef LWM_PP_SKIP_X
-                if (act_prev) fwd_phase_pv<1, kPpRing>(cx, pb, acc);
-#endif
-                act = u < n && !fwd_wave_skips(p, cx, kt0 + u, INFER);
-#ifndef LWM_PP_SKIP_X
-                if (act) fwd_phase_s<0, kPpRing>(cx, qf, st);
-#endif
-                if (u + 1 < n) pp_write_k<1>(cx, stg);
-                if (u < n) pp_write_v<0>(cx, stg);
-                pp_load_kv(p, kb, vb, clampt(kt0 + u + 2), clampt(kt0 + u + 1), tid, stg);
-                PROF_KEEP(st[1][15]);
-                PROF_T(1);
-                block_sync();
-                PROF_T(2);
-                if (u == n) break;
-                // ---- Y_u
-#ifndef LWM_PP_SKIP_Y
-                if (act) fwd_phase_softmax<0, INFER>(p, cx, kt0 + u, st, pb, m_run, l_run, acc);
-#endif
-                pp_write_meta<1>(cx, mreg, kt0 + u + 1, p.Sk);
-                pp_load_meta(p, b, clampt(kt0 + u + 2), tid, mreg);
-                act_prev = act;
-                PROF_KEEP(pb[1][1]);
-                PROF_T(3);
-                block_sync();
-                PROF_T(4);
-                PROF_ADD(pa, 0, 0, 1);   // X phase body (P.V + S MFMAs + staging)
-                PROF_ADD(pa, 1, 1, 2);   // barrier after X
-                PROF_ADD(pa, 2, 2, 3);   // Y phase body (softmax)
-                PROF_ADD(pa, 3, 3, 4);   // barrier after Y
-#ifdef LWM_PROF
-                pa.v[5] += 1;
-#endif
-                // ---- X_{u+1}
-#ifndef LWM_PP_SKIP_X
-                if (act_prev) fwd_phase_pv<0, kPpRing>(cx, pb, acc);
-#endif
-                act = u + 1 < n && !fwd_wave_skips(p, cx, kt0 + u + 1, INFER);
-#ifndef LWM_PP_SKIP_X
-                if (act) fwd_phase_s<1, kPpRing>(cx, qf, st);
-#endif
-                if (u + 2 < n) pp_write_k<0>(cx, stg);
-                if (u + 1 < n) pp_write_v<1>(cx, stg);
-                pp_load_kv(p, kb, vb, clampt(kt0 + u + 3), clampt(kt0 + u + 2), tid, stg);
-                block_sync();
-                if (u + 1 == n) break;
-                // ---- Y_{u+1}
-#ifndef LWM_PP_SKIP_Y
-                if (act) fwd_phase_softmax<1, INFER>(p, cx, kt0 + u + 1, st, pb, m_run, l_run, acc);
-#endif
-                pp_write_meta<0>(cx, mreg, kt0 + u + 2, p.Sk);
-                pp_load_meta(p, b, clampt(kt0 + u + 3), tid, mreg);
-                act_prev = act;
-                block_sync();
-                u += 2;
-            }
-            if (!grp_b) block_sync();
-        }
-    } else
     if (kt0 < nkt) {
         FwdStage stg;
         fwd_stage_load(p, kb, vb, b, kt0, tid, stg);
@@ -595,6 +446,5 @@ LWM_DEVICE void attn_fwd_body(const AttnParams& p) {
 
 LWM_KERNEL(kFwdThreads) void attn_fwd_kernel(AttnParams p) { attn_fwd_body<false>(p); }
 LWM_KERNEL(kFwdThreads) void attn_fwd_infer_kernel(AttnParams p) { attn_fwd_body<true>(p); }
-LWM_KERNEL(kFwdThreads) void attn_fwd_pp_kernel(AttnParams p) { attn_fwd_body<false, true>(p); }
 
 }  // namespace lwm

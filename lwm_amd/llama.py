@@ -20,7 +20,7 @@ from . import ops as _ops
 from .llama_ops import (LLaMAMLP, RMSNorm, apply_rotary_emb, chunked_lm_head_loss,
                         precompute_freqs_cis)
 from .ringattention import (blockwise_feedforward, concatenate_to_cache, ringattention,
-                            ringattention_inference)
+                            ringattention_inference, sp_size_rank)
 
 # The model sizes of lwm/llama.py:33-130:
 # name: (hidden, intermediate, layers, heads, max_sequence_length, rms_norm_eps)
@@ -74,6 +74,17 @@ class LLaMAConfig:
         self.scan_mlp_chunk_size, self.theta = scan_mlp_chunk_size, theta
         for k, v in kwargs.items():
             setattr(self, k, v)
+        self._validate()
+
+    def _validate(self):
+        """The attention kernels are written for head_dim 128 (LWM-7B, lwm/llama.py:70-81; also the 13b /
+        30b / 65b sizes).  A size they cannot run -- the 3b table entry has head_dim 100 -- is refused
+        here, when the config is made, not at the first kernel launch."""
+        h, d = self.num_attention_heads, self.hidden_size
+        if h <= 0 or d % h or d // h != 128:
+            raise NotImplementedError(
+                f"hidden_size {d} / num_attention_heads {h}: head_dim must be 128 for the MI355X attention "
+                f"kernels (lwm_amd/csrc/attn_common.h); this is the '3b' entry of the reference's size table")
 
     def update(self, updates):
         """ConfigDict-style in-place update; a string is parsed like --update_llama_config."""
@@ -81,6 +92,7 @@ class LLaMAConfig:
             updates = parse_config_updates(updates)
         for k, v in dict(updates).items():
             setattr(self, k, v)
+        self._validate()
         return self
 
     def to_dict(self):
@@ -115,8 +127,8 @@ class LLaMAConfig:
 
 
 def _multi_rank():
-    import torch.distributed as dist
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """More than one rank along the bound "sp" axis (never the WORLD size: see set_sp_group)."""
+    return sp_size_rank("sp")[0] > 1
 
 
 def _dense(i, o, std, dtype):
@@ -142,7 +154,12 @@ class LLaMAAttention(torch.nn.Module):
             return self._cached(xq, xk, xv.contiguous(), attention_mask, cache).reshape(B, S, d) @ self.wo
         bias = None
         if attention_mask is not None:                                        # (:527-537)
-            m = attention_mask.reshape(B, 1, 1, S)
+            # the bias is NOT sharded over "sp" (lwm/llama.py:563): it covers the global sequence
+            n_sp = sp_size_rank("sp")[0]
+            if attention_mask.shape[-1] != S * n_sp:
+                raise ValueError(f"attention_mask covers {attention_mask.shape[-1]} positions; the sequence ring "
+                                 f"needs the global length {S * n_sp} (= local {S} x sp {n_sp}) on every rank")
+            m = attention_mask.reshape(B, 1, 1, S * n_sp)
             bias = torch.where(m > 0, 0.0, torch.finfo(torch.float32).min)
         out = ringattention(xq, xk, xv.contiguous(), bias, segment_ids, axis_name="sp", float32_logits=True,
                             cache_idx=None,
@@ -166,8 +183,10 @@ class LLaMAAttention(torch.nn.Module):
             _ops.kv_cache_write_at(ck, xk.contiguous(), cache["index_dev"])
             _ops.kv_cache_write_at(cv, xv, cache["index_dev"])
             return ringattention_inference(xq.contiguous(), ck, cv, cache["mask_dev"], axis_name="sp")
-        max_len, idx = ck.shape[1], int(cache["cache_index"])
-        if Q > 1 and not _multi_rank():
+        n_sp, r_sp = sp_size_rank("sp")
+        # the cache is sharded over "sp" (lwm/llama.py:454-467): every rank holds max_length/sp rows
+        max_len, idx = ck.shape[1] * n_sp, int(cache["cache_index"])
+        if Q > 1 and n_sp == 1:
             # prefill into the cache: the same mask, handed over as its structure (see
             # ringattention_inference) -- key tiles past cache_index + Q are never read
             cache["cache_index"] = concatenate_to_cache(ck, cv, xk.contiguous(), xv, idx, axis_name="sp")
@@ -175,7 +194,10 @@ class LLaMAAttention(torch.nn.Module):
             return ringattention_inference(xq.contiguous(), ck, cv, None, axis_name="sp", causal_offset=idx,
                                            key_valid=kvld)
         ar = torch.arange(max_len, device=xq.device)
-        mask = (ar[None, :] <= (torch.arange(Q, device=xq.device) + idx)[:, None])[None, None].expand(B, 1, Q, max_len)
+        # a sharded prefill block (Q > 1) holds the queries [r*Q, (r+1)*Q) of the update; a decode query
+        # is replicated (lwm/llama.py:599)
+        q0 = idx + (r_sp * Q if Q > 1 else 0)
+        mask = (ar[None, :] <= (torch.arange(Q, device=xq.device) + q0)[:, None])[None, None].expand(B, 1, Q, max_len)
         if attention_mask is not None:
             mask = mask & (attention_mask[:, None, None, :max_len] > 0)
         cache["cache_index"] = concatenate_to_cache(ck, cv, xk.contiguous(), xv, idx, axis_name="sp")
@@ -222,6 +244,14 @@ class LLaMAForCausalLM(torch.nn.Module):
         return self._freqs
 
     def hidden_states(self, input_ids, attention_mask=None, segment_ids=None, position_ids=None, cache=None):
+        n_sp, r_sp = sp_size_rank("sp")
+        if n_sp > 1 and position_ids is None and cache is None:
+            # contiguous ownership (lwm/llama.py:560-562): this rank's rows are global positions r*S..(r+1)*S-1
+            S = input_ids.shape[1]
+            position_ids = (torch.arange(S, device=input_ids.device, dtype=torch.int32) + r_sp * S)[None] \
+                .expand(input_ids.shape[0], S).contiguous()
+        if n_sp > 1 and position_ids is None:
+            raise ValueError("cached inference over a sequence ring needs explicit global position_ids")
         x = torch.nn.functional.embedding(input_ids.long(), self.wte)
         fc = self._table(x.device)
         for i, blk in enumerate(self.h):
@@ -234,7 +264,11 @@ class LLaMAForCausalLM(torch.nn.Module):
         device = device or self.wte.device
         H = self.cfg.num_attention_heads
         D = self.cfg.hidden_size // H
-        z = lambda: torch.zeros(batch_size, max_length, H, D, dtype=self.dtype, device=device)
+        n_sp = sp_size_rank("sp")[0]
+        if max_length % n_sp:
+            raise ValueError(f"max_length {max_length} is not divisible by the sp ring size {n_sp}")
+        # sharded over "sp": each rank holds its contiguous max_length/sp rows (lwm/llama.py:454-467)
+        z = lambda: torch.zeros(batch_size, max_length // n_sp, H, D, dtype=self.dtype, device=device)
         return [dict(cached_key=z(), cached_value=z(), cache_index=0) for _ in self.h]
 
     @torch.no_grad()

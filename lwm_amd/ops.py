@@ -335,6 +335,8 @@ def groupnorm_silu(x, gamma, beta, *, groups=32, eps=1e-6, silu=True, out=None, 
     """flax nn.GroupNorm (+ nn.silu) over NHWC / (B, ..., C) f32 (lwm_groupnorm_silu_f32)."""
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc) if B else 0
+    if gamma.numel() != Cc or beta.numel() != Cc:
+        raise ValueError(f"groupnorm_silu: scale/bias have {gamma.numel()}/{beta.numel()} elements, x has {Cc} channels")
     L = lib()
     need = L.lwm_groupnorm_workspace_bytes(B, HW, Cc, groups)
     if workspace is None or workspace.numel() * workspace.element_size() < need:

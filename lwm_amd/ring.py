@@ -547,6 +547,10 @@ def ring_attention(q, k, v, *, group=None, causal=True, segment_ids=None, key_va
             comm = SingleComm()
         elif group is None and dist.get_world_size() == 1:
             comm = SingleComm()
+        elif group is None:
+            # never default to WORLD: a data-parallel job would silently ring its replicas
+            raise RuntimeError("ring_attention in a multi-process job needs the sequence-parallel group "
+                               "(group=... or comm=...; torch.distributed.group.WORLD for a pure ring)")
         else:
             comm = TorchRingComm(group)
     block = block_ops if block_ops is not None else HipBlockOps

@@ -12,18 +12,41 @@ import torch
 from .ring import (HipBlockOps, SingleComm, TorchRingComm, cache_update, ring_attention,
                    ring_inference)
 
-_SP_GROUP = {"group": None}
+_SP_GROUP = {"group": None, "bound": False}
 
 
 def set_sp_group(group):
-    """Bind mesh axis name "sp" (lwm/llama.py:201-203) to a process group."""
+    """Bind mesh axis name "sp" (lwm/llama.py:201-203) to a process group (`dist.group.WORLD` for a
+    job that is one sequence ring; None unbinds)."""
     _SP_GROUP["group"] = group
+    _SP_GROUP["bound"] = group is not None
 
 
 def _resolve_axis(axis_name):
+    """axis name -> process group.  An UNBOUND "sp" axis in a multi-process job is an error, not the
+    WORLD group: a data-parallel job that never called set_sp_group must not silently run a sequence
+    ring across its replicas (the reference's mesh always names the axis, lwm/llama.py:201-203)."""
     if axis_name is None or isinstance(axis_name, str):
+        if not _SP_GROUP["bound"]:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                raise RuntimeError(
+                    'mesh axis "sp" is not bound to a process group: call '
+                    "lwm_amd.ringattention.set_sp_group(group) (lwm_amd.mesh.sp_group builds it from "
+                    "--mesh_dim; pass torch.distributed.group.WORLD for a pure sequence ring)")
         return _SP_GROUP["group"]
     return axis_name  # already a ProcessGroup
+
+
+def sp_size_rank(axis_name="sp"):
+    """(size, rank) of this process along the "sp" axis; (1, 0) outside torch.distributed."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1, 0
+    g = _resolve_axis(axis_name)
+    if g is None:
+        return 1, 0
+    return dist.get_world_size(g), dist.get_rank(g)
 
 
 def ringattention(q, k, v, attn_bias, segment_ids, axis_name="sp", float32_logits=True,
@@ -59,6 +82,8 @@ def _comm(group):
         return SingleComm()
     if group is None and dist.get_world_size() == 1:
         return SingleComm()
+    if group is None:   # unbound "sp" axis: _resolve_axis has raised already for axis names
+        raise RuntimeError("no sequence-parallel group: call set_sp_group first")
     return TorchRingComm(group)
 
 

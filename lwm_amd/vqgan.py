@@ -116,7 +116,10 @@ def random_params(config: VQGANConfig | None = None, seed: int = 0):
             c = out_c
         if lvl != 0:
             bp["Upsample_0"] = {"Conv_0": conv(c, c)}
-        dec[f"UpsamplingBlock_{lvl}"] = bp
+        # flax names compact submodules by CREATION order and the reference Decoder creates them in
+        # reversed(range(num_resolutions)) order (lwm/vqgan.py:180): the block of the deepest level is
+        # UpsamplingBlock_0 (768 channels, has Upsample_0), the full-resolution one UpsamplingBlock_{nres-1}
+        dec[f"UpsamplingBlock_{nres - 1 - lvl}"] = bp
     dec["GroupNorm_0"] = gn(c)
     dec["Conv_1"] = conv(c, cfg.num_channels)
 
@@ -198,8 +201,8 @@ class VQGAN:
         cfg = self.config
         h = self._conv(p["Conv_0"], z)
         h = self._mid(p["MidBlock_0"], h)
-        for lvl in reversed(range(cfg.num_resolutions)):
-            bp = p[f"UpsamplingBlock_{lvl}"]
+        for order, lvl in enumerate(reversed(range(cfg.num_resolutions))):
+            bp = p[f"UpsamplingBlock_{order}"]            # creation-order auto-name (lwm/vqgan.py:180)
             for i in range(cfg.num_res_blocks + 1):
                 h = self._resnet(bp[f"ResnetBlock_{i}"], h)
             if lvl != 0:

@@ -156,7 +156,11 @@ def load_hf_llama(path, dtype=torch.bfloat16, device="cuda", **config_updates):
 
 # ------------------------------------------------------------------ flax msgpack stream
 _EXT_NDARRAY, _EXT_COMPLEX, _EXT_NPSCALAR = 1, 2, 3
-_CHUNK_KEY = "__msgpack_chunks__"
+# flax.serialization._chunk writes {'__msgpack_chunked_array__': True, 'shape': {'0': d0, ...},
+# 'chunks': {'0': flat piece, ...}} for leaves above MAX_CHUNK_SIZE = 2**30 bytes (every stacked
+# f32 kernel of a scan_layers 7B checkpoint).  The second spelling is accepted for older writers.
+_CHUNK_KEYS = ("__msgpack_chunked_array__", "__msgpack_chunks__")
+_MAX_CHUNK_BYTES = 2 ** 30
 
 
 def _np_from(shape, dtype_name, buf):
@@ -179,12 +183,19 @@ def _ext_hook(code, data):
     return msgpack.ExtType(code, data)
 
 
+def _index_dict_to_list(d):
+    """flax `_dict_to_tuple`: {'0': a, '1': b, ...} (or a list / tuple) -> [a, b, ...] in index order."""
+    if isinstance(d, dict):
+        get = lambda i: d[str(i)] if str(i) in d else d[i]
+        return [get(i) for i in range(len(d))]
+    return list(d)
+
+
 def _unchunk(x):
     if isinstance(x, dict):
-        if _CHUNK_KEY in x:                            # flax splits leaves above 2**30 bytes
-            n = x[_CHUNK_KEY]
-            shape = tuple(x["shape"])
-            parts = [x["chunks"][str(i)] if str(i) in x["chunks"] else x["chunks"][i] for i in range(n)]
+        if any(k in x for k in _CHUNK_KEYS):           # flax.serialization._unchunk
+            shape = tuple(int(v) for v in _index_dict_to_list(x["shape"]))
+            parts = _index_dict_to_list(x["chunks"])
             if isinstance(parts[0], torch.Tensor):
                 return torch.cat([p.reshape(-1) for p in parts]).reshape(shape)
             return np.concatenate([np.asarray(p).reshape(-1) for p in parts]).reshape(shape)
@@ -214,9 +225,10 @@ def read_flax_stream(path_or_file):
             f.close()
 
 
-def write_flax_stream(path_or_file, flat):
+def write_flax_stream(path_or_file, flat, max_chunk_bytes=_MAX_CHUNK_BYTES):
     """Inverse of read_flax_stream for numpy / torch leaves (used by the tests and for exporting
-    harness weights in the reference's format)."""
+    harness weights in the reference's format).  Leaves above `max_chunk_bytes` are split the way
+    flax.serialization._chunk splits them."""
     import msgpack
     f = open(path_or_file, "wb") if isinstance(path_or_file, (str, os.PathLike)) else path_or_file
     try:
@@ -230,24 +242,48 @@ def write_flax_stream(path_or_file, flat):
             else:
                 val = np.ascontiguousarray(val)
                 name, raw, shape = val.dtype.name, val.tobytes(), val.shape
-            leaf = msgpack.packb(msgpack.ExtType(_EXT_NDARRAY, msgpack.packb((list(shape), name, raw), use_bin_type=True)),
-                                 use_bin_type=True)
+            ext = lambda shp, buf: msgpack.ExtType(_EXT_NDARRAY, msgpack.packb((list(shp), name, buf), use_bin_type=True))
+            if len(raw) > max_chunk_bytes:             # flax.serialization._chunk
+                item = len(raw) // max(1, int(np.prod(shape)))
+                per = max(1, max_chunk_bytes // item) * item
+                pieces = [raw[i:i + per] for i in range(0, len(raw), per)]
+                tree = {"__msgpack_chunked_array__": True,
+                        "shape": {str(i): int(d) for i, d in enumerate(shape)},
+                        "chunks": {str(i): ext((len(pc) // item,), pc) for i, pc in enumerate(pieces)}}
+                leaf = msgpack.packb(tree, use_bin_type=True)
+            else:
+                leaf = msgpack.packb(ext(shape, raw), use_bin_type=True)
             f.write(packer.pack((tuple(key.split("/")), leaf)))
     finally:
         if f is not path_or_file:
             f.close()
 
 
-def flax_llama_to_lwm(flat, prefix="params/"):
+def flax_llama_to_lwm(flat, prefix="params/", param_scan_axis=0):
     """Flat flax names of FlaxLLaMAForCausalLM (lwm/llama.py:982-1106: `transformer/wte/embedding`,
     `transformer/h/<i>/attention/wq/kernel`, ..., `transformer/ln_f/kernel`, `lm_head/kernel`)
-    -> harness names.  Layouts already match (flax Dense kernels are (in, out))."""
+    -> harness names.  Layouts already match (flax Dense kernels are (in, out)).
+
+    scan_layers=True -- the reference's default (lwm/llama.py:158) and what every launcher sets --
+    stores ONE stacked leaf per parameter under `transformer/h/scan_decoder/...` (nn.scan named
+    'scan_decoder', lwm/llama.py:927-941) with the layer index on axis `param_scan_axis`
+    (lwm/llama.py:159); those are unstacked into h.<i>.* here."""
     out = {}
     for k, v in flat.items():
         if not k.startswith(prefix):
             continue                                   # optimizer state, step
         k = k[len(prefix):]
         t = v if isinstance(v, torch.Tensor) else torch.from_numpy(np.array(v))
+        m = re.match(r"^transformer/h/scan_decoder/(attention|feed_forward)/(w[qkvo123])/kernel$", k)
+        if m:
+            for i, layer in enumerate(t.unbind(param_scan_axis)):
+                out[f"h.{i}.{m.group(1)}.{m.group(2)}"] = layer
+            continue
+        m = re.match(r"^transformer/h/scan_decoder/(attention_norm|ffn_norm)/kernel$", k)
+        if m:
+            for i, layer in enumerate(t.unbind(param_scan_axis)):
+                out[f"h.{i}.{m.group(1)}.kernel"] = layer
+            continue
         if k == "transformer/wte/embedding":
             out["wte"] = t
         elif k == "transformer/ln_f/kernel":
@@ -279,15 +315,43 @@ class _FrozenDictShim(dict):
         self.update(state.get("_dict", state) if isinstance(state, dict) else state)
 
 
+# Everything a pickled parameter tree / config dict legitimately references.  Anything else --
+# os.system, builtins.eval, a reduce to subprocess.Popen ... -- is refused: loading a checkpoint
+# must not be able to run code.
+_PICKLE_ALLOWED = {
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+    ("numpy", "ndarray"), ("numpy", "dtype"),
+    ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer"),
+    ("collections", "OrderedDict"), ("collections", "defaultdict"),
+    ("builtins", "dict"), ("builtins", "list"), ("builtins", "tuple"), ("builtins", "set"),
+    ("builtins", "frozenset"), ("builtins", "int"), ("builtins", "float"), ("builtins", "bool"),
+    ("builtins", "str"), ("builtins", "bytes"), ("builtins", "complex"), ("builtins", "slice"),
+}
+
+
+class _ConfigDictShim(dict):
+    """ml_collections.ConfigDict pickles as an object whose state holds `_fields`."""
+
+    def __setstate__(self, state):
+        if isinstance(state, dict):
+            self.update(state.get("_fields", state))
+
+
 class _TreeUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
         if module.startswith("jax") and name == "_reconstruct_array":
             return _reconstruct_array
         if module.startswith("flax") and name == "FrozenDict":
             return _FrozenDictShim
-        if module.split(".")[0] in ("jax", "jaxlib", "flax"):
-            raise pickle.UnpicklingError(f"{module}.{name}: not a parameter tree of arrays")
-        return super().find_class(module, name)
+        if module.startswith("ml_collections") and name in ("ConfigDict", "FrozenConfigDict"):
+            return _ConfigDictShim
+        if module.startswith("numpy") and name in ("dtype", "ndarray") or \
+                (module.startswith("numpy.dtypes") and name.endswith("DType")):
+            return super().find_class(module, name)
+        if (module, name) in _PICKLE_ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"{module}.{name}: not allowed in a parameter / config pickle")
 
 
 def _plain(x):

@@ -172,8 +172,10 @@ def decoder(p, z, cfg, clip=True):
     h = _conv(p["Conv_0"], z)
     h = mid_block(p["MidBlock_0"], h)
     nres = len(cfg["channel_mult"])
-    for lvl in reversed(range(nres)):
-        bp = p[f"UpsamplingBlock_{lvl}"]
+    for order, lvl in enumerate(reversed(range(nres))):
+        # flax auto-names follow creation order, which is reversed(range(nres)) (lwm/vqgan.py:180):
+        # UpsamplingBlock_0 is the deepest level
+        bp = p[f"UpsamplingBlock_{order}"]
         for i in range(cfg["num_res_blocks"] + 1):
             h = resnet_block(bp[f"ResnetBlock_{i}"], h)
         if lvl != 0:                        # Upsample: nearest x2 + conv (:306-319)

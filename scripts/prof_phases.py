@@ -40,15 +40,7 @@ a.out_acc = dbg.data_ptr()
 for _ in range(2):
     assert lib.lwm_attn_fwd(C.byref(a), None) == 0
     torch.cuda.synchronize()
-if os.environ.get("LWM_FWD_PP") == "1":   # columns of the ping-pong schedule (even tiles sampled)
-    d = dbg.cpu().numpy().reshape(8, 8)
-    print("forward, ping-pong schedule (q tile = last, head 0): per sampled tile")
-    print("wave       X body   barrier(X)       Y body   barrier(Y)      samples        total")
-    for w in range(8):
-        n = max(int(d[w, 5]), 1)
-        print(f"{w:4d} " + " ".join(f"{d[w, i] / n:12.1f}" for i in range(4)) + f" {int(d[w, 5]):12d} {int(d[w, 6]):12d}")
-else:
-    show("forward (q tile = last, head 0)", dbg, ["S mfma", "softmax", "PV mfma", "stage write", "barrier"])
+show("forward (q tile = last, head 0)", dbg, ["S mfma", "softmax", "PV mfma", "stage write", "barrier"])
 
 # dK/dV
 out, lse = ops.attn_fwd_block(q, k, v, causal=True)

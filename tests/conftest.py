@@ -24,3 +24,18 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Measured parity errors of this session (tests/_parity.py) -> gpurun_out/parity_stats.json."""
+    try:
+        from tests import _parity
+        if not _parity.STATS:
+            return
+        import json
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_stats.json"), "w") as f:
+            json.dump(_parity.summary(), f, indent=1, sort_keys=True)
+    except Exception:      # reporting must never fail a run
+        pass

@@ -2,15 +2,17 @@
 oracle, on seeded inputs at sizes the oracle finishes in seconds, plus
 size-independent properties at BASELINE.json's full size (S=32768, H=32).
 
-Tolerances (stated per north_star: "within a stated fp tolerance"): operands
+Tolerances (stated per north_star: "within a stated fp tolerance"; tests/_parity.py): operands
 and results are bf16 with f32 accumulation, so
-  out / dq / dk / dv : max|err| <= 2e-2 * max|ref|  and cosine >= 0.9999
+  out / dq / dk / dv : max|err| <= 8e-3 * max|ref|, cosine >= 0.9999, and per (b,s,h) row
+                       max|err_row| <= 3e-2 * max(max|ref_row|, 0.02 * max|ref|)
   lse                : max|err| <= 2e-3
 """
 import numpy as np
 import pytest
 
 from oracle import attention_ref as R
+from tests._parity import check as _check
 
 pytestmark = pytest.mark.gpu
 
@@ -23,14 +25,6 @@ def _rand(shape, seed):
 
 def _np(t):
     return t.detach().float().cpu().numpy()
-
-
-def _check(name, got, ref, tol=2e-2):
-    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
-    err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-9)
-    cos = (got * ref).sum() / max(np.sqrt((got ** 2).sum() * (ref ** 2).sum()), 1e-30)
-    assert err <= tol, f"{name}: rel max err {err:.3e} > {tol}"
-    assert cos >= 0.9999, f"{name}: cosine {cos}"
 
 
 def _masks(B, S, Sk, seg, kv, seed):
@@ -142,10 +136,10 @@ def test_cast_and_backward_carries():
     assert torch.equal(dk1, ops.cast_f32_to_bf16(ka)) and torch.equal(dv1, ops.cast_f32_to_bf16(va))
 
 
-def test_packed_documents_skip_is_exact_and_faster():
+def test_packed_documents_skip_is_exact():
     """Masked sequence packing (BASELINE config #5 style): 8192 tokens, documents of 300-2000
     tokens.  The segment-block hints make the kernels skip other documents' tiles: results are
-    bit-identical to the hint-free run, match the oracle, and the launch is faster."""
+    bit-identical to the hint-free run and match the oracle."""
     import time
     import torch
     from lwm_amd import ops
@@ -183,7 +177,8 @@ def test_packed_documents_skip_is_exact_and_faster():
             ops.SEGMENT_SKIP = True
     for a, b in zip(res[True], res[False]):
         assert torch.equal(a, b)
-    assert times[True] < 0.8 * times[False], times
+    # (not asserted: wall-clock on a shared box; the 5x figure is a bench.py leg -- "packed")
+    print("packed skip speed-up %.2fx" % (times[False] / times[True]))
     h = 2
     sl = slice(h, h + 1)
     ro, _ = R.dense_attention(_np(q[:, :, sl]), _np(k[:, :, sl]), _np(v[:, :, sl]), causal=True, seg_q=seg, seg_k=seg)
@@ -281,6 +276,28 @@ def test_full_size_properties(full):
     rq, rk, rv = R.dense_attention_bwd(_np(q[:, sl, h:h + 1]), _np(k[:, sl, h:h + 1]), _np(v[:, sl, h:h + 1]),
                                        _np(do[:, sl, h:h + 1]), causal=True)
     _check("dq window", _np(dq[:, r0:r0 + w, h:h + 1]), rq[:, r0:r0 + w])
+    # (7) a second out window, early rows of another head (short softmax rows, first key tiles)
+    h, r0 = 3, 96
+    ro, rl = R.dense_attention(_np(q[:, r0:r0 + 512, h:h + 1]), _np(k[:, :r0 + 512, h:h + 1]),
+                               _np(v[:, :r0 + 512, h:h + 1]), causal=True, q_start=r0, k_start=0)
+    _check("out window 2", _np(out[:, r0:r0 + 512, h:h + 1]), ro)
+    assert np.abs(_np(lse[:, h:h + 1, r0:r0 + 512]) - rl).max() <= 2e-3
+    # (8) dK / dV windows against the oracle.  The gradient of key j sums over queries >= j only, so
+    #     the LAST keys need few query rows (each with its full softmax row over all 32768 keys):
+    #     queries [S-1024, S) give the complete dk, dv of keys [S-1024, S).
+    S = q.shape[1]
+    for h, K0, w0, w1 in ((29, S - 1024, 0, 256), (11, S - 512, 256, 512)):
+        qs = slice(K0, S)
+        _, rk, rv = R.dense_attention_bwd(_np(q[:, qs, h:h + 1]), _np(k[:, :, h:h + 1]), _np(v[:, :, h:h + 1]),
+                                          _np(do[:, qs, h:h + 1]), causal=True, q_start=K0, k_start=0)
+        ks = slice(K0 + w0, K0 + w1)
+        _check("dk window", _np(dk[:, ks, h:h + 1]), rk[:, ks])
+        _check("dv window", _np(dv[:, ks, h:h + 1]), rv[:, ks])
+    # (9) dq of the LAST rows (longest key loops; the diagonal key block is the last contributor)
+    h, r0, w = 23, S - 256, 256
+    rq, _, _ = R.dense_attention_bwd(_np(q[:, r0:, h:h + 1]), _np(k[:, :, h:h + 1]), _np(v[:, :, h:h + 1]),
+                                     _np(do[:, r0:, h:h + 1]), causal=True, q_start=r0, k_start=0)
+    _check("dq window 2", _np(dq[:, r0:, h:h + 1]), rq)
 
 
 def test_addressing_beyond_4g_elements_at_1m_tokens():

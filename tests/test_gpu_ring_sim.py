@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 from oracle import attention_ref as R
+from tests._parity import check as _check
 
 pytestmark = pytest.mark.gpu
 
@@ -63,7 +64,9 @@ def _run_ring(n, layout_kind, S, H, packed, schedule="ring", B=1):
     mk = lambda: torch.randn(B, S, H, 128, generator=g).to(torch.bfloat16).cuda()
     q, k, v, do = mk(), mk(), mk(), mk()
     seg = None
-    if packed:
+    if callable(packed):
+        seg = packed(S).to(torch.int32)[None].expand(B, S).contiguous().cuda()
+    elif packed:
         seg = torch.zeros(B, S, dtype=torch.int32)
         seg[:, S // 3:] = 1
         seg[:, (5 * S) // 8:] = 2
@@ -93,7 +96,7 @@ def _run_ring(n, layout_kind, S, H, packed, schedule="ring", B=1):
     for t in ths:
         t.start()
     for t in ths:
-        t.join(timeout=300)
+        t.join(timeout=600)
     assert not errs, errs
     # single-device result with the same kernels
     q1, k1, v1 = (t.clone().requires_grad_(True) for t in (q, k, v))
@@ -126,6 +129,84 @@ def test_ring_n_equals_ring_1_on_gpu(n, layout_kind, packed, schedule):
     for name, a, b in zip(("out", "dq", "dk", "dv"), got, (ro, rq, rk, rv)):
         err = np.abs(f(a) - b).max() / np.abs(b).max()
         assert err <= 2e-2, (name, err)
+
+
+def _doc_windows(bounds, w=256):
+    """[(doc_start, doc_end, window_start)]: the last `w` rows of every document."""
+    return [(a, b, b - w) for a, b in zip(bounds[:-1], bounds[1:])]
+
+
+@pytest.mark.parametrize("schedule,packed", [("ring", False), ("mesh", True)])
+def test_ring8_at_config3_shard_shapes_vs_oracle(schedule, packed):
+    """BASELINE configs[2]: S = 131072 over an 8-rank zigzag ring, c = 16384 per rank (two half-chunks
+    of 8192 at global offsets r*8192 and (15-r)*8192) -- the shard shapes and (q_start, k_start)
+    offsets the metric names, through the real kernels and the real driver with thread-played ranks,
+    checked against the fp64 oracle in windows that land on the first, a middle and the last rank.
+    Unpacked run (reference "ring" schedule): out / dq windows anywhere cost 256 x (keys so far); the
+    complete dk / dv of the LAST keys need only the last queries.  Packed run ("mesh" schedule, four
+    documents ending inside the shards of ranks 4, 7, 3 and 0): every gradient of a document's last
+    rows is checkable against that document alone."""
+    import torch
+    n, S, H = 8, 131072, 2
+    bounds = [0, 40000, 70000, 100000, S]
+    seg_fn = (lambda S_: torch.bucketize(torch.arange(S_), torch.tensor(bounds[1:-1]), right=True)) if packed else False
+    got, ref, (q, k, v, do, seg) = _run_ring(n, "zigzag", S, H, seg_fn, schedule)
+    for name, a, b in zip(("out", "dq", "dk", "dv"), got, ref):      # ring 8 == ring 1 (same kernels)
+        a, b = a.float(), b.float()
+        assert ((a - b).abs().max() / b.abs().max()).item() <= 8e-3, name
+    f = lambda t, rows, h: t[:, rows, h:h + 1].float().cpu().numpy()
+    out, dq, dk, dv = got
+    if not packed:
+        # owner of row x: half-chunk x // 8192 -> rank min(c, 15 - c).  96: rank 0 (early chunk);
+        # 65408: crosses rank 7's two half-chunks; S-256: rank 0 (late chunk); 36000: rank 4
+        for h, r0 in ((0, 96), (1, 65408), (0, S - 256), (1, 36000)):
+            rows, keys = slice(r0, r0 + 256), slice(0, r0 + 256)
+            ro, _ = R.dense_attention(f(q, rows, h), f(k, keys, h), f(v, keys, h), causal=True, q_start=r0)
+            rq, _, _ = R.dense_attention_bwd(f(q, rows, h), f(k, keys, h), f(v, keys, h), f(do, rows, h),
+                                             causal=True, q_start=r0)
+            _check(f"out ring8 row {r0}", f(out, rows, h), ro)
+            _check(f"dq ring8 row {r0}", f(dq, rows, h), rq)
+        K0, h = S - 512, 1
+        rows, allk = slice(K0, S), slice(0, S)
+        _, rk, rv = R.dense_attention_bwd(f(q, rows, h), f(k, allk, h), f(v, allk, h), f(do, rows, h),
+                                          causal=True, q_start=K0)
+        _check("dk ring8 last keys", f(dk, slice(K0, K0 + 256), h), rk[:, K0:K0 + 256])
+        _check("dv ring8 last keys", f(dv, slice(K0 + 256, S), h), rv[:, K0 + 256:])
+        return
+    for i, (a, b, w0) in enumerate(_doc_windows(bounds)):
+        # a document longer than 30000 rows is too much for a dense fp64 oracle: its last rows only need
+        # the keys of the document, its last KEYS only the queries after them -- take the last 2048 rows
+        # as queries against the whole document (complete for out/dq of these rows and dk/dv of keys >= w0)
+        h = i & 1
+        qa = b - 2048
+        rows, keys = slice(qa, b), slice(a, b)
+        ro, _ = R.dense_attention(f(q, rows, h), f(k, keys, h), f(v, keys, h), causal=True, q_start=qa - a)
+        rq, rk, rv = R.dense_attention_bwd(f(q, rows, h), f(k, keys, h), f(v, keys, h), f(do, rows, h),
+                                           causal=True, q_start=qa - a)
+        win = slice(w0, b)
+        _check(f"out ring8 doc {i}", f(out, win, h), ro[:, w0 - qa:])
+        _check(f"dq ring8 doc {i}", f(dq, win, h), rq[:, w0 - qa:])
+        _check(f"dk ring8 doc {i}", f(dk, win, h), rk[:, w0 - a:])
+        _check(f"dv ring8 doc {i}", f(dv, win, h), rv[:, w0 - a:])
+
+
+def test_mesh8_at_1m_token_offsets_vs_oracle():
+    """BASELINE configs[4]'s offsets: S = 1,048,576 over an 8-rank zigzag ring under the mesh schedule
+    (c = 131072 per rank, half-chunks at global offsets up to 983040), one head, packed 4096-token
+    documents so that the fp64 oracle is a 4096 x 4096 problem wherever it is asked.  Documents are
+    sampled at the start, across the middle seam (rank 7's two half-chunks) and at the very end."""
+    import torch
+    n, S, H, doc = 8, 1 << 20, 1, 4096
+    got, ref, (q, k, v, do, seg) = _run_ring(n, "zigzag", S, H, lambda S_: torch.arange(S_) // doc, "mesh")
+    for name, a, b in zip(("out", "dq", "dk", "dv"), got, ref):
+        assert torch.equal(a, b) or ((a.float() - b.float()).abs().max() / b.float().abs().max()).item() <= 8e-3, name
+    f = lambda t, rows: t[:, rows, 0:1].float().cpu().numpy()
+    for d0 in (0, (S // 2) - doc, S // 2, 131072 * 5 + 8 * doc, S - doc):
+        rows = slice(d0, d0 + doc)
+        ro, _ = R.dense_attention(f(q, rows), f(k, rows), f(v, rows), causal=True)
+        rq, rk, rv = R.dense_attention_bwd(f(q, rows), f(k, rows), f(v, rows), f(do, rows), causal=True)
+        for name, a, b in zip(("out", "dq", "dk", "dv"), got, (ro, rq, rk, rv)):
+            _check(f"{name} mesh8@1M doc {d0 // doc}", f(a, rows), b)
 
 
 @pytest.mark.parametrize("schedule", ["ring", "mesh"])

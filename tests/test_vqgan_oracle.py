@@ -60,8 +60,8 @@ def t_encoder(p, x, cfg):
 def t_decoder(p, z, cfg):
     h = t_conv(p["Conv_0"], z)
     h = t_resnet(p["MidBlock_0"]["ResnetBlock_1"], t_resnet(p["MidBlock_0"]["ResnetBlock_0"], h))
-    for lvl in reversed(range(cfg.num_resolutions)):
-        bp = p[f"UpsamplingBlock_{lvl}"]
+    for order, lvl in enumerate(reversed(range(cfg.num_resolutions))):
+        bp = p[f"UpsamplingBlock_{order}"]
         for i in range(cfg.num_res_blocks + 1):
             h = t_resnet(bp[f"ResnetBlock_{i}"], h)
         if lvl != 0:
@@ -163,3 +163,24 @@ def test_index_mismatch_report_names_margins():
     bad.reshape(-1)[3] = (bad.reshape(-1)[3] + 1) % 1024
     n, total, text = V.index_mismatch_report(params, px, bad, cfg.as_dict())
     assert (n, total) == (1, idx.size) and "top-2 margin" in text and "pos 3" in text
+
+
+def test_decoder_tree_uses_flax_creation_order_names():
+    """flax @nn.compact numbers submodules in creation order; the reference Decoder creates its
+    UpsamplingBlocks for i_level = nres-1 .. 0 (lwm/vqgan.py:180), so in a real checkpoint
+    UpsamplingBlock_0 is the 768-channel block WITH Upsample_0 and the last one (256 -> 128 channels) has
+    none.  random_params, the oracle and the product all have to agree with that, or decode() cannot
+    run on the reference's pickle."""
+    from lwm_amd.vqgan import VQGANConfig, random_params
+    cfg = VQGANConfig.get_default_config()
+    dec = random_params(cfg, seed=0)["decoder"]
+    n = cfg.num_resolutions
+    hc, mult = cfg.hidden_channels, cfg.channel_mult
+    first, last = dec["UpsamplingBlock_0"], dec[f"UpsamplingBlock_{n - 1}"]
+    assert first["ResnetBlock_0"]["Conv_0"]["kernel"].shape[-1] == hc * mult[n - 1] == 768
+    assert "Upsample_0" in first and "Upsample_0" not in last
+    assert last["ResnetBlock_0"]["Conv_0"]["kernel"].shape[2:] == (hc * mult[1], hc * mult[0])
+    assert "Conv_2" in last["ResnetBlock_0"]           # 256 -> 128 needs the 1x1 shortcut (lwm/vqgan.py:258-262)
+    for order in range(n):
+        lvl = n - 1 - order
+        assert dec[f"UpsamplingBlock_{order}"]["ResnetBlock_2"]["Conv_1"]["kernel"].shape[-1] == hc * mult[lvl]

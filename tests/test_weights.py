@@ -128,9 +128,57 @@ def test_flax_msgpack_stream_round_trip():
     import msgpack
     part = lambda a: msgpack.ExtType(1, msgpack.packb((list(a.shape), a.dtype.name, a.tobytes()), use_bin_type=True))
     a = np.arange(12, dtype=np.float32)
-    blob = msgpack.packb({"__msgpack_chunks__": 2, "shape": [3, 4], "chunks": {"0": part(a[:6]), "1": part(a[6:])}},
-                         use_bin_type=True)
+    # flax.serialization._chunk: a True flag, shape and chunks as index-keyed dicts
+    blob = msgpack.packb({"__msgpack_chunked_array__": True, "shape": {"0": 3, "1": 4},
+                          "chunks": {"0": part(a[:5]), "1": part(a[5:10]), "2": part(a[10:])}}, use_bin_type=True)
     assert np.array_equal(W.flax_from_bytes(blob), a.reshape(3, 4))
+
+
+def test_flax_stream_scan_layers_layout_with_chunked_leaves():
+    """What the reference actually writes (scan_layers=True, lwm/llama.py:158, every scripts/run_*.sh):
+    one stacked leaf per parameter under transformer/h/scan_decoder with the layer on axis 0, large
+    leaves split by flax into index-keyed chunks.  The writer chunks like flax (threshold lowered so a
+    test-sized leaf is split); the reader must re-join and the converter must unstack."""
+    g = torch.Generator().manual_seed(1)
+    L, d, f = 3, 8, 16
+    flat = {
+        "params/transformer/wte/embedding": torch.randn(32, d, generator=g),
+        "params/transformer/ln_f/kernel": torch.ones(d),
+        "params/lm_head/kernel": torch.randn(d, 32, generator=g),
+    }
+    for w in ("wq", "wk", "wv", "wo"):
+        flat[f"params/transformer/h/scan_decoder/attention/{w}/kernel"] = torch.randn(L, d, d, generator=g)
+    for w, shp in (("w1", (d, f)), ("w2", (f, d)), ("w3", (d, f))):
+        flat[f"params/transformer/h/scan_decoder/feed_forward/{w}/kernel"] = torch.randn(L, *shp, generator=g)
+    for nm in ("attention_norm", "ffn_norm"):
+        flat[f"params/transformer/h/scan_decoder/{nm}/kernel"] = torch.randn(L, d, generator=g)
+    buf = io.BytesIO()
+    W.write_flax_stream(buf, flat, max_chunk_bytes=400)     # the (3,8,16) f32 leaves become 4 chunks each
+    raw = buf.getvalue()
+    assert b"__msgpack_chunked_array__" in raw
+    back = W.read_flax_stream(io.BytesIO(raw))
+    for k, v in flat.items():
+        assert torch.equal(torch.as_tensor(np.asarray(back[k])), v), k
+    names = W.flax_llama_to_lwm(back)
+    assert "h.2.feed_forward.w3" in names and "h.0.attention_norm.kernel" in names
+    assert len([n for n in names if n.startswith("h.")]) == L * 9
+    assert torch.equal(names["h.1.attention.wk"], flat["params/transformer/h/scan_decoder/attention/wk/kernel"][1])
+    assert torch.equal(names["h.2.ffn_norm.kernel"], flat["params/transformer/h/scan_decoder/ffn_norm/kernel"][2])
+
+
+def test_pickle_loader_refuses_callables():
+    """A checkpoint / config pickle must not be able to run code: only array and
+    container reconstructors are resolvable."""
+    class Evil:
+        def __reduce__(self):
+            import os
+            return os.system, ("true",)
+    for payload in (Evil(), {"llama_config": Evil()}):
+        with pytest.raises(pickle.UnpicklingError):
+            W.load_pickle_tree(pickle.dumps(payload))
+    import collections
+    ok = W.load_pickle_tree(pickle.dumps({"a": np.arange(3), "b": collections.OrderedDict(x=np.float32(2.0))}))
+    assert np.array_equal(ok["a"], np.arange(3)) and float(ok["b"]["x"]) == 2.0
 
 
 def test_vqgan_pickle_written_from_jax_arrays_loads_without_jax():
@@ -194,3 +242,8 @@ def test_config_tables_and_update_string(tmp_path):
     assert LLaMAConfig.load_config(f"json::{tmp_path / 'c.json'}").theta == 5e7
     with pytest.raises(ValueError):
         LLaMAConfig.load_config("yaml::x")
+    # head_dim 100: refused when the config is made, not at the first launch (the kernels are head_dim 128)
+    with pytest.raises(NotImplementedError):
+        LLaMAConfig.load_config("3b")
+    for ok in ("13b", "30b", "65b", "debug"):
+        LLaMAConfig.load_config(ok)
