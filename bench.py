@@ -14,6 +14,11 @@ N(0,1) bf16 already resident in HBM when the timed region starts.
         that moves nothing (what the exchange costs on top of the launches) and one
         layer of the SAME problem on a single GPU (like-for-like strong scaling).
 
+Launch: `python bench.py --gpus N ...` is enough -- with N > 1 and no torch.distributed
+environment the script re-executes itself under `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1` (one rank per GPU); started under torchrun by someone
+else (RANK / WORLD_SIZE set) it just takes its rank.
+
 Prints ONE JSON line (rank 0).  `value` = whole-job tokens/s = S*steps/time.
 At N=1 the line also carries `roofline`, `cpu_baseline` and secondary legs that are never
 part of `value`: vqgan, packed, model_slice, decode, generate, ring8_compute_model, elementwise.
@@ -440,6 +445,46 @@ class KernelTimer:
         return out
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sck:
+        sck.bind(("127.0.0.1", 0))
+        return sck.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed environment: become the launcher --
+    N ranks of this same script under torch.distributed.run on 127.0.0.1 -- and hand back its exit code.
+    The children see RANK / WORLD_SIZE and therefore never come here."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL peer mappings need it on this driver
+    env.setdefault("NCCL_DEBUG", "WARN")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    env["LWM_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    print("[bench] self-launch: " + " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def fail_line(args, stage, err, extra=None):
+    """A diagnosable line instead of a hang or a bare traceback: the driver's JSON parser gets
+    {"error": ...} with the stage that failed and what this rank could see."""
+    import traceback
+    rec = {"metric": "tokens/sec fwd+bwd, LWM-7B RingAttention hot path (32 layers x 32 heads x 128)",
+           "value": None, "unit": "tokens/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+           "error": {"stage": stage, "type": type(err).__name__, "message": str(err)[:2000],
+                     "rank": int(os.environ.get("RANK", "0")), "world_size": int(os.environ.get("WORLD_SIZE", "1")),
+                     "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}",
+                     "env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "HIP_VISIBLE_DEVICES",
+                                                            "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")}}}
+    if extra:
+        rec["error"].update(extra)
+    print(json.dumps(rec), flush=True)
+    traceback.print_exception(type(err), err, err.__traceback__, file=sys.stderr)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -458,7 +503,16 @@ def main():
     ap.add_argument("--packed", action="store_true",
                     help="masked sequence packing (BASELINE config #5 style): documents log-uniform in "
                          "[S/256, S/4]; FLOPs are counted over visible pairs only")
+    ap.add_argument("--init-timeout", type=int, default=180,
+                    help="seconds before a stuck RCCL rendezvous / first collective is reported as an error line")
+    ap.add_argument("--full-model", action="store_true",
+                    help="also time all 32 layers of LWM-7B fwd+bwd at S=32768 (N=1 leg `model_full`; on by default "
+                         "when no leg is disabled)")
     args = ap.parse_args()
+
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not under_launcher:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -470,21 +524,49 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
-                         f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus "
+                         f"must agree (plain `python bench.py --gpus {args.gpus}` launches the ranks itself)")
     dry = args.backend == "gloo"
-    dev_index = local_rank % torch.cuda.device_count() if dry else local_rank
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0 or (not dry and local_rank >= n_dev):
+        fail_line(args, "devices", RuntimeError(f"rank {rank} (local {local_rank}) sees {n_dev} GPU(s); "
+                                                f"--gpus {args.gpus} needs one GPU per rank (--backend gloo is the dry run)"))
+        sys.exit(3)
+    dev_index = local_rank % n_dev if dry else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    rccl_ranks_seen = None
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if dry:
-            dist.init_process_group("gloo")
-            comm = HostStagedComm(torch, dist, TorchRingComm, args.schedule)
-        else:
-            dist.init_process_group("nccl", device_id=dev)
-            comm = TorchRingComm(None, schedule=args.schedule)
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")     # a stuck collective aborts, it does not hang
+        tmo = datetime.timedelta(seconds=args.init_timeout)
+        try:
+            if dry:
+                dist.init_process_group("gloo", timeout=tmo)
+                comm = HostStagedComm(torch, dist, TorchRingComm, args.schedule)
+            else:
+                dist.init_process_group("nccl", device_id=dev, timeout=tmo)
+                comm = TorchRingComm(dist.group.WORLD, schedule=args.schedule)
+            # first contact: every rank contributes 1 through the backend that will carry the exchange
+            # (RCCL over xGMI, or gloo in the dry run) and one neighbour send/recv goes round the ring
+            one = torch.ones(1, dtype=torch.float32, device="cpu" if dry else dev)
+            dist.all_reduce(one)
+            rccl_ranks_seen = int(one.item())
+            if not dry:
+                tok = torch.full((1,), float(rank), device=dev)
+                got = torch.empty(1, device=dev)
+                for r_ in dist.batch_isend_irecv([dist.P2POp(dist.isend, tok, (rank + 1) % world),
+                                                  dist.P2POp(dist.irecv, got, (rank - 1) % world)]):
+                    r_.wait()
+                torch.cuda.synchronize()
+                if int(got.item()) != (rank - 1) % world:
+                    raise RuntimeError(f"ring send/recv probe: expected {(rank - 1) % world}, received {got.item()}")
+        except Exception as e:
+            fail_line(args, "init_process_group / first collective", e, {"backend": args.backend})
+            os._exit(4)          # do not wait on a process group that never formed
     else:
         comm = SingleComm()
 
@@ -621,6 +703,7 @@ def main():
             },
             "tokens_per_s_per_gpu": tokens_per_s / world,
             "exchange": exchange,
+            "rccl_ranks_seen": rccl_ranks_seen,
             "dry_run": "ranks share devices, messages staged through host memory; timings are not xGMI" if dry else None,
             "path_algorithmic_tflops_per_gpu": algo_flops_step / (ms_per_step * 1e-3) / 1e12 / world,
         }

@@ -1,0 +1,149 @@
+"""What the three entry points share: mesh / process-group setup from --mesh_dim, the model from
+--load_llama_config / --update_llama_config / --llama.*, checkpoints from --load_checkpoint, the
+tokenizer from --tokenizer."""
+from __future__ import annotations
+
+import os
+import sys
+
+import torch
+
+from .. import mesh as _mesh
+from ..llama import LLaMAConfig, LLaMAForCausalLM, parse_config_updates
+from ..ringattention import set_sp_group
+from ..vision_llama import VideoLLaMAConfig, VideoLLaMAForCausalLM
+
+# fields the reference copies from --llama.* onto a loaded size (lwm/train.py:104-116, lwm/vision_chat.py:152-163)
+_SCAN_FIELDS = ("scan_attention", "scan_mlp", "scan_query_chunk_size", "scan_key_chunk_size", "scan_mlp_chunk_size",
+                "scan_layers", "param_scan_axis")
+
+
+def note(msg):
+    print(f"[lwm_amd.cli] {msg}", file=sys.stderr, flush=True)
+
+
+def setup_mesh(mesh_dim: str):
+    """--mesh_dim (lwm/train.py:35; tux.get_jax_mesh) -> this process's place in the (dp, fsdp, tp, sp)
+    mesh; binds mesh axis "sp" to its process group.  One process per GPU: under torch.distributed.run
+    the world is the mesh; a plain `python -m ...` run is a 1-device mesh."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
+    m = _mesh.parse_mesh_dim(mesh_dim, world)
+    if m["tp"] != 1 or m["fsdp"] != 1:
+        # tensor / fsdp sharding of the PARAMETERS is XLA-SPMD's job in the reference; the hot path built
+        # here shards the sequence.  Refuse rather than silently replicate.
+        if world > 1:
+            raise NotImplementedError(f"mesh_dim {mesh_dim!r}: only the dp and sp axes are executed here "
+                                      f"(got fsdp={m['fsdp']}, tp={m['tp']} over {world} processes)")
+    if world > 1:
+        set_sp_group(_mesh.sp_group(m))
+    return m
+
+
+def build_config(flags, vision: bool):
+    """lwm/train.py:101-121 / lwm/vision_chat.py:150-170."""
+    cls = VideoLLaMAConfig if vision else LLaMAConfig
+    group = dict(flags.get("llama", {}))
+    if flags.load_llama_config:
+        cfg = cls.load_config(flags.load_llama_config)
+        cfg.update({k: group[k] for k in _SCAN_FIELDS if k in group})
+    else:
+        cfg = cls(**group)
+    if flags.update_llama_config:
+        cfg.update(parse_config_updates(flags.update_llama_config))
+    cfg.update(dict(mesh_dim=flags.mesh_dim))
+    return cfg
+
+
+def torch_dtype(name: str):
+    """--dtype (fp32 | bf16 | fp16, tux.get_float_dtype_by_name).  The attention kernels take bf16
+    operands with f32 logits / softmax / accumulation, so activations run in bf16 whatever is asked."""
+    if name not in ("fp32", "bf16", "fp16", "float32", "bfloat16", "float16"):
+        raise SystemExit(f"unknown --dtype {name!r}")
+    if name not in ("bf16", "bfloat16"):
+        note(f"--dtype={name}: the MI355X hot path computes on bf16 operands with f32 accumulation; running bf16")
+    return torch.bfloat16
+
+
+def build_model(cfg, vision: bool, dtype, seed: int, device):
+    torch.manual_seed(seed)
+    with torch.device(device):
+        return (VideoLLaMAForCausalLM if vision else LLaMAForCausalLM)(cfg, dtype)
+
+
+def load_checkpoint(model, spec: str):
+    """--load_checkpoint 'params::<path>' / 'flax_params::<path>' (tux StreamingCheckpointer,
+    lwm/train.py:337, scripts/run_vision_chat.sh:27) or 'hf::<dir>' (the PyTorch release, README.md:74)."""
+    if not spec:
+        note("no --load_checkpoint: randomly initialised weights (seeded)")
+        return model
+    if "::" not in spec:
+        raise SystemExit(f"--load_checkpoint {spec!r}: expected '<type>::<path>' (params, flax_params, hf)")
+    kind, path = spec.split("::", 1)
+    if not path:
+        raise SystemExit(f"--load_checkpoint {spec!r}: empty path")
+    from .. import weights as W
+    if kind in ("params", "flax_params", "trainstate_params"):
+        flat = W.read_flax_stream(path)
+        prefix = "params/params/" if any(k.startswith("params/params/") for k in flat) else "params/"
+        return W.load_params(model, W.flax_llama_to_lwm(flat, prefix=prefix), strict=False)
+    if kind == "hf":
+        sd, _ = W.read_hf_checkpoint(path)
+        return W.load_params(model, W.hf_to_lwm(sd, model.cfg.num_attention_heads), strict=False)
+    raise SystemExit(f"--load_checkpoint: unsupported type {kind!r}")
+
+
+class ByteTokenizer:
+    """--tokenizer=synthetic: bytes + 3 (0 pad, 1 bos, 2 eos).  For runs without the LLaMA
+    sentencepiece model (no network); `<vision>` / `</vision>` get two reserved ids."""
+    pad_token_id, bos_token_id, eos_token_id = 0, 1, 2
+    eos_token = "</s>"
+    _special = {"<s>": 1, "</s>": 2, "<vision>": 259, "</vision>": 260}
+
+    def encode(self, text):
+        ids, i = [], 0
+        while i < len(text):
+            for tok, tid in self._special.items():
+                if text.startswith(tok, i):
+                    ids.append(tid)
+                    i += len(tok)
+                    break
+            else:
+                ids.extend(b + 3 for b in text[i].encode("utf-8"))
+                i += 1
+        return ids
+
+    def decode(self, ids, skip_special_tokens=True):
+        return bytes(int(t) - 3 for t in ids if 3 <= int(t) < 259).decode("utf-8", errors="replace")
+
+    def batch_decode(self, batch, skip_special_tokens=True):
+        return [self.decode(row, skip_special_tokens) for row in batch]
+
+
+def load_tokenizer(name: str):
+    if name == "synthetic":
+        return ByteTokenizer()
+    try:
+        from transformers import AutoTokenizer
+        return AutoTokenizer.from_pretrained(name, local_files_only=os.path.isdir(name) or None)
+    except Exception as e:
+        raise SystemExit(f"--tokenizer={name!r} could not be loaded ({type(e).__name__}: {e}); give a local directory "
+                         f"with the LLaMA tokenizer files, or --tokenizer=synthetic for a byte-level stand-in")
+
+
+def load_vqgan(path: str, seed: int):
+    from ..vqgan import VQGAN, VQGANConfig, random_params
+    if path:
+        return VQGAN(path, replicate=False)
+    note("no --vqgan_checkpoint: VQGAN with seeded random weights")
+    cfg = VQGANConfig.get_default_config()
+    return VQGAN(params=random_params(cfg, seed), config=cfg)

@@ -62,10 +62,23 @@ def _base(q, k, v, *, q_start, k_start, causal, seg_q, seg_k, key_valid, scale):
         a.key_valid = key_valid.data_ptr()
     if seg_q is not None and SEGMENT_SKIP:
         # block-sparsity hints: whole documents of a packed batch are skipped in-kernel
-        bq, bk = segment_blocks(seg_q), segment_blocks(seg_k, key_valid)
+        bq, bk = _cached_segment_blocks(seg_q, None), _cached_segment_blocks(seg_k, key_valid)
         a.seg_blocks_q, a.seg_blocks_k = bq.data_ptr(), bk.data_ptr()
         a._keep = (bq, bk)
     return a
+
+
+def _cached_segment_blocks(seg, valid):
+    """The hint table of a segment-id tensor is computed once and kept ON that tensor object (the ring
+    driver hands the same slice objects to the forward, dQ and dK/dV launches of a block pair:
+    lwm_amd/ring.py::_MaskSlices); an in-place edit (tensor._version) or another key_valid recomputes."""
+    key = (seg._version, None if valid is None else (id(valid), valid._version))
+    hit = getattr(seg, "_lwm_seg_blocks", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    blocks = segment_blocks(seg, valid)
+    seg._lwm_seg_blocks = (key, blocks, valid)      # `valid` kept alive: its id is part of the key
+    return blocks
 
 
 SEGMENT_SKIP = True   # set False to A/B the in-kernel document skipping

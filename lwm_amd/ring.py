@@ -104,20 +104,36 @@ class TorchRingComm:
         self.schedule = schedule or os.environ.get("LWM_RING_SCHEDULE") or "mesh"
         if self.schedule not in ("ring", "mesh"):
             raise ValueError(f"unknown exchange schedule {self.schedule!r}")
+        self._pool, self._flip = {}, {}
         self._dst = dist.get_global_rank(group, (self.rank + 1) % self.size) if group is not None \
             else (self.rank + 1) % self.size
         self._src = dist.get_global_rank(group, (self.rank - 1) % self.size) if group is not None \
             else (self.rank - 1) % self.size
 
+    def pooled(self, tag, shape, dtype, device):
+        """Exchange buffers are allocated ONCE per (role, shape) and reused by every layer and step: a
+        receive into a pooled buffer is enqueued behind everything already on the compute stream (RCCL
+        work waits for the issuing stream) and every driver call waits for its own sends before it
+        returns, so a buffer is never overwritten while a kernel or a send still reads it."""
+        key = (tag, tuple(shape), dtype, str(device))
+        buf = self._pool.get(key)
+        if buf is None:
+            buf = self._pool[key] = torch.empty(tuple(shape), dtype=dtype, device=device)
+        return buf
+
     def rotate(self, tensors):
-        bufs = [torch.empty_like(t) for t in tensors]
+        # double buffer per travelling tensor: the block received at step t is sent on at step t+1
+        # while the next one lands in the other buffer
+        # (one parity per travelling SET -- the backward rotates K/V and the f32 dK/dV carries alternately)
+        sig = tuple((tuple(t.shape), t.dtype) for t in tensors)
+        flip = self._flip[sig] = self._flip.get(sig, 0) ^ 1
+        bufs = [self.pooled(("rot", sig, i, flip), t.shape, t.dtype, t.device) for i, t in enumerate(tensors)]
         p2p = []
         for t, b in zip(tensors, bufs):
             p2p.append(dist.P2POp(dist.isend, t, self._dst, self.group))
             p2p.append(dist.P2POp(dist.irecv, b, self._src, self.group))
         reqs = dist.batch_isend_irecv(p2p)
         return _Handle(reqs, bufs)
-
 
     def all_gather(self, t):
         """-> (n, *t.shape), rank-major."""
@@ -187,21 +203,41 @@ class HipBlockOps:
 
 
 # ----------------------------------------------------------------- helpers
-def _mask_slices(segment_ids, key_valid, qseg, kseg):
-    _, qlen, qg = qseg
-    _, klen, kg = kseg
-    sq = sk = kv = None
-    if segment_ids is not None:
-        sq = segment_ids[:, qg:qg + qlen].contiguous()
-        sk = segment_ids[:, kg:kg + klen].contiguous()
-    if key_valid is not None:
-        kv = key_valid[:, kg:kg + klen].contiguous()
-    return sq, sk, kv
+class _MaskSlices:
+    """Per-segment views of the replicated (B, S_global) masks, cut ONCE per driver call: the forward,
+    dQ and dK/dV launches of a (q segment, k segment) pair get the same tensor objects, so whatever a
+    block backend derives from them (the HIP backend's segment-block hint tables) is derived once."""
+
+    def __init__(self, segment_ids, key_valid):
+        self.segment_ids, self.key_valid = segment_ids, key_valid
+        self._seg, self._kv = {}, {}
+
+    def _cut(self, memo, src, g, ln):
+        if src is None:
+            return None
+        got = memo.get((g, ln))
+        if got is None:
+            got = memo[(g, ln)] = src[:, g:g + ln].contiguous()
+        return got
+
+    def __call__(self, qseg, kseg):
+        _, qlen, qg = qseg
+        _, klen, kg = kseg
+        return (self._cut(self._seg, self.segment_ids, qg, qlen), self._cut(self._seg, self.segment_ids, kg, klen),
+                self._cut(self._kv, self.key_valid, kg, klen))
 
 
 def _rows(t, seg):
     off, ln, _ = seg
     return t[:, off:off + ln]
+
+
+def _xbuf(comm, block, tag, shape, dtype, like):
+    """An exchange buffer: from the communicator's pool when it has one (TorchRingComm), else fresh."""
+    pooled = getattr(comm, "pooled", None)
+    if pooled is not None:
+        return pooled(tag, shape, dtype, like.device)
+    return block.empty(tuple(shape), dtype, like)
 
 
 def _fwd_plan(layout, rank, n, causal):
@@ -234,7 +270,7 @@ class _MeshBlocks:
     all of them in one, i.e. every xGMI link of this GPU busy at once).  get(t) -> {ki: [k_seg,
     v_seg]} of rank (r - t) mod n, waiting for that wave only."""
 
-    def __init__(self, comm, layout, tensors, causal, wave=None):
+    def __init__(self, comm, layout, tensors, causal, wave=None, block=None, tag="fwd"):
         n, r = comm.size, comm.rank
         own = layout.segments(r)
         B = tensors[0].shape[0]
@@ -251,8 +287,10 @@ class _MeshBlocks:
                 segs = layout.segments(src)
                 got = {}
                 for ki in _needed_ksegs(layout, r, src, causal):
-                    got[ki] = [torch.empty((B, segs[ki][1]) + tuple(x.shape[2:]), dtype=x.dtype,
-                                           device=x.device) for x in tensors]
+                    shp = lambda x: (B, segs[ki][1]) + tuple(x.shape[2:])
+                    got[ki] = [_xbuf(comm, block, ("mesh", tag, t, ki, j), shp(x), x.dtype, x) if block is not None
+                               else torch.empty(shp(x), dtype=x.dtype, device=x.device)
+                               for j, x in enumerate(tensors)]
                     recvs += [(src, b) for b in got[ki]]
                 self.remote[t] = got
             h = comm.exchange_async(sends, recvs)
@@ -277,6 +315,7 @@ def ring_forward(block, comm, q, k, v, *, layout, causal=True, segment_ids=None,
     n, r = comm.size, comm.rank
     B, c, H, D = q.shape
     qsegs = layout.segments(r)
+    masks = _MaskSlices(segment_ids, key_valid)
     plan = _fwd_plan(layout, r, n, causal)
     first = {}
     last = {}
@@ -297,7 +336,7 @@ def ring_forward(block, comm, q, k, v, *, layout, causal=True, segment_ids=None,
 
     k_cur = k if k.is_contiguous() else k.contiguous()
     v_cur = v if v.is_contiguous() else v.contiguous()
-    mesh = _MeshBlocks(comm, layout, [k_cur, v_cur], causal) if _is_mesh(comm) else None
+    mesh = _MeshBlocks(comm, layout, [k_cur, v_cur], causal, block=block, tag="fwd") if _is_mesh(comm) else None
     keep = []
     idx = 0
     for t in range(n):
@@ -307,7 +346,7 @@ def ring_forward(block, comm, q, k, v, *, layout, causal=True, segment_ids=None,
         while idx < len(plan) and plan[idx][0] == t:
             _, qi, ki = plan[idx]
             qs, ks = qsegs[qi], ksegs[ki]
-            sq, sk, kv = _mask_slices(segment_ids, key_valid, qs, ks)
+            sq, sk, kv = masks(qs, ks)
             fin = idx == last[qi]
             if mesh is not None:
                 held = held if held is not None else mesh.get(t)
@@ -334,6 +373,7 @@ def ring_backward(block, comm, q, k, v, out, lses, dout, *, layout, causal=True,
     n, r = comm.size, comm.rank
     B, c, H, D = q.shape
     qsegs = layout.segments(r)
+    masks = _MaskSlices(segment_ids, key_valid)
     if not dout.is_contiguous():
         dout = dout.contiguous()
     deltas = [block.bwd_delta(_rows(out, qs), _rows(dout, qs)) for qs in qsegs]
@@ -341,7 +381,7 @@ def ring_backward(block, comm, q, k, v, out, lses, dout, *, layout, causal=True,
     if n == 1 and len(qsegs) == 1:
         # single block: write bf16 results straight from the accumulators
         qs = qsegs[0]
-        sq, sk, kv = _mask_slices(segment_ids, key_valid, qs, qs)
+        sq, sk, kv = masks(qs, qs)
         kw = dict(q_start=qs[2], k_start=qs[2], causal=causal, seg_q=sq, seg_k=sk, key_valid=kv,
                   scale=scale)
         dk, dv = block.bwd_dkdv(q, k, v, dout, lses[0], deltas[0], final=True, **kw)
@@ -374,7 +414,7 @@ def ring_backward(block, comm, q, k, v, out, lses, dout, *, layout, causal=True,
         # dq first: it does not need the travelling dk/dv accumulators
         for qi, ki in pairs:
             qs, ks = qsegs[qi], ksegs[ki]
-            sq, sk, kv = _mask_slices(segment_ids, key_valid, qs, ks)
+            sq, sk, kv = masks(qs, ks)
             block.bwd_dq(_rows(q, qs), _rows(k_cur, ks), _rows(v_cur, ks), _rows(dout, qs), lses[qi],
                          deltas[qi], q_start=qs[2], k_start=ks[2], causal=causal, seg_q=sq, seg_k=sk,
                          key_valid=kv, scale=scale, dq_acc=dq_acc[qi], carry_in=dq_seen[qi], final=False)
@@ -385,7 +425,7 @@ def ring_backward(block, comm, q, k, v, out, lses, dout, *, layout, causal=True,
         fresh = set(range(nks)) if t == 0 else set()     # at step 0 the carries hold nothing yet
         for qi, ki in pairs:
             qs, ks = qsegs[qi], ksegs[ki]
-            sq, sk, kv = _mask_slices(segment_ids, key_valid, qs, ks)
+            sq, sk, kv = masks(qs, ks)
             block.bwd_dkdv(_rows(q, qs), _rows(k_cur, ks), _rows(v_cur, ks), _rows(dout, qs), lses[qi],
                            deltas[qi], q_start=qs[2], k_start=ks[2], causal=causal, seg_q=sq,
                            seg_k=sk, key_valid=kv, scale=scale, dk_acc=dk_acc[ki], dv_acc=dv_acc[ki],
@@ -424,9 +464,10 @@ def _mesh_backward(block, comm, q, k, v, lses, dout, deltas, *, layout, causal, 
     n, r = comm.size, comm.rank
     B, c, H, D = q.shape
     qsegs = layout.segments(r)
+    masks = _MaskSlices(segment_ids, key_valid)
     k_c = k if k.is_contiguous() else k.contiguous()
     v_c = v if v.is_contiguous() else v.contiguous()
-    mesh = _MeshBlocks(comm, layout, [k_c, v_c], causal)
+    mesh = _MeshBlocks(comm, layout, [k_c, v_c], causal, block=block, tag="bwd")
     dq = block.empty((B, c, H, D), q.dtype, q)
     dk = block.empty((B, c, H, D), q.dtype, q)
     dv = block.empty((B, c, H, D), q.dtype, q)
@@ -452,7 +493,7 @@ def _mesh_backward(block, comm, q, k, v, lses, dout, deltas, *, layout, causal, 
         ksegs, pairs = pairs_at(t)
         for qi, ki in pairs:
             qs, ks = qsegs[qi], ksegs[ki]
-            sq, sk, kv = _mask_slices(segment_ids, key_valid, qs, ks)
+            sq, sk, kv = masks(qs, ks)
             done_dq[qi] += 1
             fin = done_dq[qi] == n_dq[qi]
             block.bwd_dq(_rows(q, qs), held[ki][0], held[ki][1], _rows(dout, qs), lses[qi], deltas[qi],
@@ -466,11 +507,14 @@ def _mesh_backward(block, comm, q, k, v, lses, dout, deltas, *, layout, causal, 
         part = {}
         for qi, ki in pairs:
             qs, ks = qsegs[qi], ksegs[ki]
-            sq, sk, kv = _mask_slices(segment_ids, key_valid, qs, ks)
+            sq, sk, kv = masks(qs, ks)
             first = ki not in part
             if first:
-                part[ki] = (block.empty((B, ks[1], H, D), torch.float32, q),
-                            block.empty((B, ks[1], H, D), torch.float32, q))
+                # a REMOTE block's partial is sent to its owner: pooled (the send is waited for before
+                # this call returns); the local block's partial (t == 0) feeds the final reduction only
+                mk = (lambda w: _xbuf(comm, block, ("part", t, ki, w), (B, ks[1], H, D), torch.float32, q)) if t else \
+                     (lambda w: block.empty((B, ks[1], H, D), torch.float32, q))
+                part[ki] = (mk(0), mk(1))
             block.bwd_dkdv(_rows(q, qs), held[ki][0], held[ki][1], _rows(dout, qs), lses[qi], deltas[qi],
                            q_start=qs[2], k_start=ks[2], causal=causal, seg_q=sq, seg_k=sk, key_valid=kv,
                            scale=scale, dk_acc=part[ki][0], dv_acc=part[ki][1], carry_in=not first,
@@ -491,7 +535,7 @@ def _mesh_backward(block, comm, q, k, v, lses, dout, deltas, *, layout, causal, 
         got, recvs = {}, []
         for ki in _needed_ksegs(layout, giver, r, causal):
             ln = own[ki][1]
-            got[ki] = (block.empty((B, ln, H, D), torch.float32, q), block.empty((B, ln, H, D), torch.float32, q))
+            got[ki] = tuple(_xbuf(comm, block, ("ret", t, ki, w), (B, ln, H, D), torch.float32, q) for w in (0, 1))
             recvs += [(giver, got[ki][0]), (giver, got[ki][1])]
         returned[t] = (got, comm.exchange_async(sends, recvs))
     local = run_dkdv(0, mesh.get(0))

@@ -41,11 +41,29 @@ def test_committed_bench_line_follows_the_contract():
 
 
 def test_bench_cli_contract_without_a_gpu():
-    """--gpus N must match WORLD_SIZE (the driver launches N > 1 under torch.distributed.run)."""
-    env = dict(os.environ, WORLD_SIZE="1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+    """`python bench.py --gpus N` must launch its own N ranks (the driver's N > 1 command may be the plain
+    one); under a launcher --gpus must agree with WORLD_SIZE; and with no GPU to give to a rank the run ends
+    with a diagnosable JSON error line and a non-zero code -- never a hang, never a bare traceback."""
+    bench = os.path.join(ROOT, "bench.py")
+    # (1) launched by someone else with the wrong size
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
-    h = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    # (2) plain command, no torch.distributed environment: self-launch under torch.distributed.run
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0", "--backend", "gloo",
+                        "--init-timeout", "60"], capture_output=True, text=True, env=env, timeout=600)
+    assert "self-launch" in r.stderr and "torch.distributed.run" in r.stderr and "--nproc-per-node=2" in r.stderr
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    import torch
+    if not torch.cuda.is_available():
+        # both ranks report, from inside the launched processes, that they have no device
+        assert r.returncode != 0
+        assert lines and all(l["value"] is None and l["error"]["stage"] == "devices" for l in lines)
+        assert {l["error"]["world_size"] for l in lines} == {2} and {l["error"]["rank"] for l in lines} == {0, 1}
+    else:
+        assert r.returncode == 0 and lines[-1]["n_gpus"] == 2 and lines[-1]["rccl_ranks_seen"] == 2
+    h = subprocess.run([sys.executable, bench, "--help"], capture_output=True, text=True, timeout=300)
     for flag in ("--gpus", "--steps", "--warmup"):
         assert flag in h.stdout

@@ -1,0 +1,147 @@
+"""The entry points keep the reference's command lines (SURVEY.md section 8b "CLI"): every flag that the
+reference's own launch scripts pass -- scripts/run_train_text.sh, run_train_vision_text.sh,
+run_vision_chat.sh, run_sample_image.sh, run_sample_video.sh, restated here argument for argument --
+must parse, land in the right place, and drive the same configuration objects."""
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+TRAIN_TEXT = [  # scripts/run_train_text.sh:19-55
+    "--modality=text", "--mesh_dim=!1,-1,2,2", "--dtype=fp32", "--total_steps=200", "--log_freq=1",
+    "--save_model_freq=0", "--save_milestone_freq=10", "--load_llama_config=debug",
+    "--update_llama_config=dict(theta=10000,max_sequence_length=2048,scan_attention=True,scan_query_chunk_size=256,"
+    "scan_key_chunk_size=512,scan_mlp=True,scan_mlp_chunk_size=1024,scan_layers=True)",
+    "--tokenizer=LargeWorldModel/LWM-Text-1M", "--optimizer.type=adamw", "--optimizer.accumulate_gradient_steps=1",
+    "--optimizer.adamw_optimizer.weight_decay=0.1", "--optimizer.adamw_optimizer.lr=8e-5",
+    "--optimizer.adamw_optimizer.end_lr=8e-5", "--optimizer.adamw_optimizer.lr_warmup_steps=5",
+    "--optimizer.adamw_optimizer.lr_decay_steps=200", "--use_data_sharded_loader=True", "--train_dataset.type=json",
+    "--train_dataset.text_processor.fields=text", "--train_dataset.json_dataset.path=",
+    "--train_dataset.json_dataset.seq_length=2048", "--train_dataset.json_dataset.batch_size=1024",
+    "--train_dataset.json_dataset.tokenizer_processes=16", "--train_dataset.json_dataset.use_data_sharded_loader=True",
+    "--checkpointer.save_optimizer_state=True", "--autoresume=False", "--logger.append_uuid=False",
+    "--logger.online=False", "--logger.project_id=lwm", "--logger.experiment_id=example-text-train",
+    "--logger.experiment_note=", "--logger.output_dir=", "--logger.wandb_dir=/root/experiment_output/lwm"]
+
+TRAIN_VISION = [  # scripts/run_train_vision_text.sh:19-60 (the flags that differ)
+    "--modality=vision,text", "--mesh_dim=!1,-1,2,2", "--load_llama_config=debug",
+    "--update_llama_config=dict(theta=50000000,max_sequence_length=2048,scan_attention=True,scan_query_chunk_size=512,"
+    "scan_key_chunk_size=1024,scan_mlp=True,scan_mlp_chunk_size=8192,scan_layers=True)",
+    "--train_dataset.type=json_vision", "--train_dataset.vision_text_processor.fields_from_example=fields",
+    "--train_dataset.vision_text_processor.max_n_frames=4", "--train_dataset.json_vision_dataset.mode=no_pad",
+    "--train_dataset.json_vision_dataset.seq_length=2048", "--train_dataset.json_vision_dataset.batch_size=8",
+    "--train_dataset.json_vision_dataset.tokenizer_parallel_chunk_size=2"]
+
+VISION_CHAT = [  # scripts/run_vision_chat.sh:16-28
+    "--prompt=What is the video about?", "--input_file=clip.npy", "--vqgan_checkpoint=", "--mesh_dim=!1,1,-1,1",
+    "--dtype=fp32", "--load_llama_config=7b", "--max_n_frames=8",
+    "--update_llama_config=dict(sample_mode='text',theta=50000000,max_sequence_length=131072,scan_attention=False,"
+    "scan_query_chunk_size=128,scan_key_chunk_size=128,scan_mlp=False,scan_mlp_chunk_size=2048,scan_layers=True)",
+    "--load_checkpoint=params::/ckpt/params", "--tokenizer=LargeWorldModel/LWM-Text-1M"]
+
+SAMPLE_VIDEO = [  # scripts/run_sample_video.sh:15-33 (run_sample_image.sh is the n_frames=1 subset)
+    "--prompt=Fireworks over the city", "--output_file=fireworks.mp4", "--temperature_image=1.0",
+    "--temperature_video=1.0", "--top_k_image=8192", "--top_k_video=1000", "--cfg_scale_image=5.0",
+    "--cfg_scale_video=1.0", "--vqgan_checkpoint=", "--n_frames=8", "--mesh_dim=!1,1,-1,1", "--dtype=fp32",
+    "--load_llama_config=7b",
+    "--update_llama_config=dict(sample_mode='vision',theta=50000000,max_sequence_length=32768,scan_attention=False,"
+    "scan_query_chunk_size=128,scan_key_chunk_size=128,scan_mlp=False,scan_mlp_chunk_size=8192,scan_layers=True)",
+    "--load_checkpoint=params::/ckpt/params", "--tokenizer=LargeWorldModel/LWM-Text-1M"]
+
+
+def _script_flags(name):
+    """Flag NAMES the reference's launch script passes (read from /root/reference when it is there)."""
+    import re
+    path = os.path.join("/root/reference/scripts", name)
+    if not os.path.exists(path):
+        return None
+    return set(re.findall(r"^\s+--([A-Za-z_.]+)=", open(path).read(), flags=re.M))
+
+
+def test_every_flag_of_the_reference_scripts_parses():
+    from lwm_amd.cli import train, vision_chat, vision_generation
+    from lwm_amd.cli._flags import parse
+    from lwm_amd.cli._common import build_config
+    F = parse(train.DEFAULTS, train.GROUPS, TRAIN_TEXT, "train")
+    assert F.modality == "text" and F.total_steps == 200 and F.autoresume is False and F.log_freq == 1
+    assert F.optimizer["adamw_optimizer"] == dict(weight_decay=0.1, lr=8e-5, end_lr=8e-5, lr_warmup_steps=5, lr_decay_steps=200)
+    assert F.train_dataset["json_dataset"]["seq_length"] == 2048 and F.train_dataset["text_processor"]["fields"] == "text"
+    assert train._shape_from_dataset(F.train_dataset, False) == (1024, 2048)
+    cfg = build_config(F, vision=False)
+    assert (cfg.hidden_size, cfg.num_hidden_layers, cfg.theta, cfg.max_sequence_length) == (256, 2, 10000, 2048)
+    assert cfg.scan_query_chunk_size == 256 and cfg.scan_layers is True and cfg.mesh_dim == "!1,-1,2,2"
+    # schedule: linear warm-up to lr over 5 steps, then flat (end_lr == lr)
+    opt = F.optimizer["adamw_optimizer"]
+    assert train.lr_at(0, opt) == 0.0 and abs(train.lr_at(5, opt) - 8e-5) < 1e-12 and abs(train.lr_at(150, opt) - 8e-5) < 1e-12
+
+    F = parse(train.DEFAULTS, train.GROUPS, TRAIN_VISION, "train")
+    assert F.modality == "vision,text" and train._shape_from_dataset(F.train_dataset, True) == (8, 2048)
+    cfg = build_config(F, vision=True)
+    assert cfg.vision_vocab_size == 8448 and cfg.theta == 50000000 and cfg.scan_mlp_chunk_size == 8192
+
+    F = parse(vision_chat.DEFAULTS, vision_chat.GROUPS, VISION_CHAT, "vision_chat")
+    assert F.prompt == "What is the video about?" and F.max_n_frames == 8 and F.temperature == 0.2
+    cfg = build_config(F, vision=True)
+    assert cfg.sample_mode == "text" and cfg.max_sequence_length == 131072 and cfg.hidden_size == 4096
+
+    F = parse(vision_generation.DEFAULTS, vision_generation.GROUPS, SAMPLE_VIDEO, "vision_generation")
+    assert F.n_frames == 8 and F.top_k_video == 1000 and F.cfg_scale_image == 5.0 and F.output_file == "fireworks.mp4"
+    assert build_config(F, vision=True).sample_mode == "vision"
+
+    # the flag NAMES of the scripts themselves (when the reference tree is at hand) are all known
+    for script, mod in (("run_train_text.sh", train), ("run_train_vision_text.sh", train),
+                        ("run_vision_chat.sh", vision_chat), ("run_sample_image.sh", vision_generation),
+                        ("run_sample_video.sh", vision_generation)):
+        names = _script_flags(script)
+        if names is None:
+            continue
+        for n in names:
+            assert n in mod.DEFAULTS or n.split(".")[0] in mod.GROUPS, (script, n)
+
+    with pytest.raises(SystemExit):
+        parse(train.DEFAULTS, train.GROUPS, ["--no_such_flag=1"], "train")
+    # absl forms: `--flag value`, bare booleans, --noflag
+    F = parse(train.DEFAULTS, train.GROUPS, ["--seed", "7", "--autoresume", "--nouse_data_sharded_loader"], "train")
+    assert F.seed == 7 and F.autoresume is True and F.use_data_sharded_loader is False
+
+
+def test_mesh_dim_strings_of_the_scripts():
+    from lwm_amd.mesh import parse_mesh_dim
+    assert parse_mesh_dim("!1,-1,2,2", 8) == dict(dp=1, fsdp=2, tp=2, sp=2)
+    assert parse_mesh_dim("!1,1,-1,1", 1) == dict(dp=1, fsdp=1, tp=1, sp=1)
+    assert parse_mesh_dim("1,-1,1,1", 1)["fsdp"] == 1
+
+
+def test_byte_tokenizer_round_trip():
+    from lwm_amd.cli._common import ByteTokenizer
+    t = ByteTokenizer()
+    ids = t.encode("<s>You are. USER: hé\n<vision></vision> ASSISTANT:")
+    assert ids[0] == 1 and 259 in ids and 260 in ids
+    assert t.decode(ids) == "You are. USER: hé\n ASSISTANT:"
+
+
+@pytest.mark.gpu
+def test_one_step_of_each_entry_point_on_the_debug_model(tmp_path):
+    import numpy as np
+    from lwm_amd.cli import train, vision_chat, vision_generation
+    small = ["--load_llama_config=debug", "--mesh_dim=1,-1,1,1", "--dtype=bf16", "--tokenizer=synthetic"]
+    hist = train.main(small + ["--modality=text", "--total_steps=2", "--log_freq=1",
+                               "--update_llama_config=dict(theta=10000,max_sequence_length=2048,scan_query_chunk_size=256)",
+                               "--train_dataset.json_dataset.seq_length=1024", "--train_dataset.json_dataset.batch_size=2",
+                               "--optimizer.adamw_optimizer.lr=1e-3", "--optimizer.adamw_optimizer.lr_warmup_steps=1"])
+    assert len(hist) == 2 and all(np.isfinite(h["loss"]) for h in hist) and 8.0 < hist[0]["loss"] < 13.0
+    hist = train.main(small + ["--modality=vision,text", "--total_steps=1",
+                               "--train_dataset.type=json_vision", "--train_dataset.json_vision_dataset.seq_length=512",
+                               "--train_dataset.json_vision_dataset.batch_size=1"])
+    assert np.isfinite(hist[0]["loss"]) and "vision_loss" in hist[0]
+    # vision chat: 2 synthetic frames -> VQGAN codes -> prompt -> 4 sampled tokens
+    ans = vision_chat.main(small + ["--prompt=What is the video about?", "--input_file=synthetic:2", "--max_n_frames=2",
+                                    "--update_llama_config=dict(sample_mode='text',max_sequence_length=2048,vocab_size=32000)"],
+                           max_new_tokens=4)
+    assert isinstance(ans, str)
+    out = str(tmp_path / "img.npy")
+    img = vision_generation.main(small + ["--prompt=Fireworks", f"--output_file={out}", "--n_frames=1", "--top_k_image=50",
+                                          "--cfg_scale_image=5.0",
+                                          "--update_llama_config=dict(sample_mode='vision',max_sequence_length=2048)"])
+    assert img.shape == (1, 256, 256, 3) and img.dtype == np.uint8 and np.load(out).shape == (1, 256, 256, 3)
