@@ -503,6 +503,10 @@ def main():
     ap.add_argument("--packed", action="store_true",
                     help="masked sequence packing (BASELINE config #5 style): documents log-uniform in "
                          "[S/256, S/4]; FLOPs are counted over visible pairs only")
+    ap.add_argument("--fused-bwd", action="store_true",
+                    help="A/B: run the backward as the one-launch lwm_attn_bwd_fused (5 GEMM units executed) instead "
+                         "of lwm_attn_bwd_dkdv + lwm_attn_bwd_dq (7); also LWM_FUSED_BWD=1")
+    ap.add_argument("--two-kernel-bwd", action="store_true", help="(default) the two-kernel backward")
     ap.add_argument("--init-timeout", type=int, default=180,
                     help="seconds before a stuck RCCL rendezvous / first collective is reported as an error line")
     ap.add_argument("--full-model", action="store_true",
@@ -520,6 +524,11 @@ def main():
     from lwm_amd.ring import (HipBlockOps, SeqLayout, SingleComm, TorchRingComm, ring_backward,
                               ring_forward)
 
+    import lwm_amd.ring as _ring
+    if args.fused_bwd:
+        _ring.FUSED_BACKWARD = True
+    if args.two_kernel_bwd:
+        _ring.FUSED_BACKWARD = False
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -598,6 +607,7 @@ def main():
         bwd_delta = staticmethod(lambda *a, **kw: timer.run("attn_bwd_delta_kernel", ops.attn_bwd_delta, *a, **kw))
         bwd_dq = staticmethod(lambda *a, **kw: timer.run("attn_bwd_dq_kernel", ops.attn_bwd_dq_block, *a, **kw))
         bwd_dkdv = staticmethod(lambda *a, **kw: timer.run("attn_bwd_dkdv_kernel", ops.attn_bwd_dkdv_block, *a, **kw))
+        bwd_fused = staticmethod(lambda *a, **kw: timer.run("attn_bwd_fused_kernel", ops.attn_bwd_fused_block, *a, **kw))
 
     def step():
         for _ in range(args.layers):
@@ -713,9 +723,11 @@ def main():
             # dominant kernel by total time; algorithmic FLOPs per launch: fwd = 2 GEMM
             # units; the backward's 5 algorithmic units are apportioned to its two launches
             # by executed share (dkdv 4/7, dq 3/7) -- DESIGN.md "Work accounting".
+            # The one-launch backward executes exactly its 5 algorithmic units.
             algo_units = {"attn_fwd_kernel": 2.0, "attn_bwd_dkdv_kernel": 5.0 * 4 / 7,
-                          "attn_bwd_dq_kernel": 5.0 * 3 / 7}
-            exec_units = {"attn_fwd_kernel": 2.0, "attn_bwd_dkdv_kernel": 4.0, "attn_bwd_dq_kernel": 3.0}
+                          "attn_bwd_dq_kernel": 5.0 * 3 / 7, "attn_bwd_fused_kernel": 5.0}
+            exec_units = {"attn_fwd_kernel": 2.0, "attn_bwd_dkdv_kernel": 4.0, "attn_bwd_dq_kernel": 3.0,
+                          "attn_bwd_fused_kernel": 5.0}
             cand = {n: d for n, d in ks.items() if n in algo_units}
             dom = max(cand, key=lambda n: cand[n]["total_ms"])
             avg_s = cand[dom]["avg_ms"] * 1e-3

@@ -93,12 +93,29 @@ typedef struct LwmAttnArgs {
      * Results are unchanged (the per-element mask is still applied).  NULL = no skipping. */
     const int32_t* seg_blocks_q;
     const int32_t* seg_blocks_k;
+    /* lwm_attn_bwd_fused only: carry_in / final_out govern dk, dv; these two govern dq (a ring driver
+     * finishes a q segment and a k segment at different steps).  bwd_workspace: caller-owned device
+     * memory of lwm_attn_bwd_fused_workspace_bytes() bytes (work-queue tickets + per-tile counters;
+     * the launch zeroes it on `stream`, it need not persist between launches). */
+    int32_t dq_carry_in, dq_final_out;
+    void* bwd_workspace;
 } LwmAttnArgs;
 
 int lwm_attn_fwd(const LwmAttnArgs* args, void* stream);
 int lwm_attn_bwd_delta(const LwmAttnArgs* args, void* stream);
 int lwm_attn_bwd_dq(const LwmAttnArgs* args, void* stream);
 int lwm_attn_bwd_dkdv(const LwmAttnArgs* args, void* stream);
+
+/* The whole backward of one ring step in ONE launch: dq, dk and dv from S and dP computed once -- the
+ * reference's 5 GEMMs per chunk pair instead of the 7 that
+ * lwm_attn_bwd_dq + lwm_attn_bwd_dkdv execute between them.  Same operands and mask semantics; results
+ * agree with the two-kernel path to f32 re-association (dq is accumulated per 256-key block, in ascending
+ * key order -- deterministic).  dq_acc ([B,Sq,H,D] f32) is required unless a single key block covers Sk
+ * with dq_final_out = 1 and dq_carry_in = 0: it is the accumulator the key blocks add into (and the dq
+ * carry of a ring).  seg_blocks_* hints are ignored (every tile inside the causal range is visited; the
+ * element mask is authoritative) -- packed batches run faster through the two-kernel path. */
+int64_t lwm_attn_bwd_fused_workspace_bytes(int32_t B, int32_t H, int32_t Sq);
+int lwm_attn_bwd_fused(const LwmAttnArgs* args, void* stream);
 
 /* (min, max) of segment_ids over each block of 32 rows, excluding rows whose valid[] is 0
  * (valid may be NULL); an all-invalid block gets (INT32_MAX, INT32_MIN).

@@ -12,6 +12,28 @@ inline int fail(int code, const char* fmt, const char* a = "", long x = 0, long 
     return code;
 }
 
+// memset on the stream (never synchronises)
+inline int zero_device(void* p, size_t bytes, void* stream) {
+    hipError_t e = hipMemsetAsync(p, 0, bytes, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(-3, "%s: hipMemsetAsync: %ld", "zero_device", (long)e);
+    return 0;
+}
+
+// compute units of the current device (persistent kernels launch one workgroup per CU)
+inline long device_cu_count() {
+    static thread_local int cached_dev = -1;
+    static thread_local long cached_n = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev != cached_dev) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached_dev = dev;
+        cached_n = n;
+    }
+    return cached_n;
+}
+
 template <class... KArgs, class... Args>
 inline int launch(const char* name, void (*kernel)(KArgs...), long grid, int threads,
                   size_t lds_bytes, void* stream, Args... args) {

@@ -9,6 +9,7 @@
 #include "attn_common.h"
 #include "attn_fwd.h"
 #include "attn_bwd.h"
+#include "attn_bwd_fused.h"
 #include "attn_decode.h"
 #include "misc_kernels.h"
 #include "llama_elem.h"

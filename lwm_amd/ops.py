@@ -280,6 +280,73 @@ def attn_bwd_dkdv_block(q, k, v, dout, lse, delta, *, q_start=0, k_start=0, caus
     return (dk, dv) if final else (dk_acc, dv_acc)
 
 
+_FUSED_WS = {}
+
+
+def _fused_workspace(B, H, Sq, device):
+    """int32 scratch of lwm_attn_bwd_fused (work-queue tickets + per-tile counters); the launch zeroes it
+    itself, so one buffer per (device, stream) is reused by every call."""
+    L = lib()
+    need = int(L.lwm_attn_bwd_fused_workspace_bytes(B, H, Sq))
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    ws = _FUSED_WS.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = _FUSED_WS[key] = torch.empty(max(need // 4, 64), dtype=torch.int32, device=device)
+    return ws
+
+
+def fused_backward_gave_up(device=None):
+    """True if a wait inside lwm_attn_bwd_fused hit its spin limit since the workspace was last zeroed
+    (diagnostic for tests: synchronises)."""
+    device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    ws = _FUSED_WS.get((str(device), torch.cuda.current_stream(device).cuda_stream))
+    return ws is not None and bool(ws[16].item() != 0)
+
+
+def attn_bwd_fused_block(q, k, v, dout, lse, delta, *, q_start=0, k_start=0, causal=True, seg_q=None, seg_k=None,
+                         key_valid=None, scale=None, dq=None, dk=None, dv=None, dq_acc=None, dk_acc=None,
+                         dv_acc=None, dq_carry_in=False, dq_final=True, carry_in=False, final=True):
+    """The whole backward of one ring step in one launch (lwm_attn_bwd_fused): S and dP are computed once
+    (5 GEMM units instead of 7).  `carry_in` / `final` govern dk, dv; `dq_carry_in` / `dq_final` govern dq.
+    dq_acc (f32 (B,Sq,H,D)) is the accumulator the 256-key blocks add into -- allocated here when absent.
+    Returns (dq or dq_acc, dk or dk_acc, dv or dv_acc)."""
+    B, Sq, H, D = q.shape
+    Sk = k.shape[1]
+    a = _bwd_base(q, k, v, dout, lse, delta,
+                  dict(q_start=q_start, k_start=k_start, causal=causal, seg_q=seg_q, seg_k=seg_k,
+                       key_valid=key_valid, scale=scale))
+    a.seg_blocks_q, a.seg_blocks_k = None, None       # the fused kernel visits every tile (hints unused)
+    if final:
+        if dk is None:
+            dk = torch.empty((B, Sk, H, D), dtype=torch.bfloat16, device=q.device)
+        if dv is None:
+            dv = torch.empty((B, Sk, H, D), dtype=torch.bfloat16, device=q.device)
+        a.dk, a.dv = _t4(dk, "dk"), _t4(dv, "dv")
+    else:
+        if dk_acc is None:
+            dk_acc = torch.empty((B, Sk, H, D), dtype=torch.float32, device=q.device)
+        if dv_acc is None:
+            dv_acc = torch.empty((B, Sk, H, D), dtype=torch.float32, device=q.device)
+    a.dk_acc = _f32(dk_acc, "dk_acc", (B, Sk, H, D))
+    a.dv_acc = _f32(dv_acc, "dv_acc", (B, Sk, H, D))
+    if dq_final:
+        if dq is None:
+            dq = torch.empty((B, Sq, H, D), dtype=torch.bfloat16, device=q.device)
+        a.dq = _t4(dq, "dq")
+    if dq_acc is None and (Sk > 256 or not dq_final or dq_carry_in):
+        if dq_carry_in:
+            raise ValueError("attn_bwd_fused_block: dq_carry_in needs dq_acc")
+        dq_acc = torch.empty((B, Sq, H, D), dtype=torch.float32, device=q.device)
+    a.dq_acc = _f32(dq_acc, "dq_acc", (B, Sq, H, D))
+    a.carry_in, a.final_out = int(bool(carry_in)), int(bool(final))
+    a.dq_carry_in, a.dq_final_out = int(bool(dq_carry_in)), int(bool(dq_final))
+    ws = _fused_workspace(B, H, Sq, q.device)
+    a.bwd_workspace = ws.data_ptr()
+    L = lib()
+    _capi.check(L, L.lwm_attn_bwd_fused(C.byref(a), _stream_ptr()), "lwm_attn_bwd_fused")
+    return (dq if dq_final else dq_acc), (dk if final else dk_acc), (dv if final else dv_acc)
+
+
 def cast_f32_to_bf16(src, dst=None):
     if not src.is_cuda or src.dtype != torch.float32 or not src.is_contiguous():
         raise ValueError("cast_f32_to_bf16: expected contiguous f32 device tensor")

@@ -187,6 +187,7 @@ class HipBlockOps:
     bwd_delta = staticmethod(_ops.attn_bwd_delta)
     bwd_dq = staticmethod(_ops.attn_bwd_dq_block)
     bwd_dkdv = staticmethod(_ops.attn_bwd_dkdv_block)
+    bwd_fused = staticmethod(_ops.attn_bwd_fused_block)
     cast = staticmethod(_ops.cast_f32_to_bf16)
     sum_cast = staticmethod(_ops.sum_f32_to_bf16)
     fwd_splitk = staticmethod(_ops.attn_fwd_splitk)
@@ -200,6 +201,19 @@ class HipBlockOps:
     @staticmethod
     def zeros(shape, dtype, like):
         return torch.zeros(shape, dtype=dtype, device=like.device)
+
+
+# The one-launch backward (lwm_attn_bwd_fused: S and dP computed once, 5 GEMM units instead of 7) is OPT-IN
+# (LWM_FUSED_BWD=1, bench.py --fused-bwd): on MI355X it measures 28-30 ms per layer at S = 32768 against
+# 26.5 ms for lwm_attn_bwd_dkdv + lwm_attn_bwd_dq -- what it saves in MFMA work it spends on the ordered
+# read-modify-write of dq through L2 (profiles/r02_fused_ab.md).  Where enabled it is
+# used when no segment ids are given; packed batches keep the two-kernel path, whose segment-block hints
+# skip whole documents.
+FUSED_BACKWARD = os.environ.get("LWM_FUSED_BWD", "0") == "1"
+
+
+def _use_fused(block, segment_ids):
+    return FUSED_BACKWARD and segment_ids is None and hasattr(block, "bwd_fused")
 
 
 # ----------------------------------------------------------------- helpers
@@ -384,6 +398,8 @@ def ring_backward(block, comm, q, k, v, out, lses, dout, *, layout, causal=True,
         sq, sk, kv = masks(qs, qs)
         kw = dict(q_start=qs[2], k_start=qs[2], causal=causal, seg_q=sq, seg_k=sk, key_valid=kv,
                   scale=scale)
+        if _use_fused(block, segment_ids):
+            return block.bwd_fused(q, k, v, dout, lses[0], deltas[0], dq_final=True, final=True, **kw)
         dk, dv = block.bwd_dkdv(q, k, v, dout, lses[0], deltas[0], final=True, **kw)
         dq = block.bwd_dq(q, k, v, dout, lses[0], deltas[0], final=True, **kw)
         return dq, dk, dv
@@ -521,13 +537,37 @@ def _mesh_backward(block, comm, q, k, v, lses, dout, deltas, *, layout, causal, 
                            final=False)
         return part
 
+    def run_fused(t, held):
+        """dq (chained) and the dk/dv partial of a REMOTE block in one launch per (q segment, k segment)."""
+        ksegs, pairs = pairs_at(t)
+        part = {}
+        for qi, ki in pairs:
+            qs, ks = qsegs[qi], ksegs[ki]
+            sq, sk, kv = masks(qs, ks)
+            done_dq[qi] += 1
+            fin = done_dq[qi] == n_dq[qi]
+            first = ki not in part
+            if first:
+                part[ki] = tuple(_xbuf(comm, block, ("part", t, ki, w), (B, ks[1], H, D), torch.float32, q) for w in (0, 1))
+            if dq_acc[qi] is None:          # a q segment with a single contribution still needs the accumulator
+                dq_acc[qi] = block.empty((B, qs[1], H, D), torch.float32, q)
+            block.bwd_fused(_rows(q, qs), held[ki][0], held[ki][1], _rows(dout, qs), lses[qi], deltas[qi],
+                            q_start=qs[2], k_start=ks[2], causal=causal, seg_q=sq, seg_k=sk, key_valid=kv, scale=scale,
+                            dq=_rows(dq, qs) if fin else None, dq_acc=dq_acc[qi], dq_carry_in=done_dq[qi] > 1,
+                            dq_final=fin, dk_acc=part[ki][0], dv_acc=part[ki][1], carry_in=not first, final=False)
+        return part
+
     own = layout.segments(r)
+    fused = _use_fused(block, segment_ids)
     run_dq(0, mesh.get(0))
     returned = {}     # t -> ({ki: (dk, dv)} received from rank r+t for MY segments, handle)
     for t in range(1, n):
         held = mesh.get(t)
-        run_dq(t, held)
-        part = run_dkdv(t, held)
+        if fused:
+            part = run_fused(t, held)
+        else:
+            run_dq(t, held)
+            part = run_dkdv(t, held)
         owner, giver = (r - t) % n, (r + t) % n
         sends = []
         for ki in _needed_ksegs(layout, r, owner, causal):   # == sorted(part)

@@ -1,6 +1,7 @@
 // tests/emu/launch.h -- host-emulation launch glue (TEST INFRASTRUCTURE ONLY).
 #pragma once
 #include <stdio.h>
+#include <string.h>
 
 namespace lwm {
 
@@ -10,6 +11,13 @@ inline int fail(int code, const char* fmt, const char* a = "", long x = 0, long 
     snprintf(g_err, sizeof(g_err), fmt, a, x, y);
     return code;
 }
+
+inline int zero_device(void* p, size_t bytes, void* stream) {
+    (void)stream;
+    memset(p, 0, bytes);
+    return 0;
+}
+inline long device_cu_count() { return 24; }   // a few "XCDs" worth of persistent workgroups
 
 template <class... KArgs, class... Args>
 inline int launch(const char* name, void (*kernel)(KArgs...), long grid, int threads,

@@ -206,6 +206,7 @@ LWM_DEVICE int block_idx_z() { return emu::g_blk->bz; }
 LWM_DEVICE int grid_dim_x() { return emu::g_blk->gx; }
 LWM_DEVICE lds_t dyn_lds() { return emu::kLdsBase; }
 LWM_DEVICE void block_sync() { emu::block_barrier(); }
+LWM_DEVICE void block_sync_lds() { emu::block_barrier(); }
 
 LWM_DEVICE f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
     emu::Wave& w = emu::g_blk->waves[emu::g_lane->tid >> 6];
@@ -221,6 +222,29 @@ LWM_DEVICE f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
         for (int k = 0; k < 16; ++k) {
             float av = (float)w.a[(k >> 3) * 32 + row][k & 7];
             float bv = (float)w.b[(k >> 3) * 32 + col][k & 7];
+            s += av * bv;
+        }
+        d[r] = s;
+    }
+    emu::wave_sync();
+    return d;
+}
+
+// v_mfma_f32_16x16x32_bf16: A[row = l&15][k = 8*(l>>4) + j], B[k][col = l&15], C[row = 4*(l>>4) + r][col = l&15]
+LWM_DEVICE f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+    emu::Wave& w = emu::g_blk->waves[emu::g_lane->tid >> 6];
+    int l = emu::g_lane->tid & 63;
+    w.a[l] = a;
+    w.b[l] = b;
+    emu::wave_sync();
+    f32x4 d;
+    int col = l & 15, g = l >> 4;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * g + r;
+        float s = c[r];
+        for (int k = 0; k < 32; ++k) {
+            float av = (float)w.a[(k >> 3) * 16 + row][k & 7];
+            float bv = (float)w.b[(k >> 3) * 16 + col][k & 7];
             s += av * bv;
         }
         d[r] = s;
@@ -267,6 +291,7 @@ LWM_DEVICE bf16x8 lds_read_b128(lds_t a) { bf16x8 v; memcpy(&v, emu::lds_ptr(a, 
 LWM_DEVICE f32x4 lds_read_f32x4(lds_t a) { f32x4 v; memcpy(&v, emu::lds_ptr(a, 16, 16), 16); return v; }
 LWM_DEVICE u32x4 lds_read_u32x4(lds_t a) { u32x4 v; memcpy(&v, emu::lds_ptr(a, 16, 16), 16); return v; }
 LWM_DEVICE void lds_write_b128(lds_t a, u32x4 v) { memcpy(emu::lds_ptr(a, 16, 16), &v, 16); }
+LWM_DEVICE void lds_write_b64(lds_t a, u32x2 v) { memcpy(emu::lds_ptr(a, 8, 8), &v, 8); }
 LWM_DEVICE void lds_write_f32x4(lds_t a, f32x4 v) { memcpy(emu::lds_ptr(a, 16, 16), &v, 16); }
 LWM_DEVICE void lds_write_i32(lds_t a, int32_t v) { memcpy(emu::lds_ptr(a, 4, 4), &v, 4); }
 LWM_DEVICE void lds_write_f32(lds_t a, float v) { memcpy(emu::lds_ptr(a, 4, 4), &v, 4); }
@@ -278,7 +303,12 @@ LWM_DEVICE void glds_load_b128(const void* g, lds_t wave_base) {
     int l = emu::g_lane->tid & 63;
     memcpy(emu::lds_ptr(wave_base + 16 * l, 16, 16), g, 16);
 }
+LWM_DEVICE void glds_load_b32(const void* g, lds_t wave_base) {
+    int l = emu::g_lane->tid & 63;
+    memcpy(emu::lds_ptr(wave_base + 4 * l, 4, 4), g, 4);
+}
 LWM_DEVICE void glds_wait_all() {}
+LWM_DEVICE void wait_vmem_all() {}
 LWM_DEVICE int wave_uniform(int x) { return x; }
 LWM_DEVICE void sched_fence() {}
 template <int A, int B>
@@ -286,6 +316,7 @@ LWM_DEVICE void sched_mfma_dsread() {}
 template <int N>
 LWM_DEVICE void sleep_cycles64() {}
 LWM_DEVICE uint32_t opaque(uint32_t x) { return x; }
+LWM_DEVICE void pin_value(float) {}
 LWM_DEVICE void prio_hi() {}
 LWM_DEVICE void prio_lo() {}
 template <int N>
@@ -333,6 +364,29 @@ LWM_DEVICE void global_store_b128(void* p, u32x4 v) { memcpy(p, &v, 16); }
 LWM_DEVICE void global_store_b64(void* p, u32x2 v) { memcpy(p, &v, 8); }
 LWM_DEVICE f32x4 global_load_f32x4(const float* p) { f32x4 v; memcpy(&v, p, 16); return v; }
 LWM_DEVICE void global_store_f32x4(float* p, f32x4 v) { memcpy(p, &v, 16); }
+
+// inter-workgroup hand-off: blocks run on different host threads, so the flag is a release/acquire pair and
+// the "XCC id" is the block index modulo 8 (what the hardware does in practice; the kernel must not rely on it)
+LWM_DEVICE int xcc_id() { return emu::g_blk->bx & 7; }
+LWM_DEVICE int load_i32_l2(const int32_t* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+LWM_DEVICE void store_i32_plain(int32_t* p, int32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+LWM_DEVICE int atomic_add_i32(int32_t* p, int32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+LWM_DEVICE int atomic_cas_i32(int32_t* p, int32_t expected, int32_t desired) {
+    __atomic_compare_exchange_n(p, &expected, desired, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+    return expected;
+}
+LWM_DEVICE void spin_pause() {
+    emu::g_blk->progress++;     // waiting on ANOTHER block is not a deadlock of this one
+    emu::yield();
+}
+LWM_DEVICE f32x4 global_load_f32x4_l2(const float* base, uint32_t byte_off) {
+    f32x4 v;
+    memcpy(&v, (const char*)base + byte_off, 16);
+    return v;
+}
+
+LWM_DEVICE void global_store_f32x4_async(float* p, f32x4 v) { memcpy(p, &v, 16); }
+LWM_DEVICE void global_store_b64_async(void* p, u32x2 v) { memcpy(p, &v, 8); }
 
 LWM_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
     union { bf16_t h[2]; uint32_t u; } x;

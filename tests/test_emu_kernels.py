@@ -10,6 +10,15 @@ from oracle import attention_ref as R
 from tests import _emu
 
 
+@pytest.fixture(params=[False, True], ids=["two_kernel_bwd", "fused_bwd"])
+def bwd_path(request):
+    """Every backward test runs through both lwm_attn_bwd_dkdv + lwm_attn_bwd_dq and lwm_attn_bwd_fused."""
+    old = _emu.FUSED_BWD
+    _emu.FUSED_BWD = request.param
+    yield request.param
+    _emu.FUSED_BWD = old
+
+
 def _rnd(shape, seed):
     return R.round_bf16(np.random.default_rng(seed).standard_normal(shape).astype(np.float32))
 
@@ -38,7 +47,7 @@ def _masks(B, S, Sk, seg, kv):
     (1, 100, 290, 1, False, False, True),     # q_len != kv_len
     (1, 1, 65, 1, False, False, False),
 ])
-def test_emulated_fwd_bwd(B, Sq, Sk, H, causal, seg, kv):
+def test_emulated_fwd_bwd(B, Sq, Sk, H, causal, seg, kv, bwd_path):
     q, k, v, do = _rnd((B, Sq, H, 128), 1), _rnd((B, Sk, H, 128), 2), _rnd((B, Sk, H, 128), 3), \
         _rnd((B, Sq, H, 128), 4)
     kw = dict(causal=causal, **_masks(B, Sq, Sk, seg, kv))
@@ -54,7 +63,7 @@ def test_emulated_fwd_bwd(B, Sq, Sk, H, causal, seg, kv):
 
 
 @pytest.mark.parametrize("Sq,Sk", [(0, 64), (64, 0), (1, 1), (33, 1), (257, 3)])
-def test_emulated_empty_and_degenerate_shapes(Sq, Sk):
+def test_emulated_empty_and_degenerate_shapes(Sq, Sk, bwd_path):
     """Empty query / key blocks (a rank whose shard sees nothing yet, an empty cache) and one-row
     blocks: no out-of-bounds access, out = 0 and lse = -inf where no key exists, zero gradients."""
     B, H = 1, 2
@@ -77,7 +86,7 @@ def test_emulated_empty_and_degenerate_shapes(Sq, Sk):
         assert near(dq, rq) and near(dk, rk) and near(dv, rv)
 
 
-def test_emulated_ring_carries():
+def test_emulated_ring_carries(bwd_path):
     """two kv blocks with f32 carries (a 2-step ring on one q block) == one shot,
     forward and backward, with global position offsets."""
     B, S, H = 1, 256, 1
@@ -143,7 +152,7 @@ def test_emulated_sum_f32_to_bf16():
 
 
 @pytest.mark.parametrize("monotone", [True, False])
-def test_emulated_packed_documents_are_skipped_not_changed(monotone):
+def test_emulated_packed_documents_are_skipped_not_changed(monotone, bwd_path):
     """Packed batch of several documents spanning many tiles: with the segment-block hints the
     kernels walk only their own documents' tiles; results equal the oracle and the hint-free run."""
     B, S, H = 1, 1536, 1

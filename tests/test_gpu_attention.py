@@ -70,6 +70,7 @@ def test_fwd_bwd_vs_oracle(B, Sq, Sk, H, causal, seg, kv):
     delta = ops.attn_bwd_delta(out, dod)
     dk, dv = ops.attn_bwd_dkdv_block(qd, kd, vd, dod, lse, delta, **kw)
     dq = ops.attn_bwd_dq_block(qd, kd, vd, dod, lse, delta, **kw)
+    fq, fk, fv = ops.attn_bwd_fused_block(qd, kd, vd, dod, lse, delta, **kw)     # one launch, S and dP once
     torch.cuda.synchronize()
     okw = dict(causal=causal, seg_q=seg_q, seg_k=seg_k, key_valid=key_valid)
     ro, rl = R.dense_attention(_np(q), _np(k), _np(v), **okw)
@@ -83,6 +84,49 @@ def test_fwd_bwd_vs_oracle(B, Sq, Sk, H, causal, seg, kv):
     _check("dq", _np(dq), rq)
     _check("dk", _np(dk), rk)
     _check("dv", _np(dv), rv)
+    _check("dq fused", _np(fq), rq)
+    _check("dk fused", _np(fk), rk)
+    _check("dv fused", _np(fv), rv)
+    # dk, dv: the same sums in the same order as the two-kernel path -> identical bits
+    assert torch.equal(fk, dk) and torch.equal(fv, dv)
+
+
+def test_fused_backward_is_deterministic_and_ordered():
+    """lwm_attn_bwd_fused accumulates dq across 256-key blocks through global memory, ordered by per-tile
+    counters.  Many key blocks per head, more work items than CUs, uneven head count (queues of different
+    length), carries in and out: repeated launches must give identical bits, equal to the oracle; and the
+    f32 carry path (dq_carry_in / not final) must add exactly onto what is there."""
+    import torch
+    from lwm_amd import ops
+    B, S, H = 2, 4096, 5
+    q, k, v, do = (_rand((B, S, H, 128), s).cuda() for s in (61, 62, 63, 64))
+    out, lse = ops.attn_fwd_block(q, k, v, causal=True)
+    delta = ops.attn_bwd_delta(out, do)
+    ref = ops.attn_bwd_fused_block(q, k, v, do, lse, delta, causal=True)
+    torch.cuda.synchronize()
+    assert not ops.fused_backward_gave_up()
+    for _ in range(4):
+        got = ops.attn_bwd_fused_block(q, k, v, do, lse, delta, causal=True)
+        torch.cuda.synchronize()
+        assert not ops.fused_backward_gave_up()
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+    f = lambda t: _np(t[:1, :, 2:3])
+    rq, rk, rv = R.dense_attention_bwd(f(q), f(k), f(v), f(do), causal=True)
+    _check("dq fused 4096", f(ref[0]), rq)
+    _check("dk fused 4096", f(ref[1]), rk)
+    _check("dv fused 4096", f(ref[2]), rv)
+    # carries: start from a known f32 dq carry, leave the result in f32
+    carry = torch.randn(B, S, H, 128, device="cuda")
+    acc = carry.clone()
+    dqa, dka, dva = ops.attn_bwd_fused_block(q, k, v, do, lse, delta, causal=True, dq_acc=acc, dq_carry_in=True,
+                                             dq_final=False, final=False)
+    plain = ops.attn_bwd_fused_block(q, k, v, do, lse, delta, causal=True, dq_final=False, final=False)
+    torch.cuda.synchronize()
+    assert dqa.data_ptr() == acc.data_ptr()
+    assert ((dqa - carry) - plain[0]).abs().max().item() <= 1e-4 * plain[0].abs().max().item()
+    assert torch.equal(dka, plain[1]) and torch.equal(dva, plain[2])
+    assert torch.equal(ops.cast_f32_to_bf16(plain[0]), ref[0])
 
 
 def test_softmax_rescale_branch_is_exercised():
