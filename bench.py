@@ -80,7 +80,7 @@ VQGAN_ENC_GFLOP, VQGAN_DEC_GFLOP = 216.6, 477.4   # per 256x256 frame, SURVEY.md
 MFMA_F32_PEAK_TFLOPS = 157.3                      # exact-f32 MFMA, MI355X_MICROARCH.md
 
 
-def vqgan_leg(torch, frames=32, reps=3):
+def vqgan_leg(torch, frames=32, reps=3, config4_frames=1020):
     """Secondary leg (not part of `value`): VQGAN encode/decode of synthetic
     256x256 frames U(-1,1), random weights of the default VQGANConfig
     (lwm/vqgan.py:62-77), frames resident in HBM; plus the C oracle on the host
@@ -109,11 +109,29 @@ def vqgan_leg(torch, frames=32, reps=3):
 
     t_enc, (_, idx) = timed(lambda: vq.encode(px))
     t_dec, _ = timed(lambda: vq.decode(idx))
+    # BASELINE configs[3]: a 256K-token vision-language sequence = floor(262144 / 257) = 1020 frames
+    # (lwm/vision_chat.py:91-108 tokenises them one by one); here in chunks of `frames`, frames resident in HBM
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n_chunks = -(-config4_frames // frames)
+    e0.record()
+    n_codes = 0
+    for c in range(n_chunks):
+        n = min(frames, config4_frames - c * frames)
+        _, ids = vq.encode(px[:n])
+        n_codes += ids.numel()
+    e1.record()
+    torch.cuda.synchronize()
+    t_cfg4 = e0.elapsed_time(e1) * 1e-3
     res = {
         "workload": f"VQGAN default config, {frames} frames 256x256, f32 (exact-f32 MFMA), random weights",
         "encode_frames_per_s": frames / t_enc, "decode_frames_per_s": frames / t_dec,
         "encode_tflops": frames * VQGAN_ENC_GFLOP / t_enc / 1e3,
         "decode_tflops": frames * VQGAN_DEC_GFLOP / t_dec / 1e3,
+        "config4_tokenisation": {
+            "workload": f"{config4_frames} frames 256x256 -> {n_codes} codes (+1 delimiter each = {config4_frames * 257} tokens: "
+                        f"BASELINE configs[3]'s 256K vision-language sequence), encode in chunks of {frames}",
+            "seconds": t_cfg4, "frames_per_s": config4_frames / t_cfg4,
+            "tflops": config4_frames * VQGAN_ENC_GFLOP / t_cfg4 / 1e3},
         "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TFLOPS,
                      "achieved": frames * VQGAN_DEC_GFLOP / t_dec / 1e3,
                      "frac": frames * VQGAN_DEC_GFLOP / t_dec / 1e3 / MFMA_F32_PEAK_TFLOPS,
@@ -217,7 +235,83 @@ def model_slice_leg(torch, S=32768):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"workload": f"LWM-7B 2-layer slice + lm_head, B=1, S={S}, bf16, fwd+bwd", "ms": dt * 1e3,
-            "tokens_per_s": S / dt, "loss": float(loss)}
+            "tokens_per_s": S / dt, "loss": float(loss.detach())}
+
+
+def model_full_leg(torch, S=32768, layers=N_LAYERS):
+    """Secondary leg: ALL 32 layers of LWM-7B (6.74 B parameters, random
+    init, bf16) at S = 32768, one forward+backward through the harness on ONE MI355X -- embedding, 32 x
+    (RMSNorm, QKV, RoPE, RingAttention ring=1, wo, RMSNorm, blockwise SwiGLU FFN with chunk recompute),
+    final norm, chunked lm_head + cross-entropy.  No optimizer step (the hot path ends at the gradients).
+    Model FLOPs per token: 6 x 6.74e9 dense + 7 x S x d_model x L attention."""
+    from lwm_amd.llama import LLaMAConfig, LLaMAForCausalLM
+    cfg = LLaMAConfig.load_config("7b", num_hidden_layers=layers, max_sequence_length=S, theta=1e7)
+    torch.manual_seed(0)
+    with torch.device("cuda"):
+        model = LLaMAForCausalLM(cfg)
+    n_params = sum(p.numel() for p in model.parameters())
+    tok = torch.randint(0, cfg.vocab_size, (1, S + 1), device="cuda")
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        loss, _ = model.loss(tok[:, :-1], tok[:, 1:], chunk=8192)
+        loss.backward()
+        return loss
+
+    step()
+    torch.cuda.synchronize()
+    peak0 = torch.cuda.max_memory_allocated()
+    t0 = time.perf_counter()
+    loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dense = 6.0 * n_params * S
+    attn = 7.0 * gemm_unit_flops(S) * layers
+    out = {"workload": f"LWM-7B, all {layers} layers + embedding + lm_head ({n_params / 1e9:.2f} B parameters), B=1, S={S}, "
+                       f"bf16, forward+backward, one GPU",
+           "ms_per_step": dt * 1e3, "tokens_per_s": S / dt, "loss": float(loss.detach()),
+           "model_tflops": (dense + attn) / dt / 1e12, "attention_share_of_flops": attn / (dense + attn),
+           "peak_hbm_gib": peak0 / 2 ** 30}
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
+def packed_1m_leg(torch, S=1 << 20, layers=2):
+    """Optional leg (--packed-1m): BASELINE configs[4]'s problem on ONE GPU -- a 1,048,576-token batch of packed
+    documents (log-uniform lengths in [4K, 256K]), attention forward+backward of `layers`
+    layers; FLOPs counted over visible (same-document, causal) pairs only."""
+    import numpy as np
+    from lwm_amd.ring import HipBlockOps, SeqLayout, SingleComm, ring_backward, ring_forward
+    rng = np.random.default_rng(0)
+    seg = np.zeros((1, S), np.int32)
+    pos, d, lens = 0, 0, []
+    while pos < S:
+        ln = min(int(np.exp(rng.uniform(np.log(4096), np.log(262144)))), S - pos)
+        seg[:, pos:pos + ln] = d
+        lens.append(ln)
+        pos, d = pos + ln, d + 1
+    segd = torch.from_numpy(seg).cuda()
+    g = torch.Generator(device="cuda").manual_seed(2)
+    mk = lambda: torch.randn(1, S, N_HEADS, HEAD_DIM, generator=g, device="cuda", dtype=torch.bfloat16)
+    q, k, v, do = mk(), mk(), mk(), mk()
+    lay, comm = SeqLayout("contiguous", 1, S), SingleComm()
+
+    def layer():
+        out, lses = ring_forward(HipBlockOps, comm, q, k, v, layout=lay, causal=True, segment_ids=segd)
+        ring_backward(HipBlockOps, comm, q, k, v, out, lses, do, layout=lay, causal=True, segment_ids=segd)
+
+    layer()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(layers):
+        layer()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / layers
+    flops = 7.0 * sum(float(l) * l for l in lens) * D_MODEL
+    return {"workload": f"attention fwd+bwd, S={S}, {len(lens)} packed documents (lengths {min(lens)}..{max(lens)}), "
+                        f"32 heads, per layer, one GPU [BASELINE configs[4] problem]",
+            "s_per_layer": dt, "tokens_per_s_32_layers": S / (dt * N_LAYERS), "algorithmic_tflops": flops / dt / 1e12}
 
 
 def decode_leg(torch, K=131072):
@@ -507,11 +601,14 @@ def main():
                     help="A/B: run the backward as the one-launch lwm_attn_bwd_fused (5 GEMM units executed) instead "
                          "of lwm_attn_bwd_dkdv + lwm_attn_bwd_dq (7); also LWM_FUSED_BWD=1")
     ap.add_argument("--two-kernel-bwd", action="store_true", help="(default) the two-kernel backward")
+    ap.add_argument("--c-ring", action="store_true",
+                    help="N > 1: run the exchange through the C-ABI ring driver (lwm_ring_attn_fwd/bwd: RCCL send/recv on a "
+                         "side HIP stream, contiguous ownership, the reference's ring schedule) instead of lwm_amd/ring.py")
     ap.add_argument("--init-timeout", type=int, default=180,
                     help="seconds before a stuck RCCL rendezvous / first collective is reported as an error line")
-    ap.add_argument("--full-model", action="store_true",
-                    help="also time all 32 layers of LWM-7B fwd+bwd at S=32768 (N=1 leg `model_full`; on by default "
-                         "when no leg is disabled)")
+    ap.add_argument("--no-full-model", action="store_true", help="skip the N=1 leg `model_full` (all 32 layers of LWM-7B)")
+    ap.add_argument("--packed-1m", action="store_true",
+                    help="also run the 1M-token packed-documents leg (BASELINE configs[4]'s problem on one GPU, ~25 s)")
     args = ap.parse_args()
 
     under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
@@ -609,8 +706,20 @@ def main():
         bwd_dkdv = staticmethod(lambda *a, **kw: timer.run("attn_bwd_dkdv_kernel", ops.attn_bwd_dkdv_block, *a, **kw))
         bwd_fused = staticmethod(lambda *a, **kw: timer.run("attn_bwd_fused_kernel", ops.attn_bwd_fused_block, *a, **kw))
 
+    c_ring = None
+    if args.c_ring and world > 1 and not dry:
+        from lwm_amd.ring_c import CRing
+        if args.layout != "contiguous":
+            args.layout = "contiguous"
+            layout = SeqLayout("contiguous", world, S)
+        c_ring = CRing(dist.group.WORLD)
+
     def step():
         for _ in range(args.layers):
+            if c_ring is not None:
+                o_, l_ = c_ring.forward(q, k, v, causal=True, segment_ids=segment_ids)
+                c_ring.backward(q, k, v, o_, l_, do, causal=True, segment_ids=segment_ids)
+                continue
             out, lses = ring_forward(TimedOps, comm, q, k, v, layout=layout, causal=True, segment_ids=segment_ids)
             ring_backward(TimedOps, comm, q, k, v, out, lses, do, layout=layout, causal=True,
                           segment_ids=segment_ids)
@@ -709,7 +818,8 @@ def main():
                              + (" [BASELINE configs[1]]" if world == 1 and S == 32768 and not args.packed else "")
                              + (" [BASELINE configs[2] problem]" if world > 1 and S == 131072 else "")),
                 "seq_len": S, "ring": world, "layers": args.layers,
-                "exchange_schedule": getattr(comm, "schedule", None) if world > 1 else None,
+                "exchange_schedule": ("ring (C-ABI driver, RCCL on a side stream)" if c_ring is not None else
+                                      getattr(comm, "schedule", None)) if world > 1 else None,
             },
             "tokens_per_s_per_gpu": tokens_per_s / world,
             "exchange": exchange,
@@ -747,6 +857,10 @@ def main():
                 res["vqgan"] = vqgan_leg(torch)
                 res["packed"] = packed_leg(torch)
                 res["model_slice"] = model_slice_leg(torch)
+                if not args.no_full_model:
+                    res["model_full"] = model_full_leg(torch)
+                if args.packed_1m:
+                    res["packed_1m"] = packed_1m_leg(torch)
                 res["decode"] = decode_leg(torch)
                 res["generate"] = generate_leg(torch)
                 res["ring8_compute_model"] = ring_model_leg(torch)

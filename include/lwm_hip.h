@@ -117,6 +117,63 @@ int lwm_attn_bwd_dkdv(const LwmAttnArgs* args, void* stream);
 int64_t lwm_attn_bwd_fused_workspace_bytes(int32_t B, int32_t H, int32_t Sq);
 int lwm_attn_bwd_fused(const LwmAttnArgs* args, void* stream);
 
+/* ------------------------------------------------------------------ the sequence ring
+ * The exchange that lax.ppermute performs under ringattention (lwm/llama.py:539-569, SURVEY.md Appendix
+ * A.1), driven from C: for ring step t rank r holds the K/V block of rank (r - t) mod n, runs the local
+ * queries against it on the COMPUTE stream while the block travels on to rank r+1 and the next one arrives
+ * from rank r-1 on the SIDE stream (grouped ncclSend / ncclRecv of RCCL over xGMI), hipEvents handing the
+ * double buffer back and forth.  The backward rotates K, V and the f32 dK/dV carries of the block; after n
+ * steps they are home.  Ownership is the reference's: rank r holds positions [r*c, (r+1)*c) (contiguous,
+ * lwm/llama.py:560-562); attn_bias / segment_ids are replicated, full length (lwm/llama.py:563-564).
+ *
+ * A ring object holds no device memory: the caller passes a workspace of lwm_ring_workspace_bytes()
+ * bytes (K/V double buffer, f32 carries, mask slices), which must stay untouched until the compute stream
+ * has passed the call.  Transports:
+ *   lwm_ring_create            an existing ncclComm_t of the "sp" group (RCCL is resolved at run time:
+ *                              dlsym in the process, else dlopen librccl.so -- the library has no link-time
+ *                              dependency on it);
+ *   lwm_ring_create_from_id    the library creates (and owns) the communicator from an ncclUniqueId
+ *                              (lwm_ring_unique_id on rank 0, broadcast by the host's own means);
+ *   lwm_ring_create_transport  any send/recv pair given as function pointers (tests drive the schedule
+ *                              through it with in-process mailboxes; n = 1 needs no transport at all).
+ */
+typedef struct LwmRing LwmRing;
+
+typedef struct LwmRingTransport {
+    void* ctx;
+    int (*group_start)(void* ctx);
+    /* enqueue on `stream` (a hipStream_t): send `bytes` bytes at `buf` to ring rank `peer` / receive from it */
+    int (*send)(void* ctx, const void* buf, int64_t bytes, int32_t peer, void* stream);
+    int (*recv)(void* ctx, void* buf, int64_t bytes, int32_t peer, void* stream);
+    int (*group_end)(void* ctx);
+} LwmRingTransport;
+
+typedef struct LwmRingArgs {
+    LwmTensor4 q, k, v;      /* local shards [B,c,H,D] bf16; k and v dense (they are sent as they are) */
+    LwmTensor4 out;          /* fwd: written; bwd: read */
+    float* lse;              /* [B,H,c] f32: fwd writes, bwd reads */
+    LwmTensor4 dout;         /* bwd in */
+    LwmTensor4 dq, dk, dv;   /* bwd out, [B,c,H,D] bf16 */
+    const int32_t* segment_ids; /* [B,S_global] or NULL -- replicated, full length */
+    const uint8_t* key_valid;   /* [B,S_global] or NULL */
+    int32_t B, c, H, D;      /* c = local sequence length = S_global / n */
+    float scale;
+    int32_t causal;
+    void* workspace;         /* lwm_ring_workspace_bytes(B, c, H, D, backward) bytes, 256-byte aligned */
+} LwmRingArgs;
+
+int lwm_ring_create(void* nccl_comm, int32_t rank, int32_t n, void* side_stream, LwmRing** out);
+int lwm_ring_unique_id(void* id128);   /* 128 bytes = ncclUniqueId */
+int lwm_ring_create_from_id(const void* id128, int32_t rank, int32_t n, void* side_stream, LwmRing** out);
+int lwm_ring_create_transport(const LwmRingTransport* transport, int32_t rank, int32_t n, void* side_stream,
+                              LwmRing** out);
+int lwm_ring_destroy(LwmRing* ring);
+int64_t lwm_ring_workspace_bytes(int32_t B, int32_t c, int32_t H, int32_t D, int32_t backward);
+int lwm_ring_attn_fwd(LwmRing* ring, const LwmRingArgs* args, void* compute_stream);
+int lwm_ring_attn_bwd(LwmRing* ring, const LwmRingArgs* args, void* compute_stream);
+/* bytes this ring object has sent since creation (diagnostic) */
+int64_t lwm_ring_bytes_sent(const LwmRing* ring);
+
 /* (min, max) of segment_ids over each block of 32 rows, excluding rows whose valid[] is 0
  * (valid may be NULL); an all-invalid block gets (INT32_MAX, INT32_MIN).
  * blocks: [B][ceil(S/32)][2] int32. */
@@ -243,7 +300,7 @@ int lwm_vq_gather_f32(const float* codebook, const int32_t* idx, const float* z,
 
 const char* lwm_last_error(void);
 int lwm_version(void);
-/* sizeof(LwmAttnArgs) (which = 0) / sizeof(LwmConvArgs) (1) as compiled into the library:
+/* sizeof(LwmAttnArgs) (which = 0) / sizeof(LwmConvArgs) (1) / sizeof(LwmRingArgs) (2) as compiled into the library:
  * lets a foreign-language binding verify its struct mirror at load time. */
 int lwm_sizeof(int which);
 

@@ -37,6 +37,25 @@ class LwmAttnArgs(C.Structure):
     ]
 
 
+class LwmRingArgs(C.Structure):
+    _fields_ = [
+        ("q", LwmTensor4), ("k", LwmTensor4), ("v", LwmTensor4), ("out", LwmTensor4),
+        ("lse", C.c_void_p), ("dout", LwmTensor4), ("dq", LwmTensor4), ("dk", LwmTensor4), ("dv", LwmTensor4),
+        ("segment_ids", C.c_void_p), ("key_valid", C.c_void_p),
+        ("B", C.c_int32), ("c", C.c_int32), ("H", C.c_int32), ("D", C.c_int32),
+        ("scale", C.c_float), ("causal", C.c_int32), ("workspace", C.c_void_p),
+    ]
+
+
+RING_GROUP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+RING_SEND_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)
+
+
+class LwmRingTransport(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("group_start", RING_GROUP_FN), ("send", RING_SEND_FN), ("recv", RING_SEND_FN),
+                ("group_end", RING_GROUP_FN)]
+
+
 class LwmConvArgs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p),
                 ("y", C.c_void_p)] + [(n, C.c_int32) for n in (
@@ -52,6 +71,16 @@ PROTOTYPES = {
     "lwm_attn_bwd_dkdv": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
     "lwm_attn_bwd_fused": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
     "lwm_attn_bwd_fused_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "lwm_ring_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "lwm_ring_unique_id": (C.c_int, [C.c_void_p]),
+    "lwm_ring_create_from_id": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "lwm_ring_create_transport": (C.c_int, [C.POINTER(LwmRingTransport), C.c_int32, C.c_int32, C.c_void_p,
+                                            C.POINTER(C.c_void_p)]),
+    "lwm_ring_destroy": (C.c_int, [C.c_void_p]),
+    "lwm_ring_workspace_bytes": (C.c_int64, [C.c_int32] * 5),
+    "lwm_ring_attn_fwd": (C.c_int, [C.c_void_p, C.POINTER(LwmRingArgs), C.c_void_p]),
+    "lwm_ring_attn_bwd": (C.c_int, [C.c_void_p, C.POINTER(LwmRingArgs), C.c_void_p]),
+    "lwm_ring_bytes_sent": (C.c_int64, [C.c_void_p]),
     "lwm_attn_segment_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "lwm_attn_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, LwmTensor4, C.c_void_p, C.c_void_p,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
@@ -89,7 +118,7 @@ def bind(lib):
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    for which, cls in ((0, LwmAttnArgs), (1, LwmConvArgs)):
+    for which, cls in ((0, LwmAttnArgs), (1, LwmConvArgs), (2, LwmRingArgs)):
         if lib.lwm_sizeof(which) != C.sizeof(cls):
             raise ImportError(f"{cls.__name__}: ctypes mirror is {C.sizeof(cls)} bytes, library has "
                               f"{lib.lwm_sizeof(which)} (include/lwm_hip.h and lwm_amd/_capi.py out of step)")

@@ -14,3 +14,4 @@
 #include "misc_kernels.h"
 #include "llama_elem.h"
 #include "api.inc"
+#include "ring_driver.inc"

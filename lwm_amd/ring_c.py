@@ -1,0 +1,146 @@
+"""The sequence ring driven from C (include/lwm_hip.h, lwm_ring_*): RCCL ncclSend / ncclRecv of the K/V
+blocks (and, in the backward, of the f32 dK/dV carries) on a side HIP stream, hipEvents handing a double
+buffer between the exchange and the attention kernels on the compute stream -- the replacement of the
+lax.ppermute under `ringattention` (lwm/llama.py:539-569) for hosts that are not
+Python.  This module is the thin torch caller: it creates the ring object, owns the workspace tensor and
+wraps the two entry points in an autograd Function.
+
+Ownership is the reference's contiguous one (rank r holds positions [r*c, (r+1)*c), lwm/llama.py:560-562)
+and the schedule is the reference's ring.  The Python driver (lwm_amd/ring.py) additionally offers the
+zigzag ownership and the full-mesh schedule; `ring_attention_c` is the C-ABI path with the same results
+as ring.py's (layout="contiguous", schedule="ring")."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _capi
+from ._lib import lib
+from .ops import _t4
+
+
+class CRing:
+    """One ring object per (process group, device).  transport: None = RCCL (a communicator is created from
+    an ncclUniqueId broadcast over `group`), or a _capi.LwmRingTransport (tests)."""
+
+    def __init__(self, group=None, *, rank=None, size=None, transport=None, device=None):
+        import torch.distributed as dist
+        L = lib()
+        if rank is None:
+            if dist.is_available() and dist.is_initialized():
+                rank, size = dist.get_rank(group), dist.get_world_size(group)
+            else:
+                rank, size = 0, 1
+        self.rank, self.size = int(rank), int(size)
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.side = torch.cuda.Stream(device=self.device) if self.size > 1 else None
+        side_ptr = C.c_void_p(self.side.cuda_stream) if self.side is not None else None
+        h = C.c_void_p()
+        self._transport = transport           # keep the callbacks alive
+        if self.size == 1:
+            rc = L.lwm_ring_create(None, 0, 1, None, C.byref(h))
+        elif transport is not None:
+            rc = L.lwm_ring_create_transport(C.byref(transport), self.rank, self.size, side_ptr, C.byref(h))
+        else:
+            ident = (C.c_char * 128)()
+            if self.rank == 0:
+                _capi.check(L, L.lwm_ring_unique_id(ident), "lwm_ring_unique_id")
+            box = [bytes(ident)]
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(box, src=src, group=group)
+            ident = (C.c_char * 128).from_buffer_copy(box[0])
+            rc = L.lwm_ring_create_from_id(ident, self.rank, self.size, side_ptr, C.byref(h))
+        _capi.check(L, rc, "lwm_ring_create")
+        self._h = h
+        self._ws = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().lwm_ring_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def bytes_sent(self):
+        return int(lib().lwm_ring_bytes_sent(self._h))
+
+    def _workspace(self, B, c, H, D, backward):
+        need = int(lib().lwm_ring_workspace_bytes(B, c, H, D, int(backward)))
+        if self._ws is None or self._ws.numel() < need + 256:
+            self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+        off = (-self._ws.data_ptr()) % 256
+        return self._ws.data_ptr() + off
+
+    def _args(self, q, k, v, out, lse, segment_ids, key_valid, scale, causal, backward):
+        B, c, H, D = q.shape
+        a = _capi.LwmRingArgs()
+        a.q, a.k, a.v, a.out = _t4(q, "q"), _t4(k, "k"), _t4(v, "v"), _t4(out, "out")
+        a.lse = lse.data_ptr()
+        a.B, a.c, a.H, a.D = B, c, H, D
+        a.scale = float(scale) if scale is not None else 1.0 / D ** 0.5
+        a.causal = int(bool(causal))
+        Sg = c * self.size
+        if segment_ids is not None:
+            if segment_ids.dtype != torch.int32 or tuple(segment_ids.shape) != (B, Sg) or not segment_ids.is_contiguous():
+                raise ValueError(f"segment_ids: expected contiguous int32 {(B, Sg)} (replicated, full length)")
+            a.segment_ids = segment_ids.data_ptr()
+        if key_valid is not None:
+            if key_valid.dtype != torch.uint8 or tuple(key_valid.shape) != (B, Sg) or not key_valid.is_contiguous():
+                raise ValueError(f"key_valid: expected contiguous uint8 {(B, Sg)} (replicated, full length)")
+            a.key_valid = key_valid.data_ptr()
+        a.workspace = self._workspace(B, c, H, D, backward)
+        return a
+
+    def forward(self, q, k, v, *, causal=True, segment_ids=None, key_valid=None, scale=None):
+        B, c, H, D = q.shape
+        k, v = k.contiguous(), v.contiguous()
+        out = torch.empty((B, c, H, D), dtype=torch.bfloat16, device=q.device)
+        lse = torch.empty((B, H, c), dtype=torch.float32, device=q.device)
+        a = self._args(q, k, v, out, lse, segment_ids, key_valid, scale, causal, False)
+        L = lib()
+        _capi.check(L, L.lwm_ring_attn_fwd(self._h, C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                    "lwm_ring_attn_fwd")
+        return out, lse
+
+    def backward(self, q, k, v, out, lse, dout, *, causal=True, segment_ids=None, key_valid=None, scale=None):
+        B, c, H, D = q.shape
+        k, v, dout = k.contiguous(), v.contiguous(), dout.contiguous()
+        dq, dk, dv = (torch.empty((B, c, H, D), dtype=torch.bfloat16, device=q.device) for _ in range(3))
+        a = self._args(q, k, v, out, lse, segment_ids, key_valid, scale, causal, True)
+        a.dout, a.dq, a.dk, a.dv = _t4(dout, "dout"), _t4(dq, "dq"), _t4(dk, "dk"), _t4(dv, "dv")
+        L = lib()
+        _capi.check(L, L.lwm_ring_attn_bwd(self._h, C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                    "lwm_ring_attn_bwd")
+        return dq, dk, dv
+
+
+class _RingAttentionC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, ring, causal, segment_ids, key_valid, scale):
+        out, lse = ring.forward(q, k, v, causal=causal, segment_ids=segment_ids, key_valid=key_valid, scale=scale)
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.cfg = (ring, causal, segment_ids, key_valid, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        ring, causal, segment_ids, key_valid, scale = ctx.cfg
+        dq, dk, dv = ring.backward(q, k, v, out, lse, dout, causal=causal, segment_ids=segment_ids,
+                                   key_valid=key_valid, scale=scale)
+        return dq, dk, dv, None, None, None, None, None
+
+
+def ring_attention_c(q, k, v, ring: CRing, *, causal=True, segment_ids=None, key_valid=None, scale=None):
+    """Differentiable ring attention on the local (B, S/n, H, D) shards through lwm_ring_attn_fwd / _bwd."""
+    if segment_ids is not None and segment_ids.dtype != torch.int32:
+        segment_ids = segment_ids.to(torch.int32)
+    if key_valid is not None and key_valid.dtype != torch.uint8:
+        key_valid = (key_valid != 0).to(torch.uint8)
+    return _RingAttentionC.apply(q, k, v, ring, causal, segment_ids, key_valid, scale)

@@ -18,3 +18,18 @@
 #include "vqgan_conv.h"
 #include "vqgan_misc.h"
 #include "vqgan_api.inc"
+
+// The ring driver is HIP-runtime code (streams, events, RCCL): not emulated.  The emulated library still
+// exports the symbols so that one ctypes binding serves both builds.
+extern "C" {
+#define LWM_EMU_NO_RING(ret, name, ...) ret name(__VA_ARGS__) { return (ret)lwm::fail(LWM_EUNSUPPORTED, "%s", #name ": not in the host emulation"); }
+LWM_EMU_NO_RING(int, lwm_ring_create, void*, int32_t, int32_t, void*, LwmRing**)
+LWM_EMU_NO_RING(int, lwm_ring_unique_id, void*)
+LWM_EMU_NO_RING(int, lwm_ring_create_from_id, const void*, int32_t, int32_t, void*, LwmRing**)
+LWM_EMU_NO_RING(int, lwm_ring_create_transport, const LwmRingTransport*, int32_t, int32_t, void*, LwmRing**)
+LWM_EMU_NO_RING(int, lwm_ring_destroy, LwmRing*)
+LWM_EMU_NO_RING(int64_t, lwm_ring_workspace_bytes, int32_t, int32_t, int32_t, int32_t, int32_t)
+LWM_EMU_NO_RING(int, lwm_ring_attn_fwd, LwmRing*, const LwmRingArgs*, void*)
+LWM_EMU_NO_RING(int, lwm_ring_attn_bwd, LwmRing*, const LwmRingArgs*, void*)
+LWM_EMU_NO_RING(int64_t, lwm_ring_bytes_sent, const LwmRing*)
+}
