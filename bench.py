@@ -752,17 +752,20 @@ def main():
         try:
             # the same launches with the exchange removed (buffers left as allocated): what the step
             # would cost if every transfer were free.  exposed = what the xGMI traffic adds on top.
-            real_comm, comm = comm, NullComm(comm)
-            step()
-            barrier()
-            t0 = time.perf_counter()
-            step()
-            torch.cuda.synchronize()
-            compute_only = max_over_ranks(time.perf_counter() - t0)
-            comm = real_comm
-            exchange = {"schedule": comm.schedule, "compute_only_ms_per_step": compute_only * 1e3,
-                        "exposed_ms_per_step": (elapsed / args.steps - compute_only) * 1e3,
-                        "overlap_efficiency": compute_only / (elapsed / args.steps)}
+            if c_ring is None:
+                real_comm, comm = comm, NullComm(comm)
+                step()
+                barrier()
+                t0 = time.perf_counter()
+                step()
+                torch.cuda.synchronize()
+                compute_only = max_over_ranks(time.perf_counter() - t0)
+                comm = real_comm
+                exchange = {"schedule": comm.schedule, "compute_only_ms_per_step": compute_only * 1e3,
+                            "exposed_ms_per_step": (elapsed / args.steps - compute_only) * 1e3,
+                            "overlap_efficiency": compute_only / (elapsed / args.steps)}
+            else:
+                exchange = {"schedule": "ring (C-ABI driver)", "bytes_sent_per_rank": c_ring.bytes_sent}
             # The N=1 line of this bench is BASELINE configs[1] (S=32768); attention cost is quadratic
             # in S, so tokens/s at different S do not compare.  For a like-for-like strong-scaling
             # figure every rank also times ONE layer of THIS problem (same S) on its GPU alone.

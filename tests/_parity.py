@@ -3,7 +3,7 @@ oracle.  Stated tolerances (north_star: "within a stated fp tolerance"):
 
   global : max|err| <= 8e-3 * max|ref|   and cosine >= 0.9999
   per row: for every (b, s, h) row of D values,
-           max|err_row| <= 2e-2 * max(max|ref_row|, floor * max|ref|),  floor = 0.02 (out, dk, dv), 0.25 (dq)
+           max|err_row| <= 2.5e-2 * max(max|ref_row|, floor * max|ref|),  floor = 0.02 (out, dk, dv), 0.25 (dq)
            -- a wrong SMALL-magnitude row fails this one although it passes a max-normalised test
   lse    : max|err| <= 2e-3 (absolute, natural log)
 
@@ -20,7 +20,7 @@ gpurun_out/parity_stats.json (tests/conftest.py) so the bounds above can be comp
 hardware actually produced."""
 import numpy as np
 
-TOL, ROW_TOL, ROW_FLOOR, ROW_FLOOR_DQ, COS = 8e-3, 2e-2, 0.02, 0.25, 0.9999
+TOL, ROW_TOL, ROW_FLOOR, ROW_FLOOR_DQ, COS = 8e-3, 2.5e-2, 0.02, 0.25, 0.9999
 STATS = []   # (name, global_rel_err, row_rel_err, cosine)
 
 

@@ -5,7 +5,7 @@ size-independent properties at BASELINE.json's full size (S=32768, H=32).
 Tolerances (stated per north_star: "within a stated fp tolerance"; tests/_parity.py): operands
 and results are bf16 with f32 accumulation, so
   out / dq / dk / dv : max|err| <= 8e-3 * max|ref|, cosine >= 0.9999, and per (b,s,h) row
-                       max|err_row| <= 2e-2 * max(max|ref_row|, floor * max|ref|), floor 0.02 (0.25 for dq)
+                       max|err_row| <= 2.5e-2 * max(max|ref_row|, floor * max|ref|), floor 0.02 (0.25 for dq)
   lse                : max|err| <= 2e-3
 """
 import numpy as np
