@@ -154,23 +154,26 @@ def vqgan_leg(torch, frames=32, reps=3, config4_frames=1020):
     return res
 
 
+PROFILE_ROUND = "r02"      # only PMC summaries of THIS round's kernels may label this round's bench line
+
+
 def pmc_traffic(kernel, S):
-    """HBM bytes per launch of `kernel` from the committed PMC passes of this same
-    command (profiles/*pmc_attention*.json: FETCH_SIZE x2 gfx950 correction +
-    WRITE_SIZE, separate rocprofv3 --pmc passes).  bench.py cannot collect
-    counters itself; null when no profile of this workload is committed."""
+    """(HBM bytes per launch of `kernel`, profile file) from the committed PMC passes of this same command
+    and ROUND (profiles/r02*pmc_attention*.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
+    rocprofv3 --pmc passes).  bench.py cannot collect counters itself; (None, None) when no profile of this
+    workload and round is committed -- a stale file must not label a newer kernel."""
     if S != 32768:
-        return None
+        return None, None
     import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_attention*.json"))):
+    best = (None, None)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", PROFILE_ROUND + "*pmc_attention*.json"))):
         try:
             ks = json.load(open(f))["kernels"]
         except Exception:
             continue
         for name, d in ks.items():
             if name.startswith(kernel) and "hbm_traffic_bytes" in d:
-                best = d["hbm_traffic_bytes"]
+                best = (d["hbm_traffic_bytes"], os.path.relpath(f, ROOT))
     return best
 
 
@@ -848,7 +851,7 @@ def main():
             res["roofline"] = {
                 "kernel": dom, "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
-                "traffic": pmc_traffic(dom, S),
+                "traffic": pmc_traffic(dom, S)[0], "traffic_profile": pmc_traffic(dom, S)[1],
                 "avg_launch_ms": cand[dom]["avg_ms"],
                 "executed_tflops": exec_units[dom] * unit / avg_s / 1e12,
                 "all_kernels_algorithmic_tflops": {

@@ -14,16 +14,25 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01x"
+dirs = sys.argv[2:] or ["pmc"]          # gpurun_out/<dir>: several runs (e.g. pmc pmc_fused) are merged by kernel name
 csv.field_size_limit(1 << 30)
 kern = {}
-for fn in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pmc", "pass*_counter_collection.csv"))):
+files = []
+for d in dirs:
+    files += sorted(glob.glob(os.path.join(ROOT, "gpurun_out", d, "pass*_counter_collection.csv")))
+owner = {}       # kernel -> the run directory it is taken from (a kernel that appears in several runs counts once)
+for fn in files:
     pas = re.search(r"(pass\d+)_", os.path.basename(fn)).group(1)
+    run = os.path.basename(os.path.dirname(fn))
     with open(fn, newline="") as f:
         for row in csv.DictReader(f):
             name = row["Kernel_Name"]
             if not name.startswith("lwm::attn"):
                 continue
-            k = kern.setdefault(name.split("(")[0].replace("lwm::", ""), {"duration_ns_by_pass": {}})
+            short = name.split("(")[0].replace("lwm::", "")
+            if owner.setdefault(short, run) != run:
+                continue
+            k = kern.setdefault(short, {"duration_ns_by_pass": {}, "run": run})
             k[row["Counter_Name"]] = k.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
             k["VGPR_Count"] = int(row["VGPR_Count"]) + int(row.get("Accum_VGPR_Count") or 0)
             k["duration_ns_by_pass"][pas] = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
