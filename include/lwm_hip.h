@@ -99,6 +99,12 @@ typedef struct LwmAttnArgs {
      * the launch zeroes it on `stream`, it need not persist between launches). */
     int32_t dq_carry_in, dq_final_out;
     void* bwd_workspace;
+    /* lwm_attn_bwd_dq and lwm_attn_bwd_fused: 0 = dq_acc is [B,Sq,H,D] (rows of one head 16 KiB apart),
+     * 1 = head-major [B,H,Sq,D].  The fused backward reads and rewrites a 32-query tile of dq_acc once per
+     * 256-key block; with the 2^14-byte row stride of the first layout the 32 rows of a tile fall into the same
+     * L2 sets and the whole stream misses (measured: 59 GB of HBM traffic per launch at S = 32768) -- give it
+     * the head-major layout. */
+    int32_t dq_acc_head_major;
 } LwmAttnArgs;
 
 int lwm_attn_fwd(const LwmAttnArgs* args, void* stream);
@@ -110,7 +116,7 @@ int lwm_attn_bwd_dkdv(const LwmAttnArgs* args, void* stream);
  * reference's 5 GEMMs per chunk pair instead of the 7 that
  * lwm_attn_bwd_dq + lwm_attn_bwd_dkdv execute between them.  Same operands and mask semantics; results
  * agree with the two-kernel path to f32 re-association (dq is accumulated per 256-key block, in ascending
- * key order -- deterministic).  dq_acc ([B,Sq,H,D] f32) is required unless a single key block covers Sk
+ * key order -- deterministic).  dq_acc (f32; layout per dq_acc_head_major) is required unless a single key block covers Sk
  * with dq_final_out = 1 and dq_carry_in = 0: it is the accumulator the key blocks add into (and the dq
  * carry of a ring).  seg_blocks_* hints are ignored (every tile inside the causal range is visited; the
  * element mask is authoritative) -- packed batches run faster through the two-kernel path. */

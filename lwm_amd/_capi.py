@@ -34,6 +34,7 @@ class LwmAttnArgs(C.Structure):
         ("k_splits", C.c_int32),
         ("seg_blocks_q", C.c_void_p), ("seg_blocks_k", C.c_void_p),
         ("dq_carry_in", C.c_int32), ("dq_final_out", C.c_int32), ("bwd_workspace", C.c_void_p),
+        ("dq_acc_head_major", C.c_int32),
     ]
 
 

@@ -277,7 +277,7 @@ LWM_KERNEL(kDqThreads) void attn_bwd_dq_kernel(AttnParams p) {
 
     if (q_ok) {
         const int64_t orow = (int64_t)b * p.dq_sb + (int64_t)q_row * p.dq_ss + (int64_t)h * p.dq_sh;
-        const int64_t arow = (((int64_t)b * p.Sq + q_row) * p.H + h) * kHeadDim;
+        const int64_t arow = (int64_t)b * p.dqa_sb + (int64_t)q_row * p.dqa_ss + (int64_t)h * p.dqa_sh;
         for (int db = 0; db < 4; ++db)
             for (int rq = 0; rq < 4; ++rq) {
                 int d0 = 32 * db + 8 * rq + 4 * hi;

@@ -31,8 +31,11 @@
 //     executed whatever the dispatcher does;
 //   * within an XCD: a wave stores its slice of the tile plainly (L1 is write-through; the store is
 //     acknowledged by L2), waits vmcnt(0) -- one step later, when it costs nothing -- and then stores the
-//     slice's counter; the reader polls the counter and then loads the slice with sc1 loads (miss-always
-//     in L1, served by that same L2).  Ordering is per wave slice (16 head dims), no barrier involved.
+//     slice's counter; the reader polls the counter (sc1: never from L1) and then loads the slice with PLAIN
+//     loads from that same L2 -- its own L1 cannot hold the lines (invalidated once per work item; a slice
+//     is whole 128-byte lines read once per item by the one wave that owns them).  An sc1 / nt load of a
+//     line that is dirty in L2 is served from memory instead (measured: the whole read-modify-write stream
+//     became HBM traffic, 59 GB per launch).  Ordering is per wave slice (32 head dims x 16 queries).
 //   * progress: an item waits only for the item with the next-lower ticket of the same queue, which
 //     was taken earlier by a workgroup that is running -- no dependence on dispatch order.
 #pragma once
@@ -252,19 +255,25 @@ LWM_DEVICE void fb_tile_c(const FusedCtx& cx, const bf16x8 (&pb)[2], const bf16x
     prio_lo();
 }
 
-// dQ^T[16 head dims of this wave][32 queries] = K^T . dS^T over the workgroup's 256 keys (dS^T buffer BUF).
+// dQ^T[32 head dims][16 queries] of this wave = K^T . dS^T over the workgroup's 256 keys (dS^T buffer BUF).
+// Wave w owns head dims 32*(w&3) .. +31 and queries 16*(w>>2) .. +15 of the tile: per query row that is
+// 128 contiguous bytes of the f32 accumulator -- whole cache lines, shared with no other wave (the ordered
+// hand-off is per wave, and a line shared by two waves could be stale in L1 for the second one).
+// acc[t] is the 16x16 tile of head dims 32*(w&3) + 16t .. +15.
 template <int BUF>
 LWM_DEVICE void fb_dq_product(const FusedCtx& cx, f32x4 (&acc)[2]) {
     // operand addresses of k-step 0: 16-lane group kg covers keys 8kg..8kg+7 of the step
     const int lane = (int)opaque((uint32_t)cx.lane);
     const int i = lane & 15, kg = lane >> 4, j = i >> 2, cc = i & 3;
-    const int d = 16 * cx.wave + 4 * cc;
+    const int db = cx.wave & 3, qh = cx.wave >> 2;
+    const int d = 32 * db + 4 * cc;              // d-tile 1 = +16 head dims = +2 sixteen-byte slots (swizzled per row below)
     const int row = 8 * kg + j;
-    const uint32_t klo = cx.lds + tile_off(row, d >> 3) + (d & 7) * 2;
-    const uint32_t kup = cx.lds + tile_off(row + 4, d >> 3) + (d & 7) * 2;
+    const uint32_t klo0 = cx.lds + tile_off(row, d >> 3) + (d & 7) * 2;
+    const uint32_t kup0 = cx.lds + tile_off(row + 4, d >> 3) + (d & 7) * 2;
+    const uint32_t klo1 = cx.lds + tile_off(row, (d + 16) >> 3) + (d & 7) * 2;
+    const uint32_t kup1 = cx.lds + tile_off(row + 4, (d + 16) >> 3) + (d & 7) * 2;
     const lds_t dsb = cx.lds + kFbOffDs + BUF * kFbDsBytes;
-    const uint32_t l0 = dsb + ds_off(row, cc), u0 = dsb + ds_off(row + 4, cc);
-    // query half 1 = chunk + 4: the XOR term only touches chunk bits 0..2, so it is address ^ 32
+    const uint32_t l0 = dsb + ds_off(row, 4 * qh + cc), u0 = dsb + ds_off(row + 4, 4 * qh + cc);
     acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
     acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto cat = [](bf16x4 lo, bf16x4 up) {
@@ -274,11 +283,11 @@ LWM_DEVICE void fb_dq_product(const FusedCtx& cx, f32x4 (&acc)[2]) {
         return o;
     };
     // k-step ks covers keys 32ks..32ks+31: +32 key rows = +8192 B in the K block, +2048 B in dS^T
-    bf16x8 a[2], b0[2], b1[2];
+    bf16x8 a0[2], a1[2], bq[2];
     auto load = [&](int ks) {
-        a[ks & 1] = cat(lds_read_tr16(klo + ks * 8192), lds_read_tr16(kup + ks * 8192));
-        b0[ks & 1] = cat(lds_read_tr16(l0 + ks * 2048), lds_read_tr16(u0 + ks * 2048));
-        b1[ks & 1] = cat(lds_read_tr16((l0 ^ 32u) + ks * 2048), lds_read_tr16((u0 ^ 32u) + ks * 2048));
+        a0[ks & 1] = cat(lds_read_tr16(klo0 + ks * 8192), lds_read_tr16(kup0 + ks * 8192));
+        a1[ks & 1] = cat(lds_read_tr16(klo1 + ks * 8192), lds_read_tr16(kup1 + ks * 8192));
+        bq[ks & 1] = cat(lds_read_tr16(l0 + ks * 2048), lds_read_tr16(u0 + ks * 2048));
     };
     prio_hi();
     load(0);
@@ -286,40 +295,43 @@ LWM_DEVICE void fb_dq_product(const FusedCtx& cx, f32x4 (&acc)[2]) {
     for (int ks = 0; ks < 8; ++ks) {
         if (ks + 1 < 8) load(ks + 1);
         sched_fence();
-        acc[0] = mfma_16x16x32(a[ks & 1], b0[ks & 1], acc[0]);
-        acc[1] = mfma_16x16x32(a[ks & 1], b1[ks & 1], acc[1]);
+        acc[0] = mfma_16x16x32(a0[ks & 1], bq[ks & 1], acc[0]);
+        acc[1] = mfma_16x16x32(a1[ks & 1], bq[ks & 1], acc[1]);
         sched_fence();
     }
     prio_lo();
 }
 
-// ---- ordered accumulation of this wave's dQ slice (16 head dims x 32 queries of tile `qt`) into global
+// ---- ordered accumulation of this wave's dQ slice (32 head dims x 16 queries of tile `qt`) into global
 // memory.  Ordering is PER WAVE SLICE: wave w of key block kbi waits for wave w of key block kbi-1 on
 // flag[(hb*nqt + qt)*8 + w], so no workgroup barrier sits between a wave's stores and its publication.
 struct DqRmw {
-    f32x4 prev[2];
-    const float* tile;      // wave-uniform base of the tile's accumulator rows (or null)
-    bool ok[2];
+    f32x4 prev[2];          // the two 16-dim tiles of this lane's query row
+    const float* tile;      // wave-uniform base of the tile's accumulator rows
+    bool ok;                // the lane's query row exists
 };
 
-// after the flag says the previous contributor is done: start reading what it left (rows past Sq are
-// clamped, not predicated: see fb_stage_issue)
-LWM_DEVICE void fb_dq_load(const AttnParams& p, const FusedCtx& cx, int b, int h, int qt, DqRmw& w) {
+// after the flag says the previous contributor is done: start reading what it left.  Plain loads, served by
+// the XCD's L2 (an sc1 load of a dirty line is served from MEMORY: write-back + refetch).  This CU's L1 cannot
+// hold an older copy: it is invalidated at the start of every work item and within an item every line of the
+// accumulator is read exactly once, by the one wave that owns it (the idle first step reads elsewhere).
+// Rows past Sq are clamped, not predicated (fb_stage_issue).
+LWM_DEVICE void fb_dq_load(const AttnParams& p, const FusedCtx& cx, int b, int h, int qt, bool real, const float* dummy,
+                           DqRmw& w) {
     const int lane = (int)opaque((uint32_t)cx.lane);
     const int n = lane & 15, kg = lane >> 4;
-    const int d0 = 16 * cx.wave + 4 * kg;
+    const int db = cx.wave & 3, qh = cx.wave >> 2;
     const int64_t row0 = (int64_t)qt * kDkvBQ;
-    // p.dq_acc is always valid here: the API requires it whenever a tile has a second contributor or a carry;
-    // with neither (one key block, no carry) the loaded values are discarded, any readable address will do
-    const float* basep = p.dq_acc ? p.dq_acc : (const float*)p.lse;
-    w.tile = p.dq_acc ? basep + ((((int64_t)b * p.Sq + row0) * p.H + h) * kHeadDim) : basep;
-    const uint32_t rstride = p.dq_acc ? (uint32_t)p.H * kHeadDim * 4u : 0u;
+    const bool use = real && p.dq_acc != nullptr;
+    w.tile = use ? p.dq_acc + ((int64_t)b * p.dqa_sb + row0 * p.dqa_ss + (int64_t)h * p.dqa_sh) : dummy;
+    const uint32_t rstride = use ? (uint32_t)p.dqa_ss * 4u : 0u;
     const int rows_left = (int)(p.Sq - row0);        // >= 1
-    for (int qh = 0; qh < 2; ++qh) {
-        const int r = 16 * qh + n;
-        w.ok[qh] = r < rows_left;
-        const int rc = w.ok[qh] ? r : rows_left - 1;
-        w.prev[qh] = global_load_f32x4_l2(w.tile, (uint32_t)rc * rstride + (p.dq_acc ? (uint32_t)d0 * 4u : 0u));
+    const int r = 16 * qh + n;
+    w.ok = r < rows_left;
+    const int rc = w.ok ? r : rows_left - 1;
+    for (int t = 0; t < 2; ++t) {
+        const int d0 = 32 * db + 16 * t + 4 * kg;
+        w.prev[t] = global_load_f32x4_cached(w.tile, (uint32_t)rc * rstride + (use ? (uint32_t)d0 * 4u : 0u));
     }
 }
 
@@ -328,32 +340,31 @@ LWM_DEVICE void fb_dq_store(const AttnParams& p, const FusedCtx& cx, int b, int 
                             bool do_store, const DqRmw& w, const f32x4 (&acc)[2]) {
     const int lane = (int)opaque((uint32_t)cx.lane);
     const int n = lane & 15, kg = lane >> 4;
-    const int d0 = 16 * cx.wave + 4 * kg;
-    const int64_t row0 = (int64_t)qt * kDkvBQ;
-    const int64_t rstride = (int64_t)p.H * kHeadDim;
+    const int db = cx.wave & 3, qh = cx.wave >> 2;
+    const int64_t row = (int64_t)qt * kDkvBQ + 16 * qh + n;
     const bool to_bf16 = last && p.dq_final_out;
-    // both halves are computed (both accumulator reads retired) BEFORE the first store is issued: with a
-    // store in between, the wait for the second read would also wait for that store (one in-order counter)
-    // (the accumulator that was read is dropped by a bit mask, not a branch: a uniform branch around the
-    // only use of a loaded register leaves it "maybe pending" for hipcc, see fb_stage_issue)
+    // both 16-dim tiles are computed (both accumulator reads retired) BEFORE the first store is issued: with a
+    // store in between, the wait for the second read would also wait for that store (one in-order counter).
+    // The accumulator that was read is dropped by a bit mask, not a branch (a uniform branch around the only
+    // use of a loaded register leaves it "maybe pending" for hipcc, see fb_stage_issue).
     const uint32_t keep = use_prev ? 0xffffffffu : 0u;
     f32x4 o[2];
-    for (int qh = 0; qh < 2; ++qh)
+    for (int t = 0; t < 2; ++t)
         for (int j = 0; j < 4; ++j) {
-            const float pj = w.prev[qh][j];     // (a copy: __builtin_bit_cast of a vector ELEMENT reads element 0)
+            const float pj = w.prev[t][j];     // (a copy: __builtin_bit_cast of a vector ELEMENT reads element 0)
             const float pv = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, pj) & keep);
-            o[qh][j] = fmaf(acc[qh][j], p.scale, pv);
-            pin_value(o[qh][j]);                    // pin the use HERE: LLVM otherwise sinks it into the store's branch
+            o[t][j] = fmaf(acc[t][j], p.scale, pv);
+            pin_value(o[t][j]);                 // pin the use HERE: LLVM otherwise sinks it into the store's branch
         }
     sched_fence();
-    for (int qh = 0; qh < 2; ++qh) {
-        const int r = 16 * qh + n;
-        if (!do_store || !w.ok[qh]) continue;
+    if (!do_store || !w.ok) return;
+    for (int t = 0; t < 2; ++t) {
+        const int d0 = 32 * db + 16 * t + 4 * kg;
         if (to_bf16) {
-            bf16_t* dst = p.dq + (int64_t)b * p.dq_sb + (row0 + r) * p.dq_ss + (int64_t)h * p.dq_sh + d0;
-            global_store_b64_async(dst, u32x2{pack_bf16x2(o[qh][0], o[qh][1]), pack_bf16x2(o[qh][2], o[qh][3])});
+            bf16_t* dst = p.dq + (int64_t)b * p.dq_sb + row * p.dq_ss + (int64_t)h * p.dq_sh + d0;
+            global_store_b64_async(dst, u32x2{pack_bf16x2(o[t][0], o[t][1]), pack_bf16x2(o[t][2], o[t][3])});
         } else {
-            global_store_f32x4_async(p.dq_acc + (((int64_t)b * p.Sq + row0 + r) * p.H + h) * kHeadDim + d0, o[qh]);
+            global_store_f32x4_async(p.dq_acc + ((int64_t)b * p.dqa_sb + row * p.dqa_ss + (int64_t)h * p.dqa_sh) + d0, o[t]);
         }
     }
 }
@@ -379,9 +390,10 @@ LWM_DEVICE void fb_wait_turn(int seen, int order, const int32_t* flag, int32_t* 
 template <int BUF, int PB>
 LWM_DEVICE void fb_step(const AttnParams& p, const FusedCtx& cx, const bf16x8 (&vf)[8], f32x16 (&dk)[4], f32x16 (&dv)[4],
                         int b, int h, int qt, int krel, int qlim, bool has_prev, int qt_prev, bool has_pub, int qt_pub,
-                        int kbi, int qt_next, bool tail_block, int32_t* flags_h, int32_t* err) {
-    // Without a previous tile (step 0 of an item) the same instruction stream runs on tile `qt` itself
-    // with nothing stored: straight-line code keeps hipcc's waits where they belong (fb_stage_issue).
+                        int kbi, int qt_next, bool tail_block, int32_t* flags_h, int32_t* err, const float* dummy) {
+    // Without a previous tile (step 0 of an item) the same instruction stream runs with nothing stored and the
+    // accumulator read pointed at `dummy` (read-only data): straight-line code keeps hipcc's waits where they
+    // belong (fb_stage_issue), and no line of the accumulator enters this CU's L1 before its turn.
     const int qp = has_prev ? qt_prev : qt;
     const int32_t* const flag_prev = flags_h + ((int64_t)qp * 8 + cx.wave);
     const int order = has_prev ? kbi : 0;            // key block 0 waits for nobody
@@ -394,7 +406,7 @@ LWM_DEVICE void fb_step(const AttnParams& p, const FusedCtx& cx, const bf16x8 (&
     f32x4 acc[2];
     DqRmw w;
     fb_dq_product<PB>(cx, acc);
-    fb_dq_load(p, cx, b, h, qp, w);
+    fb_dq_load(p, cx, b, h, qp, has_prev, dummy, w);
     fb_tile_c<BUF>(cx, pb, dsb, dk, dv);
     fb_dq_store(p, cx, b, h, qp, kbi != 0 || p.dq_carry_in, qp < qt_next || tail_block, has_prev, w, acc);
 }
@@ -451,6 +463,7 @@ LWM_KERNEL(kFbThreads) void attn_bwd_fused_kernel(AttnParams p, int32_t* ws) {
             const bf16_t* dob = p.dout + (int64_t)b * p.do_sb + (int64_t)h * p.do_sh;
             int32_t* const flags_h = sems + (int64_t)hb * nqt_all * 8;
 
+            l1_invalidate();       // no line of the dq accumulator from an earlier item may survive in this CU's L1
             // ---- this lane's key: V fragments in registers, key meta
             const int k_row = kbi * kDkvBK + wave * 32 + l31;
             const bool k_ok = k_row < p.Sk;
@@ -523,14 +536,14 @@ LWM_KERNEL(kFbThreads) void attn_bwd_fused_kernel(AttnParams p, int32_t* ws) {
                     const bool more1 = i + 1 < n;
                     fb_stage_issue<1>(p, cx, qb, dob, lse2, b, h, LWM_FQT(more1 ? i + 1 : i));
                     fb_step<0, 1>(p, cx, vf, dk, dv, b, h, LWM_FQT(i), krel_of(LWM_FQT(i)), qlim_of(LWM_FQT(i)), i > 0,
-                                  LWM_FQT(i - 1), i > 1, LWM_FQT(i - 2), kbi, qt_next, tail_block, flags_h, ws + kFbWsErr);
+                                  LWM_FQT(i - 1), i > 1, LWM_FQT(i - 2), kbi, qt_next, tail_block, flags_h, ws + kFbWsErr, lse2);
                     block_sync_lds();      // (not __syncthreads: the dq stores stay in flight, see wave_ops.h)
                     if (!more1) break;
                     const bool more2 = i + 2 < n;
                     fb_stage_issue<0>(p, cx, qb, dob, lse2, b, h, LWM_FQT(more2 ? i + 2 : i + 1));
                     fb_step<1, 0>(p, cx, vf, dk, dv, b, h, LWM_FQT(i + 1), krel_of(LWM_FQT(i + 1)), qlim_of(LWM_FQT(i + 1)),
                                   true, LWM_FQT(i), i > 0, LWM_FQT(i - 1), kbi, qt_next, tail_block, flags_h,
-                                  ws + kFbWsErr);
+                                  ws + kFbWsErr, lse2);
                     block_sync_lds();
                 }
                 // drain: the dQ of the last tile (n-1) and the two publications still owed
@@ -546,7 +559,7 @@ LWM_KERNEL(kFbThreads) void attn_bwd_fused_kernel(AttnParams p, int32_t* ws) {
                     DqRmw w;
                     if ((n - 1) & 1) fb_dq_product<1>(cx, acc);
                     else fb_dq_product<0>(cx, acc);
-                    fb_dq_load(p, cx, b, h, qt_last, w);
+                    fb_dq_load(p, cx, b, h, qt_last, true, lse2, w);
                     fb_dq_store(p, cx, b, h, qt_last, !first || p.dq_carry_in, qt_last < qt_next || tail_block, true, w, acc);
                     wait_vmem_all();
                     if (lane == 0) store_i32_plain(flag_last, kbi + 1);

@@ -64,6 +64,7 @@ struct AttnParams {
     int32_t final_out;         // write bf16 results (else f32 *_acc)
     int32_t dq_carry_in;       // fused backward only: the same two switches for dq (carry_in /
     int32_t dq_final_out;      // final_out then govern dk, dv)
+    int64_t dqa_sb, dqa_ss, dqa_sh;   // element strides of dq_acc: [B,Sq,H,D] or head-major [B,H,Sq,D]
     // forward only: dense boolean mask and split-K (see include/lwm_hip.h)
     const uint8_t* dense_mask;
     int64_t msk_sb, msk_sq;

@@ -262,6 +262,21 @@ LWM_DEVICE void global_store_b64_async(void* p, u32x2 v) {
     asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
+// The same 16 bytes with a PLAIN load (L1 allowed).  An sc1 / nt load of a line that the XCD's L2 holds
+// DIRTY is served from memory (write-back + refetch: rocprofv3 shows the whole dq read-modify-write of
+// attn_bwd_fused.h as HBM traffic, 59 GB per launch); a plain load is served by the L2.  The caller makes
+// sure this CU's L1 cannot hold an older copy of the line (l1_invalidate() + each line read once).
+LWM_DEVICE f32x4 global_load_f32x4_cached(const float* base, uint32_t byte_off) {
+    const uint64_t a = (uint64_t)base;
+    const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, 0x7fffffff, 0x00020000);
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+// Drop every line of this CU's vector L1 (buffer_inv sc1; the XCD's L2 is untouched).  ~2 us: once per
+// work item, not per tile.
+LWM_DEVICE void l1_invalidate() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+
 LWM_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
     union { bf16_t h[2]; uint32_t u; } x;
     x.h[0] = (bf16_t)lo;

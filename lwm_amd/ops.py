@@ -234,7 +234,7 @@ def _bwd_base(q, k, v, dout, lse, delta, kw):
 
 def attn_bwd_dq_block(q, k, v, dout, lse, delta, *, q_start=0, k_start=0, causal=True,
                       seg_q=None, seg_k=None, key_valid=None, scale=None, dq=None, dq_acc=None,
-                      carry_in=False, final=True):
+                      carry_in=False, final=True, acc_head_major=False):
     B, Sq, H, D = q.shape
     a = _bwd_base(q, k, v, dout, lse, delta,
                   dict(q_start=q_start, k_start=k_start, causal=causal, seg_q=seg_q, seg_k=seg_k,
@@ -244,8 +244,9 @@ def attn_bwd_dq_block(q, k, v, dout, lse, delta, *, q_start=0, k_start=0, causal
             dq = torch.empty((B, Sq, H, D), dtype=torch.bfloat16, device=q.device)
         a.dq = _t4(dq, "dq")
     elif dq_acc is None:
-        dq_acc = torch.empty((B, Sq, H, D), dtype=torch.float32, device=q.device)
-    a.dq_acc = _f32(dq_acc, "dq_acc", (B, Sq, H, D))
+        dq_acc = torch.empty(_acc_shape(B, Sq, H, D, acc_head_major), dtype=torch.float32, device=q.device)
+    a.dq_acc = _f32(dq_acc, "dq_acc", _acc_shape(B, Sq, H, D, acc_head_major))
+    a.dq_acc_head_major = int(bool(acc_head_major))
     a.carry_in = int(bool(carry_in))
     a.final_out = int(bool(final))
     L = lib()
@@ -283,6 +284,12 @@ def attn_bwd_dkdv_block(q, k, v, dout, lse, delta, *, q_start=0, k_start=0, caus
 _FUSED_WS = {}
 
 
+def _acc_shape(B, Sq, H, D, head_major):
+    """dq accumulator: (B,Sq,H,D), or head-major (B,H,Sq,D) -- the layout the fused backward wants (a 32-query
+    tile of a head is then 16 KiB contiguous instead of 32 rows 16 KiB apart, which thrash one L2 set)."""
+    return (B, H, Sq, D) if head_major else (B, Sq, H, D)
+
+
 def _fused_workspace(B, H, Sq, device):
     """int32 scratch of lwm_attn_bwd_fused (work-queue tickets + per-tile counters); the launch zeroes it
     itself, so one buffer per (device, stream) is reused by every call."""
@@ -305,10 +312,12 @@ def fused_backward_gave_up(device=None):
 
 def attn_bwd_fused_block(q, k, v, dout, lse, delta, *, q_start=0, k_start=0, causal=True, seg_q=None, seg_k=None,
                          key_valid=None, scale=None, dq=None, dk=None, dv=None, dq_acc=None, dk_acc=None,
-                         dv_acc=None, dq_carry_in=False, dq_final=True, carry_in=False, final=True):
+                         dv_acc=None, dq_carry_in=False, dq_final=True, carry_in=False, final=True,
+                         acc_head_major=True):
     """The whole backward of one ring step in one launch (lwm_attn_bwd_fused): S and dP are computed once
     (5 GEMM units instead of 7).  `carry_in` / `final` govern dk, dv; `dq_carry_in` / `dq_final` govern dq.
-    dq_acc (f32 (B,Sq,H,D)) is the accumulator the 256-key blocks add into -- allocated here when absent.
+    dq_acc is the f32 accumulator the 256-key blocks add into, head-major (B,H,Sq,D) unless
+    acc_head_major=False -- allocated here when absent.
     Returns (dq or dq_acc, dk or dk_acc, dv or dv_acc)."""
     B, Sq, H, D = q.shape
     Sk = k.shape[1]
@@ -336,8 +345,9 @@ def attn_bwd_fused_block(q, k, v, dout, lse, delta, *, q_start=0, k_start=0, cau
     if dq_acc is None and (Sk > 256 or not dq_final or dq_carry_in):
         if dq_carry_in:
             raise ValueError("attn_bwd_fused_block: dq_carry_in needs dq_acc")
-        dq_acc = torch.empty((B, Sq, H, D), dtype=torch.float32, device=q.device)
-    a.dq_acc = _f32(dq_acc, "dq_acc", (B, Sq, H, D))
+        dq_acc = torch.empty(_acc_shape(B, Sq, H, D, acc_head_major), dtype=torch.float32, device=q.device)
+    a.dq_acc = _f32(dq_acc, "dq_acc", _acc_shape(B, Sq, H, D, acc_head_major))
+    a.dq_acc_head_major = int(bool(acc_head_major))
     a.carry_in, a.final_out = int(bool(carry_in)), int(bool(final))
     a.dq_carry_in, a.dq_final_out = int(bool(dq_carry_in)), int(bool(dq_final))
     ws = _fused_workspace(B, H, Sq, q.device)

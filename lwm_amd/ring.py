@@ -498,7 +498,11 @@ def _mesh_backward(block, comm, q, k, v, lses, dout, deltas, *, layout, causal, 
     for t in range(n):
         for qi, _ in pairs_at(t)[1]:
             n_dq[qi] += 1
-    dq_acc = [block.empty((B, ln, H, D), torch.float32, q) if n_dq[qi] > 1 else None
+    fused = _use_fused(block, segment_ids)
+    # (the fused backward wants its dq accumulator head-major, see ops._acc_shape; the dQ kernel takes either)
+    acc_shape = (lambda ln: (B, H, ln, D)) if fused else (lambda ln: (B, ln, H, D))
+    hm = dict(acc_head_major=True) if fused else {}
+    dq_acc = [block.empty(acc_shape(ln), torch.float32, q) if n_dq[qi] > 1 else None
               for qi, (_, ln, _) in enumerate(qsegs)]
     done_dq = [0] * len(qsegs)
     for qi, (off, ln, _) in enumerate(qsegs):
@@ -515,7 +519,7 @@ def _mesh_backward(block, comm, q, k, v, lses, dout, deltas, *, layout, causal, 
             block.bwd_dq(_rows(q, qs), held[ki][0], held[ki][1], _rows(dout, qs), lses[qi], deltas[qi],
                          q_start=qs[2], k_start=ks[2], causal=causal, seg_q=sq, seg_k=sk, key_valid=kv,
                          scale=scale, dq=_rows(dq, qs) if fin else None, dq_acc=dq_acc[qi],
-                         carry_in=done_dq[qi] > 1, final=fin)
+                         carry_in=done_dq[qi] > 1, final=fin, **hm)
 
     def run_dkdv(t, held):
         """-> {ki: (dk_part, dv_part)} f32, for the key segments that got a contribution."""
@@ -550,7 +554,7 @@ def _mesh_backward(block, comm, q, k, v, lses, dout, deltas, *, layout, causal, 
             if first:
                 part[ki] = tuple(_xbuf(comm, block, ("part", t, ki, w), (B, ks[1], H, D), torch.float32, q) for w in (0, 1))
             if dq_acc[qi] is None:          # a q segment with a single contribution still needs the accumulator
-                dq_acc[qi] = block.empty((B, qs[1], H, D), torch.float32, q)
+                dq_acc[qi] = block.empty(acc_shape(qs[1]), torch.float32, q)
             block.bwd_fused(_rows(q, qs), held[ki][0], held[ki][1], _rows(dout, qs), lses[qi], deltas[qi],
                             q_start=qs[2], k_start=ks[2], causal=causal, seg_q=sq, seg_k=sk, key_valid=kv, scale=scale,
                             dq=_rows(dq, qs) if fin else None, dq_acc=dq_acc[qi], dq_carry_in=done_dq[qi] > 1,
@@ -558,7 +562,6 @@ def _mesh_backward(block, comm, q, k, v, lses, dout, deltas, *, layout, causal, 
         return part
 
     own = layout.segments(r)
-    fused = _use_fused(block, segment_ids)
     run_dq(0, mesh.get(0))
     returned = {}     # t -> ({ki: (dk, dv)} received from rank r+t for MY segments, handle)
     for t in range(1, n):

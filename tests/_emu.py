@@ -164,10 +164,16 @@ def attn_bwd(q, k, v, out, lse, dout, *, causal=True, q_start=0, k_start=0, seg_
     _capi.check(L, L.lwm_attn_bwd_delta(C.byref(a), None), "lwm_attn_bwd_delta")
     if fused:
         a.dq_carry_in, a.dq_final_out = a.carry_in, a.final_out
+        # the fused kernel's accumulator layout: head-major (B,H,Sq,D); the test keeps (B,Sq,H,D) arrays
+        hm = aligned((B, H, Sq, D), np.float32)
+        hm[...] = dq_acc.transpose(0, 2, 1, 3)
+        a.dq_acc = hm.ctypes.data
+        a.dq_acc_head_major = 1
         ws = aligned((max(L.lwm_attn_bwd_fused_workspace_bytes(B, H, Sq), 16) // 4,), np.int32)
         ws[...] = -7     # the launch must zero it itself
         a.bwd_workspace = ws.ctypes.data
         _capi.check(L, L.lwm_attn_bwd_fused(C.byref(a), None), "lwm_attn_bwd_fused")
+        dq_acc[...] = hm.transpose(0, 2, 1, 3)
     else:
         _capi.check(L, L.lwm_attn_bwd_dkdv(C.byref(a), None), "lwm_attn_bwd_dkdv")
         _capi.check(L, L.lwm_attn_bwd_dq(C.byref(a), None), "lwm_attn_bwd_dq")

@@ -385,6 +385,8 @@ LWM_DEVICE f32x4 global_load_f32x4_l2(const float* base, uint32_t byte_off) {
     return v;
 }
 
+LWM_DEVICE f32x4 global_load_f32x4_cached(const float* base, uint32_t byte_off) { return global_load_f32x4_l2(base, byte_off); }
+LWM_DEVICE void l1_invalidate() {}
 LWM_DEVICE void global_store_f32x4_async(float* p, f32x4 v) { memcpy(p, &v, 16); }
 LWM_DEVICE void global_store_b64_async(void* p, u32x2 v) { memcpy(p, &v, 8); }
 

@@ -117,7 +117,7 @@ def test_fused_backward_is_deterministic_and_ordered():
     _check("dk fused 4096", f(ref[1]), rk)
     _check("dv fused 4096", f(ref[2]), rv)
     # carries: start from a known f32 dq carry, leave the result in f32
-    carry = torch.randn(B, S, H, 128, device="cuda")
+    carry = torch.randn(B, H, S, 128, device="cuda")      # the fused kernel's accumulator is head-major (B,H,S,D)
     acc = carry.clone()
     dqa, dka, dva = ops.attn_bwd_fused_block(q, k, v, do, lse, delta, causal=True, dq_acc=acc, dq_carry_in=True,
                                              dq_final=False, final=False)
@@ -126,7 +126,11 @@ def test_fused_backward_is_deterministic_and_ordered():
     assert dqa.data_ptr() == acc.data_ptr()
     assert ((dqa - carry) - plain[0]).abs().max().item() <= 1e-4 * plain[0].abs().max().item()
     assert torch.equal(dka, plain[1]) and torch.equal(dva, plain[2])
-    assert torch.equal(ops.cast_f32_to_bf16(plain[0]), ref[0])
+    assert torch.equal(ops.cast_f32_to_bf16(plain[0]).transpose(1, 2), ref[0])
+    # the other accumulator layout gives the same numbers (only slower: its tile rows thrash one L2 set)
+    alt = ops.attn_bwd_fused_block(q, k, v, do, lse, delta, causal=True, dq_final=False, final=False,
+                                   acc_head_major=False)
+    assert torch.equal(alt[0], plain[0].transpose(1, 2))
 
 
 def test_softmax_rescale_branch_is_exercised():
