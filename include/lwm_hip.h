@@ -101,9 +101,8 @@ typedef struct LwmAttnArgs {
     void* bwd_workspace;
     /* lwm_attn_bwd_dq and lwm_attn_bwd_fused: 0 = dq_acc is [B,Sq,H,D] (rows of one head 16 KiB apart),
      * 1 = head-major [B,H,Sq,D].  The fused backward reads and rewrites a 32-query tile of dq_acc once per
-     * 256-key block; with the 2^14-byte row stride of the first layout the 32 rows of a tile fall into the same
-     * L2 sets and the whole stream misses (measured: 59 GB of HBM traffic per launch at S = 32768) -- give it
-     * the head-major layout. */
+     * 256-key block; head-major makes that tile 16 KiB contiguous (whole cache lines per wave, fewer partial
+     * write-backs: 18 instead of 26 GB written per launch at S = 32768) -- give it the head-major layout. */
     int32_t dq_acc_head_major;
 } LwmAttnArgs;
 

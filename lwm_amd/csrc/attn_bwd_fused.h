@@ -52,7 +52,8 @@ constexpr int kFbOffStats = kFbOffDs + 2 * kFbDsBytes;
 // stats block: lse2[32] | delta[32] | seg[32] | 128 B landing pad of the 64-lane segment-id DMA
 constexpr int kFbStatBytes = 4 * kDkvBQ * 4;
 constexpr int kFbOffCtl = kFbOffStats + 2 * kFbStatBytes;
-constexpr int kFbLdsBytes = kFbOffCtl + 64;
+constexpr int kFbOffPoll = kFbOffCtl + 64;          // 8 waves x 256 B: where each wave's flag poll lands
+constexpr int kFbLdsBytes = kFbOffPoll + 8 * 256;
 
 // workspace (int32): [0,8) tickets | [8,16) queue owner (0 = unclaimed, xcc+1) | [16] spin-limit flag |
 // [32, 32 + B*H*nqt*8) per-(b,h,tile,wave) counters | then f32 [B,H,Sq]: LSE in log2 units (+inf where the
@@ -63,14 +64,16 @@ constexpr int kFbWsErr = 16;
 // raises ws[kFbWsErr]: results are then wrong, but the GPU is not left spinning (every spin is bounded).
 constexpr int kFbSpinLimit = 1 << 20;
 // A key block starts its walk only when its predecessor is already kFbSlack tiles ahead.  Consecutive key
-// blocks form a pipeline with blocking and no buffers (a block can never overtake the one before it): at the
-// minimal distance every hiccup of any block stalls all its followers and the chain runs at the pace of the
-// slowest step of 32 co-resident blocks.  A few tiles of distance absorb that; the price is the pipeline
-// fill, 32 x kFbSlack steps once per XCD.  Measured at S = 32768: 0 -> 28.4 ms, 2 -> 27.9, 4 -> 32, 8 -> 36:
-// a longer chain of tiles in flight (32 blocks x distance x 32 KiB of Q, dO and dq tile) falls out of the
-// XCD's 4 MiB L2, which costs more than the stalls it avoids.
+// blocks form a pipeline with blocking and no buffers (a block can never overtake the one before it); the
+// distance between two of them is the hand-off latency (store -> flag -> poll: about two steps) plus this
+// slack.  A tile of dq (16 KiB f32) and its Q/dO tiles (16 KiB) are re-used by the next block one distance
+// later, with the tiles of all 32 co-resident blocks of the XCD in between: LRU distance = 32 x distance x
+// 32 KiB, i.e. 2.5 MiB at distance 2.5 and 4.6 MiB at 4.5 -- against a 4 MiB L2.  rocprofv3 at S = 32768:
+// slack 2 -> 36 GB fetched per launch (TCC_MISS 2.9e8), slack 0 -> 19 GB (1.5e8); time 28.3 vs 27.7 ms
+// (0/1/2/3: 27.7 / 27.9 / 28.3 / 29.9; scripts/micro/l2_handoff.hip shows the same chain, alone, running
+// entirely out of L2).
 #ifndef LWM_FB_SLACK
-#define LWM_FB_SLACK 2
+#define LWM_FB_SLACK 0
 #endif
 constexpr int kFbSlack = LWM_FB_SLACK;
 
@@ -84,6 +87,7 @@ struct FusedCtx {
     int tid;
     int32_t kseg;       // segment id of this lane's key (kSegInvalid: padded / out of range)
     bool has_meta;
+    int n_dma;          // LDS-DMA instructions this wave issues per fb_stage_issue (wave-uniform)
     float c;            // scale * log2(e)
 };
 
@@ -311,10 +315,10 @@ struct DqRmw {
     bool ok;                // the lane's query row exists
 };
 
-// after the flag says the previous contributor is done: start reading what it left.  Plain loads, served by
-// the XCD's L2 (an sc1 load of a dirty line is served from MEMORY: write-back + refetch).  This CU's L1 cannot
-// hold an older copy: it is invalidated at the start of every work item and within an item every line of the
-// accumulator is read exactly once, by the one wave that owns it (the idle first step reads elsewhere).
+// after the flag says the previous contributor is done: start reading what it left.  Agent-scope (sc1) loads:
+// they bypass this CU's L1 (which could hold the line from an earlier work item) and are served by the XCD's
+// L2, where the predecessor's plain stores left the line (scripts/micro/l2_handoff.hip: FETCH_SIZE = first
+// touch only; the same chain with plain loads hits L2 too but takes 2.3 us per hop instead of 0.8).
 // Rows past Sq are clamped, not predicated (fb_stage_issue).
 LWM_DEVICE void fb_dq_load(const AttnParams& p, const FusedCtx& cx, int b, int h, int qt, bool real, const float* dummy,
                            DqRmw& w) {
@@ -331,7 +335,7 @@ LWM_DEVICE void fb_dq_load(const AttnParams& p, const FusedCtx& cx, int b, int h
     const int rc = w.ok ? r : rows_left - 1;
     for (int t = 0; t < 2; ++t) {
         const int d0 = 32 * db + 16 * t + 4 * kg;
-        w.prev[t] = global_load_f32x4_cached(w.tile, (uint32_t)rc * rstride + (use ? (uint32_t)d0 * 4u : 0u));
+        w.prev[t] = global_load_f32x4_l2(w.tile, (uint32_t)rc * rstride + (use ? (uint32_t)d0 * 4u : 0u));
     }
 }
 
@@ -369,16 +373,36 @@ LWM_DEVICE void fb_dq_store(const AttnParams& p, const FusedCtx& cx, int b, int 
     }
 }
 
+// per-phase accounting of fb_step, -DLWM_PROF builds only (scripts/micro/fused_bench prints it): slots =
+// S/dP phase, counted wait, turn wait, dQ product, dV/dK phase, full wait, accumulate + store, barrier, steps
+#ifdef LWM_PROF
+struct FbProf { uint32_t v[9]; uint32_t last; };
+#define FB_LAP(pf, slot)                                               \
+    do {                                                               \
+        const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime();  \
+        (pf).v[slot] += now_ - (pf).last;                              \
+        (pf).last = now_;                                              \
+    } while (0)
+#else
+struct FbProf {};
+#define FB_LAP(pf, slot)
+#endif
+
 // wait until `flag` (this wave's slice of the tile) shows that `order` contributors are done
 LWM_DEVICE void fb_wait_turn(int seen, int order, const int32_t* flag, int32_t* err) {
-    for (int spins = 0; wave_uniform(seen) < order; ++spins) {
-        if (spins >= kFbSpinLimit) {
+    // The common case (the predecessor is ahead) must not meet a compiler-visible vector-memory load: hipcc
+    // would put the s_waitcnt vmcnt(0) of the spin loop's load in front of the first test as well, and that
+    // wait also drains the staging DMA in flight.  Hence the test outside, the loop bottom-tested.
+    if (wave_uniform(seen) >= order) return;
+    int spins = 0;
+    do {
+        if (++spins > kFbSpinLimit) {
             store_i32_plain(err, 1);
             break;
         }
         spin_pause();
         seen = load_i32_l2(flag);
-    }
+    } while (wave_uniform(seen) < order);
 }
 
 // One step of the tile loop: tile `qt` (LDS buffer BUF) and the dQ of the PREVIOUS tile `qt_prev` (its dS^T
@@ -390,25 +414,46 @@ LWM_DEVICE void fb_wait_turn(int seen, int order, const int32_t* flag, int32_t* 
 template <int BUF, int PB>
 LWM_DEVICE void fb_step(const AttnParams& p, const FusedCtx& cx, const bf16x8 (&vf)[8], f32x16 (&dk)[4], f32x16 (&dv)[4],
                         int b, int h, int qt, int krel, int qlim, bool has_prev, int qt_prev, bool has_pub, int qt_pub,
-                        int kbi, int qt_next, bool tail_block, int32_t* flags_h, int32_t* err, const float* dummy) {
+                        int kbi, int qt_next, bool tail_block, int32_t* flags_h, int32_t* err, const float* dummy,
+                        const bf16_t* qb, const bf16_t* dob, int qt_stage, FbProf& pf) {
+    (void)pf;
     // Without a previous tile (step 0 of an item) the same instruction stream runs with nothing stored and the
     // accumulator read pointed at `dummy` (read-only data): straight-line code keeps hipcc's waits where they
     // belong (fb_stage_issue), and no line of the accumulator enters this CU's L1 before its turn.
     const int qp = has_prev ? qt_prev : qt;
     const int32_t* const flag_prev = flags_h + ((int64_t)qp * 8 + cx.wave);
     const int order = has_prev ? kbi : 0;            // key block 0 waits for nobody
-    const int seen = load_i32_l2(flag_prev);
+    // Vector-memory operations retire in issue order.  Issued here, in this order: [the dq stores of the last
+    // step] -> the flag poll (an LDS-DMA: its answer lands in LDS, no register, no compiler-tracked load) ->
+    // the staging DMA of the next tile.  After the S/dP phase "at most the staging DMA outstanding" therefore
+    // means "stores in L2, poll answered" -- without waiting for the staging, which has the whole step to land.
+    const lds_t poll = cx.lds + kFbOffPoll + (uint32_t)cx.wave * 256;
+    FB_LAP(pf, 7);             // since the end of the previous step: the tile barrier
+    glds_load_b32_l2(flag_prev, poll);
+    fb_stage_issue<BUF ^ 1>(p, cx, qb, dob, dummy, b, h, qt_stage);
     bf16x8 pb[2], dsb[2];
     fb_tile_ab<BUF>(p, cx, vf, krel, qlim, pb, dsb);
-    wait_vmem_all();           // last step's dq stores are in L2; the next tile's DMA, issued a phase ago, landed
+    FB_LAP(pf, 0);
+    if (cx.n_dma == 3) wait_vmem_le<3>();
+    else wait_vmem_le<2>();
+    FB_LAP(pf, 1);
     if (has_pub && cx.lane == 0) store_i32_plain(flags_h + ((int64_t)qt_pub * 8 + cx.wave), kbi + 1);
-    fb_wait_turn(seen, order, flag_prev, err);
+    fb_wait_turn(lds_read_i32(poll + 4 * (uint32_t)cx.lane), order, flag_prev, err);
+    FB_LAP(pf, 2);
     f32x4 acc[2];
     DqRmw w;
     fb_dq_product<PB>(cx, acc);
+    FB_LAP(pf, 3);
     fb_dq_load(p, cx, b, h, qp, has_prev, dummy, w);
     fb_tile_c<BUF>(cx, pb, dsb, dk, dv);
+    FB_LAP(pf, 4);
+    wait_vmem_all();           // the staged tile (the barrier that follows publishes it) and the accumulator read
+    FB_LAP(pf, 5);
     fb_dq_store(p, cx, b, h, qp, kbi != 0 || p.dq_carry_in, qp < qt_next || tail_block, has_prev, w, acc);
+    FB_LAP(pf, 6);
+#ifdef LWM_PROF
+    pf.v[8] += 1;
+#endif
 }
 
 LWM_KERNEL(kFbThreads) void attn_bwd_fused_kernel(AttnParams p, int32_t* ws) {
@@ -431,6 +476,7 @@ LWM_KERNEL(kFbThreads) void attn_bwd_fused_kernel(AttnParams p, int32_t* ws) {
     cx.lane = lane;
     cx.wave = wave;
     cx.c = p.scale * kLog2e;
+    cx.n_dma = (wave == 0 || (wave == 1 && p.seg_q)) ? 3 : 2;   // Q, dO (+ row statistics / segment ids)
 
     const int my_xcc = wave_uniform(xcc_id()) & (kFbQueues - 1);
     for (int qi = 0; qi < kFbQueues; ++qi) {
@@ -463,7 +509,6 @@ LWM_KERNEL(kFbThreads) void attn_bwd_fused_kernel(AttnParams p, int32_t* ws) {
             const bf16_t* dob = p.dout + (int64_t)b * p.do_sb + (int64_t)h * p.do_sh;
             int32_t* const flags_h = sems + (int64_t)hb * nqt_all * 8;
 
-            l1_invalidate();       // no line of the dq accumulator from an earlier item may survive in this CU's L1
             // ---- this lane's key: V fragments in registers, key meta
             const int k_row = kbi * kDkvBK + wave * 32 + l31;
             const bool k_ok = k_row < p.Sk;
@@ -513,6 +558,8 @@ LWM_KERNEL(kFbThreads) void attn_bwd_fused_kernel(AttnParams p, int32_t* ws) {
                 dk[i] = zero_f32x16();
                 dv[i] = zero_f32x16();
             }
+            FbProf pf = {};
+            FB_LAP(pf, 7);
 #define LWM_FQT(i) (nqt_all - 1 - (i))
             if (n > 0) {
                 if (!p.seg_q && tid < 2 * kDkvBQ)       // no segment ids: the table reads 0 (= kseg of every valid key)
@@ -534,16 +581,15 @@ LWM_KERNEL(kFbThreads) void attn_bwd_fused_kernel(AttnParams p, int32_t* ws) {
                 // tile (unconditional instruction stream).
                 for (int i = 0; i < n; i += 2) {
                     const bool more1 = i + 1 < n;
-                    fb_stage_issue<1>(p, cx, qb, dob, lse2, b, h, LWM_FQT(more1 ? i + 1 : i));
                     fb_step<0, 1>(p, cx, vf, dk, dv, b, h, LWM_FQT(i), krel_of(LWM_FQT(i)), qlim_of(LWM_FQT(i)), i > 0,
-                                  LWM_FQT(i - 1), i > 1, LWM_FQT(i - 2), kbi, qt_next, tail_block, flags_h, ws + kFbWsErr, lse2);
+                                  LWM_FQT(i - 1), i > 1, LWM_FQT(i - 2), kbi, qt_next, tail_block, flags_h, ws + kFbWsErr, lse2,
+                                  qb, dob, LWM_FQT(more1 ? i + 1 : i), pf);
                     block_sync_lds();      // (not __syncthreads: the dq stores stay in flight, see wave_ops.h)
                     if (!more1) break;
                     const bool more2 = i + 2 < n;
-                    fb_stage_issue<0>(p, cx, qb, dob, lse2, b, h, LWM_FQT(more2 ? i + 2 : i + 1));
                     fb_step<1, 0>(p, cx, vf, dk, dv, b, h, LWM_FQT(i + 1), krel_of(LWM_FQT(i + 1)), qlim_of(LWM_FQT(i + 1)),
                                   true, LWM_FQT(i), i > 0, LWM_FQT(i - 1), kbi, qt_next, tail_block, flags_h,
-                                  ws + kFbWsErr, lse2);
+                                  ws + kFbWsErr, lse2, qb, dob, LWM_FQT(more2 ? i + 2 : i + 1), pf);
                     block_sync_lds();
                 }
                 // drain: the dQ of the last tile (n-1) and the two publications still owed
@@ -566,6 +612,10 @@ LWM_KERNEL(kFbThreads) void attn_bwd_fused_kernel(AttnParams p, int32_t* ws) {
                 }
             }
 #undef LWM_FQT
+#ifdef LWM_PROF
+            if (hb == 0 && kbi == nkb / 2 && lane == 0 && p.out_acc)     // one mid-chain item reports
+                for (int i = 0; i < 9; ++i) ((unsigned long long*)p.out_acc)[wave * 10 + i] = pf.v[i];
+#endif
             // ---- dK, dV of this key block
             if (k_ok) {
                 const int64_t krow_o = (int64_t)b * p.dk_sb + (int64_t)k_row * p.dk_ss + (int64_t)h * p.dk_sh;

@@ -136,6 +136,23 @@ LWM_DEVICE void glds_load_b32(const void* g, lds_t wave_base) {
         : "v"(g), "s"(wave_base)
         : "memory");
 }
+// the same with agent scope (sc1: the load bypasses this CU's L1) -- a flag poll whose answer lands in LDS, so
+// that no VGPR and no compiler-inserted s_waitcnt is involved until the wave decides to look at it
+LWM_DEVICE void glds_load_b32_l2(const void* g, lds_t wave_base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+        "global_load_lds_dword %1, off sc1\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(g), "s"(wave_base)
+        : "memory");
+}
+// wait until at most N of this wave's vector-memory operations are outstanding (they retire in issue order)
+template <int N>
+LWM_DEVICE void wait_vmem_le() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");   // asm: hipcc neither merges nor drops it
+}
 LWM_DEVICE void glds_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // The same wait as an instruction the compiler SEES (it updates hipcc's own scoreboard: no second,
 // badly placed vmcnt(0) for operations this one already covered).  gfx9 encoding: vmcnt = bits 3:0 and
@@ -261,21 +278,6 @@ LWM_DEVICE void global_store_f32x4_async(float* p, f32x4 v) {
 LWM_DEVICE void global_store_b64_async(void* p, u32x2 v) {
     asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
-
-// The same 16 bytes with a PLAIN load (L1 allowed).  An sc1 / nt load of a line that the XCD's L2 holds
-// DIRTY is served from memory (write-back + refetch: rocprofv3 shows the whole dq read-modify-write of
-// attn_bwd_fused.h as HBM traffic, 59 GB per launch); a plain load is served by the L2.  The caller makes
-// sure this CU's L1 cannot hold an older copy of the line (l1_invalidate() + each line read once).
-LWM_DEVICE f32x4 global_load_f32x4_cached(const float* base, uint32_t byte_off) {
-    const uint64_t a = (uint64_t)base;
-    const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
-                       (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
-    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, 0x7fffffff, 0x00020000);
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
-}
-// Drop every line of this CU's vector L1 (buffer_inv sc1; the XCD's L2 is untouched).  ~2 us: once per
-// work item, not per tile.
-LWM_DEVICE void l1_invalidate() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 
 LWM_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
     union { bf16_t h[2]; uint32_t u; } x;

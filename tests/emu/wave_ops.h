@@ -307,6 +307,13 @@ LWM_DEVICE void glds_load_b32(const void* g, lds_t wave_base) {
     int l = emu::g_lane->tid & 63;
     memcpy(emu::lds_ptr(wave_base + 4 * l, 4, 4), g, 4);
 }
+LWM_DEVICE void glds_load_b32_l2(const void* g, lds_t wave_base) {
+    int l = emu::g_lane->tid & 63;
+    int32_t v = __atomic_load_n((const int32_t*)g, __ATOMIC_ACQUIRE);
+    memcpy(emu::lds_ptr(wave_base + 4 * l, 4, 4), &v, 4);
+}
+template <int N>
+LWM_DEVICE void wait_vmem_le() {}
 LWM_DEVICE void glds_wait_all() {}
 LWM_DEVICE void wait_vmem_all() {}
 LWM_DEVICE int wave_uniform(int x) { return x; }
@@ -385,8 +392,6 @@ LWM_DEVICE f32x4 global_load_f32x4_l2(const float* base, uint32_t byte_off) {
     return v;
 }
 
-LWM_DEVICE f32x4 global_load_f32x4_cached(const float* base, uint32_t byte_off) { return global_load_f32x4_l2(base, byte_off); }
-LWM_DEVICE void l1_invalidate() {}
 LWM_DEVICE void global_store_f32x4_async(float* p, f32x4 v) { memcpy(p, &v, 16); }
 LWM_DEVICE void global_store_b64_async(void* p, u32x2 v) { memcpy(p, &v, 8); }
 
