@@ -62,6 +62,9 @@ struct ConvCfg {
     static_assert(kConvKC % BROWS == 0 && BP >= 1 && BN / 4 <= NT, "B staging shape");
 };
 
+template <int N>
+struct IntTag { static constexpr int value = N; };
+
 LWM_DEVICE f32x4 zero_f32x4() {
     f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
     return z;
@@ -249,23 +252,229 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
         block_sync();
     }
 
-    // ---- epilogue: + bias [+ residual] [clip], one float per (pixel, channel)
+    // ---- epilogue: + bias [+ residual] [clip], one float per (pixel, channel).  32-bit offsets inside the
+    // tile; rows past M are clamped for the residual read and skipped for the store; the 16 residual reads of
+    // an accumulator are issued together (a rolled loop would wait for each in turn).
+    {
+        const int64_t tile_base = m0 * p.Cout;
+        float* const yb = p.y + tile_base;
+        const float* const rb = p.res ? p.res + tile_base : p.y;
+        const int64_t left = p.M - m0;                    // >= 1 rows of this tile exist
+        const int rows = left < BM ? (int)left : BM;
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int co = n0 + (wn * NB + j) * 32 + l31;
+                const bool col_ok = co < p.Cout;
+                const int coc = col_ok ? co : p.Cout - 1;
+                const float bv = p.bias ? p.bias[coc] : 0.0f;
+                uint32_t off[16];
+                float rv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = (wm * MB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    off[r] = (uint32_t)(ml < rows ? ml : rows - 1) * (uint32_t)p.Cout + (uint32_t)coc;
+                }
+                if (p.res) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[r] = rb[off[r]];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = (wm * MB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    float v = acc[i][j][r];
+                    if (p.bias) v = v + bv;
+                    if (p.res) v = v + rv[r];
+                    if (p.clip) v = v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);
+                    if (col_ok && ml < rows) yb[off[r]] = v;
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Patch-resident form for the 3x3 stride-1 SAME convolutions with 128 or 256 input channels (with or
+// without the nearest x2 upsample folded in) -- 85 % of the VQGAN's FLOPs.  Same arithmetic, same order,
+// bit-identical results; what changes is where the operands come from:
+//   * A: the workgroup's output tile is TH x 16 pixels of ONE image; its (TH+2) x 18 input halo patch, ALL
+//     input channels, is brought into LDS ONCE by LDS-DMA (global_load_lds_dwordx4: no registers, no VALU)
+//     and the nine taps read it at shifted addresses.  The generic kernel re-stages the A tile per tap and
+//     chunk (9x the traffic, plus the address arithmetic and ds_writes of a register-staged tile).
+//     Pixel row = CIN*4 bytes; 16-byte slot L of patch pixel pp sits at L ^ (pp & 15): the 16 pixels of a
+//     tile row are 16 consecutive pp, so a ds_read_b128 lane group covers all 16 slots of a 256-byte bank
+//     row; the swizzle is applied on the SOURCE address of the DMA (the LDS side of a DMA is lane-linear).
+//     Out-of-image pixels are zero-filled with ds_writes after the DMA has landed.
+//   * B: never in LDS.  A lane's B operand of one MFMA is ONE float, w[tap][cin][cout = its column]; the 32
+//     lanes of a half-wave read 128 contiguous bytes.  The 16*NB floats of the next (tap, chunk) are
+//     fetched into registers (buffer loads, L1/L2 hits: every workgroup walks the same 9*CIN*Cout*4 bytes)
+//     while the current ones are consumed.
+// After the prologue there is NO barrier: the waves of a workgroup drift apart and fill each other's gaps.
+template <int CIN, int TH, int WM, int WN, int NB>
+struct PatchCfg {
+    static constexpr int NW = WM * WN, NT = 64 * NW, TW = 16;
+    static constexpr int BM = TH * TW, BN = 32 * NB * WN;
+    static constexpr int MB = BM / (32 * WM);          // 32-pixel blocks per wave
+    static constexpr int PW = TW + 2, PH = TH + 2, PPX = PH * PW;
+    static constexpr int ROWB = CIN * 4;               // bytes per patch pixel
+    static constexpr int SPP = CIN / 4;                // 16-byte slots per pixel
+    static constexpr int LDS_BYTES = PPX * ROWB;
+    static constexpr int NINS = PPX * SPP / 64;        // patch DMA wave-instructions
+    static constexpr int NCH = CIN / kConvKC;
+    static_assert(BM % (32 * WM) == 0 && (PPX * SPP) % 64 == 0 && SPP >= 16 && LDS_BYTES <= 160 * 1024, "patch shape");
+    static_assert((NINS + NW - 1) / NW <= 32, "zero-fill mask is 32 bits");
+    static_assert(NCH % 2 == 0, "the chunk loop is unrolled by two");
+};
+
+template <int CIN, int TH, int WM, int WN, int NB>
+LWM_DEVICE void conv_patch_body(const ConvParams& p) {
+    using Cfg = PatchCfg<CIN, TH, WM, WN, NB>;
+    constexpr int MB = Cfg::MB, BN = Cfg::BN, NCH = Cfg::NCH, PW = Cfg::PW, NW = Cfg::NW;
+    constexpr int nit = 9 * NCH;
+    const lds_t lds = dyn_lds();
+    const int tid = thread_idx();
+    const int wave = wave_uniform(tid >> 6), lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int ntn = p.Cout / BN;
+    const int bn = block_idx_x() % ntn;
+    int64_t bm = block_idx_x() / ntn;
+    const int tiles_x = p.Wo / Cfg::TW, tiles_y = p.Ho / TH;
+    const int tx0 = (int)(bm % tiles_x) * Cfg::TW;
+    bm /= tiles_x;
+    const int ty0 = (int)(bm % tiles_y) * TH;
+    const int b = (int)(bm / tiles_y);
+    const int n0 = bn * BN;
+    const int Hv = p.Hin << p.up_shift, Wv = p.Win << p.up_shift;
+    const float* const xb = p.x + (int64_t)b * p.Hin * p.Win * CIN;
+
+    // ---- B operands: row (it*32 + 4u + 2t + hi) of the [9*CIN][Cout] kernel matrix, column n0 + wn*NB*32 + j*32 + l31
+    const uint32_t b_voff = (uint32_t)(hi * p.Cout + n0 + wn * NB * 32 + l31) * 4u;
+    const uint32_t b_rowb = (uint32_t)p.Cout * 4u;
+    float bq[2][8][2][NB];
+    auto load_b = [&](int it, int set) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    bq[set][u][t][j] = global_load_f32_at(p.w, b_voff + (uint32_t)j * 128u, (uint32_t)(it * 32 + 4 * u + 2 * t) * b_rowb);
+    };
+    load_b(0, 0);
+
+    // ---- the halo patch (every lane fetches SOME valid address; out-of-image slots are overwritten with
+    // zeros once the DMA has landed)
+    uint32_t zmask = 0;
+    for (int k = 0; k * NW + wave < Cfg::NINS; ++k) {
+        const int g = (k * NW + wave) * 64 + lane;     // 16-byte slot of the patch image
+        const int pp = g / Cfg::SPP, q = g - pp * Cfg::SPP;
+        const int lslot = q ^ (pp & 15);
+        const int py = pp / PW, px = pp - py * PW;
+        const int vy = ty0 + py - 1, vx = tx0 + px - 1;
+        const bool ok = vy >= 0 && vy < Hv && vx >= 0 && vx < Wv;
+        const int sy = ok ? (vy >> p.up_shift) : 0, sx = ok ? (vx >> p.up_shift) : 0;
+        glds_load_b128(xb + ((int64_t)sy * p.Win + sx) * CIN + lslot * 4, lds + (uint32_t)(k * NW + wave) * 1024);
+        zmask |= ok ? 0u : (1u << k);
+    }
+    glds_wait_all();
+    for (int k = 0; k * NW + wave < Cfg::NINS; ++k)
+        if ((zmask >> k) & 1) lds_write_f32x4(lds + (uint32_t)((k * NW + wave) * 64 + lane) * 16, zero_f32x4());
+    block_sync_lds();
+
+    // ---- A fragment addressing
+    int pp0[MB];                                        // patch pixel of tap (0, 0) for this lane's pixel
+    for (int i = 0; i < MB; ++i) {
+        const int px = (wm * MB + i) * 32 + l31;
+        pp0[i] = (px / Cfg::TW) * PW + (px % Cfg::TW);
+    }
+    f32x4 ar[2][MB];
+    auto load_a = [&](int it, int u, int set) {        // k-quad u of tile `it`
+        const int tap = it / NCH, ch = it - tap * NCH;
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int tapoff = kh * PW + kw;
+        for (int i = 0; i < MB; ++i) {
+            const int pp = pp0[i] + tapoff;
+            ar[set][i] = lds_read_f32x4(lds + (uint32_t)pp * Cfg::ROWB + (uint32_t)(((ch * 8 + u) ^ (pp & 15)) << 4));
+        }
+    };
+
+    f32x16 acc[MB][NB], acc_tap[MB][NB];
     for (int i = 0; i < MB; ++i)
         for (int j = 0; j < NB; ++j) {
-            const int co = n0 + (wn * NB + j) * 32 + l31;
-            if (co >= p.Cout) continue;
-            const float bv = p.bias ? p.bias[co] : 0.0f;
+            acc[i][j] = zero_f32x16();
+            acc_tap[i][j] = zero_f32x16();
+        }
+
+    auto tile = [&](int it, auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;
+        if (it + 1 < nit) load_b(it + 1, SET ^ 1);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int as = u & 1;
+            if (u + 1 < 8) load_a(it, u + 1, as ^ 1);
+            else if (it + 1 < nit) load_a(it + 1, 0, as ^ 1);
+            sched_fence();
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                for (int i = 0; i < MB; ++i) {
+                    const float af = hi ? ar[as][i][2 * t + 1] : ar[as][i][2 * t];
+                    for (int j = 0; j < NB; ++j) acc_tap[i][j] = mfma_32x32x2_f32(af, bq[SET][u][t][j], acc_tap[i][j]);
+                }
+            sched_fence();
+        }
+    };
+    load_a(0, 0, 0);
+    for (int tap = 0; tap < 9; ++tap) {
+        for (int ch = 0; ch < NCH; ch += 2) {          // (NCH is even: the register sets alternate 0, 1)
+            tile(tap * NCH + ch, IntTag<0>{});
+            tile(tap * NCH + ch + 1, IntTag<1>{});
+        }
+        for (int i = 0; i < MB; ++i)                   // tap finished: s = s + P_t
+            for (int j = 0; j < NB; ++j) {
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] + acc_tap[i][j][r];
+                acc_tap[i][j] = zero_f32x16();
+            }
+    }
+
+    // ---- epilogue: + bias [+ residual] [clip].  Offsets are 32-bit inside the tile (uniform 64-bit base); the
+    // 16 residual reads of an accumulator are issued together (a rolled loop would wait for each in turn).
+    const int64_t tile_base = (((int64_t)b * p.Ho + ty0) * p.Wo + tx0) * p.Cout + n0;
+    float* const yb = p.y + tile_base;
+    const float* const rb = p.res ? p.res + tile_base : p.y;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int col = (wn * NB + j) * 32 + l31;
+        const float bv = p.bias ? p.bias[n0 + col] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            uint32_t off[16];
+            float rv[16];
+#pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + (wm * MB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (m >= p.M) continue;
+                const int px = (wm * MB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                off[r] = (uint32_t)((px / Cfg::TW) * p.Wo + px % Cfg::TW) * (uint32_t)p.Cout + (uint32_t)col;
+            }
+            if (p.res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = rb[off[r]];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
                 float v = acc[i][j][r];
                 if (p.bias) v = v + bv;
-                if (p.res) v = v + p.res[m * p.Cout + co];
+                if (p.res) v = v + rv[r];
                 if (p.clip) v = v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);
-                p.y[m * p.Cout + co] = v;
+                yb[off[r]] = v;
             }
         }
+    }
 }
+
+using PatchC128 = PatchCfg<128, 4, 2, 2, 2>;   // 64 pixels x 128 channels, 4 waves, 54 KiB: two workgroups per CU
+using PatchC256 = PatchCfg<256, 4, 2, 4, 2>;   // 64 pixels x 256 channels, 8 waves, 108 KiB
+LWM_KERNEL_OCC(256, 2) void conv_patch_c128(ConvParams p) { conv_patch_body<128, 4, 2, 2, 2>(p); }
+LWM_KERNEL(512) void conv_patch_c256(ConvParams p) { conv_patch_body<256, 4, 2, 4, 2>(p); }
 
 LWM_KERNEL_OCC(256, 2) void conv_igemm_128x128(ConvParams p) { conv_igemm_body<2, 2, 2, 2, true>(p); }
 LWM_KERNEL(256) void conv_igemm_128x64(ConvParams p) { conv_igemm_body<4, 1, 1, 2, true>(p); }

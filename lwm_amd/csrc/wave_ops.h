@@ -279,6 +279,16 @@ LWM_DEVICE void global_store_b64_async(void* p, u32x2 v) {
     asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
+// one float at base + voff + soff bytes (base and soff wave-uniform: soff rides in an SGPR, the address costs
+// no VALU); plain cache policy
+LWM_DEVICE float global_load_f32_at(const float* base, uint32_t voff, uint32_t soff) {
+    const uint64_t a = (uint64_t)base;
+    const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, 0x7fffffff, 0x00020000);
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+
 LWM_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
     union { bf16_t h[2]; uint32_t u; } x;
     x.h[0] = (bf16_t)lo;

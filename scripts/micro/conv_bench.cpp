@@ -1,0 +1,119 @@
+// conv_bench.cpp -- times lwm_conv2d_nhwc_f32 on the VQGAN's dominant layer shapes through the C ABI, without
+// Python:   conv_bench <liblwm_hip.so> [frames=32] [reps=3]
+// Per shape: HIP-event ms, TFLOP/s (2*M*K*N), fraction of the 157.3 TF exact-f32 MFMA roof and an
+// order-independent 64-bit checksum of the output bits (two libraries that agree bit for bit print the same).
+// Build: hipcc -O2 --offload-arch=gfx950 -I include -o scripts/micro/conv_bench scripts/micro/conv_bench.cpp -ldl
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "lwm_hip.h"
+
+#define CK(x)                                                       \
+    do {                                                            \
+        hipError_t e_ = (x);                                        \
+        if (e_ != hipSuccess) {                                     \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); \
+            exit(2);                                                \
+        }                                                           \
+    } while (0)
+
+__global__ void fill_f32(float* p, size_t n, uint32_t seed, float amp) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        uint32_t h = (uint32_t)i * 2654435761u ^ seed;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        p[i] = ((h & 0xffffff) * (1.0f / 8388608.0f) - 1.0f) * amp;
+    }
+}
+__global__ void bit_sum(const uint32_t* p, size_t n, unsigned long long* out) {
+    unsigned long long s = 0;
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) s += (unsigned long long)p[i] * (2 * (i % 1000003) + 1);
+    atomicAdd(out, s);
+}
+
+struct Shape {
+    const char* name;
+    int H, W, Cin, Cout, up, res;
+};
+
+int main(int argc, char** argv) {
+    if (argc < 2) {
+        fprintf(stderr, "usage: conv_bench <lib> [frames] [reps]\n");
+        return 2;
+    }
+    const int B = argc > 2 ? atoi(argv[2]) : 32, reps = argc > 3 ? atoi(argv[3]) : 3;
+    void* lib = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
+    if (!lib) {
+        fprintf(stderr, "dlopen: %s\n", dlerror());
+        return 2;
+    }
+    auto conv = (int (*)(const LwmConvArgs*, void*))dlsym(lib, "lwm_conv2d_nhwc_f32");
+    auto last_error = (const char* (*)(void))dlsym(lib, "lwm_last_error");
+    // 3x3 SAME layers of the default VQGAN (ch 128, ch_mult 1,1,2,2,4) that carry the FLOPs
+    const Shape shapes[] = {
+        {"enc/dec 256^2 128->128 (+res)", 256, 256, 128, 128, 0, 1},
+        {"dec up 128^2->256^2 128->128", 128, 128, 128, 128, 1, 0},
+        {"128^2 128->128 (+res)", 128, 128, 128, 128, 0, 1},
+        {"dec 128^2 256->128", 128, 128, 256, 128, 0, 0},
+        {"dec up 64^2->128^2 256->256", 64, 64, 256, 256, 1, 0},
+        {"64^2 256->256 (+res)", 64, 64, 256, 256, 0, 1},
+        {"enc 64^2 128->256", 64, 64, 128, 256, 0, 0},
+        {"32^2 256->256 (+res)", 32, 32, 256, 256, 0, 1},
+        {"16^2 512->512 (generic kernel)", 16, 16, 512, 512, 0, 1},
+    };
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    unsigned long long* dsum;
+    CK(hipMalloc(&dsum, 8));
+    double tot_flop = 0, tot_ms = 0;
+    for (const Shape& s : shapes) {
+        const int Ho = s.H << s.up, Wo = s.W << s.up;
+        const size_t nx = (size_t)B * s.H * s.W * s.Cin, nw = (size_t)9 * s.Cin * s.Cout, ny = (size_t)B * Ho * Wo * s.Cout;
+        float *x, *w, *bias, *res, *y;
+        CK(hipMalloc(&x, nx * 4));
+        CK(hipMalloc(&w, nw * 4));
+        CK(hipMalloc(&bias, s.Cout * 4));
+        CK(hipMalloc(&res, ny * 4));
+        CK(hipMalloc(&y, ny * 4));
+        fill_f32<<<2048, 256>>>(x, nx, 1u, 1.0f);
+        fill_f32<<<256, 256>>>(w, nw, 2u, 0.03f);
+        fill_f32<<<1, 256>>>(bias, s.Cout, 3u, 0.1f);
+        fill_f32<<<2048, 256>>>(res, ny, 4u, 1.0f);
+        LwmConvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x = x; a.w = w; a.bias = bias; a.residual = s.res ? res : nullptr; a.y = y;
+        a.B = B; a.Hin = s.H; a.Win = s.W; a.Cin = s.Cin; a.Cout = s.Cout; a.KH = 3; a.KW = 3;
+        a.stride = 1; a.pad = 1; a.up_shift = s.up; a.Ho = Ho; a.Wo = Wo;
+        if (conv(&a, nullptr) != 0) {
+            fprintf(stderr, "conv: %s\n", last_error());
+            return 2;
+        }
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, 0));
+        for (int r = 0; r < reps; ++r) conv(&a, nullptr);
+        CK(hipEventRecord(e1, 0));
+        CK(hipDeviceSynchronize());
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        ms /= reps;
+        CK(hipMemset(dsum, 0, 8));
+        bit_sum<<<1024, 256>>>((const uint32_t*)y, ny, dsum);
+        unsigned long long h = 0;
+        CK(hipMemcpy(&h, dsum, 8, hipMemcpyDeviceToHost));
+        const double flop = 2.0 * B * Ho * Wo * 9.0 * s.Cin * s.Cout;
+        tot_flop += flop;
+        tot_ms += ms;
+        printf("  %-34s %8.3f ms  %6.1f TF/s  %.3f of roof  bits %016llx\n", s.name, ms, flop / ms * 1e-9, flop / ms * 1e-9 / 157.3, h);
+        CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(bias)); CK(hipFree(res)); CK(hipFree(y));
+    }
+    printf("%s  frames %d: %.1f TF/s over the listed layers (%.3f of roof)\n", argv[1], B, tot_flop / tot_ms * 1e-9,
+           tot_flop / tot_ms * 1e-9 / 157.3);
+    return 0;
+}

@@ -2,6 +2,7 @@
 #pragma once
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 namespace lwm {
 
@@ -22,7 +23,8 @@ inline long device_cu_count() { return 24; }   // a few "XCDs" worth of persiste
 template <class... KArgs, class... Args>
 inline int launch(const char* name, void (*kernel)(KArgs...), long grid, int threads,
                   size_t lds_bytes, void* stream, Args... args) {
-    (void)name; (void)stream;
+    (void)stream;
+    if (getenv("LWM_EMU_TRACE")) fprintf(stderr, "emu-launch %s grid=%ld threads=%d\n", name, grid, threads);
     if (grid <= 0) return 0;
     emu::launch(emu::Dim3{(int)grid, 1, 1}, threads, lds_bytes ? lds_bytes : 16,
                 [=]() { kernel(args...); });

@@ -386,6 +386,11 @@ LWM_DEVICE void spin_pause() {
     emu::g_blk->progress++;     // waiting on ANOTHER block is not a deadlock of this one
     emu::yield();
 }
+LWM_DEVICE float global_load_f32_at(const float* base, uint32_t voff, uint32_t soff) {
+    float v;
+    memcpy(&v, (const char*)base + voff + soff, 4);
+    return v;
+}
 LWM_DEVICE f32x4 global_load_f32x4_l2(const float* base, uint32_t byte_off) {
     f32x4 v;
     memcpy(&v, (const char*)base + byte_off, 16);

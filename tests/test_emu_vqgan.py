@@ -54,6 +54,44 @@ def test_conv_large_tile_variant():
     assert np.array_equal(got, R.conv2d(x, w, b))
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,kw", [
+    (1, 32, 48, 128, 128, {}),                    # conv_patch_c128: 24 tiles of 4x16, every image edge
+    (2, 16, 48, 128, 256, {}),                    # two images, two channel tiles
+    (1, 16, 24, 128, 128, dict(up_shift=1)),      # Upsample folded in: 32x48 output
+    (1, 16, 16, 256, 256, {}),                    # 4 tiles of 4x16: too few for the machine -> generic kernel
+    (1, 16, 48, 256, 256, {}),                    # conv_patch_c256: 12 tiles of 4x16 pixels x 256 channels
+    (1, 8, 24, 256, 256, dict(up_shift=1)),       # c256 + Upsample
+    (1, 16, 48, 256, 128, {}),                    # 256 -> 128 channels: generic kernel
+])
+def test_conv_patch_resident_bit_exact(B, H, W, Cin, Cout, kw):
+    """3x3 stride-1 SAME with 128 / 256 input channels: the halo-patch kernel (vqgan_conv.h::conv_patch_body)
+    must be bit-identical to the oracle -- same taps-then-channels order as the generic kernel."""
+    x, w, b = _conv_case(11, B, H, W, Cin, Cout, 3)
+    res = _rng(12).standard_normal((B, H << kw.get("up_shift", 0), W << kw.get("up_shift", 0), Cout)).astype(np.float32)
+    got = _emu.conv2d(x, w, b, residual=res, **kw)
+    assert np.array_equal(got, R.conv2d(x, w, b, residual=res, **kw)), np.abs(got - R.conv2d(x, w, b, residual=res, **kw)).max()
+
+
+def test_conv_patch_resident_is_what_runs(capfd, monkeypatch):
+    """The dispatch really takes the patch kernels for these shapes (the emulation traces its launches)."""
+    monkeypatch.setenv("LWM_EMU_TRACE", "1")
+    x, w, b = _conv_case(14, 1, 32, 48, 128, 128, 3)
+    _emu.conv2d(x, w, b)
+    x, w, b = _conv_case(15, 1, 16, 48, 256, 256, 3)
+    _emu.conv2d(x, w, b)
+    x, w, b = _conv_case(16, 1, 16, 16, 256, 256, 3)     # too few tiles for the machine: generic kernel
+    _emu.conv2d(x, w, b)
+    err = capfd.readouterr().err
+    names = [l.split()[1] for l in err.splitlines() if l.startswith("emu-launch")]
+    assert names[0] == "conv_patch_c128" and names[1] == "conv_patch_c256" and names[2].startswith("conv_igemm"), names
+
+
+def test_conv_patch_resident_no_bias_clip():
+    x, w, _ = _conv_case(13, 1, 32, 48, 128, 128, 3)
+    x *= 4.0
+    assert np.array_equal(_emu.conv2d(x, w, None, clip=True), R.conv2d(x, w, None, clip=True))
+
+
 @pytest.mark.parametrize("C,HW,silu", [(128, 100, True), (256, 64, True), (512, 33, False), (768, 16, True)])
 def test_groupnorm_silu_bit_exact(C, HW, silu):
     g = _rng(5)

@@ -55,6 +55,25 @@ def test_conv_residual():
     assert np.array_equal(got.cpu().numpy(), R.conv2d(x, w, b, residual=res))
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,kw", [
+    (2, 64, 64, 128, 128, {}),                    # conv_patch_c128: 128 tiles of 4x16 pixels
+    (1, 64, 64, 128, 256, dict(up_shift=1)),      # Upsample folded in, two channel tiles
+    (2, 64, 64, 256, 256, {}),                    # conv_patch_c256: 128 tiles of 4x16 pixels x 256 channels
+    (1, 32, 64, 256, 256, dict(up_shift=1)),      # c256 + Upsample, non-square image
+    (1, 96, 80, 128, 128, {}),                    # 24 x 5 tiles: odd tile counts, every edge
+])
+def test_conv_patch_resident_bit_exact(B, H, W, Cin, Cout, kw):
+    """3x3 stride-1 SAME with 128 / 256 input channels and enough tiles for the chip: the halo-patch kernels
+    (vqgan_conv.h::conv_patch_body; A patch resident in LDS, B operands straight from L1/L2) -- bit-equal to
+    the oracle, with bias, residual and the folded upsample."""
+    from lwm_amd import ops
+    x, w, b = _conv_inputs(21, B, H, W, Cin, Cout, 3)
+    up = kw.get("up_shift", 0)
+    res = np.random.default_rng(22).standard_normal((B, H << up, W << up, Cout)).astype(np.float32)
+    got = ops.conv2d_nhwc(_dev(x), _dev(w), _dev(b), residual=_dev(res), **kw)
+    assert np.array_equal(got.cpu().numpy(), R.conv2d(x, w, b, residual=res, **kw))
+
+
 def test_conv_full_resolution_layer():
     """One encoder level-0 conv at BASELINE size: 256x256x128 -> 128 (19.3 GFLOP)."""
     from lwm_amd import ops
