@@ -115,5 +115,44 @@ int main(int argc, char** argv) {
     }
     printf("%s  frames %d: %.1f TF/s over the listed layers (%.3f of roof)\n", argv[1], B, tot_flop / tot_ms * 1e-9,
            tot_flop / tot_ms * 1e-9 / 157.3);
+    // GroupNorm + SiLU on the two largest activation shapes (HBM bound: 4 B read twice + 4 B written per element)
+    auto gn = (int (*)(const float*, const float*, const float*, float*, void*, int32_t, int64_t, int32_t, int32_t, float, int32_t,
+                       void*))dlsym(lib, "lwm_groupnorm_silu_f32");
+    auto gn_ws = (int64_t (*)(int32_t, int64_t, int32_t, int32_t))dlsym(lib, "lwm_groupnorm_workspace_bytes");
+    const int gshapes[][2] = {{256 * 256, 128}, {128 * 128, 128}, {128 * 128, 256}, {64 * 64, 256}};
+    for (auto& g : gshapes) {
+        const int64_t HW = g[0];
+        const int C = g[1];
+        const size_t n = (size_t)B * HW * C;
+        float *x, *y, *gam, *bet;
+        void* ws;
+        CK(hipMalloc(&x, n * 4));
+        CK(hipMalloc(&y, n * 4));
+        CK(hipMalloc(&gam, C * 4));
+        CK(hipMalloc(&bet, C * 4));
+        CK(hipMalloc(&ws, gn_ws(B, HW, C, 32)));
+        fill_f32<<<2048, 256>>>(x, n, 7u, 2.0f);
+        fill_f32<<<1, 256>>>(gam, C, 8u, 1.0f);
+        fill_f32<<<1, 256>>>(bet, C, 9u, 0.2f);
+        if (gn(x, gam, bet, y, ws, B, HW, C, 32, 1e-6f, 1, nullptr) != 0) {
+            fprintf(stderr, "gn: %s\n", last_error());
+            return 2;
+        }
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, 0));
+        for (int r = 0; r < reps; ++r) gn(x, gam, bet, y, ws, B, HW, C, 32, 1e-6f, 1, nullptr);
+        CK(hipEventRecord(e1, 0));
+        CK(hipDeviceSynchronize());
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        ms /= reps;
+        CK(hipMemset(dsum, 0, 8));
+        bit_sum<<<1024, 256>>>((const uint32_t*)y, n, dsum);
+        unsigned long long h = 0;
+        CK(hipMemcpy(&h, dsum, 8, hipMemcpyDeviceToHost));
+        printf("  groupnorm+silu HW=%-6lld C=%-3d  %8.3f ms  %5.2f TB/s (12 B/element)  bits %016llx\n", (long long)HW, C, ms,
+               12.0 * n / ms * 1e-9, h);
+        CK(hipFree(x)); CK(hipFree(y)); CK(hipFree(gam)); CK(hipFree(bet)); CK(hipFree(ws));
+    }
     return 0;
 }
