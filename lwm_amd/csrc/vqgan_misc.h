@@ -115,23 +115,31 @@ LWM_KERNEL(kGnThreads) void gn_stats_kernel(GnParams p) {
     }
 }
 
-// grid = ceil(B*G / 64), 64 threads
+// grid = B*G workgroups of 64 threads, LDS = NS * 16 bytes: the lanes fetch the (b, g) column of the slice
+// partials side by side, then ONE lane adds them in slice order (the contract's order) out of LDS -- a
+// single thread walking the 256 slices through global memory took 40 us per launch.
 LWM_KERNEL(64) void gn_finalize_kernel(GnParams p) {
-    const int idx = block_idx_x() * 64 + thread_idx();
-    if (idx >= p.B * p.G) return;
-    const int b = idx / p.G, g = idx % p.G;
+    const lds_t lds = dyn_lds();
+    const int tid = thread_idx();
+    const int b = block_idx_x() / p.G, g = block_idx_x() % p.G;
+    for (int i = tid; i < p.NS; i += 64) {
+        const double* o = p.part + (((int64_t)b * p.NS + i) * p.G + g) * 2;
+        lds_write_f64(lds + i * 16, o[0]);
+        lds_write_f64(lds + i * 16 + 8, o[1]);
+    }
+    block_sync();
+    if (tid != 0) return;
     double ts = 0.0, tss = 0.0;
     for (int i = 0; i < p.NS; ++i) {
-        const double* o = p.part + (((int64_t)b * p.NS + i) * p.G + g) * 2;
-        ts += o[0];
-        tss += o[1];
+        ts += lds_read_f64(lds + i * 16);
+        tss += lds_read_f64(lds + i * 16 + 8);
     }
     const double n = (double)p.HW * (double)(p.C / p.G);
     const double mean = ts / n;
     double var = tss / n - mean * mean;
     var = var < 0.0 ? 0.0 : var;
-    p.stats[idx * 2] = (float)mean;
-    p.stats[idx * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+    p.stats[block_idx_x() * 2] = (float)mean;
+    p.stats[block_idx_x() * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
 }
 
 LWM_DEVICE f32x4 gn_apply_quad(f32x4 v, float mean, const float (&mul)[4], const float (&bet)[4], int silu) {
