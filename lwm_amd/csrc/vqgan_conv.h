@@ -473,7 +473,8 @@ LWM_DEVICE void conv_patch_body(const ConvParams& p) {
 
 // (an 8 x 16-pixel tile with 8 waves for 128 input channels -- 90 KiB, one workgroup per CU -- measured 2-3 %
 // slower than two 4 x 16 workgroups; 64 x 128-channel tiles with 8 waves for 256 input channels 12 % slower than
-// 64 x 256)
+// 64 x 256; a 2 x 16-pixel x 256-channel tile for 512 input channels -- 144 KiB -- no faster than the generic
+// kernel: its B stream needs 16 bytes per clock and CU from L2)
 using PatchC128 = PatchCfg<128, 4, 2, 2, 2>;   // 64 pixels x 128 channels, 4 waves, 54 KiB: two workgroups per CU
 using PatchC256 = PatchCfg<256, 4, 2, 4, 2>;   // 64 pixels x 256 channels, 8 waves, 108 KiB
 LWM_KERNEL_OCC(256, 2) void conv_patch_c128(ConvParams p) { conv_patch_body<128, 4, 2, 2, 2>(p); }

@@ -65,7 +65,10 @@ int main(int argc, char** argv) {
         {"64^2 256->256 (+res)", 64, 64, 256, 256, 0, 1},
         {"enc 64^2 128->256", 64, 64, 128, 256, 0, 0},
         {"32^2 256->256 (+res)", 32, 32, 256, 256, 0, 1},
-        {"16^2 512->512 (generic kernel)", 16, 16, 512, 512, 0, 1},
+        {"32^2 512->512 (+res)", 32, 32, 512, 512, 0, 1},
+        {"dec up 32^2->64^2 512->512", 32, 32, 512, 512, 1, 0},
+        {"dec 64^2 512->256", 64, 64, 512, 256, 0, 0},
+        {"16^2 768->768 (+res)", 16, 16, 768, 768, 0, 1},
     };
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
