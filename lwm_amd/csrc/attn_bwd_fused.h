@@ -53,7 +53,8 @@ constexpr int kFbOffStats = kFbOffDs + 2 * kFbDsBytes;
 constexpr int kFbStatBytes = 4 * kDkvBQ * 4;
 constexpr int kFbOffCtl = kFbOffStats + 2 * kFbStatBytes;
 constexpr int kFbOffPoll = kFbOffCtl + 64;          // 8 waves x 256 B: where each wave's flag poll lands
-constexpr int kFbLdsBytes = kFbOffPoll + 8 * 256;
+constexpr int kFbOffDq = kFbOffPoll + 8 * 256;      // 8 waves x 2 KiB: the accumulator slice each wave is about to add to
+constexpr int kFbLdsBytes = kFbOffDq + 8 * 2048;
 
 // workspace (int32): [0,8) tickets | [8,16) queue owner (0 = unclaimed, xcc+1) | [16] spin-limit flag |
 // [32, 32 + B*H*nqt*8) per-(b,h,tile,wave) counters | then f32 [B,H,Sq]: LSE in log2 units (+inf where the
@@ -310,8 +311,7 @@ LWM_DEVICE void fb_dq_product(const FusedCtx& cx, f32x4 (&acc)[2]) {
 // memory.  Ordering is PER WAVE SLICE: wave w of key block kbi waits for wave w of key block kbi-1 on
 // flag[(hb*nqt + qt)*8 + w], so no workgroup barrier sits between a wave's stores and its publication.
 struct DqRmw {
-    f32x4 prev[2];          // the two 16-dim tiles of this lane's query row
-    const float* tile;      // wave-uniform base of the tile's accumulator rows
+    float* acc;             // this lane's 4 floats of d-tile 0 in the f32 accumulator (d-tile 1: + 16 floats)
     bool ok;                // the lane's query row exists
 };
 
@@ -327,16 +327,18 @@ LWM_DEVICE void fb_dq_load(const AttnParams& p, const FusedCtx& cx, int b, int h
     const int db = cx.wave & 3, qh = cx.wave >> 2;
     const int64_t row0 = (int64_t)qt * kDkvBQ;
     const bool use = real && p.dq_acc != nullptr;
-    w.tile = use ? p.dq_acc + ((int64_t)b * p.dqa_sb + row0 * p.dqa_ss + (int64_t)h * p.dqa_sh) : dummy;
-    const uint32_t rstride = use ? (uint32_t)p.dqa_ss * 4u : 0u;
+    const float* tile = use ? p.dq_acc + ((int64_t)b * p.dqa_sb + row0 * p.dqa_ss + (int64_t)h * p.dqa_sh) : dummy;
+    const int64_t rstride = use ? p.dqa_ss : 0;
     const int rows_left = (int)(p.Sq - row0);        // >= 1
     const int r = 16 * qh + n;
     w.ok = r < rows_left;
     const int rc = w.ok ? r : rows_left - 1;
-    for (int t = 0; t < 2; ++t) {
-        const int d0 = 32 * db + 16 * t + 4 * kg;
-        w.prev[t] = global_load_f32x4_l2(w.tile, (uint32_t)rc * rstride + (use ? (uint32_t)d0 * 4u : 0u));
-    }
+    // by LDS-DMA: lane l's 16 bytes of d-tile t land at slot + 1024 t + 16 l -- no registers are held while the
+    // dQ product and the dV/dK phase run, and the read can be issued before both
+    const lds_t slot = cx.lds + kFbOffDq + (uint32_t)cx.wave * 2048;
+    const float* src = tile + (int64_t)rc * rstride + (use ? 32 * db + 4 * kg : 0);
+    w.acc = const_cast<float*>(src);                 // (stored to only when `use` and w.ok: then it IS the lane's slot)
+    for (int t = 0; t < 2; ++t) glds_load_b128_l2(src + (use ? 16 * t : 0), slot + 1024 * t);
 }
 
 // prev + scale * partial -> f32 accumulator, or bf16 dq when this is the tile's last contributor
@@ -352,14 +354,17 @@ LWM_DEVICE void fb_dq_store(const AttnParams& p, const FusedCtx& cx, int b, int 
     // The accumulator that was read is dropped by a bit mask, not a branch (a uniform branch around the only
     // use of a loaded register leaves it "maybe pending" for hipcc, see fb_stage_issue).
     const uint32_t keep = use_prev ? 0xffffffffu : 0u;
+    const lds_t slot = cx.lds + kFbOffDq + (uint32_t)cx.wave * 2048 + 16 * (uint32_t)lane;
     f32x4 o[2];
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t) {
+        const f32x4 prev = lds_read_f32x4(slot + 1024 * t);
         for (int j = 0; j < 4; ++j) {
-            const float pj = w.prev[t][j];     // (a copy: __builtin_bit_cast of a vector ELEMENT reads element 0)
+            const float pj = prev[j];          // (a copy: __builtin_bit_cast of a vector ELEMENT reads element 0)
             const float pv = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, pj) & keep);
             o[t][j] = fmaf(acc[t][j], p.scale, pv);
             pin_value(o[t][j]);                 // pin the use HERE: LLVM otherwise sinks it into the store's branch
         }
+    }
     sched_fence();
     if (!do_store || !w.ok) return;
     for (int t = 0; t < 2; ++t) {
@@ -368,7 +373,7 @@ LWM_DEVICE void fb_dq_store(const AttnParams& p, const FusedCtx& cx, int b, int 
             bf16_t* dst = p.dq + (int64_t)b * p.dq_sb + row * p.dq_ss + (int64_t)h * p.dq_sh + d0;
             global_store_b64_async(dst, u32x2{pack_bf16x2(o[t][0], o[t][1]), pack_bf16x2(o[t][2], o[t][3])});
         } else {
-            global_store_f32x4_async(p.dq_acc + ((int64_t)b * p.dqa_sb + row * p.dqa_ss + (int64_t)h * p.dqa_sh) + d0, o[t]);
+            global_store_f32x4_async(w.acc + 16 * t, o[t]);
         }
     }
 }
@@ -442,9 +447,9 @@ LWM_DEVICE void fb_step(const AttnParams& p, const FusedCtx& cx, const bf16x8 (&
     FB_LAP(pf, 2);
     f32x4 acc[2];
     DqRmw w;
+    fb_dq_load(p, cx, b, h, qp, has_prev, dummy, w);
     fb_dq_product<PB>(cx, acc);
     FB_LAP(pf, 3);
-    fb_dq_load(p, cx, b, h, qp, has_prev, dummy, w);
     fb_tile_c<BUF>(cx, pb, dsb, dk, dv);
     FB_LAP(pf, 4);
     wait_vmem_all();           // the staged tile (the barrier that follows publishes it) and the accumulator read
@@ -603,9 +608,10 @@ LWM_KERNEL(kFbThreads) void attn_bwd_fused_kernel(AttnParams p, int32_t* ws) {
                     fb_wait_turn(seen, kbi, flag_last, ws + kFbWsErr);
                     f32x4 acc[2];
                     DqRmw w;
+                    fb_dq_load(p, cx, b, h, qt_last, true, lse2, w);
                     if ((n - 1) & 1) fb_dq_product<1>(cx, acc);
                     else fb_dq_product<0>(cx, acc);
-                    fb_dq_load(p, cx, b, h, qt_last, true, lse2, w);
+                    wait_vmem_all();       // the accumulator slice has landed in LDS
                     fb_dq_store(p, cx, b, h, qt_last, !first || p.dq_carry_in, qt_last < qt_next || tail_block, true, w, acc);
                     wait_vmem_all();
                     if (lane == 0) store_i32_plain(flag_last, kbi + 1);

@@ -136,6 +136,16 @@ LWM_DEVICE void glds_load_b32(const void* g, lds_t wave_base) {
         : "v"(g), "s"(wave_base)
         : "memory");
 }
+// 16-byte form with agent scope (sc1: bypasses this CU's L1, served by the XCD's L2)
+LWM_DEVICE void glds_load_b128_l2(const void* g, lds_t wave_base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(g), "s"(wave_base)
+        : "memory");
+}
 // the same with agent scope (sc1: the load bypasses this CU's L1) -- a flag poll whose answer lands in LDS, so
 // that no VGPR and no compiler-inserted s_waitcnt is involved until the wave decides to look at it
 LWM_DEVICE void glds_load_b32_l2(const void* g, lds_t wave_base) {

@@ -152,6 +152,18 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(&gave_up, (int32_t*)ws + 16, 4, hipMemcpyDeviceToHost));
         cs_fused = checksum(dq);
         cs_dk_f = checksum(dk);
+    {
+            unsigned long long h[80];
+            CK(hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost));
+            if (h[8]) {
+                printf("per-step 100 MHz ticks of one mid-chain key block (wave: S/dP, counted wait, turn, dQ, dV/dK, full wait, store, barrier | steps)\n");
+                for (int w = 0; w < 8; ++w) {
+                    printf("  wave %d:", w);
+                    for (int i = 0; i < 8; ++i) printf(" %7.1f", (double)h[w * 10 + i] / (double)h[w * 10 + 8]);
+                    printf(" | %llu\n", h[w * 10 + 8]);
+                }
+            }
+        }
     }
     if (do_two) {
         a.dq_acc_head_major = 0;
@@ -160,18 +172,6 @@ int main(int argc, char** argv) {
         ms_dq = time_ms([&] { bdq(&a, nullptr); });
         cs_two = checksum(dq);
         cs_dk_t = checksum(dk);
-    }
-    {
-        unsigned long long h[80];
-        CK(hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost));
-        if (h[8]) {
-            printf("per-step 100 MHz ticks of one mid-chain key block (wave: S/dP, counted wait, turn, dQ, dV/dK, full wait, store, barrier | steps)\n");
-            for (int w = 0; w < 8; ++w) {
-                printf("  wave %d:", w);
-                for (int i = 0; i < 8; ++i) printf(" %7.1f", (double)h[w * 10 + i] / (double)h[w * 10 + 8]);
-                printf(" | %llu\n", h[w * 10 + 8]);
-            }
-        }
     }
     a.out_acc = nullptr;
     printf("%-40s S=%d H=%d fwd %.3f  fused %.3f ms (gave_up %d)  delta %.3f dkdv %.3f dq %.3f  |dq| fused %.6f two %.6f  |dk| %.6f %.6f\n",

@@ -307,6 +307,7 @@ LWM_DEVICE void glds_load_b32(const void* g, lds_t wave_base) {
     int l = emu::g_lane->tid & 63;
     memcpy(emu::lds_ptr(wave_base + 4 * l, 4, 4), g, 4);
 }
+LWM_DEVICE void glds_load_b128_l2(const void* g, lds_t wave_base) { glds_load_b128(g, wave_base); }
 LWM_DEVICE void glds_load_b32_l2(const void* g, lds_t wave_base) {
     int l = emu::g_lane->tid & 63;
     int32_t v = __atomic_load_n((const int32_t*)g, __ATOMIC_ACQUIRE);
