@@ -286,7 +286,7 @@ int lwm_conv2d_nhwc_f32(const LwmConvArgs* args, void* stream);
 /* flax nn.GroupNorm (num_groups G, eps, affine) over x [B,HW,C], optionally
  * followed by nn.silu (lwm/vqgan.py:161-162,181-182,251-255).  `workspace` is
  * caller-owned device memory of lwm_groupnorm_workspace_bytes() bytes (f64
- * partial sums); y may alias x. */
+ * slice partials, then the f32 mean / rstd per image and group); y may alias x. */
 int64_t lwm_groupnorm_workspace_bytes(int32_t B, int64_t HW, int32_t C, int32_t G);
 int lwm_groupnorm_silu_f32(const float* x, const float* gamma, const float* beta, float* y,
                            void* workspace, int32_t B, int64_t HW, int32_t C, int32_t G, float eps,
