@@ -72,6 +72,23 @@ def test_conv_patch_resident_bit_exact(B, H, W, Cin, Cout, kw):
     assert np.array_equal(got, R.conv2d(x, w, b, residual=res, **kw)), np.abs(got - R.conv2d(x, w, b, residual=res, **kw)).max()
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_conv_patch_resident_random_shapes(seed):
+    """Seeded random geometry inside (and just outside) the patch kernels' domain: batch, image height a
+    multiple of 4, width a multiple of 16 or not, 128 / 256 input channels, 128 / 256 / 384 outputs, upsample."""
+    g = _rng(100 + seed)
+    B = int(g.integers(1, 3))
+    H = 4 * int(g.integers(2, 7))
+    W = 16 * int(g.integers(1, 4)) + (8 if seed == 3 else 0)     # seed 3: width not a multiple of 16 -> generic kernel
+    Cin = int(g.choice([128, 256]))
+    Cout = int(g.choice([128, 256, 384]))
+    up = int(g.integers(0, 2))
+    kw = dict(up_shift=1) if up else {}
+    x, w, b = _conv_case(200 + seed, B, H, W, Cin, Cout, 3)
+    res = _rng(300 + seed).standard_normal((B, H << up, W << up, Cout)).astype(np.float32)
+    assert np.array_equal(_emu.conv2d(x, w, b, residual=res, **kw), R.conv2d(x, w, b, residual=res, **kw)), (B, H, W, Cin, Cout, up)
+
+
 def test_conv_patch_resident_is_what_runs(capfd, monkeypatch):
     """The dispatch really takes the patch kernels for these shapes (the emulation traces its launches)."""
     monkeypatch.setenv("LWM_EMU_TRACE", "1")
