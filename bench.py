@@ -241,14 +241,21 @@ def model_slice_leg(torch, S=32768):
             "tokens_per_s": S / dt, "loss": float(loss.detach())}
 
 
-def model_full_leg(torch, S=32768, layers=N_LAYERS):
+def model_full_leg(torch, S=32768, layers=N_LAYERS, mlp_chunk=8192, scan_mlp=False):
     """Secondary leg: ALL 32 layers of LWM-7B (6.74 B parameters, random
     init, bf16) at S = 32768, one forward+backward through the harness on ONE MI355X -- embedding, 32 x
     (RMSNorm, QKV, RoPE, RingAttention ring=1, wo, RMSNorm, blockwise SwiGLU FFN with chunk recompute),
     final norm, chunked lm_head + cross-entropy.  No optimizer step (the hot path ends at the gradients).
     Model FLOPs per token: 6 x 6.74e9 dense + 7 x S x d_model x L attention."""
     from lwm_amd.llama import LLaMAConfig, LLaMAForCausalLM
-    cfg = LLaMAConfig.load_config("7b", num_hidden_layers=layers, max_sequence_length=S, theta=1e7)
+    # scan_mlp / scan_mlp_chunk_size are the reference's own knobs (lwm/llama.py:673-678, :728-734): True = FFN in
+    # sequence chunks with its activations recomputed in the backward (the TPU memory setting; chunk 1024 by
+    # default, 8192 in scripts/run_train_vision_text.sh), False = one pass, activations kept (scripts/run_sample_*.sh).
+    # With 288 GB per GPU the 32K-token step fits without recompute (144 GiB peak); measured on MI355X:
+    # scan_mlp=False 2.39 s, chunk 32768 / 16384 / 8192 / 4096 / 1024 with recompute 2.48 / 2.51 / 2.55 / 2.61 / 2.86 s.
+    torch.cuda.reset_peak_memory_stats()
+    cfg = LLaMAConfig.load_config("7b", num_hidden_layers=layers, max_sequence_length=S, theta=1e7,
+                                  scan_mlp_chunk_size=mlp_chunk, scan_mlp=scan_mlp)
     torch.manual_seed(0)
     with torch.device("cuda"):
         model = LLaMAForCausalLM(cfg)
@@ -271,7 +278,8 @@ def model_full_leg(torch, S=32768, layers=N_LAYERS):
     dense = 6.0 * n_params * S
     attn = 7.0 * gemm_unit_flops(S) * layers
     out = {"workload": f"LWM-7B, all {layers} layers + embedding + lm_head ({n_params / 1e9:.2f} B parameters), B=1, S={S}, "
-                       f"bf16, forward+backward, one GPU",
+                       f"bf16, forward+backward, one GPU, scan_mlp={scan_mlp}",
+           "scan_mlp": scan_mlp, "scan_mlp_chunk_size": mlp_chunk,
            "ms_per_step": dt * 1e3, "tokens_per_s": S / dt, "loss": float(loss.detach()),
            "model_tflops": (dense + attn) / dt / 1e12, "attention_share_of_flops": attn / (dense + attn),
            "peak_hbm_gib": peak0 / 2 ** 30}
