@@ -4,8 +4,8 @@ seeded float32 parameters in the flax auto-named tree of lwm/vqgan.py.  numpy's 
 versions, so the parameters are regenerated instead of stored."""
 import numpy as np
 
-# a miniature of lwm/vqgan.py:62-77 (GroupNorm's 32 groups force channel counts that are multiples of 32)
-CFG = dict(resolution=32, num_channels=3, hidden_channels=32, channel_mult=(1, 2, 2), num_res_blocks=2,
+# a miniature of lwm/vqgan.py:62-77 (the HIP GroupNorm wants 4 channels per group: 128 is the narrowest width)
+CFG = dict(resolution=32, num_channels=3, hidden_channels=128, channel_mult=(1, 2, 2), num_res_blocks=2,
            attn_resolutions=(), no_attn_mid_block=True, z_channels=64, num_embeddings=256,
            quantized_embed_dim=64, resample_with_conv=True)
 SEED = 20240911
