@@ -142,3 +142,44 @@ def test_property_blockwise_ring_equals_dense(ring, chunks, qc, kc, causal, nseg
         one, _ = R.dense_attention(q[:, sl], k[:, sl], v[:, sl], causal=causal, key_valid=kv[:, sl])
         rows = kv[0, sl].astype(bool) if not causal else np.ones(b - a, bool)
         assert np.abs(one - ref[:, sl])[:, rows].max() < 1e-9
+
+
+@pytest.mark.parametrize("case", ["causal", "dense", "packed+padding", "offset"])
+def test_dense_oracle_matches_torch_sdpa(case):
+    """An anchor that is not ours: PyTorch's own scaled_dot_product_attention (float64, math path) with the
+    boolean mask of lwm/llama.py:572-592 spelled out by hand, and its autograd gradients, against the fp64 dense
+    oracle and its analytic backward -- output, lse-free, dq, dk, dv."""
+    B, S, H, D = 2, 96, 3, 16
+    q, k, v, do = [a.astype(np.float64) for a in _data(B, S, H, D, 11)]
+    kw = {}
+    mask = np.ones((B, S, S), bool)
+    ii, jj = np.arange(S)[:, None], np.arange(S)[None, :]
+    if case in ("causal", "packed+padding"):
+        kw["causal"] = True
+        mask &= (jj <= ii)[None]
+    else:
+        kw["causal"] = False
+    if case == "packed+padding":
+        seg = np.zeros((B, S), np.int32)
+        seg[:, 30:70] = 1
+        seg[:, 70:] = 2
+        valid = np.ones((B, S), np.uint8)
+        valid[1, 90:] = 0
+        kw.update(seg_q=seg, seg_k=seg, key_valid=valid)
+        mask &= seg[:, :, None] == seg[:, None, :]
+        mask &= valid[:, None, :] != 0
+    if case == "offset":                       # a ring step: this q block sits 40 tokens after the k block
+        kw.update(causal=True, q_start=40, k_start=0)
+        mask &= (jj <= ii + 40)[None]
+    tq, tk, tv = [torch.tensor(a.transpose(0, 2, 1, 3), requires_grad=True) for a in (q, k, v)]      # (B,H,S,D)
+    out_t = torch.nn.functional.scaled_dot_product_attention(tq, tk, tv, attn_mask=torch.tensor(mask)[:, None])
+    out_t.backward(torch.tensor(do.transpose(0, 2, 1, 3)))
+    out, _ = R.dense_attention(q, k, v, **kw)
+    dq, dk, dv = R.dense_attention_bwd(q, k, v, do, **kw)
+    rows = mask.any(-1)                        # (a row with no visible key: the oracle returns 0, SDPA returns NaN)
+    sel = np.broadcast_to(rows[:, :, None, None], out.shape)
+    ref = out_t.detach().numpy().transpose(0, 2, 1, 3)
+    assert np.abs(out - ref)[sel].max() < 1e-12
+    for got, t in ((dq, tq), (dk, tk), (dv, tv)):
+        g = np.nan_to_num(t.grad.numpy().transpose(0, 2, 1, 3))
+        assert np.abs(got - g).max() < 1e-11, case
