@@ -5,8 +5,9 @@ this module.  Nothing under lwm_amd/ does.
 
 PARITY UNPINNED (see oracle/vqgan_ref.c): lwm/vqgan.py is flax code that cannot
 be executed here (the encoder + quantiser are checked against HF transformers'
-ChameleonVQVAE, a third-party implementation of the same architecture:
-tests/golden/gen_hf_vqvae_golden.py, tests/test_golden.py); the arithmetic primitives are restated in C (libvqgan_ref.so,
+ChameleonVQVAE and the decoder network against HF's JanusVQVAEDecoder, third-party
+implementations of the same architecture: tests/golden/gen_hf_vqvae_golden.py,
+tests/test_golden.py); the arithmetic primitives are restated in C (libvqgan_ref.so,
 built by oracle/Makefile) and this module composes them exactly as the flax
 modules of lwm/vqgan.py do, walking the same parameter tree
 ({'encoder': {'Conv_0': {'kernel','bias'}, 'DownsamplingBlock_0': {...}}, ...},

@@ -6,8 +6,11 @@ changes], Downsample = zero pad (0,1,0,1) + conv3x3 stride 2, mid block without 
 
 The reference's flax modules cannot be imported in this image; this anchors the oracle's encoder + quantiser
 (layer order, padding side of the Downsample, GroupNorm grouping / eps, the shortcut rule, HWIO kernels,
-the argmin) against code that is not ours.  The decoder has no counterpart in HF and stays anchored by
-tests/test_vqgan_oracle.py only.
+the argmin) against code that is not ours.  The DECODER network is anchored the same way on HF's JanusVQVAEDecoder
+(conv_in, mid block, per level num_res_blocks + 1 ResnetBlocks and nearest x2 + conv3x3 upsampling in reversed
+level order, GroupNorm -> swish -> conv_out): Janus puts attention blocks into the mid block and the deepest
+level, which lwm's configuration does not have (no_attn_mid_block, attn_resolutions = ()) -- each is
+`x + proj_out(attn(norm(x)))`, so zeroing proj_out makes it the identity and the rest is lwm's decoder.
 
     python tests/golden/gen_hf_vqvae_golden.py      # needs `transformers`; writes hf_vqvae_tiny.npz
 """
@@ -96,10 +99,48 @@ def main():
     out = {"z": h.permute(0, 2, 3, 1).numpy(),                                                       # float64, pre-quantisation
            "indices": idx.reshape(2, side, side).numpy().astype(np.int32),
            "gap": gap.reshape(2, side, side).numpy(),
+           "decoder_out": janus_decoder_out(),                                                        # float64, before the clip
            "transformers_version": np.array(transformers.__version__)}
     dst = os.path.join(HERE, "hf_vqvae_tiny.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst), "bytes; min argmin gap", float(gap.min()), "median", float(gap.median()))
+
+
+def janus_decoder_out():
+    from transformers.models.janus.configuration_janus import JanusVQVAEConfig
+    from transformers.models.janus.modeling_janus import JanusVQVAEAttnBlock, JanusVQVAEDecoder
+    cfg = JanusVQVAEConfig(base_channels=CFG["hidden_channels"], channel_multiplier=list(CFG["channel_mult"]),
+                           num_res_blocks=CFG["num_res_blocks"], latent_channels=CFG["z_channels"], in_channels=3,
+                           out_channels=3, embed_dim=CFG["quantized_embed_dim"], num_embeddings=CFG["num_embeddings"],
+                           double_latent=False, dropout=0.0)
+    dec = JanusVQVAEDecoder(cfg).eval().double()
+    tree = F.decoder_tree()["decoder"]
+    attn_params = 0
+    with torch.no_grad():
+        _put_conv(dec.conv_in, tree["Conv_0"])
+        _put_resnet(dec.mid.block_1, tree["MidBlock_0"]["ResnetBlock_0"])
+        _put_resnet(dec.mid.block_2, tree["MidBlock_0"]["ResnetBlock_1"])
+        for order, up in enumerate(dec.up):                      # HF appends in reversed-level order too
+            bp = tree[f"UpsamplingBlock_{order}"]
+            for i, b in enumerate(up.block):
+                _put_resnet(b, bp[f"ResnetBlock_{i}"])
+            assert hasattr(up, "upsample") == ("Upsample_0" in bp)
+            if hasattr(up, "upsample"):
+                _put_conv(up.upsample.conv, bp["Upsample_0"]["Conv_0"])
+        _put_gn(dec.norm_out, tree["GroupNorm_0"])
+        _put_conv(dec.conv_out, tree["Conv_1"])
+        for m in dec.modules():                                  # attention blocks -> identity
+            if isinstance(m, JanusVQVAEAttnBlock):
+                m.proj_out.weight.zero_()
+                m.proj_out.bias.zero_()
+                attn_params += sum(p.numel() for p in m.parameters())
+    n_hf = sum(p.numel() for p in dec.parameters())
+    n_tree = sum(v.size for v in _leaves(tree))
+    assert n_hf == n_tree + attn_params, (n_hf, n_tree, attn_params)     # every other HF parameter was overwritten
+    z = torch.from_numpy(F.latents()).double().permute(0, 3, 1, 2)
+    with torch.no_grad():
+        y = dec(z)
+    return y.permute(0, 2, 3, 1).numpy()
 
 
 def _leaves(t):

@@ -1,5 +1,5 @@
 """The tiny VQGAN shared by tests/golden/gen_hf_vqvae_golden.py (which loads it into HF transformers'
-ChameleonVQVAE) and tests/test_golden.py (which feeds it to the oracle and the HIP kernels): configuration and
+ChameleonVQVAE encoder / JanusVQVAE decoder) and tests/test_golden.py (which feeds it to the oracle and the HIP kernels): configuration and
 seeded float32 parameters in the flax auto-named tree of lwm/vqgan.py.  numpy's PCG64 stream is stable across
 versions, so the parameters are regenerated instead of stored."""
 import numpy as np
@@ -11,9 +11,7 @@ CFG = dict(resolution=32, num_channels=3, hidden_channels=128, channel_mult=(1, 
 SEED = 20240911
 
 
-def lwm_tree():
-    g = np.random.default_rng(SEED)
-
+def _makers(g):
     def conv(cin, cout, k=3):
         return {"kernel": (g.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32),
                 "bias": (0.1 * g.standard_normal(cout)).astype(np.float32)}
@@ -27,6 +25,12 @@ def lwm_tree():
             p["Conv_2"] = conv(cin, cout, 1)
         return p
 
+    return conv, gn, resnet
+
+
+def lwm_tree():
+    g = np.random.default_rng(SEED)
+    conv, gn, resnet = _makers(g)
     hc, mult = CFG["hidden_channels"], CFG["channel_mult"]
     enc = {"Conv_0": conv(CFG["num_channels"], hc)}
     c = hc
@@ -48,3 +52,32 @@ def lwm_tree():
 def pixels():
     g = np.random.default_rng(SEED + 1)
     return (g.random((2, CFG["resolution"], CFG["resolution"], 3)) * 2 - 1).astype(np.float32)      # NHWC, as lwm feeds it
+
+
+def decoder_tree():
+    """'post_quant_conv' and 'decoder' of the same model (their own random stream: the encoder's values above stay
+    what the committed encoder vectors were made with).  UpsamplingBlock_<order> in flax creation order =
+    reversed levels (lwm/vqgan.py:180)."""
+    g = np.random.default_rng(SEED + 2)
+    conv, gn, resnet = _makers(g)
+    hc, mult = CFG["hidden_channels"], CFG["channel_mult"]
+    c = hc * mult[-1]
+    dec = {"Conv_0": conv(CFG["z_channels"], c),
+           "MidBlock_0": {"ResnetBlock_0": resnet(c, c), "ResnetBlock_1": resnet(c, c)}}
+    for order, lvl in enumerate(reversed(range(len(mult)))):
+        bp = {}
+        for i in range(CFG["num_res_blocks"] + 1):
+            bp[f"ResnetBlock_{i}"] = resnet(c, hc * mult[lvl])
+            c = hc * mult[lvl]
+        if lvl != 0:
+            bp["Upsample_0"] = {"Conv_0": conv(c, c)}
+        dec[f"UpsamplingBlock_{order}"] = bp
+    dec["GroupNorm_0"] = gn(c)
+    dec["Conv_1"] = conv(c, CFG["num_channels"])
+    return {"post_quant_conv": conv(CFG["quantized_embed_dim"], CFG["z_channels"], 1), "decoder": dec}
+
+
+def latents():
+    g = np.random.default_rng(SEED + 3)
+    side = CFG["resolution"] // 2 ** (len(CFG["channel_mult"]) - 1)
+    return g.standard_normal((2, side, side, CFG["z_channels"])).astype(np.float32)                  # NHWC decoder input
