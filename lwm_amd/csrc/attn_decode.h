@@ -20,7 +20,7 @@
 namespace lwm {
 
 constexpr int kDecThreads = 512;
-constexpr int kDecUnroll = 4;
+constexpr int kDecUnroll = 4;     // (2 and 8 measured: 368.7 / 358.2 us against 356.1 at 131072 keys, 512 pieces)
 
 LWM_DEVICE void unpack_bf16x8(u32x4 raw, float (&f)[8]) {
     for (int j = 0; j < 4; ++j) {

@@ -86,11 +86,13 @@ struct CombineParams {
 };
 
 // Workgroup = one (b, q, h) row: thread t owns d-quad t & 31 and partials
-// t >> 5, t >> 5 + 8, ... (8 subsets walked concurrently, each an online-softmax merge
-// in (m, l, acc) form), then the 8 subset states are merged through LDS.  A thread per
-// output element with a serial loop over P was latency-bound for decode (P ~ 1k pieces,
-// 1k threads in all).  D = 128.
-LWM_KERNEL(256) void attn_combine_kernel(CombineParams p) {
+// t >> 5, t >> 5 + kCombineSubs, ... (kCombineSubs subsets walked concurrently, each an online-softmax merge
+// in (m, l, acc) form), then the subset states are merged through LDS.  A thread per
+// output element with a serial loop over P was latency-bound for decode (P ~ 512 pieces); with 8 subsets the
+// 64 dependent steps still cost 26 us beside a 356 us decode launch, with 32 they cost a quarter.  D = 128.
+constexpr int kCombineSubs = 32;
+constexpr int kCombineThreads = 32 * kCombineSubs;
+LWM_KERNEL(kCombineThreads) void attn_combine_kernel(CombineParams p) {
     const lds_t lds = dyn_lds();
     const int tid = thread_idx();
     const int dq = tid & 31, sub = tid >> 5;
@@ -103,17 +105,31 @@ LWM_KERNEL(256) void attn_combine_kernel(CombineParams p) {
         const int64_t oi = (((int64_t)b * p.Sq + q) * p.H + h) * p.D + dq * 4;
         float m = -INFINITY, l = 0.0f;
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int s = sub; s < p.P; s += 8) {
-            const float ls = p.lse_parts[s * part_l + li];
-            if (ls == -INFINITY) continue;
-            f32x4 o = global_load_f32x4(p.o_parts + s * part_o + oi);
-            const float mn = fmaxf(m, ls);
-            const float wa = expf(m - mn), wb = expf(ls - mn);   // m = -inf: wa = 0
-            l = l * wa + wb;
-            for (int j = 0; j < 4; ++j) acc[j] = acc[j] * wa + o[j] * wb;
-            m = mn;
+        // four partials in flight per thread (the pieces were written by other XCDs a moment ago: every load is a
+        // trip to the fabric, and one at a time they cost ~1 us each); loads are unconditional, pieces past P
+        // re-read the last one and are skipped like empty pieces (lse = -inf)
+        for (int s0 = sub; s0 < p.P; s0 += 4 * kCombineSubs) {
+            float ls[4];
+            f32x4 o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int s = s0 + u * kCombineSubs;
+                const int sc = s < p.P ? s : p.P - 1;
+                ls[u] = p.lse_parts[sc * part_l + li];
+                o[u] = global_load_f32x4(p.o_parts + sc * part_o + oi);
+                if (s >= p.P) ls[u] = -INFINITY;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (ls[u] == -INFINITY) continue;
+                const float mn = fmaxf(m, ls[u]);
+                const float wa = expf(m - mn), wb = expf(ls[u] - mn);   // m = -inf: wa = 0
+                l = l * wa + wb;
+                for (int j = 0; j < 4; ++j) acc[j] = acc[j] * wa + o[u][j] * wb;
+                m = mn;
+            }
         }
-        // merge the 8 subset states: [sub][dq] -> (m, l, acc[4]) = 24 B
+        // merge the subset states: [sub][dq] -> (m, l, acc[4]) = 24 B
         const lds_t slot = lds + (uint32_t)(sub * 32 + dq) * 32;
         lds_write_f32(slot, m);
         lds_write_f32(slot + 4, l);
@@ -121,11 +137,11 @@ LWM_KERNEL(256) void attn_combine_kernel(CombineParams p) {
         block_sync();
         if (sub == 0) {
             float mx = -INFINITY;
-            for (int s = 0; s < 8; ++s) mx = fmaxf(mx, lds_read_f32(lds + (uint32_t)(s * 32 + dq) * 32));
+            for (int s = 0; s < kCombineSubs; ++s) mx = fmaxf(mx, lds_read_f32(lds + (uint32_t)(s * 32 + dq) * 32));
             float den = 0.0f;
             f32x4 r = {0.0f, 0.0f, 0.0f, 0.0f};
             if (mx != -INFINITY) {
-                for (int s = 0; s < 8; ++s) {
+                for (int s = 0; s < kCombineSubs; ++s) {
                     const lds_t sl = lds + (uint32_t)(s * 32 + dq) * 32;
                     const float ms = lds_read_f32(sl);
                     if (ms == -INFINITY) continue;
