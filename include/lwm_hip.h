@@ -248,6 +248,21 @@ int lwm_swiglu_fwd_bf16(const void* a, const void* b, void* y, int64_t n, void* 
 int lwm_swiglu_bwd_bf16(const void* a, const void* b, const void* g, void* da, void* db, int64_t n,
                         void* stream);
 
+/* y[r, :] = x[r, :] . W for rows <= 4 -- the projections of a cached-decode step (one token per batch row
+ * against the [K, N] bf16 kernels wq/wk/wv/wo, w1/w2/w3, lm_head; x @ kernel as flax nn.Dense computes it,
+ * lwm/llama.py:427-432, :659, :1075-1106).  HBM-bound: W is read once (2*K*N bytes), f32 accumulation in a fixed
+ * order (deterministic).  x: [rows, K] bf16, row stride ldx; w: [K, N] bf16 dense; y: [rows, N] bf16 (row
+ * stride ldy) and / or y_f32: [rows, N] f32 dense; workspace: lwm_gemv_workspace_bytes() bytes, 16-byte aligned.
+ * N % 8 == 0, K % 32 == 0, K <= 12288.
+ * lwm_gemv_multi_bf16: 1..3 kernels that share x (wq | wk | wv; w1 | w3) in ONE pair of launches; w, y, ldy,
+ * y_f32, N are arrays of nmat entries (y or y_f32 may be NULL as a whole or per entry); workspace: the sum of
+ * lwm_gemv_workspace_bytes(rows, K, N[i]). */
+int64_t lwm_gemv_workspace_bytes(int32_t rows, int32_t K, int32_t N);
+int lwm_gemv_bf16(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, float* y_f32, void* workspace,
+                  int32_t rows, int32_t K, int32_t N, void* stream);
+int lwm_gemv_multi_bf16(const void* x, int64_t ldx, int32_t nmat, const void* const* w, void* const* y, const int64_t* ldy,
+                        float* const* y_f32, const int32_t* N, void* workspace, int32_t rows, int32_t K, void* stream);
+
 /* tux.cross_entropy_loss_and_accuracy as used at lwm/train.py:177-181, :192-201, per row of
  * bf16 logits [rows, V] (V % 8 == 0, V <= 32768): nll[r] = logsumexp(row) - row[target[r]] in
  * f32; correct[r] = (first argmax == target[r]) (may be NULL); and, if dlogits != NULL, the

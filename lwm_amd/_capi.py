@@ -97,6 +97,12 @@ PROTOTYPES = {
     "lwm_swiglu_fwd_bf16": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_void_p]),
     "lwm_swiglu_bwd_bf16": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_void_p]),
     "lwm_softmax_ce_bf16": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.c_void_p]),
+    "lwm_gemv_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "lwm_gemv_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "lwm_gemv_multi_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                      C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_void_p,
+                                      C.c_int32, C.c_int32, C.c_void_p]),
     "lwm_cast_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "lwm_sum_f32_to_bf16": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "lwm_conv2d_nhwc_f32": (C.c_int, [C.POINTER(LwmConvArgs), C.c_void_p]),

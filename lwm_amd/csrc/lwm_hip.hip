@@ -13,5 +13,6 @@
 #include "attn_decode.h"
 #include "misc_kernels.h"
 #include "llama_elem.h"
+#include "gemv.h"
 #include "api.inc"
 #include "ring_driver.inc"

@@ -217,6 +217,10 @@ LWM_DEVICE void set_prio() { __builtin_amdgcn_s_setprio(N); }
 LWM_DEVICE float xhalf(float x) {
     return __shfl_xor(x, 32, 64);
 }
+// lane `src_lane`'s x for every lane, as a scalar operand (v_readlane_b32; src_lane wave-uniform)
+LWM_DEVICE float lane_value(float x, int src_lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src_lane));
+}
 LWM_DEVICE float shfl_xor_f(float x, int m) { return __shfl_xor(x, m, 64); }
 LWM_DEVICE int shfl_xor_i(int x, int m) { return __shfl_xor(x, m, 64); }
 

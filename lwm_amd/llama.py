@@ -17,7 +17,7 @@ import math
 import torch
 
 from . import ops as _ops
-from .llama_ops import (LLaMAMLP, RMSNorm, apply_rotary_emb, chunked_lm_head_loss,
+from .llama_ops import (LLaMAMLP, RMSNorm, apply_rotary_emb, chunked_lm_head_loss, dense, dense_multi,
                         precompute_freqs_cis)
 from .ringattention import (blockwise_feedforward, concatenate_to_cache, ringattention,
                             ringattention_inference, sp_size_rank)
@@ -148,10 +148,10 @@ class LLaMAAttention(torch.nn.Module):
     def forward(self, x, freqs_cis, attention_mask=None, segment_ids=None, position_ids=None, cache=None):
         B, S, d = x.shape
         split = lambda t: t.reshape(B, S, self.num_heads, self.head_dim)      # reshape, no transpose (:434-438)
-        xq, xk, xv = split(x @ self.wq), split(x @ self.wk), split(x @ self.wv)
+        xq, xk, xv = (split(t) for t in dense_multi(x, (self.wq, self.wk, self.wv)))
         xq, xk = apply_rotary_emb(xq, xk, freqs_cis, position_ids)
         if cache is not None:
-            return self._cached(xq, xk, xv.contiguous(), attention_mask, cache).reshape(B, S, d) @ self.wo
+            return dense(self._cached(xq, xk, xv.contiguous(), attention_mask, cache).reshape(B, S, d), self.wo)
         bias = None
         if attention_mask is not None:                                        # (:527-537)
             # the bias is NOT sharded over "sp" (lwm/llama.py:563): it covers the global sequence
@@ -295,7 +295,8 @@ class LLaMAForCausalLM(torch.nn.Module):
         else:
             pos = torch.arange(S, dtype=torch.int32, device=dev)[None].expand(B, S)
         pos = pos.clamp_min(0).to(torch.int32).contiguous()
-        head = self.lm_head.float()
+        head = self.lm_head        # f32 logits: bf16 operands are exact in f32, so `dense(.., torch.float32)` on the
+        #                            bf16 kernel forms the same products as h.float() @ kernel.float() and reads half the bytes
         tokens, logits_out = [input_ids], []
 
         def emit(logits):
@@ -310,7 +311,7 @@ class LLaMAForCausalLM(torch.nn.Module):
         n_eager = max_new_tokens if not graph else min(1, max_new_tokens)
         for _ in range(n_eager):
             h = self.hidden_states(step_in, ext, None, pos, cache)
-            step_in = emit(h[:, -1].float() @ head)
+            step_in = emit(dense(h[:, -1], head, torch.float32))
             pos = (pos[:, -1:] + 1).contiguous()
         if graph and max_new_tokens > 1:
             import torch.distributed as dist
@@ -325,7 +326,7 @@ class LLaMAForCausalLM(torch.nn.Module):
                 mask = ((ar[None, :] <= idx) & (ext > 0))[:, None, None, :]
                 for c in dcache:
                     c["mask_dev"] = mask
-                logits = self.hidden_states(tok, ext, None, posd, dcache)[:, -1].float() @ head
+                logits = dense(self.hidden_states(tok, ext, None, posd, dcache)[:, -1], head, torch.float32)
                 tok.copy_(logits.argmax(-1, keepdim=True).to(tok.dtype))
                 posd.add_(1)
                 idx.add_(1)

@@ -256,9 +256,73 @@ def swiglu(a, b):
     return _SwiGLU.apply(a, b)
 
 
+_GEMV_WS = {}
+
+
+def gemv_multi(x, kernels, out_dtype=torch.bfloat16):
+    """x (rows <= 4, K) bf16 against 1..3 kernels (K, N_i) bf16 that share it -> [(rows, N_i)] in `out_dtype`
+    (bf16 or f32) through ONE lwm_gemv_multi_bf16 call: every kernel streamed once from HBM, f32 accumulation
+    along a fixed tree."""
+    rows, K = x.shape
+    if x.dtype != torch.bfloat16 or x.stride(1) != 1 or any(
+            k.dtype != torch.bfloat16 or not k.is_contiguous() or k.shape[0] != K for k in kernels):
+        raise ValueError("gemv: expected bf16 x (contiguous rows) and contiguous bf16 (K, N) kernels")
+    L = lib()
+    n = len(kernels)
+    Ns = [int(k.shape[1]) for k in kernels]
+    key = (x.device, rows, K, tuple(Ns))
+    ws = _GEMV_WS.get(key)
+    if ws is None:                     # (one workspace per shape: a hipGraph replays with the pointers it captured)
+        need = sum(L.lwm_gemv_workspace_bytes(rows, K, N) for N in Ns)
+        ws = _GEMV_WS[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
+    ys = [torch.empty(rows, N, dtype=out_dtype, device=x.device) for N in Ns]
+    f32 = out_dtype == torch.float32
+    vp = C.c_void_p * n
+    w_arr = vp(*[k.data_ptr() for k in kernels])
+    y_arr = vp(*[y.data_ptr() for y in ys])
+    _capi.check(L, L.lwm_gemv_multi_bf16(x.data_ptr(), x.stride(0), n, w_arr, None if f32 else y_arr, (C.c_int64 * n)(*Ns),
+                                         y_arr if f32 else None, (C.c_int32 * n)(*Ns), ws.data_ptr(), rows, K,
+                                         _stream_ptr()), "lwm_gemv_multi_bf16")
+    return ys
+
+
+def gemv(x, kernel, out_dtype=torch.bfloat16):
+    return gemv_multi(x, [kernel], out_dtype)[0]
+
+
+def _decode_rows(x, kernels):
+    rows = x.numel() // x.shape[-1]
+    ok = rows <= 4 and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 32 == 0 and x.shape[-1] <= 12288 and \
+        not (torch.is_grad_enabled() and (x.requires_grad or any(k.requires_grad for k in kernels))) and \
+        all(k.dtype == torch.bfloat16 and k.is_contiguous() and k.shape[1] % 8 == 0 for k in kernels)
+    return rows if ok else 0
+
+
+def dense(x, kernel, out_dtype=None):
+    """flax nn.Dense without bias, `x @ kernel` (lwm/llama.py:427-432, :659).  A cached-decode step (at most four
+    rows in all, no autograd) streams the kernel through lwm_gemv_bf16; everything else is the library GEMM."""
+    return dense_multi(x, (kernel,), out_dtype)[0]
+
+
+def dense_multi(x, kernels, out_dtype=None):
+    """[x @ k for k in kernels] -- projections that share their input (wq | wk | wv, w1 | w3).  In a cached-decode
+    step they ride in one GEMV launch pair."""
+    rows = _decode_rows(x, kernels)
+    if rows:
+        x2 = x.reshape(rows, x.shape[-1])
+        out = []
+        for i in range(0, len(kernels), 3):
+            out += gemv_multi(x2, list(kernels[i:i + 3]), out_dtype or torch.bfloat16)
+        return [y.reshape(*x.shape[:-1], y.shape[-1]) for y in out]
+    if out_dtype in (None, x.dtype):
+        return [x @ k for k in kernels]
+    return [x.to(out_dtype) @ k.to(out_dtype) for k in kernels]
+
+
 class LLaMAMLP(torch.nn.Module):
     """FlaxLLaMAMLP (lwm/llama.py:623-661): w2(silu(w1 x) * w3 x), flax Dense kernels
-    (in, out), no bias.  The three GEMMs are library GEMMs (hipBLASLt via torch.matmul)."""
+    (in, out), no bias.  The three GEMMs are library GEMMs (hipBLASLt via torch.matmul); in a cached-decode
+    step (<= 4 rows) they are lwm_gemv_bf16 launches (`dense`)."""
 
     def __init__(self, hidden_size, intermediate_size, dtype=torch.bfloat16, initializer_range=0.02):
         super().__init__()
@@ -267,4 +331,5 @@ class LLaMAMLP(torch.nn.Module):
             mk(hidden_size, intermediate_size)
 
     def forward(self, x):
-        return swiglu((x @ self.w1).contiguous(), (x @ self.w3).contiguous()) @ self.w2
+        gate, up = dense_multi(x, (self.w1, self.w3))
+        return dense(swiglu(gate.contiguous(), up.contiguous()), self.w2)

@@ -13,9 +13,17 @@ from . import _capi
 from ._lib import lib
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream_ptr(stream=None):
-    s = stream if stream is not None else torch.cuda.current_stream()
-    return C.c_void_p(s.cuda_stream)
+    """The HIP stream the launches go to: torch's current stream of the current device (the raw-handle query is
+    ~10x cheaper than building a torch.cuda.Stream object -- a decode step asks some 50 times per token)."""
+    if stream is not None:
+        return C.c_void_p(stream.cuda_stream)
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def _t4(t, name):

@@ -348,3 +348,37 @@ def kv_cache_write_at(cache_bits, src_bits, index, row_offset, src_row0, nrows):
                                            idx.ctypes.data, row_offset, S, src_row0, nrows, H * D, None),
                 "lwm_kv_cache_write_at")
     return cache_bits
+
+
+def gemv(x, w, want_f32=False):
+    """x (rows, K), w (K, N) float32 arrays holding bf16 values -> (rows, N) through lwm_gemv_bf16."""
+    L = lib()
+    xb, wb = bf16_array(x), bf16_array(w)
+    rows, K = x.shape
+    N = w.shape[1]
+    ws = aligned((max(L.lwm_gemv_workspace_bytes(rows, K, N), 16) // 4,), np.float32)
+    y = aligned((rows, N), np.uint16)
+    yf = aligned((rows, N), np.float32)
+    _capi.check(L, L.lwm_gemv_bf16(xb.ctypes.data, K, wb.ctypes.data, y.ctypes.data, N, yf.ctypes.data if want_f32 else None,
+                                   ws.ctypes.data, rows, K, N, None), "lwm_gemv_bf16")
+    return (from_bf16_bits(y), yf.copy()) if want_f32 else from_bf16_bits(y)
+
+
+def gemv_multi(x, ws, want_f32=False):
+    """1..3 kernels that share x through ONE lwm_gemv_multi_bf16 call."""
+    import ctypes as C
+    L = lib()
+    xb = bf16_array(x)
+    wbs = [bf16_array(w) for w in ws]
+    rows, K = x.shape
+    Ns = [w.shape[1] for w in ws]
+    n = len(ws)
+    wsz = sum(max(L.lwm_gemv_workspace_bytes(rows, K, N), 16) for N in Ns)
+    work = aligned((wsz // 4,), np.float32)
+    ys = [aligned((rows, N), np.float32 if want_f32 else np.uint16) for N in Ns]
+    vp = C.c_void_p * n
+    y_arr = vp(*[y.ctypes.data for y in ys])
+    _capi.check(L, L.lwm_gemv_multi_bf16(xb.ctypes.data, K, n, vp(*[w.ctypes.data for w in wbs]), None if want_f32 else y_arr,
+                                         (C.c_int64 * n)(*Ns), y_arr if want_f32 else None, (C.c_int32 * n)(*Ns),
+                                         work.ctypes.data, rows, K, None), "lwm_gemv_multi_bf16")
+    return [y.copy() if want_f32 else from_bf16_bits(y) for y in ys]

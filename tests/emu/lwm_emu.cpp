@@ -14,6 +14,7 @@
 #include "attn_decode.h"
 #include "misc_kernels.h"
 #include "llama_elem.h"
+#include "gemv.h"
 #include "api.inc"
 #include "vqgan_conv.h"
 #include "vqgan_misc.h"

@@ -349,6 +349,15 @@ LWM_DEVICE int shfl_xor_i(int x, int m) {
     return r;
 }
 LWM_DEVICE float xhalf(float x) { return shfl_xor_f(x, 32); }
+LWM_DEVICE float lane_value(float x, int src_lane) {       // v_readlane_b32: every lane gets lane `src_lane`'s x
+    emu::Wave& w = emu::g_blk->waves[emu::g_lane->tid >> 6];
+    int l = emu::g_lane->tid & 63;
+    w.f[l] = x;
+    emu::wave_sync();
+    float r = w.f[src_lane & 63];
+    emu::wave_sync();
+    return r;
+}
 LWM_DEVICE bool wave_any(bool x) {
     emu::Wave& w = emu::g_blk->waves[emu::g_lane->tid >> 6];
     int l = emu::g_lane->tid & 63;

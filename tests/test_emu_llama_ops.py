@@ -75,3 +75,38 @@ def test_softmax_cross_entropy(B, S, V):
     assert abs(float((cor * w.reshape(-1)).sum()) - acc) <= 1e-6
     assert cor[0] == 1
     assert np.abs(dl.reshape(B, S, V) - dref).max() <= 2 ** -8 * np.abs(dref).max() + 1e-9
+
+
+@pytest.mark.parametrize("rows,K,N", [(1, 256, 512), (2, 96, 40), (4, 160, 1032), (3, 128, 8)])
+def test_gemv_decode_projection(rows, K, N):
+    """lwm_gemv_bf16 (the projections of a cached-decode step): ragged K tile (K % 128 != 0), ragged and tiny N
+    tiles, 1..4 rows; f32 accumulation, so the f32 result equals the exact product to f32 rounding and the bf16
+    result is its rounding."""
+    x, w = _rnd((rows, K), 21), _rnd((K, N), 22, 0.1)
+    yb, yf = _emu.gemv(x, w, want_f32=True)
+    ref = x.astype(np.float64) @ w.astype(np.float64)
+    assert np.abs(yf - ref).max() <= 2e-6 * np.abs(ref).max() * np.sqrt(K)
+    assert np.array_equal(yb, round_bf16(yf))
+    assert np.array_equal(_emu.gemv(x, w), yb)                      # bf16-only output: same values
+
+
+def test_gemv_multi_shares_x():
+    """wq | wk | wv (or w1 | w3) in one launch pair: each output equals the single-matrix call bit for bit."""
+    x = _rnd((2, 160), 31)
+    ws = [_rnd((160, n), 32 + i, 0.1) for i, n in enumerate((520, 64, 1032))]
+    got = _emu.gemv_multi(x, ws, want_f32=True)
+    for w, g in zip(ws, got):
+        assert np.array_equal(g, _emu.gemv(x, w, want_f32=True)[1])
+    gb = _emu.gemv_multi(x, ws[:2])
+    assert np.array_equal(gb[0], _emu.gemv(x, ws[0])) and np.array_equal(gb[1], _emu.gemv(x, ws[1]))
+
+
+def test_gemv_validation():
+    import ctypes as C
+    L = _emu.lib()
+    buf = _emu.aligned((4096,), np.float32)
+    p = buf.ctypes.data
+    assert L.lwm_gemv_bf16(p, 64, p, p, 64, None, p, 5, 64, 64, None) == -2       # rows > 4
+    assert L.lwm_gemv_bf16(p, 64, p, p, 60, None, p, 1, 64, 60, None) == -2       # N % 8
+    assert L.lwm_gemv_bf16(p, 64, p, None, 64, None, p, 1, 64, 64, None) == -1    # no output
+    assert L.lwm_gemv_workspace_bytes(2, 4096, 11008) == 32 * 2 * 11008 * 4

@@ -150,3 +150,40 @@ def test_swiglu_fwd_bwd():
     da, db = R.swiglu_bwd(a, b, g)
     assert np.abs(_np(ad.grad) - da).max() <= 2 ** -7 * np.abs(da).max() + 1e-6
     assert np.abs(_np(bd.grad) - db).max() <= 2 ** -7 * np.abs(db).max() + 1e-6
+
+
+@pytest.mark.parametrize("rows,K,N", [(1, 4096, 4096), (3, 4096, 11008), (1, 11008, 4096), (2, 4096, 32000), (4, 4096, 12288)])
+def test_gemv_decode_projection_7b_shapes(rows, K, N):
+    """lwm_gemv_bf16 at LWM-7B's projection shapes (attention, FFN in / out, lm_head) against the f32 product."""
+    import torch
+    from lwm_amd.llama_ops import gemv
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(rows, K, generator=g, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(K, N, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    yf = gemv(x, w, torch.float32)
+    ref = x.double() @ w.double()
+    assert (yf.double() - ref).abs().max() <= 1e-5 * ref.abs().max()
+    yb = gemv(x, w)
+    assert torch.equal(yb, yf.to(torch.bfloat16))
+    assert torch.equal(gemv(x, w, torch.float32), yf)                # deterministic
+
+
+def test_dense_routes_decode_rows_through_gemv():
+    """`dense` = flax nn.Dense without bias: <= 4 rows without autograd take lwm_gemv_bf16, anything else the
+    library GEMM; both agree to bf16 rounding."""
+    import torch
+    from lwm_amd.llama_ops import dense
+    g = torch.Generator(device="cuda").manual_seed(6)
+    w = (torch.randn(4096, 4096, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    x = torch.randn(2, 1, 4096, generator=g, device="cuda").to(torch.bfloat16)
+    with torch.no_grad():
+        a = dense(x, w)
+    b = x @ w
+    assert a.shape == b.shape and (a.float() - b.float()).abs().max() <= 2 ** -7 * b.float().abs().max()
+    wp = torch.nn.Parameter(w)
+    y = dense(x, wp)                                                  # autograd on: library GEMM, differentiable
+    y.float().sum().backward()
+    assert wp.grad is not None
+    big = torch.randn(2, 8, 4096, generator=g, device="cuda").to(torch.bfloat16)
+    with torch.no_grad():
+        assert torch.equal(dense(big, w), big @ w)
