@@ -316,7 +316,24 @@ def dense_multi(x, kernels, out_dtype=None):
         return [y.reshape(*x.shape[:-1], y.shape[-1]) for y in out]
     if out_dtype in (None, x.dtype):
         return [x @ k for k in kernels]
-    return [x.to(out_dtype) @ k.to(out_dtype) for k in kernels]
+    return [x.to(out_dtype) @ _as_dtype(k, out_dtype) for k in kernels]
+
+
+_CAST_CACHE = {}
+
+
+def _as_dtype(k, dtype):
+    """kernel.to(dtype), kept while the kernel is unchanged (a sampling loop with more than four rows asks for the
+    f32 copy of the same head at every step)."""
+    if torch.is_grad_enabled() and k.requires_grad:
+        return k.to(dtype)
+    key = (k.data_ptr(), dtype, tuple(k.shape))
+    hit = _CAST_CACHE.get(key)
+    if hit is None or hit[0] != k._version:
+        if len(_CAST_CACHE) > 8:
+            _CAST_CACHE.clear()
+        hit = _CAST_CACHE[key] = (k._version, k.detach().to(dtype))
+    return hit[1]
 
 
 class LLaMAMLP(torch.nn.Module):

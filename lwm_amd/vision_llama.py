@@ -9,7 +9,7 @@ from __future__ import annotations
 import torch
 
 from .llama import LLaMAConfig, LLaMAForCausalLM, _dense
-from .llama_ops import chunked_lm_head_loss
+from .llama_ops import chunked_lm_head_loss, dense
 
 
 class VideoLLaMAConfig(LLaMAConfig):
@@ -113,11 +113,11 @@ class VideoLLaMAForCausalLM(LLaMAForCausalLM):
         B, S = input_ids.shape
         max_length = max_length or (S + max_new_tokens)
         h, cache, ext, pos = self._prefill(input_ids, vision_masks, attention_mask, max_length)
-        head = self.lm_head.float()
+        head = self.lm_head        # (f32 logits from the bf16 kernel: llama_ops.dense)
         out = torch.full((B, max_new_tokens), int(pad_token_id), dtype=input_ids.dtype, device=input_ids.device)
         done = torch.zeros(B, dtype=torch.bool, device=input_ids.device)
         for i in range(max_new_tokens):
-            tok = self._pick(h.float() @ head, temperature, top_k, do_sample, generator).to(input_ids.dtype)
+            tok = self._pick(dense(h, head, torch.float32), temperature, top_k, do_sample, generator).to(input_ids.dtype)
             out[:, i] = torch.where(done, out[:, i], tok[:, 0])
             if eos_token_id is not None:
                 done |= tok[:, 0] == eos_token_id
@@ -144,10 +144,10 @@ class VideoLLaMAForCausalLM(LLaMAForCausalLM):
         cfg = torch.as_tensor(cfg_scales, dtype=torch.float32, device=input_ids.device).reshape(-1, 1).expand(B, 1)
         max_length = max_length or (S + max_new_tokens)
         h, cache, ext, pos = self._prefill(input_ids, vision_masks, attention_mask, max_length)
-        head = self._vision_kernel().float()
+        head = self._vision_kernel().contiguous()
         out = torch.empty((B, max_new_tokens), dtype=input_ids.dtype, device=input_ids.device)
         for i in range(max_new_tokens):
-            logits = h.float() @ head
+            logits = dense(h, head, torch.float32)
             cond, uncond = logits[:B], logits[B:]
             tok = self._pick(uncond + cfg * (cond - uncond), temperature, top_k, True, generator).to(input_ids.dtype)
             if (i + 1) % 257 == 0:
