@@ -12,8 +12,6 @@ Names, parameter layouts and config knobs follow the reference: flax Dense kerne
 """
 from __future__ import annotations
 
-import math
-
 import torch
 
 from . import ops as _ops

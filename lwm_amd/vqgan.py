@@ -18,7 +18,6 @@ VectorQuantizer (:187-221), VQGANModel.encode/decode (:117-141).
 """
 from __future__ import annotations
 
-import pickle
 
 import numpy as np
 import torch
