@@ -7,9 +7,11 @@ LWM-7B (32 heads x 128, lwm/llama.py:70-81) over one synthetic packed batch
 N(0,1) bf16 already resident in HBM when the timed region starts.
 
   N=1 : BASELINE.json configs[1]  (S=32768, ring=1, no send/recv)
-  N>1 : BASELINE.json configs[2]'s problem (S=131072) ring-sharded over N GPUs
-        (zigzag ownership for causal balance), K/V and dK/dV exchanged over RCCL
-        (mesh schedule by default, --schedule ring for the reference's pattern).
+  N>1 : the SAME problem (S=32768) ring-sharded over N GPUs -- strong scaling, so that the per-N values of
+        N = 1, 2, 4, 8 compare (attention cost is quadratic in S: a different S per N would not); zigzag
+        ownership for causal balance, K/V and dK/dV exchanged over RCCL (mesh schedule by default,
+        --schedule ring for the reference's pattern).  `--seq 131072` is BASELINE configs[2]'s problem
+        (128K over the ring), `--seq 1048576 --packed` configs[4]'s.
         Also reported at N>1 (object `exchange`): the step re-run with a communicator
         that moves nothing (what the exchange costs on top of the launches) and one
         layer of the SAME problem on a single GPU (like-for-like strong scaling).
@@ -689,7 +691,7 @@ def main():
     else:
         comm = SingleComm()
 
-    S = args.seq or (32768 if world == 1 else 131072)
+    S = args.seq or 32768        # the SAME problem at every N (strong scaling); --seq 131072 = BASELINE configs[2]
     layout = SeqLayout(args.layout, world, S)
     c = layout.local_len
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -832,7 +834,8 @@ def main():
                              f"causal, ring={world}" + (f", layout={layout.kind}" if world > 1 else "")
                              + (f", masked packing ({len(lens)} documents)" if args.packed else "")
                              + (" [BASELINE configs[1]]" if world == 1 and S == 32768 and not args.packed else "")
-                             + (" [BASELINE configs[2] problem]" if world > 1 and S == 131072 else "")),
+                             + (" [BASELINE configs[2] problem]" if world > 1 and S == 131072 else "")
+                             + (" [BASELINE configs[1] problem, ring-sharded]" if world > 1 and S == 32768 else "")),
                 "seq_len": S, "ring": world, "layers": args.layers,
                 "exchange_schedule": ("ring (C-ABI driver, RCCL on a side stream)" if c_ring is not None else
                                       getattr(comm, "schedule", None)) if world > 1 else None,
