@@ -883,6 +883,7 @@ def main():
                 res["decode"] = decode_leg(torch)
                 res["generate"] = generate_leg(torch)
                 res["ring8_compute_model"] = ring_model_leg(torch)
+                res["ring8_compute_model_32k"] = ring_model_leg(torch, S=32768)     # what `--gpus 8` runs by default
                 res["elementwise"] = elementwise_leg(torch)
         print(json.dumps(res), flush=True)
     if world > 1:
