@@ -57,3 +57,7 @@ def test_stub_forward_and_conv_agree_with_the_package():
     w = torch.randn(3, 3, 32, 64, generator=g).cuda() / 17
     b = torch.randn(64, generator=g).cuda()
     assert torch.equal(ns["conv3x3_same"](x, w, b), ops.conv2d_nhwc(x, w, b))
+    from lwm_amd.llama_ops import gemv
+    xd = torch.randn(2, 4096, generator=g).to(torch.bfloat16).cuda()
+    kd = (torch.randn(4096, 4096, generator=g) * 0.02).to(torch.bfloat16).cuda()
+    assert torch.equal(ns["dense_decode"](xd, kd), gemv(xd, kd))
