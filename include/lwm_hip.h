@@ -178,6 +178,12 @@ int lwm_ring_attn_fwd(LwmRing* ring, const LwmRingArgs* args, void* compute_stre
 int lwm_ring_attn_bwd(LwmRing* ring, const LwmRingArgs* args, void* compute_stream);
 /* bytes this ring object has sent since creation (diagnostic) */
 int64_t lwm_ring_bytes_sent(const LwmRing* ring);
+/* Diagnostic: ONE grouped exchange with ourselves through the ring's transport -- send `bytes` bytes at src to
+ * our own ring rank and receive them into dst -- enqueued on the ring's side stream and handed over by the same
+ * events an attention step uses (compute stream -> side stream -> compute stream).  With a ring made by
+ * lwm_ring_create_from_id(n = 1) this is a complete first contact with RCCL on a single GPU: the run-time symbol
+ * table, the by-value ncclUniqueId, ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on a non-default stream. */
+int lwm_ring_selftest(LwmRing* ring, const void* src, void* dst, int64_t bytes, void* compute_stream);
 
 /* (min, max) of segment_ids over each block of 32 rows, excluding rows whose valid[] is 0
  * (valid may be NULL); an all-invalid block gets (INT32_MAX, INT32_MIN).

@@ -82,6 +82,7 @@ PROTOTYPES = {
     "lwm_ring_attn_fwd": (C.c_int, [C.c_void_p, C.POINTER(LwmRingArgs), C.c_void_p]),
     "lwm_ring_attn_bwd": (C.c_int, [C.c_void_p, C.POINTER(LwmRingArgs), C.c_void_p]),
     "lwm_ring_bytes_sent": (C.c_int64, [C.c_void_p]),
+    "lwm_ring_selftest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "lwm_attn_segment_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "lwm_attn_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, LwmTensor4, C.c_void_p, C.c_void_p,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

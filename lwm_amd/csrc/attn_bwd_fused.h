@@ -10,34 +10,29 @@
 // Shape.  A work item = (batch*head, block of 256 keys).  The workgroup (8 waves, wave w owns keys
 // 32w..32w+31) keeps dK^T/dV^T accumulators and its V fragments in registers and the K block in LDS,
 // and walks the 32-query tiles from the last one down to its causal diagonal, as attn_bwd_dkdv does.
-// New per tile:
+// Per tile, beyond what that kernel does:
 //   * dS^T (bf16, [256 keys][32 queries]) is written to LDS by the waves that produced it;
-//   * one step later every wave w multiplies it by K^T for its 16 head dims:
-//         dQ^T[16w..16w+15][32 q] = K^T[16 d][256 keys] . dS^T[256 keys][32 q]
-//     on v_mfma_f32_16x16x32_bf16 (both operands by ds_read_b64_tr_b16 from the [key][*] images),
-//     i.e. the reduction over the workgroup's 256 keys happens inside the MFMA accumulator;
-//   * the 32 x 128 f32 partial is ADDED to the dq accumulator in global memory.  The key blocks of
-//     one head add to a query tile in a FIXED order (ascending key block) enforced by a per-tile
-//     counter -- deterministic, no atomics on data.  A tile's accumulator is touched by consecutive
-//     key blocks within a few microseconds of each other and stays in L2 meanwhile.
+//   * one step later every wave w multiplies it by K for its 32 head dims and 16 of the queries:
+//         dQ[16 q][32 d] = dS[16 q][256 keys] . K[256 keys][32 d]
+//     on v_mfma_f32_16x16x32_bf16 (both operands by ds_read_b64_tr_b16 from the [key][*] images):
+//     the reduction over the workgroup's 256 keys happens inside the MFMA accumulator, and a lane ends
+//     up holding one head dim of four query rows, so that
+//   * the partial is ADDED to the f32 dq accumulator in global memory by fire-and-forget
+//     global_atomic_add_f32: 16 consecutive lanes = 64 contiguous bytes of one (query, head) row.
+//     Nothing is read back, nothing is waited for, no key block waits for another.  The accumulator
+//     must hold zeros (or the ring's dq carry) at launch and is converted to bf16 by a separate
+//     streaming pass (lwm_attn_bwd_fused does both).  dq is therefore summed in a run-dependent order:
+//     its last f32 bits vary between runs (dk, dv do not; profiles/r03_parity_stats.json has the spread);
+//     the deterministic path is the two-kernel backward.
 //
-// Who may read what (MI355X: one L2 per XCD, L2s not coherent with each other, per-CU L1 never
-// refreshed by other CUs' stores -- MI355X_MICROARCH.md "inter-workgroup visibility"):
-//   * all key blocks of one (batch, head) are executed by workgroups of ONE XCD.  This is enforced,
-//     not assumed: work is handed out through 8 queues (heads hb with hb % 8 == q), a queue is
-//     CLAIMED (atomic CAS) by the XCC id (s_getreg HW_REG_XCC_ID) of the first workgroup that takes
-//     from it, and only workgroups with that XCC id take from it afterwards.  Persistent workgroups
-//     drain their own XCD's queue first and then claim whatever is unclaimed, so every item is
-//     executed whatever the dispatcher does;
-//   * within an XCD: a wave stores its slice of the tile plainly (L1 is write-through; the store is
-//     acknowledged by L2), waits vmcnt(0) -- one step later, when it costs nothing -- and then stores the
-//     slice's counter; the reader polls the counter (sc1: never from L1) and then loads the slice with PLAIN
-//     loads from that same L2 -- its own L1 cannot hold the lines (invalidated once per work item; a slice
-//     is whole 128-byte lines read once per item by the one wave that owns them).  An sc1 / nt load of a
-//     line that is dirty in L2 is served from memory instead (measured: the whole read-modify-write stream
-//     became HBM traffic, 59 GB per launch).  Ordering is per wave slice (32 head dims x 16 queries).
-//   * progress: an item waits only for the item with the next-lower ticket of the same queue, which
-//     was taken earlier by a workgroup that is running -- no dependence on dispatch order.
+// Where the adds are performed (MI355X: one L2 per XCD, L2s not coherent with each other --
+// MI355X_MICROARCH.md "inter-workgroup visibility"): see wave_ops.h::atomic_add_f32_at.  Work is handed
+// out through 8 queues (heads hb with hb % 8 == q); a queue is CLAIMED (atomic CAS) by the XCC id
+// (s_getreg HW_REG_XCC_ID) of the first workgroup that takes from it and only workgroups of that XCD
+// take from it afterwards; persistent workgroups drain their own XCD's queue and then claim what is
+// unclaimed.  All key blocks of one (batch, head) -- the only contributors to that head's dq rows -- are
+// therefore executed by ONE XCD whatever the dispatcher does: their Q / dO stream is shared in that L2,
+// and the adds may be performed there (LWM_ATOMIC_AGENT = 0) instead of at the memory side.
 #pragma once
 
 namespace lwm {
@@ -52,31 +47,13 @@ constexpr int kFbOffStats = kFbOffDs + 2 * kFbDsBytes;
 // stats block: lse2[32] | delta[32] | seg[32] | 128 B landing pad of the 64-lane segment-id DMA
 constexpr int kFbStatBytes = 4 * kDkvBQ * 4;
 constexpr int kFbOffCtl = kFbOffStats + 2 * kFbStatBytes;
-constexpr int kFbOffPoll = kFbOffCtl + 64;          // 8 waves x 256 B: where each wave's flag poll lands
-constexpr int kFbOffDq = kFbOffPoll + 8 * 256;      // 8 waves x 2 KiB: the accumulator slice each wave is about to add to
-constexpr int kFbLdsBytes = kFbOffDq + 8 * 2048;
+constexpr int kFbOffScan = kFbOffCtl + 64;          // seg_narrow scratch (8 waves x 8 B)
+constexpr int kFbLdsBytes = kFbOffScan + 64;
 
-// workspace (int32): [0,8) tickets | [8,16) queue owner (0 = unclaimed, xcc+1) | [16] spin-limit flag |
-// [32, 32 + B*H*nqt*8) per-(b,h,tile,wave) counters | then f32 [B,H,Sq]: LSE in log2 units (+inf where the
-// row has no visible key), written by attn_bwd_lse2_kernel before the main launch
+// workspace (int32): [0,8) tickets | [8,16) queue owner (0 = unclaimed, xcc+1) | [16,32) unused |
+// then f32 [B,H,Sq]: LSE in log2 units (+inf where the row has no visible key), written by
+// attn_bwd_lse2_kernel before the main launch
 constexpr int kFbWsHeader = 32;
-constexpr int kFbWsErr = 16;
-// A wait that does not end within this many polls (~0.5 s; a healthy wait is a few polls) gives up and
-// raises ws[kFbWsErr]: results are then wrong, but the GPU is not left spinning (every spin is bounded).
-constexpr int kFbSpinLimit = 1 << 20;
-// A key block starts its walk only when its predecessor is already kFbSlack tiles ahead.  Consecutive key
-// blocks form a pipeline with blocking and no buffers (a block can never overtake the one before it); the
-// distance between two of them is the hand-off latency (store -> flag -> poll: about two steps) plus this
-// slack.  A tile of dq (16 KiB f32) and its Q/dO tiles (16 KiB) are re-used by the next block one distance
-// later, with the tiles of all 32 co-resident blocks of the XCD in between: LRU distance = 32 x distance x
-// 32 KiB, i.e. 2.5 MiB at distance 2.5 and 4.6 MiB at 4.5 -- against a 4 MiB L2.  rocprofv3 at S = 32768:
-// slack 2 -> 36 GB fetched per launch (TCC_MISS 2.9e8), slack 0 -> 19 GB (1.5e8); time 28.3 vs 27.7 ms
-// (0/1/2/3: 27.7 / 27.9 / 28.3 / 29.9; scripts/micro/l2_handoff.hip shows the same chain, alone, running
-// entirely out of L2).
-#ifndef LWM_FB_SLACK
-#define LWM_FB_SLACK 0
-#endif
-constexpr int kFbSlack = LWM_FB_SLACK;
 
 // Per-lane state that lives across the whole tile loop is kept to a minimum (the loop runs at the
 // 256-register limit: 128 accumulator + 32 V-fragment registers are pinned): fragment addresses are
@@ -88,7 +65,6 @@ struct FusedCtx {
     int tid;
     int32_t kseg;       // segment id of this lane's key (kSegInvalid: padded / out of range)
     bool has_meta;
-    int n_dma;          // LDS-DMA instructions this wave issues per fb_stage_issue (wave-uniform)
     float c;            // scale * log2(e)
 };
 
@@ -105,12 +81,38 @@ LWM_KERNEL(256) void attn_bwd_lse2_kernel(const float* lse, float* lse2, int64_t
     }
 }
 
+// dq (bf16, [B,Sq,H,D] strided) = bf16(dq_acc) -- dq_acc in either layout (AttnParams::dqa_*).
+// One thread = 8 head dims of one (b, q, h) row: 32 B in, 16 B out.
+constexpr int kFbCastThreads = 256;
+LWM_KERNEL(kFbCastThreads) void attn_bwd_dq_cast_kernel(AttnParams p) {
+    const int64_t n = (int64_t)p.B * p.Sq * p.H * (kHeadDim / 8);
+    for (int64_t i = (int64_t)block_idx_x() * kFbCastThreads + thread_idx(); i < n;
+         i += (int64_t)grid_dim_x() * kFbCastThreads) {
+        const int d8 = (int)(i & 15);
+        int64_t r = i >> 4;
+        // walk the ACCUMULATOR's layout so that the 32-byte reads of consecutive threads are contiguous
+        int64_t b, q, h;
+        if (p.dqa_sh > p.dqa_ss) {      // head-major [B,H,Sq,D]
+            q = r % p.Sq; r /= p.Sq;
+            h = r % p.H; b = r / p.H;
+        } else {                        // [B,Sq,H,D]
+            h = r % p.H; r /= p.H;
+            q = r % p.Sq; b = r / p.Sq;
+        }
+        const float* src = p.dq_acc + b * p.dqa_sb + q * p.dqa_ss + h * p.dqa_sh + d8 * 8;
+        const f32x4 lo = global_load_f32x4(src), hi = global_load_f32x4(src + 4);
+        const u32x4 o = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
+                         pack_bf16x2(hi[2], hi[3])};
+        global_store_b128(p.dq + b * p.dq_sb + q * p.dq_ss + h * p.dq_sh + d8 * 8, o);
+    }
+}
+
 // Staging of the next tile: Q and dO rows AND the row statistics go global -> LDS directly (inline-asm
 // DMA, see wave_ops.h): no VGPR is involved and hipcc sees no load.  That matters beyond the registers:
 // hipcc's waitcnt insertion is flow-insensitive, and a compiler-visible load that is issued or consumed
 // under a predicate leaves a "maybe pending" mark that turns into an s_waitcnt vmcnt(N) at some later
 // redefinition of its register -- here in front of the first MFMA of the NEXT step, where vmcnt also
-// counts the just-issued DMA and the dq stores (measured: ~1 us per step).  Rows past Sq re-read the
+// counts the just-issued DMA and the atomic adds (measured: ~1 us per step).  Rows past Sq re-read the
 // last row (clamped, not predicated); the ragged tile masks them (fb_tile_ab).
 // Wave 0: lanes 0..31 lse2, lanes 32..63 delta; wave 1: segment ids (when given).
 template <int BUF>
@@ -260,25 +262,26 @@ LWM_DEVICE void fb_tile_c(const FusedCtx& cx, const bf16x8 (&pb)[2], const bf16x
     prio_lo();
 }
 
-// dQ^T[32 head dims][16 queries] of this wave = K^T . dS^T over the workgroup's 256 keys (dS^T buffer BUF).
-// Wave w owns head dims 32*(w&3) .. +31 and queries 16*(w>>2) .. +15 of the tile: per query row that is
-// 128 contiguous bytes of the f32 accumulator -- whole cache lines, shared with no other wave (the ordered
-// hand-off is per wave, and a line shared by two waves could be stale in L1 for the second one).
-// acc[t] is the 16x16 tile of head dims 32*(w&3) + 16t .. +15.
+// dQ[16 queries][32 head dims] of this wave = dS . K over the workgroup's 256 keys (dS^T buffer BUF), added to
+// the f32 accumulator.  Wave w owns head dims 32*(w&3) .. +31 and queries 16*(w>>2) .. +15 of tile `qt`.
+// MFMA 16x16x32 with A = dS (row = query l&15, k-group l>>4: 8 keys), B = K (k-group, col = head dim l&15):
+// acc[t][r] = dQ[query 4*(l>>4) + r][head dim 32*(w&3) + 16t + (l&15)] -- a 16-lane group covers 64 contiguous
+// bytes of one (query, head) row per add.
 template <int BUF>
-LWM_DEVICE void fb_dq_product(const FusedCtx& cx, f32x4 (&acc)[2]) {
-    // operand addresses of k-step 0: 16-lane group kg covers keys 8kg..8kg+7 of the step
+LWM_DEVICE void fb_dq_accumulate(const AttnParams& p, const FusedCtx& cx, int b, int h, int qt) {
     const int lane = (int)opaque((uint32_t)cx.lane);
     const int i = lane & 15, kg = lane >> 4, j = i >> 2, cc = i & 3;
     const int db = cx.wave & 3, qh = cx.wave >> 2;
     const int d = 32 * db + 4 * cc;              // d-tile 1 = +16 head dims = +2 sixteen-byte slots (swizzled per row below)
     const int row = 8 * kg + j;
+    // operand addresses of k-step 0: 16-lane group kg covers keys 8kg..8kg+7 of the step
     const uint32_t klo0 = cx.lds + tile_off(row, d >> 3) + (d & 7) * 2;
     const uint32_t kup0 = cx.lds + tile_off(row + 4, d >> 3) + (d & 7) * 2;
     const uint32_t klo1 = cx.lds + tile_off(row, (d + 16) >> 3) + (d & 7) * 2;
     const uint32_t kup1 = cx.lds + tile_off(row + 4, (d + 16) >> 3) + (d & 7) * 2;
     const lds_t dsb = cx.lds + kFbOffDs + BUF * kFbDsBytes;
     const uint32_t l0 = dsb + ds_off(row, 4 * qh + cc), u0 = dsb + ds_off(row + 4, 4 * qh + cc);
+    f32x4 acc[2];
     acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
     acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto cat = [](bf16x4 lo, bf16x4 up) {
@@ -300,167 +303,40 @@ LWM_DEVICE void fb_dq_product(const FusedCtx& cx, f32x4 (&acc)[2]) {
     for (int ks = 0; ks < 8; ++ks) {
         if (ks + 1 < 8) load(ks + 1);
         sched_fence();
-        acc[0] = mfma_16x16x32(a0[ks & 1], bq[ks & 1], acc[0]);
-        acc[1] = mfma_16x16x32(a1[ks & 1], bq[ks & 1], acc[1]);
+        acc[0] = mfma_16x16x32(bq[ks & 1], a0[ks & 1], acc[0]);
+        acc[1] = mfma_16x16x32(bq[ks & 1], a1[ks & 1], acc[1]);
         sched_fence();
     }
     prio_lo();
-}
-
-// ---- ordered accumulation of this wave's dQ slice (32 head dims x 16 queries of tile `qt`) into global
-// memory.  Ordering is PER WAVE SLICE: wave w of key block kbi waits for wave w of key block kbi-1 on
-// flag[(hb*nqt + qt)*8 + w], so no workgroup barrier sits between a wave's stores and its publication.
-struct DqRmw {
-    float* acc;             // this lane's 4 floats of d-tile 0 in the f32 accumulator (d-tile 1: + 16 floats)
-    bool ok;                // the lane's query row exists
-};
-
-// after the flag says the previous contributor is done: start reading what it left.  Agent-scope (sc1) loads:
-// they bypass this CU's L1 (which could hold the line from an earlier work item) and are served by the XCD's
-// L2, where the predecessor's plain stores left the line (scripts/micro/l2_handoff.hip: FETCH_SIZE = first
-// touch only; the same chain with plain loads hits L2 too but takes 2.3 us per hop instead of 0.8).
-// Rows past Sq are clamped, not predicated (fb_stage_issue).
-LWM_DEVICE void fb_dq_load(const AttnParams& p, const FusedCtx& cx, int b, int h, int qt, bool real, const float* dummy,
-                           DqRmw& w) {
-    const int lane = (int)opaque((uint32_t)cx.lane);
-    const int n = lane & 15, kg = lane >> 4;
-    const int db = cx.wave & 3, qh = cx.wave >> 2;
+    // ---- the adds.  Row q0 + r of the tile; a row past Sq adds 0.0 to the last row that exists (branch-free:
+    // the eight adds are one asm block, wave_ops.h).
     const int64_t row0 = (int64_t)qt * kDkvBQ;
-    const bool use = real && p.dq_acc != nullptr;
-    const float* tile = use ? p.dq_acc + ((int64_t)b * p.dqa_sb + row0 * p.dqa_ss + (int64_t)h * p.dqa_sh) : dummy;
-    const int64_t rstride = use ? p.dqa_ss : 0;
-    const int rows_left = (int)(p.Sq - row0);        // >= 1
-    const int r = 16 * qh + n;
-    w.ok = r < rows_left;
-    const int rc = w.ok ? r : rows_left - 1;
-    // by LDS-DMA: lane l's 16 bytes of d-tile t land at slot + 1024 t + 16 l -- no registers are held while the
-    // dQ product and the dV/dK phase run, and the read can be issued before both
-    const lds_t slot = cx.lds + kFbOffDq + (uint32_t)cx.wave * 2048;
-    const float* src = tile + (int64_t)rc * rstride + (use ? 32 * db + 4 * kg : 0);
-    w.acc = const_cast<float*>(src);                 // (stored to only when `use` and w.ok: then it IS the lane's slot)
-    for (int t = 0; t < 2; ++t) glds_load_b128_l2(src + (use ? 16 * t : 0), slot + 1024 * t);
-}
-
-// prev + scale * partial -> f32 accumulator, or bf16 dq when this is the tile's last contributor
-LWM_DEVICE void fb_dq_store(const AttnParams& p, const FusedCtx& cx, int b, int h, int qt, bool use_prev, bool last,
-                            bool do_store, const DqRmw& w, const f32x4 (&acc)[2]) {
-    const int lane = (int)opaque((uint32_t)cx.lane);
-    const int n = lane & 15, kg = lane >> 4;
-    const int db = cx.wave & 3, qh = cx.wave >> 2;
-    const int64_t row = (int64_t)qt * kDkvBQ + 16 * qh + n;
-    const bool to_bf16 = last && p.dq_final_out;
-    // both 16-dim tiles are computed (both accumulator reads retired) BEFORE the first store is issued: with a
-    // store in between, the wait for the second read would also wait for that store (one in-order counter).
-    // The accumulator that was read is dropped by a bit mask, not a branch (a uniform branch around the only
-    // use of a loaded register leaves it "maybe pending" for hipcc, see fb_stage_issue).
-    const uint32_t keep = use_prev ? 0xffffffffu : 0u;
-    const lds_t slot = cx.lds + kFbOffDq + (uint32_t)cx.wave * 2048 + 16 * (uint32_t)lane;
-    f32x4 o[2];
-    for (int t = 0; t < 2; ++t) {
-        const f32x4 prev = lds_read_f32x4(slot + 1024 * t);
-        for (int j = 0; j < 4; ++j) {
-            const float pj = prev[j];          // (a copy: __builtin_bit_cast of a vector ELEMENT reads element 0)
-            const float pv = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, pj) & keep);
-            o[t][j] = fmaf(acc[t][j], p.scale, pv);
-            pin_value(o[t][j]);                 // pin the use HERE: LLVM otherwise sinks it into the store's branch
-        }
+    float* const tile = p.dq_acc + ((int64_t)b * p.dqa_sb + row0 * p.dqa_ss + (int64_t)h * p.dqa_sh);
+    const int rows_left = (int)(p.Sq - row0 < kDkvBQ ? p.Sq - row0 : kDkvBQ);
+    const int q0 = 16 * qh + 4 * kg;
+    const uint32_t rstride = (uint32_t)p.dqa_ss * 4u;          // bytes between query rows (< 2 GiB / 32: checked by the host)
+    uint32_t voff[4];
+    f32x4 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bool ok = q0 + r < rows_left;
+        const int qr = ok ? q0 + r : rows_left - 1;
+        voff[r] = (uint32_t)qr * rstride + (uint32_t)(32 * db + i) * 4u;
+        o0[r] = ok ? acc[0][r] * p.scale : 0.0f;
+        o1[r] = ok ? acc[1][r] * p.scale : 0.0f;
     }
-    sched_fence();
-    if (!do_store || !w.ok) return;
-    for (int t = 0; t < 2; ++t) {
-        const int d0 = 32 * db + 16 * t + 4 * kg;
-        if (to_bf16) {
-            bf16_t* dst = p.dq + (int64_t)b * p.dq_sb + row * p.dq_ss + (int64_t)h * p.dq_sh + d0;
-            global_store_b64_async(dst, u32x2{pack_bf16x2(o[t][0], o[t][1]), pack_bf16x2(o[t][2], o[t][3])});
-        } else {
-            global_store_f32x4_async(w.acc + 16 * t, o[t]);
-        }
-    }
-}
-
-// per-phase accounting of fb_step, -DLWM_PROF builds only (scripts/micro/fused_bench prints it): slots =
-// S/dP phase, counted wait, turn wait, dQ product, dV/dK phase, full wait, accumulate + store, barrier, steps
-#ifdef LWM_PROF
-struct FbProf { uint32_t v[9]; uint32_t last; };
-#define FB_LAP(pf, slot)                                               \
-    do {                                                               \
-        const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime();  \
-        (pf).v[slot] += now_ - (pf).last;                              \
-        (pf).last = now_;                                              \
-    } while (0)
+#ifndef LWM_FB_NO_ATOMIC      // (timing-only builds of scripts/gpu_r3_*.sh switch parts of the step off)
+    atomic_add_f32_4x2(tile, voff, o0, o1);
 #else
-struct FbProf {};
-#define FB_LAP(pf, slot)
-#endif
-
-// wait until `flag` (this wave's slice of the tile) shows that `order` contributors are done
-LWM_DEVICE void fb_wait_turn(int seen, int order, const int32_t* flag, int32_t* err) {
-    // The common case (the predecessor is ahead) must not meet a compiler-visible vector-memory load: hipcc
-    // would put the s_waitcnt vmcnt(0) of the spin loop's load in front of the first test as well, and that
-    // wait also drains the staging DMA in flight.  Hence the test outside, the loop bottom-tested.
-    if (wave_uniform(seen) >= order) return;
-    int spins = 0;
-    do {
-        if (++spins > kFbSpinLimit) {
-            store_i32_plain(err, 1);
-            break;
-        }
-        spin_pause();
-        seen = load_i32_l2(flag);
-    } while (wave_uniform(seen) < order);
-}
-
-// One step of the tile loop: tile `qt` (LDS buffer BUF) and the dQ of the PREVIOUS tile `qt_prev` (its dS^T
-// in buffer PB).  Memory latencies are kept off the critical path:
-//   flag poll   issued at the top, consumed after the S/dP and softmax phases;
-//   read of the accumulator   issued after the dQ product, consumed after the dV/dK phase;
-//   stores   issued at the end, NOT waited for here: the next step's mid-point vmcnt(0) covers them and
-//            only then is this wave's flag for that tile published (one step later than the stores).
-template <int BUF, int PB>
-LWM_DEVICE void fb_step(const AttnParams& p, const FusedCtx& cx, const bf16x8 (&vf)[8], f32x16 (&dk)[4], f32x16 (&dv)[4],
-                        int b, int h, int qt, int krel, int qlim, bool has_prev, int qt_prev, bool has_pub, int qt_pub,
-                        int kbi, int qt_next, bool tail_block, int32_t* flags_h, int32_t* err, const float* dummy,
-                        const bf16_t* qb, const bf16_t* dob, int qt_stage, FbProf& pf) {
-    (void)pf;
-    // Without a previous tile (step 0 of an item) the same instruction stream runs with nothing stored and the
-    // accumulator read pointed at `dummy` (read-only data): straight-line code keeps hipcc's waits where they
-    // belong (fb_stage_issue), and no line of the accumulator enters this CU's L1 before its turn.
-    const int qp = has_prev ? qt_prev : qt;
-    const int32_t* const flag_prev = flags_h + ((int64_t)qp * 8 + cx.wave);
-    const int order = has_prev ? kbi : 0;            // key block 0 waits for nobody
-    // Vector-memory operations retire in issue order.  Issued here, in this order: [the dq stores of the last
-    // step] -> the flag poll (an LDS-DMA: its answer lands in LDS, no register, no compiler-tracked load) ->
-    // the staging DMA of the next tile.  After the S/dP phase "at most the staging DMA outstanding" therefore
-    // means "stores in L2, poll answered" -- without waiting for the staging, which has the whole step to land.
-    const lds_t poll = cx.lds + kFbOffPoll + (uint32_t)cx.wave * 256;
-    FB_LAP(pf, 7);             // since the end of the previous step: the tile barrier
-    glds_load_b32_l2(flag_prev, poll);
-    fb_stage_issue<BUF ^ 1>(p, cx, qb, dob, dummy, b, h, qt_stage);
-    bf16x8 pb[2], dsb[2];
-    fb_tile_ab<BUF>(p, cx, vf, krel, qlim, pb, dsb);
-    FB_LAP(pf, 0);
-    if (cx.n_dma == 3) wait_vmem_le<3>();
-    else wait_vmem_le<2>();
-    FB_LAP(pf, 1);
-    if (has_pub && cx.lane == 0) store_i32_plain(flags_h + ((int64_t)qt_pub * 8 + cx.wave), kbi + 1);
-    fb_wait_turn(lds_read_i32(poll + 4 * (uint32_t)cx.lane), order, flag_prev, err);
-    FB_LAP(pf, 2);
-    f32x4 acc[2];
-    DqRmw w;
-    fb_dq_load(p, cx, b, h, qp, has_prev, dummy, w);
-    fb_dq_product<PB>(cx, acc);
-    FB_LAP(pf, 3);
-    fb_tile_c<BUF>(cx, pb, dsb, dk, dv);
-    FB_LAP(pf, 4);
-    wait_vmem_all();           // the staged tile (the barrier that follows publishes it) and the accumulator read
-    FB_LAP(pf, 5);
-    fb_dq_store(p, cx, b, h, qp, kbi != 0 || p.dq_carry_in, qp < qt_next || tail_block, has_prev, w, acc);
-    FB_LAP(pf, 6);
-#ifdef LWM_PROF
-    pf.v[8] += 1;
+    asm volatile("" ::"v"(o0), "v"(o1), "v"(voff[3]));
 #endif
 }
 
+#ifdef LWM_FB_NO_DQ
+#define LWM_FB_DQ(x) (void)0
+#else
+#define LWM_FB_DQ(x) x
+#endif
 LWM_KERNEL(kFbThreads) void attn_bwd_fused_kernel(AttnParams p, int32_t* ws) {
     const lds_t lds = dyn_lds();
     const int tid = thread_idx();
@@ -471,8 +347,7 @@ LWM_KERNEL(kFbThreads) void attn_bwd_fused_kernel(AttnParams p, int32_t* ws) {
     const int HB = p.H * p.B;
     int32_t* const tickets = ws;
     int32_t* const owners = ws + kFbQueues;
-    int32_t* const sems = ws + kFbWsHeader;
-    const float* const lse2 = (const float*)(ws + kFbWsHeader + (int64_t)HB * nqt_all * 8);
+    const float* const lse2 = (const float*)(ws + kFbWsHeader);
     const lds_t ctl = lds + kFbOffCtl;
 
     FusedCtx cx;
@@ -481,7 +356,6 @@ LWM_KERNEL(kFbThreads) void attn_bwd_fused_kernel(AttnParams p, int32_t* ws) {
     cx.lane = lane;
     cx.wave = wave;
     cx.c = p.scale * kLog2e;
-    cx.n_dma = (wave == 0 || (wave == 1 && p.seg_q)) ? 3 : 2;   // Q, dO (+ row statistics / segment ids)
 
     const int my_xcc = wave_uniform(xcc_id()) & (kFbQueues - 1);
     for (int qi = 0; qi < kFbQueues; ++qi) {
@@ -505,14 +379,13 @@ LWM_KERNEL(kFbThreads) void attn_bwd_fused_kernel(AttnParams p, int32_t* ws) {
             block_sync();
             if (ticket >= items) break;
             const int hb = que + kFbQueues * (ticket / nkb);
-            const int kbi = ticket % nkb;      // ascending: the order of accumulation into dq
+            const int kbi = ticket % nkb;      // ascending: under a causal mask the longest walks first
             const int b = hb / p.H, h = hb % p.H;
 
             const bf16_t* qb = p.q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
             const bf16_t* kb = p.k + (int64_t)b * p.k_sb + (int64_t)h * p.k_sh;
             const bf16_t* vb = p.v + (int64_t)b * p.v_sb + (int64_t)h * p.v_sh;
             const bf16_t* dob = p.dout + (int64_t)b * p.do_sb + (int64_t)h * p.do_sh;
-            int32_t* const flags_h = sems + (int64_t)hb * nqt_all * 8;
 
             // ---- this lane's key: V fragments in registers, key meta
             const int k_row = kbi * kDkvBK + wave * 32 + l31;
@@ -539,20 +412,23 @@ LWM_KERNEL(kFbThreads) void attn_bwd_fused_kernel(AttnParams p, int32_t* ws) {
                 if (kr < p.Sk) val = global_load_b128(kb + (int64_t)kr * p.k_ss + slot * 8);
                 lds_write_b128(lds + tile_off(row, slot), val);
             }
-            // ---- query tile range.  Key block 0 walks EVERY tile (it is the first contributor of each
-            // tile's dq, also of tiles that see none of this K/V block's keys: those get exact zeros);
-            // the others start at their causal diagonal.
-            auto first_tile = [&](int kblk) -> int {
-                if (!p.causal || kblk == 0) return 0;
-                int64_t d = p.k_start + (int64_t)kblk * kDkvBK - p.q_start;
-                if (d <= 0) return 0;
-                int64_t t = d / kDkvBQ;
-                return t < nqt_all ? (int)t : nqt_all;
-            };
-            const int qt0 = first_tile(kbi);
-            const int qt_next = kbi + 1 < nkb ? first_tile(kbi + 1) : nqt_all;   // tiles < qt_next: this block is the last
-            const bool tail_block = kbi == nkb - 1;
-            const int n = nqt_all - qt0;               // tiles to walk: loop index i -> tile nqt_all-1-i (walk DOWN)
+            // ---- query tile range: from the block's causal diagonal to the last tile, narrowed to the
+            // documents this key block belongs to when segment-block hints are given
+            int qt0 = 0, qt1 = nqt_all;
+            if (p.causal) {
+                int64_t d = p.k_start + (int64_t)kbi * kDkvBK - p.q_start;
+                if (d > 0) qt0 = (int)(d / kDkvBQ < nqt_all ? d / kDkvBQ : nqt_all);
+            }
+            if (p.segb_q && p.segb_k && qt0 < qt1) {
+                const int nbq = (p.Sq + 31) >> 5, nbk = (p.Sk + 31) >> 5;
+                int smin, smax, lo, hi2;
+                seg_own_range(p.segb_k + (int64_t)b * nbk * 2, nbk, kbi * (kDkvBK / 32), kDkvBK / 32, smin, smax);
+                seg_narrow<kFbThreads>(p.segb_q + (int64_t)b * nbq * 2, nbq, kDkvBQ / 32, qt0, qt1, smin, smax,
+                                       lds + kFbOffScan, tid, lo, hi2);
+                qt0 = lo;
+                qt1 = hi2;
+            }
+            const int n = qt1 - qt0;                   // tiles to walk: loop index i -> tile qt1-1-i (walk DOWN)
             auto krel_of = [&](int qt) -> int {
                 int64_t r = wk_rel - (int64_t)qt * kDkvBQ;
                 return r > 64 ? 64 : (r < -64 ? -64 : (int)r);
@@ -563,65 +439,50 @@ LWM_KERNEL(kFbThreads) void attn_bwd_fused_kernel(AttnParams p, int32_t* ws) {
                 dk[i] = zero_f32x16();
                 dv[i] = zero_f32x16();
             }
-            FbProf pf = {};
-            FB_LAP(pf, 7);
-#define LWM_FQT(i) (nqt_all - 1 - (i))
+#define LWM_FQT(i) (qt1 - 1 - (i))
             if (n > 0) {
                 if (!p.seg_q && tid < 2 * kDkvBQ)       // no segment ids: the table reads 0 (= kseg of every valid key)
                     lds_write_i32(lds + kFbOffStats + (tid >> 5) * kFbStatBytes + 2 * kDkvBQ * 4 + (tid & 31) * 4, 0);
                 fb_stage_issue<0>(p, cx, qb, dob, lse2, b, h, LWM_FQT(0));
-                if (kbi > 0 && kFbSlack > 0) {
-                    const int ahead = n - 1 < kFbSlack ? n - 1 : kFbSlack;
-                    const int32_t* const fl = flags_h + ((int64_t)LWM_FQT(ahead) * 8 + wave);
-                    fb_wait_turn(load_i32_l2(fl), kbi, fl, ws + kFbWsErr);
-                }
                 wait_vmem_all();
                 block_sync();
                 auto qlim_of = [&](int qt) -> int {
                     const int left = p.Sq - qt * kDkvBQ;
                     return left < kDkvBQ ? left : kDkvBQ;
                 };
-                // step i: tile i + the dQ of tile i-1 + the publication of tile i-2 (see fb_step).  Two steps
-                // per trip: the LDS buffers alternate.  Past the last tile the staging re-fetches the last
-                // tile (unconditional instruction stream).
+                // step i: [the dQ of tile i-1 from the dS^T it left in LDS -> atomic adds] | staging DMA of
+                // tile i+1 | S, dP, P, dS of tile i (dS^T -> LDS) | dV, dK | wait for the DMA | barrier.
+                // The adds are the OLDEST vector-memory operations of the step when its vmcnt(0) comes, with
+                // the whole step behind them.  Two steps per trip: the LDS buffers alternate.  Past the last
+                // tile the staging re-fetches the last tile (unconditional instruction stream).
                 for (int i = 0; i < n; i += 2) {
-                    const bool more1 = i + 1 < n;
-                    fb_step<0, 1>(p, cx, vf, dk, dv, b, h, LWM_FQT(i), krel_of(LWM_FQT(i)), qlim_of(LWM_FQT(i)), i > 0,
-                                  LWM_FQT(i - 1), i > 1, LWM_FQT(i - 2), kbi, qt_next, tail_block, flags_h, ws + kFbWsErr, lse2,
-                                  qb, dob, LWM_FQT(more1 ? i + 1 : i), pf);
-                    block_sync_lds();      // (not __syncthreads: the dq stores stay in flight, see wave_ops.h)
-                    if (!more1) break;
-                    const bool more2 = i + 2 < n;
-                    fb_step<1, 0>(p, cx, vf, dk, dv, b, h, LWM_FQT(i + 1), krel_of(LWM_FQT(i + 1)), qlim_of(LWM_FQT(i + 1)),
-                                  true, LWM_FQT(i), i > 0, LWM_FQT(i - 1), kbi, qt_next, tail_block, flags_h,
-                                  ws + kFbWsErr, lse2, qb, dob, LWM_FQT(more2 ? i + 2 : i + 1), pf);
-                    block_sync_lds();
+                    {
+                        const bool more1 = i + 1 < n;
+                        if (i > 0) LWM_FB_DQ(fb_dq_accumulate<1>(p, cx, b, h, LWM_FQT(i - 1)));
+                        fb_stage_issue<1>(p, cx, qb, dob, lse2, b, h, LWM_FQT(more1 ? i + 1 : i));
+                        bf16x8 pb[2], dsb[2];
+                        fb_tile_ab<0>(p, cx, vf, krel_of(LWM_FQT(i)), qlim_of(LWM_FQT(i)), pb, dsb);
+                        fb_tile_c<0>(cx, pb, dsb, dk, dv);
+                        wait_vmem_all();
+                        block_sync_lds();
+                        if (!more1) break;
+                    }
+                    {
+                        const bool more2 = i + 2 < n;
+                        LWM_FB_DQ(fb_dq_accumulate<0>(p, cx, b, h, LWM_FQT(i)));
+                        fb_stage_issue<0>(p, cx, qb, dob, lse2, b, h, LWM_FQT(more2 ? i + 2 : i + 1));
+                        bf16x8 pb[2], dsb[2];
+                        fb_tile_ab<1>(p, cx, vf, krel_of(LWM_FQT(i + 1)), qlim_of(LWM_FQT(i + 1)), pb, dsb);
+                        fb_tile_c<1>(cx, pb, dsb, dk, dv);
+                        wait_vmem_all();
+                        block_sync_lds();
+                    }
                 }
-                // drain: the dQ of the last tile (n-1) and the two publications still owed
-                {
-                    const int qt_last = LWM_FQT(n - 1);
-                    int32_t* const flag_last = flags_h + ((int64_t)qt_last * 8 + wave);
-                    const bool first = kbi == 0;
-                    const int seen = load_i32_l2(flag_last);
-                    wait_vmem_all();
-                    if (n > 1 && lane == 0) store_i32_plain(flags_h + ((int64_t)LWM_FQT(n - 2) * 8 + wave), kbi + 1);
-                    fb_wait_turn(seen, kbi, flag_last, ws + kFbWsErr);
-                    f32x4 acc[2];
-                    DqRmw w;
-                    fb_dq_load(p, cx, b, h, qt_last, true, lse2, w);
-                    if ((n - 1) & 1) fb_dq_product<1>(cx, acc);
-                    else fb_dq_product<0>(cx, acc);
-                    wait_vmem_all();       // the accumulator slice has landed in LDS
-                    fb_dq_store(p, cx, b, h, qt_last, !first || p.dq_carry_in, qt_last < qt_next || tail_block, true, w, acc);
-                    wait_vmem_all();
-                    if (lane == 0) store_i32_plain(flag_last, kbi + 1);
-                }
+                // drain: the dQ of the last tile
+                if ((n - 1) & 1) LWM_FB_DQ(fb_dq_accumulate<1>(p, cx, b, h, LWM_FQT(n - 1)));
+                else LWM_FB_DQ(fb_dq_accumulate<0>(p, cx, b, h, LWM_FQT(n - 1)));
             }
 #undef LWM_FQT
-#ifdef LWM_PROF
-            if (hb == 0 && kbi == nkb / 2 && lane == 0 && p.out_acc)     // one mid-chain item reports
-                for (int i = 0; i < 9; ++i) ((unsigned long long*)p.out_acc)[wave * 10 + i] = pf.v[i];
-#endif
             // ---- dK, dV of this key block
             if (k_ok) {
                 const int64_t krow_o = (int64_t)b * p.dk_sb + (int64_t)k_row * p.dk_ss + (int64_t)h * p.dk_sh;

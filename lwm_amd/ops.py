@@ -299,8 +299,8 @@ def _acc_shape(B, Sq, H, D, head_major):
 
 
 def _fused_workspace(B, H, Sq, device):
-    """int32 scratch of lwm_attn_bwd_fused (work-queue tickets + per-tile counters); the launch zeroes it
-    itself, so one buffer per (device, stream) is reused by every call."""
+    """int32 scratch of lwm_attn_bwd_fused (work-queue tickets + the LSE in log2 units); the launch
+    initialises it itself, so one buffer per (device, stream) is reused by every call."""
     L = lib()
     need = int(L.lwm_attn_bwd_fused_workspace_bytes(B, H, Sq))
     key = (str(device), torch.cuda.current_stream(device).cuda_stream)
@@ -310,29 +310,20 @@ def _fused_workspace(B, H, Sq, device):
     return ws
 
 
-def fused_backward_gave_up(device=None):
-    """True if a wait inside lwm_attn_bwd_fused hit its spin limit since the workspace was last zeroed
-    (diagnostic for tests: synchronises)."""
-    device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-    ws = _FUSED_WS.get((str(device), torch.cuda.current_stream(device).cuda_stream))
-    return ws is not None and bool(ws[16].item() != 0)
-
-
 def attn_bwd_fused_block(q, k, v, dout, lse, delta, *, q_start=0, k_start=0, causal=True, seg_q=None, seg_k=None,
                          key_valid=None, scale=None, dq=None, dk=None, dv=None, dq_acc=None, dk_acc=None,
                          dv_acc=None, dq_carry_in=False, dq_final=True, carry_in=False, final=True,
                          acc_head_major=True):
     """The whole backward of one ring step in one launch (lwm_attn_bwd_fused): S and dP are computed once
     (5 GEMM units instead of 7).  `carry_in` / `final` govern dk, dv; `dq_carry_in` / `dq_final` govern dq.
-    dq_acc is the f32 accumulator the 256-key blocks add into, head-major (B,H,Sq,D) unless
-    acc_head_major=False -- allocated here when absent.
+    dq_acc is the f32 accumulator the 256-key blocks ADD into (atomic adds; zeroed by the launch unless
+    dq_carry_in), head-major (B,H,Sq,D) unless acc_head_major=False -- allocated here when absent.
     Returns (dq or dq_acc, dk or dk_acc, dv or dv_acc)."""
     B, Sq, H, D = q.shape
     Sk = k.shape[1]
     a = _bwd_base(q, k, v, dout, lse, delta,
                   dict(q_start=q_start, k_start=k_start, causal=causal, seg_q=seg_q, seg_k=seg_k,
                        key_valid=key_valid, scale=scale))
-    a.seg_blocks_q, a.seg_blocks_k = None, None       # the fused kernel visits every tile (hints unused)
     if final:
         if dk is None:
             dk = torch.empty((B, Sk, H, D), dtype=torch.bfloat16, device=q.device)
@@ -350,10 +341,11 @@ def attn_bwd_fused_block(q, k, v, dout, lse, delta, *, q_start=0, k_start=0, cau
         if dq is None:
             dq = torch.empty((B, Sq, H, D), dtype=torch.bfloat16, device=q.device)
         a.dq = _t4(dq, "dq")
-    if dq_acc is None and (Sk > 256 or not dq_final or dq_carry_in):
+    if dq_acc is None:
         if dq_carry_in:
             raise ValueError("attn_bwd_fused_block: dq_carry_in needs dq_acc")
-        dq_acc = torch.empty(_acc_shape(B, Sq, H, D, acc_head_major), dtype=torch.float32, device=q.device)
+        dq_acc = _fused_dq_scratch(_acc_shape(B, Sq, H, D, acc_head_major), q.device) if dq_final else \
+            torch.empty(_acc_shape(B, Sq, H, D, acc_head_major), dtype=torch.float32, device=q.device)
     a.dq_acc = _f32(dq_acc, "dq_acc", _acc_shape(B, Sq, H, D, acc_head_major))
     a.dq_acc_head_major = int(bool(acc_head_major))
     a.carry_in, a.final_out = int(bool(carry_in)), int(bool(final))
@@ -363,6 +355,22 @@ def attn_bwd_fused_block(q, k, v, dout, lse, delta, *, q_start=0, k_start=0, cau
     L = lib()
     _capi.check(L, L.lwm_attn_bwd_fused(C.byref(a), _stream_ptr()), "lwm_attn_bwd_fused")
     return (dq if dq_final else dq_acc), (dk if final else dk_acc), (dv if final else dv_acc)
+
+
+_FUSED_DQ = {}
+
+
+def _fused_dq_scratch(shape, device):
+    """The f32 dq accumulator of a launch that also writes the bf16 dq (nothing reads it afterwards): one buffer
+    per (device, stream), reused by every layer -- stream order makes the reuse safe."""
+    n = 1
+    for s in shape:
+        n *= s
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    buf = _FUSED_DQ.get(key)
+    if buf is None or buf.numel() < n:
+        buf = _FUSED_DQ[key] = torch.empty(max(n, 1), dtype=torch.float32, device=device)
+    return buf[:n].view(shape)
 
 
 def cast_f32_to_bf16(src, dst=None):

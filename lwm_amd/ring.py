@@ -203,17 +203,19 @@ class HipBlockOps:
         return torch.zeros(shape, dtype=dtype, device=like.device)
 
 
-# The one-launch backward (lwm_attn_bwd_fused: S and dP computed once, 5 GEMM units instead of 7) is OPT-IN
-# (LWM_FUSED_BWD=1, bench.py --fused-bwd): on MI355X it measures 28-30 ms per layer at S = 32768 against
-# 26.5 ms for lwm_attn_bwd_dkdv + lwm_attn_bwd_dq -- what it saves in MFMA work it spends on the ordered
-# read-modify-write of dq through L2 (profiles/r02_fused_ab.md).  Where enabled it is
-# used when no segment ids are given; packed batches keep the two-kernel path, whose segment-block hints
-# skip whole documents.
-FUSED_BACKWARD = os.environ.get("LWM_FUSED_BWD", "0") == "1"
+# Two backward flavours:
+#   two kernels (default)  lwm_attn_bwd_dkdv + lwm_attn_bwd_dq: 7 GEMM units executed, no atomics, every output
+#                          bit-reproducible;
+#   one launch             lwm_attn_bwd_fused (LWM_FUSED_BWD=1, bench.py --fused-bwd): S and dP computed once, 5 GEMM
+#                          units; dq accumulated by fire-and-forget f32 atomic adds, so its last bits depend on the
+#                          order in which the key blocks happen to arrive (dk, dv stay bit-reproducible).
+# LWM_DETERMINISTIC=1 forces the first whatever else is set.  DESIGN.md section 3 has both measured side by side.
+DETERMINISTIC = os.environ.get("LWM_DETERMINISTIC", "0") == "1"
+FUSED_BACKWARD = not DETERMINISTIC and os.environ.get("LWM_FUSED_BWD", "0") == "1"
 
 
 def _use_fused(block, segment_ids):
-    return FUSED_BACKWARD and segment_ids is None and hasattr(block, "bwd_fused")
+    return FUSED_BACKWARD and hasattr(block, "bwd_fused")
 
 
 # ----------------------------------------------------------------- helpers

@@ -1,8 +1,8 @@
 // fused_bench.cpp -- times the attention backward of one layer through the C ABI, without Python:
 //   fused_bench <liblwm_hip.so> [S=32768] [H=32] [reps=3] [what=all|fused|two]
-// One line per library: HIP-event ms per launch of lwm_attn_bwd_fused and of dkdv + dq, the fused kernel's
-// give-up flag, and two checksums of dq (fused vs two-kernel) so that a timing variant that breaks the
-// result is visible.  Used by scripts/gpu_fused_ab.sh to sweep variant builds in one GPU call.
+// One line per library: HIP-event ms per launch of lwm_attn_fwd, lwm_attn_bwd_fused and of delta + dkdv + dq,
+// checksums of dq / dk (fused vs two-kernel) and the largest element-wise dq difference, so that a timing
+// variant that breaks the result is visible.  Used by scripts/gpu_fused_ab.sh to sweep variant builds in one GPU call.
 // Build: hipcc -O2 --offload-arch=gfx950 -I include -o scripts/micro/fused_bench scripts/micro/fused_bench.cpp -ldl
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -45,6 +45,20 @@ __global__ void abs_sum_bf16(const uint16_t* p, size_t n, double* out) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) s += fabsf(__builtin_bit_cast(float, (uint32_t)p[i] << 16));
     atomicAdd(out, s);
+}
+
+// max |a - b| and max |b| over bf16 arrays (non-negative floats order like their bit patterns)
+__global__ void max_diff_bf16(const uint16_t* a, const uint16_t* b, size_t n, unsigned long long* out) {
+    float md = 0, mr = 0;
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float x = __builtin_bit_cast(float, (uint32_t)a[i] << 16), y = __builtin_bit_cast(float, (uint32_t)b[i] << 16);
+        md = fmaxf(md, fabsf(x - y));
+        mr = fmaxf(mr, fabsf(y));
+    }
+    atomicMax(out, (unsigned long long)__builtin_bit_cast(uint32_t, md));
+    atomicMax(out + 1, (unsigned long long)__builtin_bit_cast(uint32_t, mr));
 }
 
 template <class F>
@@ -136,12 +150,9 @@ int main(int argc, char** argv) {
     const bool do_fused = strcmp(what, "two") != 0, do_two = strcmp(what, "fused") != 0;
     float ms_fused = -1, ms_dkdv = -1, ms_dq = -1, ms_delta = -1;
     const float ms_fwd = time_ms([&] { fwd(&a, nullptr); });
+    bdelta(&a, nullptr);           // delta is an input of every backward flavour
     double cs_fused = -1, cs_two = -1, cs_dk_f = -1, cs_dk_t = -1;
-    int gave_up = -1;
-    unsigned long long* prof = nullptr;   // -DLWM_PROF builds of the library report per-phase ticks through out_acc
-    CK(hipMalloc(&prof, 8 * 10 * 8));
-    CK(hipMemset(prof, 0, 8 * 10 * 8));
-    a.out_acc = (float*)prof;
+    uint16_t* dq_keep = nullptr;       // the fused dq, kept for the element-wise comparison with the two-kernel dq
     if (do_fused) {
         ms_fused = time_ms([&] {
             if (bfused(&a, nullptr) != 0) {
@@ -149,22 +160,12 @@ int main(int argc, char** argv) {
                 exit(2);
             }
         });
-        CK(hipMemcpy(&gave_up, (int32_t*)ws + 16, 4, hipMemcpyDeviceToHost));
         cs_fused = checksum(dq);
         cs_dk_f = checksum(dk);
-    {
-            unsigned long long h[80];
-            CK(hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost));
-            if (h[8]) {
-                printf("per-step 100 MHz ticks of one mid-chain key block (wave: S/dP, counted wait, turn, dQ, dV/dK, full wait, store, barrier | steps)\n");
-                for (int w = 0; w < 8; ++w) {
-                    printf("  wave %d:", w);
-                    for (int i = 0; i < 8; ++i) printf(" %7.1f", (double)h[w * 10 + i] / (double)h[w * 10 + 8]);
-                    printf(" | %llu\n", h[w * 10 + 8]);
-                }
-            }
-        }
+        CK(hipMalloc(&dq_keep, n * 2));
+        CK(hipMemcpy(dq_keep, dq, n * 2, hipMemcpyDeviceToDevice));
     }
+    double max_diff = -1, max_ref = -1;
     if (do_two) {
         a.dq_acc_head_major = 0;
         ms_delta = time_ms([&] { bdelta(&a, nullptr); });
@@ -172,9 +173,17 @@ int main(int argc, char** argv) {
         ms_dq = time_ms([&] { bdq(&a, nullptr); });
         cs_two = checksum(dq);
         cs_dk_t = checksum(dk);
+        if (dq_keep) {
+            CK(hipMemset(sums, 0, 16));
+            max_diff_bf16<<<1024, 256>>>(dq_keep, dq, n, (unsigned long long*)sums);
+            unsigned long long h[2];
+            CK(hipMemcpy(h, sums, 16, hipMemcpyDeviceToHost));
+            max_diff = __builtin_bit_cast(float, (uint32_t)h[0]);
+            max_ref = __builtin_bit_cast(float, (uint32_t)h[1]);
+        }
     }
-    a.out_acc = nullptr;
-    printf("%-40s S=%d H=%d fwd %.3f  fused %.3f ms (gave_up %d)  delta %.3f dkdv %.3f dq %.3f  |dq| fused %.6f two %.6f  |dk| %.6f %.6f\n",
-           argv[1], S, H, ms_fwd, ms_fused, gave_up, ms_delta, ms_dkdv, ms_dq, cs_fused, cs_two, cs_dk_f, cs_dk_t);
+    printf("%-40s S=%d H=%d fwd %.3f  fused %.3f ms  delta %.3f dkdv %.3f dq %.3f  |dq| fused %.6f two %.6f  "
+           "max|dq_f - dq_2| %.3e of %.3e  |dk| %.6f %.6f\n",
+           argv[1], S, H, ms_fwd, ms_fused, ms_delta, ms_dkdv, ms_dq, cs_fused, cs_two, max_diff, max_ref, cs_dk_f, cs_dk_t);
     return 0;
 }

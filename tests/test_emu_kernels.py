@@ -179,8 +179,11 @@ def test_emulated_packed_documents_are_skipped_not_changed(monotone, bwd_path):
         assert _rel(out, ro) < 1e-2 and _rel(dq, rq) < 1e-2 and _rel(dk, rk) < 1e-2 and _rel(dv, rv) < 1e-2
         fin = np.isfinite(rl)
         assert np.array_equal(np.isfinite(lse), fin) and np.abs(lse[fin] - rl[fin]).max() < 1e-4
-    for a, b in zip(outs[True], outs[False]):
-        assert np.array_equal(a, b)        # skipping removes only tiles that contribute exact zeros
+    for i, (a, b) in enumerate(zip(outs[True], outs[False])):
+        if bwd_path and i == 2:            # fused dq: f32 atomic adds in arrival order, then one bf16 rounding
+            assert np.abs(a - b).max() <= 2.0 ** -8 * np.abs(b).max()
+        else:
+            assert np.array_equal(a, b)    # skipping removes only tiles that contribute exact zeros
 
 
 def test_segment_block_table():

@@ -91,26 +91,34 @@ def test_fwd_bwd_vs_oracle(B, Sq, Sk, H, causal, seg, kv):
     assert torch.equal(fk, dk) and torch.equal(fv, dv)
 
 
-def test_fused_backward_is_deterministic_and_ordered():
-    """lwm_attn_bwd_fused accumulates dq across 256-key blocks through global memory, ordered by per-tile
-    counters.  Many key blocks per head, more work items than CUs, uneven head count (queues of different
-    length), carries in and out: repeated launches must give identical bits, equal to the oracle; and the
-    f32 carry path (dq_carry_in / not final) must add exactly onto what is there."""
+def test_fused_backward_dq_spread_and_carries():
+    """lwm_attn_bwd_fused adds the dq partials of the 256-key blocks into an f32 accumulator with fire-and-forget
+    atomic adds: dk and dv are bit-reproducible, dq is summed in arrival order.  Many key blocks per head, more
+    work items than CUs, uneven head count (queues of different length), carries in and out: repeated launches
+    give identical dk, dv and a dq that moves by no more than one bf16 rounding of an f32 re-association
+    (recorded in gpurun_out/parity_stats.json as dq_run_to_run); all equal to the oracle; and the f32 carry
+    path (dq_carry_in / not final) adds onto what is there."""
     import torch
     from lwm_amd import ops
+    from tests import _parity
     B, S, H = 2, 4096, 5
     q, k, v, do = (_rand((B, S, H, 128), s).cuda() for s in (61, 62, 63, 64))
     out, lse = ops.attn_fwd_block(q, k, v, causal=True)
     delta = ops.attn_bwd_delta(out, do)
-    ref = ops.attn_bwd_fused_block(q, k, v, do, lse, delta, causal=True)
-    torch.cuda.synchronize()
-    assert not ops.fused_backward_gave_up()
-    for _ in range(4):
+    ref = [t.clone() for t in ops.attn_bwd_fused_block(q, k, v, do, lse, delta, causal=True)]
+    dk2, dv2 = ops.attn_bwd_dkdv_block(q, k, v, do, lse, delta, causal=True)
+    assert torch.equal(ref[1], dk2) and torch.equal(ref[2], dv2)
+    spread, n_diff = 0.0, 0
+    scale = ref[0].float().abs().max().item()
+    for _ in range(6):
         got = ops.attn_bwd_fused_block(q, k, v, do, lse, delta, causal=True)
         torch.cuda.synchronize()
-        assert not ops.fused_backward_gave_up()
-        for a, b in zip(got, ref):
-            assert torch.equal(a, b)
+        assert torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
+        d = (got[0].float() - ref[0].float()).abs()
+        spread = max(spread, d.max().item() / scale)
+        n_diff = max(n_diff, int((d > 0).sum().item()))
+    _parity.STATS.append(("dq_run_to_run", spread, n_diff / ref[0].numel(), 1.0))
+    assert spread <= 2.0 ** -8, spread      # one bf16 ulp of the largest element
     f = lambda t: _np(t[:1, :, 2:3])
     rq, rk, rv = R.dense_attention_bwd(f(q), f(k), f(v), f(do), causal=True)
     _check("dq fused 4096", f(ref[0]), rq)
@@ -124,13 +132,14 @@ def test_fused_backward_is_deterministic_and_ordered():
     plain = ops.attn_bwd_fused_block(q, k, v, do, lse, delta, causal=True, dq_final=False, final=False)
     torch.cuda.synchronize()
     assert dqa.data_ptr() == acc.data_ptr()
-    assert ((dqa - carry) - plain[0]).abs().max().item() <= 1e-4 * plain[0].abs().max().item()
+    pmax = plain[0].abs().max().item()
+    assert ((dqa - carry) - plain[0]).abs().max().item() <= 1e-4 * pmax
     assert torch.equal(dka, plain[1]) and torch.equal(dva, plain[2])
-    assert torch.equal(ops.cast_f32_to_bf16(plain[0]).transpose(1, 2), ref[0])
-    # the other accumulator layout gives the same numbers (only slower: its tile rows thrash one L2 set)
+    assert (ops.cast_f32_to_bf16(plain[0]).transpose(1, 2).float() - ref[0].float()).abs().max().item() <= 2.0 ** -8 * pmax
+    # the other accumulator layout gives the same numbers
     alt = ops.attn_bwd_fused_block(q, k, v, do, lse, delta, causal=True, dq_final=False, final=False,
                                    acc_head_major=False)
-    assert torch.equal(alt[0], plain[0].transpose(1, 2))
+    assert (alt[0] - plain[0].transpose(1, 2)).abs().max().item() <= 1e-5 * pmax
 
 
 def test_softmax_rescale_branch_is_exercised():
@@ -237,6 +246,11 @@ def test_packed_documents_skip_is_exact():
     _check("dq", _np(dq[:, :, sl]), rq)
     _check("dk", _np(dk[:, :, sl]), rk)
     _check("dv", _np(dv[:, :, sl]), rv)
+    # the one-launch backward honours the hints too: dk, dv bit-identical, dq (atomic adds) within tolerance
+    delta = ops.attn_bwd_delta(out, do)
+    fq, fk, fv = ops.attn_bwd_fused_block(q, k, v, do, res[True][1], delta, causal=True, seg_q=segd, seg_k=segd)
+    assert torch.equal(fk, dk) and torch.equal(fv, dv)
+    _check("dq fused packed", _np(fq[:, :, sl]), rq)
 
 
 def test_autograd_ring1_matches_oracle():
@@ -346,6 +360,17 @@ def test_full_size_properties(full):
     rq, _, _ = R.dense_attention_bwd(_np(q[:, r0:, h:h + 1]), _np(k[:, :, h:h + 1]), _np(v[:, :, h:h + 1]),
                                      _np(do[:, r0:, h:h + 1]), causal=True, q_start=r0, k_start=0)
     _check("dq window 2", _np(dq[:, r0:, h:h + 1]), rq)
+    # (10) the one-launch backward at full size: dk, dv bit-identical to the two-kernel path, dq (atomic adds)
+    #      against the same oracle windows
+    fq, fk, fv = ops.attn_bwd_fused_block(q, k, v, do, lse, delta, causal=True)
+    assert torch.equal(fk, dk) and torch.equal(fv, dv)
+    _check("dq fused window 2", _np(fq[:, r0:, h:h + 1]), rq)
+    h, r0, w = 5, 2048, 256
+    sl = slice(0, r0 + w)
+    rq, _, _ = R.dense_attention_bwd(_np(q[:, sl, h:h + 1]), _np(k[:, sl, h:h + 1]), _np(v[:, sl, h:h + 1]),
+                                     _np(do[:, sl, h:h + 1]), causal=True)
+    _check("dq fused window", _np(fq[:, r0:r0 + w, h:h + 1]), rq[:, r0:r0 + w])
+    assert ((fq.float() - dq.float()).abs().max() / dq.float().abs().max()).item() <= 8e-3
 
 
 def test_addressing_beyond_4g_elements_at_1m_tokens():
@@ -368,8 +393,11 @@ def test_addressing_beyond_4g_elements_at_1m_tokens():
     out1 = ring_attention(q1, k1, v1, causal=True, segment_ids=seg)
     out1.backward(do[:, :, h:h + 1].contiguous())
     assert torch.equal(out.detach()[:, :, h:h + 1], out1.detach())
-    for a, b in ((q.grad, q1.grad), (k.grad, k1.grad), (v.grad, v1.grad)):
+    for a, b in ((k.grad, k1.grad), (v.grad, v1.grad)):
         assert torch.equal(a[:, :, h:h + 1], b)
+    # dq: f32 atomic adds in arrival order (bit-equal under LWM_DETERMINISTIC=1) -- one bf16 rounding apart at most
+    a, b = q.grad[:, :, h:h + 1].float(), q1.grad.float()
+    assert ((a - b).abs().max() / b.abs().max()).item() <= 2.0 ** -8
     # and the last rows of the last head are really attention over their own document
     f = lambda t: t.detach()[0, S - doc:, h].float().cpu().numpy()[None, :, None]
     ro, _ = R.dense_attention(f(q), f(k), f(v), causal=True)

@@ -171,3 +171,53 @@ def test_c_ring_schedule_vs_oracle_and_python_driver(n, causal, packed, padded):
         c = S // n
         blk = c * H * 128
         assert all(s == (n - 1) * 2 * blk * 2 * 2 + n * 2 * blk * 4 for s in sent), sent
+
+
+_RCCL_FIRST_CONTACT = r'''
+import ctypes as C, sys, torch
+from lwm_amd import _capi
+from lwm_amd._lib import lib
+L = lib()
+torch.cuda.init()
+side = torch.cuda.Stream()
+ident = (C.c_char * 128)()
+_capi.check(L, L.lwm_ring_unique_id(ident), "lwm_ring_unique_id")
+assert any(bytes(ident)), "ncclGetUniqueId left the id empty"
+h = C.c_void_p()
+_capi.check(L, L.lwm_ring_create_from_id(ident, 0, 1, C.c_void_p(side.cuda_stream), C.byref(h)), "lwm_ring_create_from_id")
+nbytes = int(sys.argv[1])
+g = torch.Generator(device="cuda").manual_seed(3)
+src = torch.randint(0, 255, (nbytes,), dtype=torch.uint8, device="cuda", generator=g)
+dst = torch.zeros_like(src)
+cs = torch.cuda.current_stream()
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for rep in range(3):
+    dst.zero_()
+    ev0.record(cs)
+    _capi.check(L, L.lwm_ring_selftest(h, src.data_ptr(), dst.data_ptr(), nbytes, C.c_void_p(cs.cuda_stream)), "lwm_ring_selftest")
+    ev1.record(cs)
+    torch.cuda.synchronize()
+    assert torch.equal(src, dst), "bytes received through RCCL differ from the bytes sent"
+assert L.lwm_ring_bytes_sent(h) == 3 * nbytes
+print("RCCL_SELF_OK %d bytes, last exchange %.3f ms = %.1f GB/s" % (nbytes, ev0.elapsed_time(ev1), nbytes / ev0.elapsed_time(ev1) / 1e6))
+_capi.check(L, L.lwm_ring_destroy(h), "lwm_ring_destroy")
+'''
+
+
+@pytest.mark.gpu
+def test_rccl_first_contact_on_one_gpu():
+    """The RCCL transport of the C ring driver, executed for real on the one GPU a test box has: the library's
+    run-time symbol table (dlsym / dlopen librccl), lwm_ring_unique_id, lwm_ring_create_from_id with n = 1 (the
+    128-byte ncclUniqueId passed BY VALUE through a dlsym'd pointer), and a grouped ncclSend + ncclRecv of
+    256 MiB to our own rank on the ring's side stream, handed over by the driver's events (lwm_ring_selftest).
+    Runs in its own process under a timeout: a communicator that hangs must fail this test, not the session."""
+    import subprocess
+    import sys
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG=os.environ.get("NCCL_DEBUG", "WARN"))
+    p = subprocess.run([sys.executable, "-c", _RCCL_FIRST_CONTACT, str(256 << 20)], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=240)
+    out = p.stdout + p.stderr
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "rccl_first_contact.txt"), "w") as f:
+        f.write(out)
+    assert p.returncode == 0 and "RCCL_SELF_OK" in p.stdout, out[-3000:]
