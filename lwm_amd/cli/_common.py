@@ -65,12 +65,16 @@ def build_config(flags, vision: bool):
 
 
 def torch_dtype(name: str):
-    """--dtype (fp32 | bf16 | fp16, tux.get_float_dtype_by_name).  The attention kernels take bf16
-    operands with f32 logits / softmax / accumulation, so activations run in bf16 whatever is asked."""
+    """--dtype (fp32 | bf16 | fp16, tux.get_float_dtype_by_name; the reference's default and every launcher's value
+    is fp32, lwm/train.py:36, scripts/run_train_text.sh:21).  The MI355X hot path exists for bf16 operands only
+    (f32 logits / softmax / accumulation, i.e. the reference's bf16 run with float32_logits=True, BASELINE configs
+    2-5); anything else is REFUSED rather than silently computed in a different precision than the command line says."""
     if name not in ("fp32", "bf16", "fp16", "float32", "bfloat16", "float16"):
         raise SystemExit(f"unknown --dtype {name!r}")
     if name not in ("bf16", "bfloat16"):
-        note(f"--dtype={name}: the MI355X hot path computes on bf16 operands with f32 accumulation; running bf16")
+        raise SystemExit(f"--dtype={name}: not supported -- the MI355X attention kernels take bf16 operands (f32 logits, "
+                         f"softmax and accumulation).  Pass --dtype=bf16 explicitly; the run is then the reference's "
+                         f"bf16 configuration, not its fp32 default.")
     return torch.bfloat16
 
 
@@ -95,10 +99,11 @@ def load_checkpoint(model, spec: str):
     if kind in ("params", "flax_params", "trainstate_params"):
         flat = W.read_flax_stream(path)
         prefix = "params/params/" if any(k.startswith("params/params/") for k in flat) else "params/"
-        return W.load_params(model, W.flax_llama_to_lwm(flat, prefix=prefix), strict=False)
+        params = W.flax_llama_to_lwm(flat, prefix=prefix, param_scan_axis=getattr(model.cfg, "param_scan_axis", 0))
+        return W.load_params(model, params, strict=False, report=note)
     if kind == "hf":
         sd, _ = W.read_hf_checkpoint(path)
-        return W.load_params(model, W.hf_to_lwm(sd, model.cfg.num_attention_heads), strict=False)
+        return W.load_params(model, W.hf_to_lwm(sd, model.cfg.num_attention_heads), strict=False, report=note)
     raise SystemExit(f"--load_checkpoint: unsupported type {kind!r}")
 
 

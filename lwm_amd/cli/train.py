@@ -71,12 +71,16 @@ def main(argv=None):
     opt = torch.optim.AdamW(model.parameters(), lr=lr_at(0, opt_cfg), betas=(float(opt_cfg.get("b1", 0.9)),
                             float(opt_cfg.get("b2", 0.95))), weight_decay=float(opt_cfg.get("weight_decay", 1e-4)))
     clip = float(opt_cfg.get("clip_gradient", 1.0))
-    gen = torch.Generator(device=dev).manual_seed(F.seed + 17 * mesh["dp"])
     import torch.distributed as dist
-    sp_rank = 0
-    if dist.is_available() and dist.is_initialized() and sp > 1:
-        from ..ringattention import sp_size_rank
-        sp_rank = sp_size_rank("sp")[1]
+    sp_rank, world_rank = 0, 0
+    if dist.is_available() and dist.is_initialized():
+        world_rank = dist.get_rank()
+        if sp > 1:
+            from ..ringattention import sp_size_rank
+            sp_rank = sp_size_rank("sp")[1]
+    # the ranks of one sp group share a batch (each holds a slice of its sequences); data-parallel replicas draw
+    # DIFFERENT batches: seed by the replica's coordinate (sp is the fastest axis of the mesh, lwm_amd/mesh.py)
+    gen = torch.Generator(device=dev).manual_seed(F.seed + 17 * (world_rank // max(sp, 1)))
     c = seq // sp
     history = []
     for step in range(int(F.total_steps)):
@@ -98,10 +102,21 @@ def main(argv=None):
                 loss, acc = model.loss(inp, tgt)
                 metrics = dict(accuracy=acc)
             (loss / accum).backward()
-        if sp > 1 or dp > 1:        # parameters are replicated: average the gradients over the job
-            for p in model.parameters():
-                if p.grad is not None:
-                    dist.all_reduce(p.grad, op=dist.ReduceOp.AVG)
+        if sp > 1 or dp > 1:        # parameters are replicated: average the gradients over the job, in buckets
+            grads = [p.grad for p in model.parameters() if p.grad is not None]
+            bucket, size = [], 0
+            for g in grads + [None]:
+                if g is None or (bucket and (size + g.numel() > (1 << 26) or g.dtype != bucket[0].dtype)):
+                    flat = torch.cat([x.reshape(-1) for x in bucket])
+                    dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+                    off = 0
+                    for x in bucket:
+                        x.copy_(flat[off:off + x.numel()].view_as(x))
+                        off += x.numel()
+                    bucket, size = [], 0
+                if g is not None:
+                    bucket.append(g)
+                    size += g.numel()
         torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
         opt.step()
         opt.zero_grad(set_to_none=True)

@@ -1,0 +1,715 @@
+// attn_fwd64.h -- blockwise attention forward, ONE WAVE PER SIMD: the training-path kernel for one
+// (q block, kv block) ring step on gfx950.  Requires wave_ops.h + attn_common.h + attn_fwd.h (constants).
+//
+// Replaces the forward of `ringattention` as called at lwm/llama.py:539-569 (blockwise online-softmax
+// update, fp32 logits, causal_block_size=1, masks per lwm/llama.py:527-537 and :572-592) -- the same
+// contract as attn_fwd.h, which stays for the dense-mask / split-K inference flavour.
+//
+// Structure (cdna_hip_programming.md, "4-wave, one-wave-per-SIMD" attention): workgroup = 4 waves = 256
+// queries; a wave owns 64 query rows (two 32-row blocks) and the SIMD's whole register file, so every K
+// fragment (ds_read_b128) and every V fragment (2 x ds_read_b64_tr_b16) feeds TWO MFMAs, fragment
+// addresses live in registers (no per-read address arithmetic), and the softmax of one key tile is
+// interleaved, in program order, with the MFMAs of its neighbours -- with a single wave on the SIMD
+// nothing else would fill the matrix pipe while the wave does its exponentials:
+//
+//   iteration i (tile i = 64 keys)       matrix pipe                     vector pipe (same wave)
+//     phase 1 (32 MFMAs)   S(i+1) = K(i+1) Q~^T - base        p(i) = exp2(S(i)), P(i) -> bf16
+//     phase 2 (32 MFMAs)   O^T   += V(i)^T P(i)^T             row sums of p(i), running max of S(i+1)
+//
+// Scores are computed transposed (S^T = K Q^T: a lane owns one query column, as in attn_fwd.h).  What is
+// new in the arithmetic:
+//   * Q is pre-multiplied by scale*log2(e) and rounded to bf16 once per workgroup ("Q~"), so a score leaves
+//     the MFMA in log2 units;
+//   * p = exp2(s*c - m*c) is ONE fma + one exp per score (m = the query's running reference, its maximum at the
+//     last rescale; scores stay raw in their registers);
+//   * the reference moves only when some row would exceed 2^kDeferLog2 (deferred rescale, as before) and the
+//     decision needs no cross-lane traffic; the rescale itself is a rare, non-interleaved block that runs
+//     after the P.V of the tile in flight is complete.
+// K/V tiles travel global -> LDS by LDS-DMA (no registers, no ds_write): K two tiles ahead, V one, one
+// workgroup barrier per tile.
+//
+// LDS map: K tile 0 | K tile 1 | V tile 0 | V tile 1 (16 KiB each) | key meta 0 | 1 | 2 (256 B each) | scan scratch
+#pragma once
+
+namespace lwm {
+
+constexpr int kF4BQ = 256;      // queries per workgroup
+constexpr int kF4BK = 64;       // keys per LDS tile
+constexpr int kF4Threads = 256;
+constexpr int kF4TileBytes = kF4BK * kRowBytes;                 // 16 KiB
+constexpr int kF4OffMeta = 4 * kF4TileBytes;
+constexpr int kF4OffScan = kF4OffMeta + 3 * kF4BK * 4;   // three key-meta buffers: tile t in buffer t % 3
+constexpr int kF4LdsBytes = kF4OffScan + 64;
+// 1: Q~ = bf16(q * scale * log2 e) -- p = exp2(S), one VALU per score, but the rounding of Q~ (2^-9 relative per
+//    element) moves a score by ~1.6e-3 and the LSE by up to ~2e-3 (measured, tests/emu); 0: Q as given, S in raw
+//    q.k units, p = exp2(S * c) -- one more multiply per score, LSE exact to f32.  (A/B: profiles/r03_fwd64.md)
+#ifndef LWM_F4_PRESCALE
+#define LWM_F4_PRESCALE 0
+#endif
+constexpr bool kF4Prescale = LWM_F4_PRESCALE != 0;
+
+struct F4Ctx {
+    uint32_t ka[8];             // K row-fragment addresses, tile 0, keys 0..31, per 16-wide d step
+    uint32_t vlo[4], vup[4];    // V transposed-fragment addresses, V tile 0, keys 0..15, per 32-wide d block
+    lds_t lds;
+    int tid, lane, hi, wave;
+    float thr[2];               // raw-score threshold of the deferred rescale: -inf until the row's reference is set,
+                                // then mref + kDeferLog2 / c
+    float mref[2];              // the reference, a raw score q.k (-inf: none yet)
+    float nbase[2];             // -mref * c (0 while mref = -inf; +mref when prescaled: f4_sub) -- the fma's addend
+    float lsum[2];              // this half-wave's partial row sum
+    float c;                    // scale * log2(e): scores -> log2 units (1 when Q is prescaled)
+    float thr_on;               // kDeferLog2 in raw score units
+};
+
+// ---- staging.  A tile = 16 pieces of 1 KiB (4 rows); a half tile (32 keys) = 8 pieces, of which wave w moves
+// pieces w and w+4.  Lane l of a piece writes physical slot l&15 of row 4*piece + (l>>4), so it fetches logical
+// slot (l&15) ^ swz(row) -- the XOR swizzle applied on the SOURCE column; swz(row) is the same for every piece
+// of a wave (its pieces are 16 rows apart).
+struct F4Stage {
+    uint32_t voff_k[4], voff_v[4];    // per-lane byte offsets of the wave's pieces j = 0..3 (rows 4w + 16j + (l>>4))
+    const char* kb;                   // K / V of this (batch, head), tile 0 (wave-uniform)
+    const char* vb;
+    int64_t ktile_bytes, vtile_bytes; // bytes between tiles
+};
+
+// N (2 or 4) LDS-DMA instructions of one wave: piece j from src + voff[j] to dst + 4096*j; src and dst
+// wave-uniform.  One asm block: M0 is saved once; hipcc sees no load (the kernel owns the wait, wave_ops.h); the
+// s_nop after the save covers a readfirstlane-made SGPR pair (VALU -> SGPR -> VMEM).
+template <int N>
+LWM_DEVICE void f4_dma(const uint32_t* voff, const char* src, lds_t dst) {
+#ifdef LWM_EMU
+    for (int j = 0; j < N; ++j) glds_load_b128(src + voff[j], dst + 4096 * j);
+#else
+    const uint64_t a = (uint64_t)src;
+    const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
+    unsigned keep;
+    if (N == 4) {
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_nop 3\n\t"
+            "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+            "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+            "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+            "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(u), "s"(dst)
+            : "memory", "scc");
+    } else {
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_nop 3\n\t"
+            "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+            "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff[0]), "v"(voff[1]), "s"(u), "s"(dst)
+            : "memory", "scc");
+    }
+#endif
+}
+
+// per-lane offsets for tile `kt` with rows clamped to Sk-1 (rows past Sk are masked through the key meta)
+LWM_DEVICE void f4_stage_offsets(const AttnParams& p, int wave, int lane, int kt, F4Stage& st) {
+    const int slot = lane & 15;
+    for (int j = 0; j < 4; ++j) {
+        const int row = 4 * (wave + 4 * j) + (lane >> 4);
+        int krow = kt * kF4BK + row;
+        krow = krow < p.Sk ? krow : p.Sk - 1;
+        const int rel = krow - kt * kF4BK;      // >= 0 for every tile that exists
+        const int col = (slot ^ swz(row)) << 3;
+        st.voff_k[j] = (uint32_t)(((int64_t)rel * p.k_ss + col) * 2);
+        st.voff_v[j] = (uint32_t)(((int64_t)rel * p.v_ss + col) * 2);
+    }
+}
+
+// key meta of tile kt -> meta buffer `buf`: segment id, or kSegInvalid for padded / out-of-range keys
+LWM_DEVICE void f4_meta_stage(const AttnParams& p, const F4Ctx& cx, int b, int kt, int buf) {
+    if (cx.tid < kF4BK) {
+        const int krow = kt * kF4BK + cx.tid;
+        const int kr = krow < p.Sk ? krow : p.Sk - 1;
+        const uint8_t kvalid = p.key_valid ? p.key_valid[(int64_t)b * p.Sk + kr] : (uint8_t)1;
+        const int32_t kseg = p.seg_k ? p.seg_k[(int64_t)b * p.Sk + kr] : 0;
+        const bool ok = krow < p.Sk && kvalid != 0;
+        lds_write_i32(cx.lds + kF4OffMeta + buf * kF4BK * 4 + cx.tid * 4, ok ? kseg : kSegInvalid);
+    }
+}
+
+// ---- hand-ordered instruction stream.  At one wave per SIMD hipcc selects the AGPR form for EVERY MFMA (C and D in
+// the accumulator file) and would copy each score tile back to VGPRs for the softmax (v_accvgpr_read x 64 per tile),
+// and its instruction selection lets pure VALU operations float to the end of a block whatever scheduling fences say.
+// So the two phases are written as `asm volatile` statements, which keep their source order: the score MFMAs in VGPR
+// form (C/D = the VGPR tuple the softmax then works on in place), the P.V MFMAs in AGPR form (O never leaves the
+// accumulator file), Q~ as an AGPR B operand, and every filler between them.  What hipcc still does: LDS reads
+// (builtins: it counts them and waits before the asm statement that consumes the fragment) and register allocation.
+// Hazards hipcc cannot see through asm (cdna_hip_programming.md section 5.7 item 2) are covered here:
+//   MFMA D (VGPR) -> VALU read      the score tile is first read a whole phase later; f4_mfma_settle() ends phase 1
+//   v_exp (trans) -> VALU consumer  the cvt of a value comes at least one MFMA after its exp
+//   VALU write -> MFMA A/B/C        P fragments are packed a phase before the MFMA that reads them
+#ifdef LWM_EMU
+LWM_DEVICE void f4_mfma_s_first(f32x16& d, bf16x8 a, bf16x8 b) { d = mfma_32x32x16(a, b, zero_f32x16()); }
+LWM_DEVICE void f4_mfma_s(f32x16& d, bf16x8 a, bf16x8 b) { d = mfma_32x32x16(a, b, d); }
+LWM_DEVICE void f4_mfma_o(f32x16& d, bf16x8 a, bf16x8 b) { d = mfma_32x32x16(a, b, d); }
+LWM_DEVICE void f4_mfma_settle() {}
+LWM_DEVICE float f4_fma(float x, float c, float d) { return fmaf(x, c, d); }
+LWM_DEVICE float f4_sub(float x, float d) { return x - d; }
+LWM_DEVICE float f4_exp2(float x) { return exp2f(x); }
+LWM_DEVICE uint32_t f4_cvt_pk(float lo, float hi) { return pack_bf16x2(lo, hi); }
+LWM_DEVICE void f4_add(float& acc, float x) { acc += x; }
+LWM_DEVICE void f4_max3(float& m, float a, float b) { m = fmaxf(fmaxf(m, a), b); }
+LWM_DEVICE bf16x8 f4_to_agpr(bf16x8 x) { return x; }
+LWM_DEVICE bf16x8 f4_load_agpr(const bf16_t* g) { return __builtin_bit_cast(bf16x8, global_load_b128(g)); }
+LWM_DEVICE void f4_load_agpr_wait(bf16x8 (&)[2][8]) {}
+LWM_DEVICE void f4_scale_acc(f32x16& d, float alpha) { d *= alpha; }
+#else
+LWM_DEVICE void f4_mfma_s_first(f32x16& d, bf16x8 a, bf16x8 b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "a"(b));
+}
+LWM_DEVICE void f4_mfma_s(f32x16& d, bf16x8 a, bf16x8 b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
+}
+LWM_DEVICE void f4_mfma_o(f32x16& d, bf16x8 a, bf16x8 b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b));
+}
+// after the last MFMA of a chain whose result compiler-generated code (or a VALU filler) reads next
+LWM_DEVICE void f4_mfma_settle() { asm volatile("s_nop 7\n\ts_nop 7"); }
+LWM_DEVICE float f4_fma(float x, float c, float d) {
+    float y;
+    asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(y) : "v"(x), "v"(c), "v"(d));
+    return y;
+}
+LWM_DEVICE float f4_sub(float x, float d) {
+    float y;
+    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(y) : "v"(x), "v"(d));
+    return y;
+}
+LWM_DEVICE float f4_exp2(float x) {
+    float y;
+    asm volatile("v_exp_f32 %0, %1" : "=v"(y) : "v"(x));
+    return y;
+}
+LWM_DEVICE uint32_t f4_cvt_pk(float lo, float hi) {
+    uint32_t y;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(y) : "v"(lo), "v"(hi));
+    return y;
+}
+LWM_DEVICE void f4_add(float& acc, float x) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(x)); }
+// a fragment whose HOME is the accumulator file: each dword is defined by an asm with an AGPR output, so that the
+// "a" operands of the MFMAs coalesce with it instead of being re-copied from a VGPR before every use
+LWM_DEVICE bf16x8 f4_to_agpr(bf16x8 x) {
+    const u32x4 v = __builtin_bit_cast(u32x4, x);
+    uint32_t w0, w1, w2, w3;
+    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(w0) : "v"(v[0]));
+    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(w1) : "v"(v[1]));
+    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(w2) : "v"(v[2]));
+    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(w3) : "v"(v[3]));
+    return __builtin_bit_cast(bf16x8, u32x4{w0, w1, w2, w3});
+}
+// 16 bytes from global memory straight into the accumulator file (gfx90a+: a load may target AGPRs).  hipcc does not
+// count the load: f4_load_agpr_wait names every destination, so that nothing is read or moved before the data is in
+// (cdna_hip_programming.md section 5.7 item 1, form ii).
+LWM_DEVICE bf16x8 f4_load_agpr(const bf16_t* g) {
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(r) : "v"(g) : "memory");
+    return __builtin_bit_cast(bf16x8, r);
+}
+LWM_DEVICE void f4_load_agpr_wait(bf16x8 (&q)[2][8]) {
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+a"(q[0][0]), "+a"(q[0][1]), "+a"(q[0][2]), "+a"(q[0][3]), "+a"(q[0][4]), "+a"(q[0][5]), "+a"(q[0][6]), "+a"(q[0][7]),
+                   "+a"(q[1][0]), "+a"(q[1][1]), "+a"(q[1][2]), "+a"(q[1][3]), "+a"(q[1][4]), "+a"(q[1][5]), "+a"(q[1][6]), "+a"(q[1][7])
+                 :
+                 : "memory");
+}
+// acc *= alpha on a tuple that lives in the accumulator file, without ever showing hipcc a VGPR copy of it
+LWM_DEVICE void f4_scale_acc(f32x16& d, float alpha) {
+#define LWM_F4_SC(i) "v_accvgpr_read_b32 %16, %" #i "\n\ts_nop 0\n\tv_mul_f32 %16, %16, %17\n\ts_nop 0\n\tv_accvgpr_write_b32 %" #i ", %16\n\t"
+    float t;
+    asm volatile(LWM_F4_SC(0) LWM_F4_SC(1) LWM_F4_SC(2) LWM_F4_SC(3) LWM_F4_SC(4) LWM_F4_SC(5) LWM_F4_SC(6) LWM_F4_SC(7)
+                 LWM_F4_SC(8) LWM_F4_SC(9) LWM_F4_SC(10) LWM_F4_SC(11) LWM_F4_SC(12) LWM_F4_SC(13) LWM_F4_SC(14) LWM_F4_SC(15) "s_nop 1"
+                 : "+a"(d[0]), "+a"(d[1]), "+a"(d[2]), "+a"(d[3]), "+a"(d[4]), "+a"(d[5]), "+a"(d[6]), "+a"(d[7]),
+                   "+a"(d[8]), "+a"(d[9]), "+a"(d[10]), "+a"(d[11]), "+a"(d[12]), "+a"(d[13]), "+a"(d[14]), "+a"(d[15]), "=&v"(t)
+                 : "v"(alpha));
+#undef LWM_F4_SC
+}
+LWM_DEVICE void f4_max3(float& m, float a, float b) { asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(a), "v"(b)); }
+#endif
+
+// ---- the two phases of one HALF tile (32 keys).  sC = the half tile being finished (scores relative to the
+// reference), pC = its probabilities (written by phase 1, summed by phase 2), sN = the next half tile's scores.
+// Template switches select what a prologue / last step needs.
+// K row fragment (d step s) of key half KHALF in the K buffer cx.ka points at; V transposed fragment f = (key step
+// f>>2 of 16 keys, d block f&3) of key half VHALF in the V buffer cx.vlo / cx.vup point at
+template <int KHALF>
+LWM_DEVICE bf16x8 f4_kread(const F4Ctx& cx, int s) { return lds_read_b128(cx.ka[s] + KHALF * 32 * kRowBytes); }
+template <int VHALF>
+LWM_DEVICE bf16x8 f4_vread(const F4Ctx& cx, int f) {
+    const uint32_t off = VHALF * 32 * kRowBytes + 16 * (f >> 2) * kRowBytes;
+    bf16x4 lo = lds_read_tr16(cx.vlo[f & 3] + off);
+    bf16x4 up = lds_read_tr16(cx.vup[f & 3] + off);
+    bf16x8 o;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+    o[4] = up[0]; o[5] = up[1]; o[6] = up[2]; o[7] = up[3];
+    return o;
+}
+
+// Phase 1 (16 MFMAs): S(next) = K Q^T  ||  p = exp2(sC*c - m*c), P -> bf16.  KHALF = key half of the NEXT half tile
+// inside the K buffer cx.ka points at; its fragments 0 and 1 are ALREADY in kfr[0], kfr[1] (requested by whoever ran
+// before: with one wave on the SIMD nothing else covers the LDS latency at the head of a phase).  VNEXT >= 0: request
+// the first two V fragments of the phase 2 that follows (key half VNEXT) during the last gaps.
+template <int KHALF, bool DO_S, bool DO_FIN, int VNEXT>
+LWM_DEVICE void f4_phase1(const F4Ctx& cx, const bf16x8 (&qf)[2][8], f32x16 (&sN)[2], const f32x16 (&sC)[2],
+                          float (&pC)[2][16], bf16x8 (&pb)[2][2], bf16x8 (&kfr)[3], bf16x8 (&vfr)[3]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const int s = g >> 1, qb = g & 1;
+        if (DO_S && qb == 0 && s + 2 < 8) kfr[(s + 2) % 3] = f4_kread<KHALF>(cx, s + 2);
+        if (VNEXT >= 0 && g == 12) vfr[0] = f4_vread<VNEXT < 0 ? 0 : VNEXT>(cx, 0);
+        if (VNEXT >= 0 && g == 14) vfr[1] = f4_vread<VNEXT < 0 ? 0 : VNEXT>(cx, 1);
+        sched_fence();
+        if (DO_S) {
+            if (s == 0) f4_mfma_s_first(sN[qb], kfr[0], qf[qb][0]);
+            else f4_mfma_s(sN[qb], kfr[s % 3], qf[qb][s]);
+        }
+        if (DO_FIN) {
+            // finish-softmax slice: elements 2g, 2g+1 of the finished half tile, flattened [qb][r]; the pair of the
+            // PREVIOUS gap is packed here (a transcendental's result is not read by the very next instruction).
+            // p = exp2(s*c - m*c): one fma (a subtract when Q is prescaled: c = 1) and one exp per score
+            const int e = 2 * g, fq = e >> 4, r = e & 15;
+            const float t0 = kF4Prescale ? f4_sub(sC[fq][r], cx.nbase[fq]) : f4_fma(sC[fq][r], cx.c, cx.nbase[fq]);
+            const float t1 = kF4Prescale ? f4_sub(sC[fq][r + 1], cx.nbase[fq]) : f4_fma(sC[fq][r + 1], cx.c, cx.nbase[fq]);
+            pC[fq][r] = f4_exp2(t0);
+            pC[fq][r + 1] = f4_exp2(t1);
+            if (g > 0) {
+                const int e0 = 2 * (g - 1), q0 = e0 >> 4, r0 = e0 & 15;
+                w[(g - 1) & 3] = f4_cvt_pk(pC[q0][r0], pC[q0][r0 + 1]);
+                if (((g - 1) & 3) == 3) pb[q0][(e0 >> 3) & 1] = __builtin_bit_cast(bf16x8, u32x4{w[0], w[1], w[2], w[3]});
+            }
+        }
+        sched_fence();
+    }
+    if (DO_FIN) {
+        w[3] = f4_cvt_pk(pC[1][14], pC[1][15]);
+        pb[1][1] = __builtin_bit_cast(bf16x8, u32x4{w[0], w[1], w[2], w[3]});
+    }
+    if (DO_S) f4_mfma_settle();
+}
+
+// Phase 2 (16 MFMAs): O^T += V^T P^T  ||  row sums of p (pC), running max of the next half tile's scores (sN).
+// VHALF = key half of the half tile being finished inside the V buffer; its fragments 0 and 1 are already in vfr[0],
+// vfr[1].  KNEXT >= 0: request the first two K fragments of the phase 1 that follows (key half KNEXT of the buffer
+// cx.ka points at NOW) during the last gaps.
+template <int VHALF, bool DO_PV, bool DO_MAX, int KNEXT>
+LWM_DEVICE void f4_phase2(F4Ctx& cx, const bf16x8 (&pb)[2][2], f32x16 (&acc)[2][4], const float (&pC)[2][16],
+                          const f32x16 (&sN)[2], float (&mx)[2], bf16x8 (&kfr)[3], bf16x8 (&vfr)[3]) {
+    float ls[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    float mp[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+    for (int h = 0; h < 16; ++h) {
+        const int f = h >> 1, qb = h & 1, t = f >> 2, db = f & 3;
+        if (DO_PV && qb == 0 && f + 2 < 8) vfr[(f + 2) % 3] = f4_vread<VHALF>(cx, f + 2);
+        if (KNEXT >= 0 && h == 12) kfr[0] = f4_kread<KNEXT < 0 ? 0 : KNEXT>(cx, 0);
+        if (KNEXT >= 0 && h == 14) kfr[1] = f4_kread<KNEXT < 0 ? 0 : KNEXT>(cx, 1);
+        sched_fence();
+        if (DO_PV) f4_mfma_o(acc[qb][db], vfr[f % 3], pb[qb][t]);
+        const int e = 2 * h, fq = e >> 4, r = e & 15;
+        if (DO_PV) {
+            f4_add(ls[fq][0], pC[fq][r]);
+            f4_add(ls[fq][1], pC[fq][r + 1]);
+        }
+        if (DO_MAX) f4_max3(mp[fq], sN[fq][r], sN[fq][r + 1]);
+        sched_fence();
+    }
+    if (DO_PV)
+        for (int q2 = 0; q2 < 2; ++q2) cx.lsum[q2] += ls[q2][0] + ls[q2][1];
+    if (DO_MAX)
+        for (int q2 = 0; q2 < 2; ++q2) mx[q2] = mp[q2];
+}
+
+// masks of one half tile on its scores (lwm/llama.py:572-592): causal, same segment, key valid.
+// rel[qb] = (query position) - (position of the TILE's key 0), clamped to [-1, 64]; key kl of the tile visible iff
+// kl <= rel.  KHALF selects keys 32*KHALF .. +31.
+template <bool HAS_META, int KHALF>
+LWM_DEVICE void f4_mask(const F4Ctx& cx, f32x16 (&sN)[2], const int (&rel)[2], const int32_t (&seg_q)[2], int mbuf) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int relh = rel[qb] - 4 * cx.hi - 32 * KHALF;       // kl = 32*KHALF + 8*g + 4*hi + j <= rel
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (HAS_META) {
+                const u32x4 sg = lds_read_u32x4(cx.lds + kF4OffMeta + mbuf * kF4BK * 4 + 16 * cx.hi + (32 * KHALF + 8 * g) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool vis = ((int32_t)sg[j] == seg_q[qb]) && (8 * g + j <= relh);
+                    sN[qb][4 * g + j] = vis ? sN[qb][4 * g + j] : -INFINITY;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sN[qb][4 * g + j] = (8 * g + j <= relh) ? sN[qb][4 * g + j] : -INFINITY;
+            }
+        }
+    }
+}
+
+// The rare block: move the reference of the rows that need it.  Runs after the P.V of the half tile in flight, so
+// everything accumulated at the old reference is rescaled exactly once.  Scores stay raw (the reference enters
+// through the fma of the exponent), so nothing of the next half tile needs touching.
+LWM_DEVICE void f4_rescale(F4Ctx& cx, const float (&mx)[2], f32x16 (&acc)[2][4]) {
+    f4_mfma_settle();      // the P.V MFMAs (asm) have written acc: hipcc does not know they are MFMAs
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float mxa = fmaxf(mx[qb], xhalf(mx[qb]));           // both halves of the wave hold keys of the column
+        const float m_new = fmaxf(cx.mref[qb], mxa);
+        const float ms = (m_new == -INFINITY) ? 0.0f : m_new;
+        const float alpha = fast_exp2((cx.mref[qb] - ms) * cx.c); // 0 while the old reference is -inf
+        cx.lsum[qb] *= alpha;
+        for (int db = 0; db < 4; ++db) f4_scale_acc(acc[qb][db], alpha);
+        cx.mref[qb] = m_new;
+        cx.nbase[qb] = kF4Prescale ? ms : -ms * cx.c;
+        cx.thr[qb] = (m_new == -INFINITY) ? -INFINITY : m_new + cx.thr_on;
+    }
+}
+
+template <bool HAS_META>
+LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
+    const lds_t lds = dyn_lds();
+    const int tid = thread_idx();
+    const int wave = wave_uniform(tid >> 6), lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+
+    // ---- block -> (q tile, head, batch): longest q tiles first; all q tiles of one (b,h) on one XCD
+    const int nqt = (p.Sq + kF4BQ - 1) / kF4BQ;
+    const int HB = p.H * p.B;
+    int lin = block_idx_x(), qt, hb;
+    if ((HB & 7) == 0) {
+        int xcd = lin & 7, i = lin >> 3;
+        hb = xcd + 8 * (i / nqt);
+        qt = nqt - 1 - (i % nqt);
+    } else {
+        hb = lin / nqt;
+        qt = nqt - 1 - (lin % nqt);
+    }
+    const int b = hb / p.H, h = hb % p.H;
+    const bf16_t* qb_ = p.q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
+
+    F4Ctx cx;
+    cx.lds = lds;
+    cx.tid = tid;
+    cx.lane = lane;
+    cx.hi = hi;
+    cx.wave = wave;
+    for (int s = 0; s < 8; ++s) cx.ka[s] = lds + tile_off(l31, 2 * s + hi);
+    {
+        const TrFragAddr t = frag_tr_addr(lds + 2 * kF4TileBytes, lane);
+        for (int db = 0; db < 4; ++db) {
+            cx.vlo[db] = t.lo[db];
+            cx.vup[db] = t.up[db];
+        }
+    }
+    const float c = p.scale * kLog2e;
+    cx.c = kF4Prescale ? 1.0f : c;
+    cx.thr_on = kF4Prescale ? kDeferLog2 : kDeferLog2 / c;
+
+    // ---- this lane's two query rows (Q~ = bf16(q * scale * log2 e) when prescaled)
+    bf16x8 qf[2][8];
+    int q_row[2];
+    bool q_ok[2];
+    int32_t seg_q[2];
+    int64_t q_pos[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        q_row[qb] = qt * kF4BQ + wave * 64 + 32 * qb + l31;
+        q_ok[qb] = q_row[qb] < p.Sq;
+        q_pos[qb] = p.q_start + q_row[qb];
+        seg_q[qb] = (HAS_META && q_ok[qb] && p.seg_q) ? p.seg_q[(int64_t)b * p.Sq + q_row[qb]] : 0;
+        if (kF4Prescale) {
+            for (int s = 0; s < 8; ++s) {
+                if (q_ok[qb]) {
+                    const bf16x8 raw = __builtin_bit_cast(bf16x8, global_load_b128(qb_ + (int64_t)q_row[qb] * p.q_ss + 16 * s + 8 * hi));
+                    bf16x8 o;
+                    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)raw[j] * c);
+                    qf[qb][s] = f4_to_agpr(o);
+                } else {
+                    qf[qb][s] = f4_to_agpr(zero_bf16x8());
+                }
+            }
+        } else {
+            // straight into the accumulator file (a row past Sq re-reads the last row: its results are never stored)
+            const int qr = q_ok[qb] ? q_row[qb] : p.Sq - 1;
+            for (int s = 0; s < 8; ++s) qf[qb][s] = f4_load_agpr(qb_ + (int64_t)qr * p.q_ss + 16 * s + 8 * hi);
+        }
+        cx.thr[qb] = -INFINITY;
+        cx.mref[qb] = -INFINITY;
+        cx.nbase[qb] = 0.0f;
+        cx.lsum[qb] = 0.0f;
+    }
+    if (!kF4Prescale) f4_load_agpr_wait(qf);
+    const int64_t wq_min = p.q_start + (int64_t)qt * kF4BQ + wave * 64;   // first / last query position of this wave
+    const int64_t wq_max = wq_min + 63;
+
+    // ---- kv tile range of the WORKGROUP (causal: skip tiles wholly in the future of its last row)
+    const int nkt_all = (p.Sk + kF4BK - 1) / kF4BK;
+    int nkt = nkt_all, kt0 = 0;
+    const int q_last = (qt * kF4BQ + kF4BQ < p.Sq ? qt * kF4BQ + kF4BQ : p.Sq) - 1;
+    if (p.causal) {
+        const int64_t d = p.q_start + q_last - p.k_start;  // last visible key index
+        if (d < 0) nkt = 0;
+        else {
+            const int64_t t = d / kF4BK + 1;
+            nkt = t < nkt_all ? (int)t : nkt_all;
+        }
+    }
+    if (HAS_META && p.segb_q && p.segb_k && nkt > 0) {      // packed sequences: skip other documents' key tiles
+        const int nbq = (p.Sq + 31) >> 5, nbk = (p.Sk + 31) >> 5;
+        int smin, smax, lo, hi2;
+        seg_own_range(p.segb_q + (int64_t)b * nbq * 2, nbq, qt * (kF4BQ / 32), kF4BQ / 32, smin, smax);
+        seg_narrow<kF4Threads>(p.segb_k + (int64_t)b * nbk * 2, nbk, kF4BK / 32, 0, nkt, smin, smax, lds + kF4OffScan, tid, lo, hi2);
+        kt0 = lo;
+        nkt = hi2;
+    }
+    const int n_wg = nkt > kt0 ? nkt - kt0 : 0;
+    // tiles this WAVE computes: [kt0, kt0 + n_w) -- its rows see nothing beyond its own diagonal tile
+    int n_w = n_wg;
+    if (p.causal) {
+        const int64_t d = wq_max - p.k_start;
+        const int64_t lim = d < 0 ? 0 : d / kF4BK + 1;
+        const int64_t nw = lim - kt0;
+        n_w = nw < 0 ? 0 : (nw < n_wg ? (int)nw : n_wg);
+    }
+    if (wave_uniform(qt * kF4BQ + wave * 64 >= p.Sq ? 1 : 0)) n_w = 0;    // a wave past the ragged end of Sq
+
+    f32x16 acc[2][4];
+    for (int qb = 0; qb < 2; ++qb)
+        for (int i = 0; i < 4; ++i) acc[qb][i] = zero_f32x16();
+
+    if (n_wg > 0) {
+        F4Stage st;
+        st.kb = (const char*)(p.k + (int64_t)b * p.k_sb + (int64_t)h * p.k_sh);
+        st.vb = (const char*)(p.v + (int64_t)b * p.v_sb + (int64_t)h * p.v_sh);
+        st.ktile_bytes = (int64_t)kF4BK * p.k_ss * 2;
+        st.vtile_bytes = (int64_t)kF4BK * p.v_ss * 2;
+        const bool ragged = (p.Sk % kF4BK) != 0;      // (then HAS_META is true: the tail rows are masked via key meta)
+        f4_stage_offsets(p, wave, lane, 0, st);       // full tiles: nothing is clamped
+        // Tile `rel` (relative to kt0) lives in LDS buffer rel & 1; K travels in HALF tiles (keys 0..31 / 32..63 =
+        // the wave's pieces j = 0,1 / 2,3), V in whole tiles.  The ragged last tile of the K/V block clamps its rows
+        // (its own offsets, recomputed: once per workgroup at most).
+        const lds_t kdst0 = lds + (uint32_t)wave * 1024, vdst0 = lds + 2 * kF4TileBytes + (uint32_t)wave * 1024;
+        auto stage_k = [&](int rel, int half) {
+            const int kt = kt0 + rel;
+            const lds_t dst = kdst0 + (rel & 1) * kF4TileBytes + half * 8192;
+            if (ragged && kt == nkt_all - 1) {
+                F4Stage s2 = st;
+                f4_stage_offsets(p, wave, lane, kt, s2);
+                f4_dma<2>(s2.voff_k + 2 * half, st.kb + kt * st.ktile_bytes, dst);
+            } else {
+                f4_dma<2>(st.voff_k + 2 * half, st.kb + kt * st.ktile_bytes, dst);
+            }
+        };
+        auto stage_v = [&](int rel) {
+            const int kt = kt0 + rel;
+            const lds_t dst = vdst0 + (rel & 1) * kF4TileBytes;
+            if (ragged && kt == nkt_all - 1) {
+                F4Stage s2 = st;
+                f4_stage_offsets(p, wave, lane, kt, s2);
+                f4_dma<4>(s2.voff_v, st.vb + kt * st.vtile_bytes, dst);
+            } else {
+                f4_dma<4>(st.voff_v, st.vb + kt * st.vtile_bytes, dst);
+            }
+        };
+        // the staging of tile iteration i: K(i+2)[0..31] -> K buffer i&1 (lower half: last read by the S of half tile
+        // 2i, one iteration ago), K(i+1)[32..63] -> K buffer (i+1)&1 (upper half: last read one iteration ago),
+        // V(i+1) -> V buffer (i+1)&1; key meta of tile i+2
+        auto stage_iter = [&](int i) {
+            if (i + 2 < n_wg) stage_k(i + 2, 0);
+            if (i + 1 < n_wg) {
+                stage_k(i + 1, 1);
+                stage_v(i + 1);
+            }
+            if (HAS_META && i + 2 < n_wg) f4_meta_stage(p, cx, b, kt0 + i + 2, (i + 2) % 3);
+        };
+        auto rel_of = [&](int rel, int (&r)[2]) {       // mask offsets of tile `rel` for the two query blocks
+            const int64_t k_pos0 = p.k_start + (int64_t)(kt0 + rel) * kF4BK;
+            for (int qb = 0; qb < 2; ++qb) {
+                const int64_t d = p.causal ? (q_pos[qb] - k_pos0) : (int64_t)kF4BK;
+                r[qb] = d > kF4BK ? kF4BK : (d < -1 ? -1 : (int)d);
+            }
+        };
+        auto needs_mask = [&](int rel) -> bool {
+            if (HAS_META) return true;
+            const int64_t k_pos0 = p.k_start + (int64_t)(kt0 + rel) * kF4BK;
+            return p.causal && k_pos0 + kF4BK - 1 > wq_min;
+        };
+
+        // ---- prologue: K(0), V(0) and the first half of K(1) in flight -> S of half tile 0, its masks, its reference
+        stage_k(0, 0);
+        stage_k(0, 1);
+        stage_v(0);
+        if (n_wg > 1) stage_k(1, 0);
+        if (HAS_META) {
+            f4_meta_stage(p, cx, b, kt0, 0);
+            if (n_wg > 1) f4_meta_stage(p, cx, b, kt0 + 1, 1);
+        }
+        glds_wait_all();
+        block_sync();
+
+        f32x16 sA[2], sB[2];
+        float pC[2][16];
+        bf16x8 pb[2][2];
+        float mx[2];
+        for (int qb = 0; qb < 2; ++qb) {
+            sA[qb] = zero_f32x16();
+            sB[qb] = zero_f32x16();
+            for (int r = 0; r < 16; ++r) pC[qb][r] = 0.0f;
+        }
+        bf16x8 kfr[3], vfr[3];
+        for (int j = 0; j < 3; ++j) {
+            kfr[j] = zero_bf16x8();
+            vfr[j] = zero_bf16x8();
+        }
+        if (n_w > 0) {
+            kfr[0] = f4_kread<0>(cx, 0);
+            kfr[1] = f4_kread<0>(cx, 1);
+            f4_phase1<0, true, false, -1>(cx, qf, sA, sB, pC, pb, kfr, vfr);
+            if (needs_mask(0)) {
+                int r[2];
+                rel_of(0, r);
+                f4_mask<HAS_META, 0>(cx, sA, r, seg_q, 0);
+            }
+            f4_phase2<0, false, true, -1>(cx, pb, acc, pC, sA, mx, kfr, vfr);
+            if (wave_any(mx[0] > cx.thr[0] || mx[1] > cx.thr[1])) f4_rescale(cx, mx, acc);
+        }
+        block_sync();      // every wave has read K(0)[0..31] before K(2)[0..31] may land on it
+
+        // Tile iteration i.  The fragment addresses in cx point at the buffers of tile i and are toggled to the other
+        // buffer as the iteration goes (K between the half steps, V at the end): ONE loop body, no unrolling.
+        //   top      the first two K fragments of half 0 are requested, then the DMA of the tiles ahead is issued
+        //   half 0   phase 1: S(2i+1) from K(i)[32..63] || finish(2i);     phase 2: P.V(2i)   from V(i)[0..31]  || sums, max(2i+1)
+        //   half 1   phase 1: S(2i+2) from K(i+1)[0..31] || finish(2i+1);  phase 2: P.V(2i+1) from V(i)[32..63] || sums, max(2i+2)
+        //   bottom   wait for the DMA, one barrier.
+        // Every phase but the first of an iteration finds its first two fragments already requested by its predecessor.
+        int32_t ktog = kF4TileBytes, vtog = kF4TileBytes;     // +16 KiB now, -16 KiB next time
+        auto toggle_k = [&]() {
+            for (int s = 0; s < 8; ++s) cx.ka[s] += (uint32_t)ktog;
+            ktog = -ktog;
+        };
+        auto toggle_v = [&]() {
+            for (int db = 0; db < 4; ++db) {
+                cx.vlo[db] += (uint32_t)vtog;
+                cx.vup[db] += (uint32_t)vtog;
+            }
+            vtog = -vtog;
+        };
+        // the wave's own tiles but the last: both half steps have a successor
+        const int n_hot = n_w > 0 ? n_w - 1 : 0;
+        int i = 0;
+        for (; i < n_hot; ++i) {
+            kfr[0] = f4_kread<1>(cx, 0);
+            kfr[1] = f4_kread<1>(cx, 1);
+            stage_iter(i);
+            f4_phase1<1, true, true, 0>(cx, qf, sB, sA, pC, pb, kfr, vfr);      // S(2i+1) from K(i)[32..63] || finish(2i)
+            if (needs_mask(i)) {
+                int r[2];
+                rel_of(i, r);
+                f4_mask<HAS_META, 1>(cx, sB, r, seg_q, i % 3);
+            }
+            toggle_k();
+            f4_phase2<0, true, true, 0>(cx, pb, acc, pC, sB, mx, kfr, vfr);     // P.V(2i) from V(i)[0..31]
+            if (wave_any(mx[0] > cx.thr[0] || mx[1] > cx.thr[1])) f4_rescale(cx, mx, acc);
+            f4_phase1<0, true, true, 1>(cx, qf, sA, sB, pC, pb, kfr, vfr);      // S(2i+2) from K(i+1)[0..31] || finish(2i+1)
+            if (needs_mask(i + 1)) {
+                int r[2];
+                rel_of(i + 1, r);
+                f4_mask<HAS_META, 0>(cx, sA, r, seg_q, (i + 1) % 3);
+            }
+            f4_phase2<1, true, true, -1>(cx, pb, acc, pC, sA, mx, kfr, vfr);    // P.V(2i+1) from V(i)[32..63]
+            if (wave_any(mx[0] > cx.thr[0] || mx[1] > cx.thr[1])) f4_rescale(cx, mx, acc);
+            toggle_v();
+            glds_wait_all();
+            block_sync();
+        }
+        // its last tile: the second half step has no successor
+        if (n_w > 0) {
+            kfr[0] = f4_kread<1>(cx, 0);
+            kfr[1] = f4_kread<1>(cx, 1);
+            stage_iter(i);
+            f4_phase1<1, true, true, 0>(cx, qf, sB, sA, pC, pb, kfr, vfr);
+            if (needs_mask(i)) {
+                int r[2];
+                rel_of(i, r);
+                f4_mask<HAS_META, 1>(cx, sB, r, seg_q, i % 3);
+            }
+            f4_phase2<0, true, true, -1>(cx, pb, acc, pC, sB, mx, kfr, vfr);
+            if (wave_any(mx[0] > cx.thr[0] || mx[1] > cx.thr[1])) f4_rescale(cx, mx, acc);
+            f4_phase1<0, false, true, 1>(cx, qf, sA, sB, pC, pb, kfr, vfr);
+            f4_phase2<1, true, false, -1>(cx, pb, acc, pC, sA, mx, kfr, vfr);
+            glds_wait_all();
+            block_sync();
+            ++i;
+        }
+        // tiles of the workgroup beyond this wave's diagonal: staging only
+        for (; i < n_wg; ++i) {
+            stage_iter(i);
+            glds_wait_all();
+            block_sync();
+        }
+    }
+
+    // ---- epilogue: normalise, merge with the ring carry, store (per query block)
+    f4_mfma_settle();
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float l_tot = cx.lsum[qb] + xhalf(cx.lsum[qb]);
+        float inv = 0.0f, lse_b = -INFINITY;
+        if (l_tot > 0.0f) {
+            inv = 1.0f / l_tot;
+            // the reference is a score of Q~ (log2 units) when prescaled, a raw q.k otherwise
+            lse_b = cx.mref[qb] * (kF4Prescale ? kLn2 : p.scale) + logf(l_tot);
+        }
+        float w_a = 0.0f, w_b = 1.0f, lse_new = lse_b;
+        const int64_t lse_idx = ((int64_t)b * p.H + h) * p.Sq + q_row[qb];
+        if (p.carry_in && q_ok[qb]) {
+            const float lse_a = p.lse_acc[lse_idx];
+            const float mxl = fmaxf(lse_a, lse_b);
+            if (mxl == -INFINITY) {
+                lse_new = -INFINITY;
+                w_a = 0.0f;
+                w_b = 0.0f;
+            } else {
+                const float ea = expf(lse_a - mxl), eb = expf(lse_b - mxl);
+                lse_new = mxl + logf(ea + eb);
+                w_a = ea / (ea + eb);
+                w_b = eb / (ea + eb);
+            }
+        }
+        if (q_ok[qb]) {
+            const float sc = inv * w_b;
+            const int64_t orow = (int64_t)b * p.o_sb + (int64_t)q_row[qb] * p.o_ss + (int64_t)h * p.o_sh;
+            const int64_t arow = (((int64_t)b * p.Sq + q_row[qb]) * p.H + h) * kHeadDim;   // the f32 carry is dense [B,Sq,H,D]
+            for (int db = 0; db < 4; ++db)
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int d0 = 32 * db + 8 * rq + 4 * hi;
+                    float o0 = acc[qb][db][4 * rq + 0] * sc, o1 = acc[qb][db][4 * rq + 1] * sc;
+                    float o2 = acc[qb][db][4 * rq + 2] * sc, o3 = acc[qb][db][4 * rq + 3] * sc;
+                    if (p.carry_in) {
+                        const float* a = p.out_acc + arow + d0;
+                        o0 += a[0] * w_a; o1 += a[1] * w_a; o2 += a[2] * w_a; o3 += a[3] * w_a;
+                    }
+                    if (p.final_out) {
+                        global_store_b64(p.out + orow + d0, u32x2{pack_bf16x2(o0, o1), pack_bf16x2(o2, o3)});
+                    } else {
+                        global_store_b128(p.out_acc + arow + d0,
+                                          u32x4{__builtin_bit_cast(uint32_t, o0), __builtin_bit_cast(uint32_t, o1),
+                                                __builtin_bit_cast(uint32_t, o2), __builtin_bit_cast(uint32_t, o3)});
+                    }
+                }
+            if (hi == 0) {
+                if (p.final_out) p.lse[lse_idx] = lse_new;
+                else p.lse_acc[lse_idx] = lse_new;
+            }
+        }
+    }
+}
+
+LWM_KERNEL(kF4Threads) void attn_fwd64_kernel(AttnParams p) { attn_fwd64_body<false>(p); }
+LWM_KERNEL(kF4Threads) void attn_fwd64_meta_kernel(AttnParams p) { attn_fwd64_body<true>(p); }
+
+}  // namespace lwm

@@ -193,6 +193,11 @@ LWM_DEVICE void sched_mfma_dsread() {
     __builtin_amdgcn_sched_group_barrier(0x008, N_MFMA, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, N_DS, 0);
 }
+// One group of a scheduling pipeline (LLVM sched_group_barrier): "N instructions of class MASK come next".  A
+// sequence of these at the end of a scheduling region describes the interleave the machine scheduler is to build.
+// MASK: 0x002 VALU (not MFMA, not transcendental), 0x008 MFMA, 0x100 LDS read, 0x200 LDS write, 0x400 transcendental.
+template <int MASK, int N>
+LWM_DEVICE void sched_group() { __builtin_amdgcn_sched_group_barrier(MASK, N, 0); }
 // s_sleep: park this wave for ~64*n cycles (n a compile-time constant 1..127).
 template <int N>
 LWM_DEVICE void sleep_cycles64() { __builtin_amdgcn_s_sleep(N); }

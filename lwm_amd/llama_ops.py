@@ -319,20 +319,16 @@ def dense_multi(x, kernels, out_dtype=None):
     return [x.to(out_dtype) @ _as_dtype(k, out_dtype) for k in kernels]
 
 
-_CAST_CACHE = {}
-
-
 def _as_dtype(k, dtype):
     """kernel.to(dtype), kept while the kernel is unchanged (a sampling loop with more than four rows asks for the
-    f32 copy of the same head at every step)."""
+    f32 copy of the same head at every step).  The copy is kept ON the tensor object (it dies with it: a cache keyed
+    by address would hand the previous model's head to a new model that the allocator placed at the same address)."""
     if torch.is_grad_enabled() and k.requires_grad:
         return k.to(dtype)
-    key = (k.data_ptr(), dtype, tuple(k.shape))
-    hit = _CAST_CACHE.get(key)
-    if hit is None or hit[0] != k._version:
-        if len(_CAST_CACHE) > 8:
-            _CAST_CACHE.clear()
-        hit = _CAST_CACHE[key] = (k._version, k.detach().to(dtype))
+    hit = getattr(k, "_lwm_cast", None)
+    if hit is None or hit[0] != (k._version, dtype, k.data_ptr()):
+        hit = ((k._version, dtype, k.data_ptr()), k.detach().to(dtype))
+        k._lwm_cast = hit
     return hit[1]
 
 

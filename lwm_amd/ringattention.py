@@ -84,7 +84,15 @@ def _comm(group):
         return SingleComm()
     if group is None:   # unbound "sp" axis: _resolve_axis has raised already for axis names
         raise RuntimeError("no sequence-parallel group: call set_sp_group first")
-    return TorchRingComm(group)
+    # one communicator per process group: its exchange-buffer pool (lwm_amd/ring.py TorchRingComm.pooled) is what
+    # makes the buffers allocate-once across layers and steps
+    cm = _COMMS.get(id(group))
+    if cm is None or cm[0] is not group:
+        cm = _COMMS[id(group)] = (group, TorchRingComm(group))
+    return cm[1]
+
+
+_COMMS = {}
 
 
 def ringattention_inference(q, k, v, attn_mask, axis_name="sp", q_sharded=None, block_ops=None, comm=None, *,

@@ -123,13 +123,19 @@ def hf_to_lwm(state_dict, num_heads):
     return out
 
 
-def load_params(model, params, strict=True):
-    """Copy {name: tensor} into a harness LLaMAForCausalLM (dtype/device of the model)."""
+def load_params(model, params, strict=True, report=None):
+    """Copy {name: tensor} into a harness LLaMAForCausalLM (dtype/device of the model).  strict=False loads what
+    matches; `report` (a callable taking one string) is then told which parameters kept their initial values and
+    which checkpoint entries found no home -- a silent partial load looks like a trained model and is not."""
     own = dict(model.named_parameters())
     missing = [n for n in own if n not in params]
     extra = [n for n in params if n not in own]
     if strict and (missing or extra):
         raise KeyError(f"checkpoint/model mismatch: missing {missing[:4]} extra {extra[:4]}")
+    if report is not None and (missing or extra):
+        report(f"checkpoint/model mismatch: {len(missing)} model parameter(s) NOT in the checkpoint (left at their "
+               f"initial values): {missing[:6]}{' ...' if len(missing) > 6 else ''}; {len(extra)} checkpoint entr"
+               f"{'y' if len(extra) == 1 else 'ies'} unused: {extra[:6]}{' ...' if len(extra) > 6 else ''}")
     with torch.no_grad():
         for n, p in own.items():
             if n in params:
@@ -286,6 +292,10 @@ def flax_llama_to_lwm(flat, prefix="params/", param_scan_axis=0):
             continue
         if k == "transformer/wte/embedding":
             out["wte"] = t
+        elif k == "transformer/vte/embedding":          # FlaxVideoLLaMA: VQGAN code embedding (lwm/vision_llama.py:264-270)
+            out["vte"] = t
+        elif k == "vision_head/kernel":                 # ... and its output head (lwm/vision_llama.py:354-360)
+            out["vision_head"] = t
         elif k == "transformer/ln_f/kernel":
             out["ln_f.kernel"] = t
         elif k == "lm_head/kernel":

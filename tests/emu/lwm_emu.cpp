@@ -9,6 +9,7 @@
 #include "lwm_hip.h"
 #include "attn_common.h"
 #include "attn_fwd.h"
+#include "attn_fwd64.h"
 #include "attn_bwd.h"
 #include "attn_bwd_fused.h"
 #include "attn_decode.h"

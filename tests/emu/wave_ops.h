@@ -321,6 +321,8 @@ LWM_DEVICE int wave_uniform(int x) { return x; }
 LWM_DEVICE void sched_fence() {}
 template <int A, int B>
 LWM_DEVICE void sched_mfma_dsread() {}
+template <int MASK, int N>
+LWM_DEVICE void sched_group() {}
 template <int N>
 LWM_DEVICE void sleep_cycles64() {}
 LWM_DEVICE uint32_t opaque(uint32_t x) { return x; }

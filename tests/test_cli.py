@@ -145,3 +145,64 @@ def test_one_step_of_each_entry_point_on_the_debug_model(tmp_path):
                                           "--cfg_scale_image=5.0",
                                           "--update_llama_config=dict(sample_mode='vision',max_sequence_length=2048)"])
     assert img.shape == (1, 256, 256, 3) and img.dtype == np.uint8 and np.load(out).shape == (1, 256, 256, 3)
+
+
+def test_dtype_flag_refuses_what_the_kernels_do_not_compute():
+    """The reference's launchers pass --dtype=fp32 (scripts/run_train_text.sh:21, lwm/train.py:36).  The MI355X
+    kernels compute on bf16 operands only: anything else is refused, loudly, instead of being run as bf16."""
+    from lwm_amd.cli._common import torch_dtype
+    import torch
+    assert torch_dtype("bf16") is torch.bfloat16 and torch_dtype("bfloat16") is torch.bfloat16
+    for name in ("fp32", "float32", "fp16"):
+        with pytest.raises(SystemExit) as e:
+            torch_dtype(name)
+        assert "--dtype=bf16" in str(e.value)
+    with pytest.raises(SystemExit):
+        torch_dtype("int8")
+
+
+def test_vision_checkpoint_round_trip_through_load_checkpoint(tmp_path):
+    """cli.vision_chat / vision_generation / train --modality=vision,text load FlaxVideoLLaMA checkpoints: besides the
+    text model's leaves those carry `transformer/vte/embedding` and `vision_head/kernel` (lwm/vision_llama.py:264-270,
+    :354-360).  A tiny scan_layers stream written in the reference's layout must land in every parameter of the
+    harness model, and a checkpoint that lacks some must say so."""
+    import torch
+    from lwm_amd import weights as W
+    from lwm_amd.cli import _common
+    from lwm_amd.vision_llama import VideoLLaMAConfig, VideoLLaMAForCausalLM
+    cfg = VideoLLaMAConfig(vocab_size=64, vision_vocab_size=48, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                           num_attention_heads=1, max_sequence_length=256)
+    torch.manual_seed(0)
+    src = VideoLLaMAForCausalLM(cfg, torch.float32)
+    own = dict(src.named_parameters())
+    flat = {"params/params/transformer/wte/embedding": own["wte"].detach(),
+            "params/params/transformer/vte/embedding": own["vte"].detach(),
+            "params/params/transformer/ln_f/kernel": own["ln_f.kernel"].detach(),
+            "params/params/lm_head/kernel": own["lm_head"].detach(),
+            "params/params/vision_head/kernel": own["vision_head"].detach()}
+    for part, names in (("attention", ("wq", "wk", "wv", "wo")), ("feed_forward", ("w1", "w2", "w3"))):
+        for n in names:
+            flat[f"params/params/transformer/h/scan_decoder/{part}/{n}/kernel"] = torch.stack(
+                [own[f"h.{i}.{part}.{n}"].detach() for i in range(2)])
+    for n in ("attention_norm", "ffn_norm"):
+        flat[f"params/params/transformer/h/scan_decoder/{n}/kernel"] = torch.stack(
+            [own[f"h.{i}.{n}.kernel"].detach() for i in range(2)])
+    path = str(tmp_path / "params")
+    W.write_flax_stream(path, flat)
+    torch.manual_seed(1)
+    dst = VideoLLaMAForCausalLM(cfg, torch.float32)
+    notes = []
+    old = _common.note
+    _common.note = notes.append
+    try:
+        _common.load_checkpoint(dst, f"params::{path}")
+        assert not notes, notes                          # nothing missing, nothing unused
+        for n, p in dst.named_parameters():
+            assert torch.equal(p, own[n]), n
+        # a text-only checkpoint into the vision model: loads, and reports what stayed at its initial value
+        text_only = {k: v for k, v in flat.items() if "vte" not in k and "vision_head" not in k}
+        W.write_flax_stream(path, text_only)
+        _common.load_checkpoint(VideoLLaMAForCausalLM(cfg, torch.float32), f"params::{path}")
+        assert len(notes) == 1 and "vte" in notes[0] and "vision_head" in notes[0]
+    finally:
+        _common.note = old

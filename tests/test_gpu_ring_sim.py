@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from oracle import attention_ref as R
-from tests._parity import check as _check
+from tests._parity import check as _check, dq_row_slack as _slack
 
 pytestmark = pytest.mark.gpu
 
@@ -117,18 +117,16 @@ def _run_ring(n, layout_kind, S, H, packed, schedule="ring", B=1):
 def test_ring_n_equals_ring_1_on_gpu(n, layout_kind, packed, schedule):
     S, H = 256 * n, 2
     got, ref, (q, k, v, do, seg) = _run_ring(n, layout_kind, S, H, packed, schedule)
-    for name, a, b in zip(("out", "dq", "dk", "dv"), got, ref):
-        a, b = a.float(), b.float()
-        err = ((a - b).abs().max() / b.abs().max()).item()
-        assert err <= 1.6e-2, (name, err)          # both are bf16 roundings of the same sums
-    # and against the fp64 oracle
     f = lambda t: t.float().cpu().numpy()
+    slack = _slack(f(do), f(ref[0]), f(k))
+    for name, a, b in zip(("out", "dq", "dk", "dv"), got, ref):     # both are bf16 roundings of the same sums
+        _check(f"{name} ring{n} vs ring1", f(a), f(b), row_slack=slack if name == "dq" else None)
+    # and against the fp64 oracle
     sg = None if seg is None else seg.cpu().numpy()
     ro, _ = R.dense_attention(f(q), f(k), f(v), causal=True, seg_q=sg, seg_k=sg)
     rq, rk, rv = R.dense_attention_bwd(f(q), f(k), f(v), f(do), causal=True, seg_q=sg, seg_k=sg)
     for name, a, b in zip(("out", "dq", "dk", "dv"), got, (ro, rq, rk, rv)):
-        err = np.abs(f(a) - b).max() / np.abs(b).max()
-        assert err <= 2e-2, (name, err)
+        _check(f"{name} ring{n}", f(a), b, row_slack=slack if name == "dq" else None)
 
 
 def _doc_windows(bounds, w=256):
@@ -165,7 +163,7 @@ def test_ring8_at_config3_shard_shapes_vs_oracle(schedule, packed):
             rq, _, _ = R.dense_attention_bwd(f(q, rows, h), f(k, keys, h), f(v, keys, h), f(do, rows, h),
                                              causal=True, q_start=r0)
             _check(f"out ring8 row {r0}", f(out, rows, h), ro)
-            _check(f"dq ring8 row {r0}", f(dq, rows, h), rq)
+            _check(f"dq ring8 row {r0}", f(dq, rows, h), rq, row_slack=_slack(f(do, rows, h), ro, f(k, keys, h)))
         K0, h = S - 512, 1
         rows, allk = slice(K0, S), slice(0, S)
         _, rk, rv = R.dense_attention_bwd(f(q, rows, h), f(k, allk, h), f(v, allk, h), f(do, rows, h),
@@ -185,7 +183,8 @@ def test_ring8_at_config3_shard_shapes_vs_oracle(schedule, packed):
                                            causal=True, q_start=qa - a)
         win = slice(w0, b)
         _check(f"out ring8 doc {i}", f(out, win, h), ro[:, w0 - qa:])
-        _check(f"dq ring8 doc {i}", f(dq, win, h), rq[:, w0 - qa:])
+        _check(f"dq ring8 doc {i}", f(dq, win, h), rq[:, w0 - qa:],
+               row_slack=_slack(f(do, win, h), ro[:, w0 - qa:], f(k, keys, h)))
         _check(f"dk ring8 doc {i}", f(dk, win, h), rk[:, w0 - a:])
         _check(f"dv ring8 doc {i}", f(dv, win, h), rv[:, w0 - a:])
 
@@ -206,16 +205,18 @@ def test_mesh8_at_1m_token_offsets_vs_oracle():
         ro, _ = R.dense_attention(f(q, rows), f(k, rows), f(v, rows), causal=True)
         rq, rk, rv = R.dense_attention_bwd(f(q, rows), f(k, rows), f(v, rows), f(do, rows), causal=True)
         for name, a, b in zip(("out", "dq", "dk", "dv"), got, (ro, rq, rk, rv)):
-            _check(f"{name} mesh8@1M doc {d0 // doc}", f(a, rows), b)
+            _check(f"{name} mesh8@1M doc {d0 // doc}", f(a, rows), b,
+                   row_slack=_slack(f(do, rows), ro, f(k, rows)) if name == "dq" else None)
 
 
 @pytest.mark.parametrize("schedule", ["ring", "mesh"])
 def test_ring_batch_2_on_gpu(schedule):
     """B = 2: every per-segment view handed to the kernels is strided in the batch dimension."""
-    got, ref, _ = _run_ring(4, "zigzag", 1024, 2, True, schedule, B=2)
+    got, ref, (q, k, v, do, seg) = _run_ring(4, "zigzag", 1024, 2, True, schedule, B=2)
+    f = lambda t: t.float().cpu().numpy()
+    slack = _slack(f(do), f(ref[0]), f(k))
     for name, a, b in zip(("out", "dq", "dk", "dv"), got, ref):
-        a, b = a.float(), b.float()
-        assert ((a - b).abs().max() / b.abs().max()).item() <= 1.6e-2, name
+        _check(f"{name} ring4 B=2", f(a), f(b), row_slack=slack if name == "dq" else None)
 
 
 def test_mesh_schedule_moves_fewer_bytes_than_the_ring():
@@ -310,4 +311,4 @@ def test_sharded_cache_and_decode_on_gpu(n):
     rmask = R.decode_mask(B, 1, max_len, start + P, am.numpy())
     ro, _ = R.dense_attention(q_dec.float().cpu().numpy(), ck.numpy(), cv.numpy(), causal=False, dense_mask=rmask)
     for r in res:
-        assert np.abs(r[3].numpy() - ro).max() / np.abs(ro).max() <= 2e-2
+        _check("out sharded decode", r[3].numpy(), ro)

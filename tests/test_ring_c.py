@@ -158,8 +158,10 @@ def test_c_ring_schedule_vs_oracle_and_python_driver(n, causal, packed, padded):
     kvn = None if kv is None else kv.cpu().numpy()
     ro, _ = R.dense_attention(f(q), f(k), f(v), causal=causal, seg_q=sg, seg_k=sg, key_valid=kvn)
     rq, rk, rv = R.dense_attention_bwd(f(q), f(k), f(v), f(do), causal=causal, seg_q=sg, seg_k=sg, key_valid=kvn)
+    from tests._parity import dq_row_slack
+    slack = dq_row_slack(f(do), ro, f(k))
     for name, a, b in zip(("out", "dq", "dk", "dv"), got, (ro, rq, rk, rv)):
-        check(f"{name} c-ring n={n}", f(a), b)
+        check(f"{name} c-ring n={n}", f(a), b, row_slack=slack if name == "dq" else None)
     # the single-device Python driver on the same data (same kernels, other association order at most)
     q1, k1, v1 = (t.clone().requires_grad_(True) for t in (q, k, v))
     o1 = ring_attention(q1, k1, v1, causal=causal, segment_ids=seg, key_valid=kv)
