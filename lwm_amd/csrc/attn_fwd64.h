@@ -109,6 +109,30 @@ LWM_DEVICE void f4_dma(const uint32_t* voff, const char* src, lds_t dst) {
 #endif
 }
 
+// ONE LDS-DMA piece, placed between MFMAs of the hot loop (five scalar/vector-memory instructions; issuing the eight
+// pieces of an iteration back to back at its top stalled the in-order wave for their whole issue time)
+LWM_DEVICE void f4_dma1(uint32_t voff, const char* src, lds_t dst) {
+#ifdef LWM_EMU
+    glds_load_b128(src + voff, dst);
+#else
+    const uint64_t a = (uint64_t)src;
+    const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_nop 3\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(u), "s"(dst)
+                 : "memory");
+#endif
+}
+// the pieces one tile iteration issues inside its four phases (all wave-uniform but the offsets)
+struct F4Dma {
+    const char* k_lo_src;   // K(i+2), keys 0..31   -> k_lo_dst (+4096 for the second piece)
+    const char* k_up_src;   // K(i+1), keys 32..63  -> k_up_dst
+    const char* v_src;      // V(i+1)               -> v_dst (+4096 j)
+    lds_t k_lo_dst, k_up_dst, v_dst;
+};
+
 // per-lane offsets for tile `kt` with rows clamped to Sk-1 (rows past Sk are masked through the key meta)
 LWM_DEVICE void f4_stage_offsets(const AttnParams& p, int wave, int lane, int kt, F4Stage& st) {
     const int slot = lane & 15;
@@ -151,11 +175,14 @@ LWM_DEVICE void f4_mfma_s_first(f32x16& d, bf16x8 a, bf16x8 b) { d = mfma_32x32x
 LWM_DEVICE void f4_mfma_s(f32x16& d, bf16x8 a, bf16x8 b) { d = mfma_32x32x16(a, b, d); }
 LWM_DEVICE void f4_mfma_o(f32x16& d, bf16x8 a, bf16x8 b) { d = mfma_32x32x16(a, b, d); }
 LWM_DEVICE void f4_mfma_settle() {}
+LWM_DEVICE void f4_settle_s(f32x16 (&)[2]) {}
+LWM_DEVICE void f4_settle_acc(f32x16 (&)[2][4]) {}
 LWM_DEVICE float f4_fma(float x, float c, float d) { return fmaf(x, c, d); }
 LWM_DEVICE float f4_sub(float x, float d) { return x - d; }
 LWM_DEVICE float f4_exp2(float x) { return exp2f(x); }
 LWM_DEVICE uint32_t f4_cvt_pk(float lo, float hi) { return pack_bf16x2(lo, hi); }
 LWM_DEVICE void f4_add(float& acc, float x) { acc += x; }
+LWM_DEVICE float f4_add2(float a, float b) { return a + b; }
 LWM_DEVICE void f4_max3(float& m, float a, float b) { m = fmaxf(fmaxf(m, a), b); }
 LWM_DEVICE bf16x8 f4_to_agpr(bf16x8 x) { return x; }
 LWM_DEVICE bf16x8 f4_load_agpr(const bf16_t* g) { return __builtin_bit_cast(bf16x8, global_load_b128(g)); }
@@ -163,7 +190,7 @@ LWM_DEVICE void f4_load_agpr_wait(bf16x8 (&)[2][8]) {}
 LWM_DEVICE void f4_scale_acc(f32x16& d, float alpha) { d *= alpha; }
 #else
 LWM_DEVICE void f4_mfma_s_first(f32x16& d, bf16x8 a, bf16x8 b) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "a"(b));
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b));   // (early clobber: D must not overlap A)
 }
 LWM_DEVICE void f4_mfma_s(f32x16& d, bf16x8 a, bf16x8 b) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
@@ -171,8 +198,15 @@ LWM_DEVICE void f4_mfma_s(f32x16& d, bf16x8 a, bf16x8 b) {
 LWM_DEVICE void f4_mfma_o(f32x16& d, bf16x8 a, bf16x8 b) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b));
 }
-// after the last MFMA of a chain whose result compiler-generated code (or a VALU filler) reads next
+// After the last MFMA of a chain whose result compiler-generated code reads next.  The wait states must sit between the
+// MFMA and its reader IN THE INSTRUCTION STREAM: a bare nop statement orders nothing (hipcc may hoist a pure VALU reader
+// of the tuple above it), so the tuples are named as read-write operands -- every later use then follows the nops.
 LWM_DEVICE void f4_mfma_settle() { asm volatile("s_nop 7\n\ts_nop 7"); }
+LWM_DEVICE void f4_settle_s(f32x16 (&s)[2]) { asm volatile("s_nop 7\n\ts_nop 7" : "+v"(s[0]), "+v"(s[1])); }
+LWM_DEVICE void f4_settle_acc(f32x16 (&a)[2][4]) {
+    asm volatile("s_nop 7\n\ts_nop 7"
+                 : "+a"(a[0][0]), "+a"(a[0][1]), "+a"(a[0][2]), "+a"(a[0][3]), "+a"(a[1][0]), "+a"(a[1][1]), "+a"(a[1][2]), "+a"(a[1][3]));
+}
 LWM_DEVICE float f4_fma(float x, float c, float d) {
     float y;
     asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(y) : "v"(x), "v"(c), "v"(d));
@@ -194,6 +228,11 @@ LWM_DEVICE uint32_t f4_cvt_pk(float lo, float hi) {
     return y;
 }
 LWM_DEVICE void f4_add(float& acc, float x) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(x)); }
+LWM_DEVICE float f4_add2(float a, float b) {
+    float y;
+    asm volatile("v_add_f32 %0, %1, %2" : "=v"(y) : "v"(a), "v"(b));
+    return y;
+}
 // a fragment whose HOME is the accumulator file: each dword is defined by an asm with an AGPR output, so that the
 // "a" operands of the MFMAs coalesce with it instead of being re-copied from a VGPR before every use
 LWM_DEVICE bf16x8 f4_to_agpr(bf16x8 x) {
@@ -252,76 +291,92 @@ LWM_DEVICE bf16x8 f4_vread(const F4Ctx& cx, int f) {
     return o;
 }
 
-// Phase 1 (16 MFMAs): S(next) = K Q^T  ||  p = exp2(sC*c - m*c), P -> bf16.  KHALF = key half of the NEXT half tile
-// inside the K buffer cx.ka points at; its fragments 0 and 1 are ALREADY in kfr[0], kfr[1] (requested by whoever ran
-// before: with one wave on the SIMD nothing else covers the LDS latency at the head of a phase).  VNEXT >= 0: request
-// the first two V fragments of the phase 2 that follows (key half VNEXT) during the last gaps.
-template <int KHALF, bool DO_S, bool DO_FIN, int VNEXT>
-LWM_DEVICE void f4_phase1(const F4Ctx& cx, const bf16x8 (&qf)[2][8], f32x16 (&sN)[2], const f32x16 (&sC)[2],
-                          float (&pC)[2][16], bf16x8 (&pb)[2][2], bf16x8 (&kfr)[3], bf16x8 (&vfr)[3]) {
+// Phase 1 (16 MFMAs): S(next) = K Q^T  ||  p = exp2(t), P -> bf16, pair sums.  t = s*c - m*c of the half tile being
+// finished was left in tC by the phase 2 before (so that the two phases carry about the same number of fillers);
+// ps receives p[2j] + p[2j+1].  KHALF = key half of the NEXT half tile inside the K buffer cx.ka points at; its
+// fragments 0..2 are ALREADY in kfr[0..2] (requested by whoever ran before: with one wave on the SIMD nothing else
+// covers the LDS latency at the head of a phase).  VNEXT >= 0: request the first three V fragments of the phase 2 that
+// follows (key half VNEXT) during the last gaps.  DMA: which LDS-DMA pieces of `dm` go out in this phase (-1 none).
+template <int KHALF, bool DO_S, bool DO_FIN, int VNEXT, int DMA>
+LWM_DEVICE void f4_phase1(const F4Ctx& cx, const bf16x8 (&qf)[2][8], f32x16 (&sN)[2], float (&tC)[2][16], float (&ps)[2][8],
+                          bf16x8 (&pb)[2][2], bf16x8 (&kfr)[4], bf16x8 (&vfr)[4], const F4Stage& st, const F4Dma& dm) {
     uint32_t w[4];
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
         const int s = g >> 1, qb = g & 1;
-        if (DO_S && qb == 0 && s + 2 < 8) kfr[(s + 2) % 3] = f4_kread<KHALF>(cx, s + 2);
-        if (VNEXT >= 0 && g == 12) vfr[0] = f4_vread<VNEXT < 0 ? 0 : VNEXT>(cx, 0);
-        if (VNEXT >= 0 && g == 14) vfr[1] = f4_vread<VNEXT < 0 ? 0 : VNEXT>(cx, 1);
+        if (DO_S && qb == 0 && s + 3 < 8) kfr[(s + 3) & 3] = f4_kread<KHALF>(cx, s + 3);
+        if (VNEXT >= 0 && g == 11) vfr[0] = f4_vread<VNEXT < 0 ? 0 : VNEXT>(cx, 0);
+        if (VNEXT >= 0 && g == 13) vfr[1] = f4_vread<VNEXT < 0 ? 0 : VNEXT>(cx, 1);
+        if (VNEXT >= 0 && g == 15) vfr[2] = f4_vread<VNEXT < 0 ? 0 : VNEXT>(cx, 2);
         sched_fence();
         if (DO_S) {
             if (s == 0) f4_mfma_s_first(sN[qb], kfr[0], qf[qb][0]);
-            else f4_mfma_s(sN[qb], kfr[s % 3], qf[qb][s]);
+            else f4_mfma_s(sN[qb], kfr[s & 3], qf[qb][s]);
         }
+        // LDS-DMA pieces of this phase (measured: a piece needs ~1000 cycles from issue to landed under load, so the
+        // last one leaves in the first half of the iteration's third phase; what is needed first goes first)
+        if (DMA == 0 && g == 2) f4_dma1(st.voff_k[2], dm.k_up_src, dm.k_up_dst);            // K(i+1), keys 32..63
+        if (DMA == 0 && g == 8) f4_dma1(st.voff_k[3], dm.k_up_src, dm.k_up_dst + 4096);
+        if (DMA == 2 && g == 1) f4_dma1(st.voff_v[3], dm.v_src, dm.v_dst + 12288);         // V(i+1), last piece
+        if (DMA == 2 && g == 5) f4_dma1(st.voff_k[0], dm.k_lo_src, dm.k_lo_dst);            // K(i+2), keys 0..31
+        if (DMA == 2 && g == 9) f4_dma1(st.voff_k[1], dm.k_lo_src, dm.k_lo_dst + 4096);
         if (DO_FIN) {
             // finish-softmax slice: elements 2g, 2g+1 of the finished half tile, flattened [qb][r]; the pair of the
-            // PREVIOUS gap is packed here (a transcendental's result is not read by the very next instruction).
-            // p = exp2(s*c - m*c): one fma (a subtract when Q is prescaled: c = 1) and one exp per score
+            // PREVIOUS gap is packed and summed here (a transcendental's result is not read by the very next instruction)
             const int e = 2 * g, fq = e >> 4, r = e & 15;
-            const float t0 = kF4Prescale ? f4_sub(sC[fq][r], cx.nbase[fq]) : f4_fma(sC[fq][r], cx.c, cx.nbase[fq]);
-            const float t1 = kF4Prescale ? f4_sub(sC[fq][r + 1], cx.nbase[fq]) : f4_fma(sC[fq][r + 1], cx.c, cx.nbase[fq]);
-            pC[fq][r] = f4_exp2(t0);
-            pC[fq][r + 1] = f4_exp2(t1);
+            tC[fq][r] = f4_exp2(tC[fq][r]);
+            tC[fq][r + 1] = f4_exp2(tC[fq][r + 1]);
             if (g > 0) {
                 const int e0 = 2 * (g - 1), q0 = e0 >> 4, r0 = e0 & 15;
-                w[(g - 1) & 3] = f4_cvt_pk(pC[q0][r0], pC[q0][r0 + 1]);
+                w[(g - 1) & 3] = f4_cvt_pk(tC[q0][r0], tC[q0][r0 + 1]);
+                ps[q0][r0 >> 1] = f4_add2(tC[q0][r0], tC[q0][r0 + 1]);
                 if (((g - 1) & 3) == 3) pb[q0][(e0 >> 3) & 1] = __builtin_bit_cast(bf16x8, u32x4{w[0], w[1], w[2], w[3]});
             }
         }
         sched_fence();
     }
     if (DO_FIN) {
-        w[3] = f4_cvt_pk(pC[1][14], pC[1][15]);
+        w[3] = f4_cvt_pk(tC[1][14], tC[1][15]);
+        ps[1][7] = f4_add2(tC[1][14], tC[1][15]);
         pb[1][1] = __builtin_bit_cast(bf16x8, u32x4{w[0], w[1], w[2], w[3]});
     }
-    if (DO_S) f4_mfma_settle();
+    if (DO_S) f4_settle_s(sN);
 }
 
-// Phase 2 (16 MFMAs): O^T += V^T P^T  ||  row sums of p (pC), running max of the next half tile's scores (sN).
-// VHALF = key half of the half tile being finished inside the V buffer; its fragments 0 and 1 are already in vfr[0],
-// vfr[1].  KNEXT >= 0: request the first two K fragments of the phase 1 that follows (key half KNEXT of the buffer
-// cx.ka points at NOW) during the last gaps.
-template <int VHALF, bool DO_PV, bool DO_MAX, int KNEXT>
-LWM_DEVICE void f4_phase2(F4Ctx& cx, const bf16x8 (&pb)[2][2], f32x16 (&acc)[2][4], const float (&pC)[2][16],
-                          const f32x16 (&sN)[2], float (&mx)[2], bf16x8 (&kfr)[3], bf16x8 (&vfr)[3]) {
-    float ls[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+// Phase 2 (16 MFMAs): O^T += V^T P^T  ||  row sums (the pair sums ps), running max of the next half tile's scores (sN)
+// and its exponents tN = s*c - m*c (one fma per score; a subtract when Q is prescaled: c = 1).
+// VHALF = key half of the half tile being finished inside the V buffer; its fragments 0..2 are already in vfr[0..2].
+// KNEXT >= 0: request the first three K fragments of the phase 1 that follows (key half KNEXT of the buffer cx.ka
+// points at NOW) during the last gaps.
+template <int VHALF, bool DO_PV, bool DO_MAX, int KNEXT, int DMA>
+LWM_DEVICE void f4_phase2(F4Ctx& cx, const bf16x8 (&pb)[2][2], f32x16 (&acc)[2][4], const float (&ps)[2][8],
+                          const f32x16 (&sN)[2], float (&tN)[2][16], float (&mx)[2], bf16x8 (&kfr)[4], bf16x8 (&vfr)[4],
+                          const F4Stage& st, const F4Dma& dm) {
+    float ls[2] = {0.f, 0.f};
     float mp[2] = {-INFINITY, -INFINITY};
 #pragma unroll
     for (int h = 0; h < 16; ++h) {
         const int f = h >> 1, qb = h & 1, t = f >> 2, db = f & 3;
-        if (DO_PV && qb == 0 && f + 2 < 8) vfr[(f + 2) % 3] = f4_vread<VHALF>(cx, f + 2);
-        if (KNEXT >= 0 && h == 12) kfr[0] = f4_kread<KNEXT < 0 ? 0 : KNEXT>(cx, 0);
-        if (KNEXT >= 0 && h == 14) kfr[1] = f4_kread<KNEXT < 0 ? 0 : KNEXT>(cx, 1);
+        if (DO_PV && qb == 0 && f + 3 < 8) vfr[(f + 3) & 3] = f4_vread<VHALF>(cx, f + 3);
+        if (KNEXT >= 0 && h == 11) kfr[0] = f4_kread<KNEXT < 0 ? 0 : KNEXT>(cx, 0);
+        if (KNEXT >= 0 && h == 13) kfr[1] = f4_kread<KNEXT < 0 ? 0 : KNEXT>(cx, 1);
+        if (KNEXT >= 0 && h == 15) kfr[2] = f4_kread<KNEXT < 0 ? 0 : KNEXT>(cx, 2);
         sched_fence();
-        if (DO_PV) f4_mfma_o(acc[qb][db], vfr[f % 3], pb[qb][t]);
+        if (DO_PV) f4_mfma_o(acc[qb][db], vfr[f & 3], pb[qb][t]);
+        if (DMA == 1 && h == 2) f4_dma1(st.voff_v[0], dm.v_src, dm.v_dst);                  // V(i+1)
+        if (DMA == 1 && h == 7) f4_dma1(st.voff_v[1], dm.v_src, dm.v_dst + 4096);
+        if (DMA == 1 && h == 12) f4_dma1(st.voff_v[2], dm.v_src, dm.v_dst + 8192);
         const int e = 2 * h, fq = e >> 4, r = e & 15;
-        if (DO_PV) {
-            f4_add(ls[fq][0], pC[fq][r]);
-            f4_add(ls[fq][1], pC[fq][r + 1]);
+        if (DO_PV) f4_add(ls[fq], ps[fq][r >> 1]);
+        if (DO_MAX) {
+            f4_max3(mp[fq], sN[fq][r], sN[fq][r + 1]);
+            tN[fq][r] = kF4Prescale ? f4_sub(sN[fq][r], cx.nbase[fq]) : f4_fma(sN[fq][r], cx.c, cx.nbase[fq]);
+            tN[fq][r + 1] = kF4Prescale ? f4_sub(sN[fq][r + 1], cx.nbase[fq]) : f4_fma(sN[fq][r + 1], cx.c, cx.nbase[fq]);
         }
-        if (DO_MAX) f4_max3(mp[fq], sN[fq][r], sN[fq][r + 1]);
         sched_fence();
     }
     if (DO_PV)
-        for (int q2 = 0; q2 < 2; ++q2) cx.lsum[q2] += ls[q2][0] + ls[q2][1];
+        for (int q2 = 0; q2 < 2; ++q2) cx.lsum[q2] += ls[q2];
     if (DO_MAX)
         for (int q2 = 0; q2 < 2; ++q2) mx[q2] = mp[q2];
 }
@@ -352,10 +407,10 @@ LWM_DEVICE void f4_mask(const F4Ctx& cx, f32x16 (&sN)[2], const int (&rel)[2], c
 }
 
 // The rare block: move the reference of the rows that need it.  Runs after the P.V of the half tile in flight, so
-// everything accumulated at the old reference is rescaled exactly once.  Scores stay raw (the reference enters
-// through the fma of the exponent), so nothing of the next half tile needs touching.
-LWM_DEVICE void f4_rescale(F4Ctx& cx, const float (&mx)[2], f32x16 (&acc)[2][4]) {
-    f4_mfma_settle();      // the P.V MFMAs (asm) have written acc: hipcc does not know they are MFMAs
+// everything accumulated at the old reference is rescaled exactly once.  Scores stay raw in their registers; the
+// exponents of the NEXT half tile (tN, already formed against the old reference) are shifted to the new one.
+LWM_DEVICE void f4_rescale(F4Ctx& cx, const float (&mx)[2], f32x16 (&acc)[2][4], float (&tN)[2][16]) {
+    f4_settle_acc(acc);    // the P.V MFMAs (asm) have written acc: hipcc does not know they are MFMAs
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const float mxa = fmaxf(mx[qb], xhalf(mx[qb]));           // both halves of the wave hold keys of the column
@@ -364,8 +419,11 @@ LWM_DEVICE void f4_rescale(F4Ctx& cx, const float (&mx)[2], f32x16 (&acc)[2][4])
         const float alpha = fast_exp2((cx.mref[qb] - ms) * cx.c); // 0 while the old reference is -inf
         cx.lsum[qb] *= alpha;
         for (int db = 0; db < 4; ++db) f4_scale_acc(acc[qb][db], alpha);
+        const float nb_new = kF4Prescale ? ms : -ms * cx.c;
+        const float dt = kF4Prescale ? -(nb_new - cx.nbase[qb]) : nb_new - cx.nbase[qb];    // change of the exponents
+        for (int r = 0; r < 16; ++r) tN[qb][r] += dt;              // (-inf stays -inf)
         cx.mref[qb] = m_new;
-        cx.nbase[qb] = kF4Prescale ? ms : -ms * cx.c;
+        cx.nbase[qb] = nb_new;
         cx.thr[qb] = (m_new == -INFINITY) ? -INFINITY : m_new + cx.thr_on;
     }
 }
@@ -552,40 +610,42 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
         block_sync();
 
         f32x16 sA[2], sB[2];
-        float pC[2][16];
+        float tt[2][16], ps[2][8];
         bf16x8 pb[2][2];
         float mx[2];
         for (int qb = 0; qb < 2; ++qb) {
             sA[qb] = zero_f32x16();
             sB[qb] = zero_f32x16();
-            for (int r = 0; r < 16; ++r) pC[qb][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) tt[qb][r] = 0.0f;
+            for (int r = 0; r < 8; ++r) ps[qb][r] = 0.0f;
+            for (int t = 0; t < 2; ++t) pb[qb][t] = zero_bf16x8();
         }
-        bf16x8 kfr[3], vfr[3];
-        for (int j = 0; j < 3; ++j) {
+        bf16x8 kfr[4], vfr[4];
+        for (int j = 0; j < 4; ++j) {
             kfr[j] = zero_bf16x8();
             vfr[j] = zero_bf16x8();
         }
+        F4Dma dm = {};
         if (n_w > 0) {
-            kfr[0] = f4_kread<0>(cx, 0);
-            kfr[1] = f4_kread<0>(cx, 1);
-            f4_phase1<0, true, false, -1>(cx, qf, sA, sB, pC, pb, kfr, vfr);
+            for (int j = 0; j < 3; ++j) kfr[j] = f4_kread<0>(cx, j);
+            f4_phase1<0, true, false, -1, -1>(cx, qf, sA, tt, ps, pb, kfr, vfr, st, dm);
             if (needs_mask(0)) {
                 int r[2];
                 rel_of(0, r);
                 f4_mask<HAS_META, 0>(cx, sA, r, seg_q, 0);
             }
-            f4_phase2<0, false, true, -1>(cx, pb, acc, pC, sA, mx, kfr, vfr);
-            if (wave_any(mx[0] > cx.thr[0] || mx[1] > cx.thr[1])) f4_rescale(cx, mx, acc);
+            f4_phase2<0, false, true, -1, -1>(cx, pb, acc, ps, sA, tt, mx, kfr, vfr, st, dm);
+            if (wave_any(mx[0] > cx.thr[0] || mx[1] > cx.thr[1])) f4_rescale(cx, mx, acc, tt);
         }
         block_sync();      // every wave has read K(0)[0..31] before K(2)[0..31] may land on it
 
         // Tile iteration i.  The fragment addresses in cx point at the buffers of tile i and are toggled to the other
         // buffer as the iteration goes (K between the half steps, V at the end): ONE loop body, no unrolling.
-        //   top      the first two K fragments of half 0 are requested, then the DMA of the tiles ahead is issued
-        //   half 0   phase 1: S(2i+1) from K(i)[32..63] || finish(2i);     phase 2: P.V(2i)   from V(i)[0..31]  || sums, max(2i+1)
-        //   half 1   phase 1: S(2i+2) from K(i+1)[0..31] || finish(2i+1);  phase 2: P.V(2i+1) from V(i)[32..63] || sums, max(2i+2)
+        //   half 0   phase 1: S(2i+1) from K(i)[32..63] || finish(2i);     phase 2: P.V(2i)   from V(i)[0..31]  || sums, max / exponents(2i+1)
+        //   half 1   phase 1: S(2i+2) from K(i+1)[0..31] || finish(2i+1);  phase 2: P.V(2i+1) from V(i)[32..63] || sums, max / exponents(2i+2)
         //   bottom   wait for the DMA, one barrier.
-        // Every phase but the first of an iteration finds its first two fragments already requested by its predecessor.
+        // Every phase but the first of an iteration finds its first fragments already requested by its predecessor;
+        // in the fast loop the eight LDS-DMA pieces of the tiles ahead go out two per phase, between MFMAs.
         int32_t ktog = kF4TileBytes, vtog = kF4TileBytes;     // +16 KiB now, -16 KiB next time
         auto toggle_k = [&]() {
             for (int s = 0; s < 8; ++s) cx.ka[s] += (uint32_t)ktog;
@@ -598,49 +658,103 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
             }
             vtog = -vtog;
         };
+        // (-DLWM_PROF builds, scripts/micro/fused_bench with LWM_PROF_DUMP=1: s_memtime laps of the tile loop --
+        // 0 phase 1 of half 0 (with the wait for its first K fragments), 1 mask + toggle, 2 phase 2 + rescale test,
+        // 3 phase 1 of half 1, 4 mask, 5 phase 2 + rescale test, 6 DMA wait, 7 barrier, 8 iterations)
+#ifdef LWM_PROF
+        unsigned long long f4p[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, f4t = __builtin_amdgcn_s_memtime();
+        const unsigned long long f4t0 = f4t;
+#define F4_LAP(slot)                                                  \
+    do {                                                              \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        f4p[slot] += now_ - f4t;                                      \
+        f4t = now_;                                                   \
+    } while (0)
+#else
+#define F4_LAP(slot)
+#endif
+#define LWM_F4_TILE(i, D0, D1, D2, D3)                                                                             \
+    do {                                                                                                            \
+        f4_phase1<1, true, true, 0, D0>(cx, qf, sB, tt, ps, pb, kfr, vfr, st, dm);   /* S(2i+1) || finish(2i) */   \
+        F4_LAP(0);                                                                                                  \
+        if (needs_mask(i)) {                                                                                        \
+            int r_[2];                                                                                              \
+            rel_of(i, r_);                                                                                          \
+            f4_mask<HAS_META, 1>(cx, sB, r_, seg_q, (i) % 3);                                                       \
+        }                                                                                                           \
+        toggle_k();                                                                                                 \
+        F4_LAP(1);                                                                                                  \
+        f4_phase2<0, true, true, 0, D1>(cx, pb, acc, ps, sB, tt, mx, kfr, vfr, st, dm);   /* P.V(2i) */            \
+        if (wave_any(mx[0] > cx.thr[0] || mx[1] > cx.thr[1])) f4_rescale(cx, mx, acc, tt);                          \
+        F4_LAP(2);                                                                                                  \
+        f4_phase1<0, true, true, 1, D2>(cx, qf, sA, tt, ps, pb, kfr, vfr, st, dm);   /* S(2i+2) || finish(2i+1) */ \
+        F4_LAP(3);                                                                                                  \
+        if (needs_mask((i) + 1)) {                                                                                  \
+            int r_[2];                                                                                              \
+            rel_of((i) + 1, r_);                                                                                    \
+            f4_mask<HAS_META, 0>(cx, sA, r_, seg_q, ((i) + 1) % 3);                                                 \
+        }                                                                                                           \
+        F4_LAP(4);                                                                                                  \
+        f4_phase2<1, true, true, -1, D3>(cx, pb, acc, ps, sA, tt, mx, kfr, vfr, st, dm);   /* P.V(2i+1) */         \
+        if (wave_any(mx[0] > cx.thr[0] || mx[1] > cx.thr[1])) f4_rescale(cx, mx, acc, tt);                          \
+        toggle_v();                                                                                                 \
+        F4_LAP(5);                                                                                                  \
+        glds_wait_all();                                                                                            \
+        F4_LAP(6);                                                                                                  \
+        block_sync();                                                                                               \
+        F4_LAP(7);                                                                                                  \
+    } while (0)
         // the wave's own tiles but the last: both half steps have a successor
         const int n_hot = n_w > 0 ? n_w - 1 : 0;
+        // ... of which those whose staging needs no decision: tiles i+1 and i+2 exist and neither is the ragged one
+        int n_fast = n_hot < n_wg - 2 ? n_hot : n_wg - 2;
+        if (ragged && n_fast > nkt_all - 1 - kt0 - 2) n_fast = nkt_all - 1 - kt0 - 2;
+        if (n_fast < 0) n_fast = 0;
+#ifdef LWM_F4_DMA_TOP      // (A/B builds only: every iteration stages at its top)
+        n_fast = 0;
+#endif
         int i = 0;
-        for (; i < n_hot; ++i) {
-            kfr[0] = f4_kread<1>(cx, 0);
-            kfr[1] = f4_kread<1>(cx, 1);
-            stage_iter(i);
-            f4_phase1<1, true, true, 0>(cx, qf, sB, sA, pC, pb, kfr, vfr);      // S(2i+1) from K(i)[32..63] || finish(2i)
-            if (needs_mask(i)) {
-                int r[2];
-                rel_of(i, r);
-                f4_mask<HAS_META, 1>(cx, sB, r, seg_q, i % 3);
-            }
-            toggle_k();
-            f4_phase2<0, true, true, 0>(cx, pb, acc, pC, sB, mx, kfr, vfr);     // P.V(2i) from V(i)[0..31]
-            if (wave_any(mx[0] > cx.thr[0] || mx[1] > cx.thr[1])) f4_rescale(cx, mx, acc);
-            f4_phase1<0, true, true, 1>(cx, qf, sA, sB, pC, pb, kfr, vfr);      // S(2i+2) from K(i+1)[0..31] || finish(2i+1)
-            if (needs_mask(i + 1)) {
-                int r[2];
-                rel_of(i + 1, r);
-                f4_mask<HAS_META, 0>(cx, sA, r, seg_q, (i + 1) % 3);
-            }
-            f4_phase2<1, true, true, -1>(cx, pb, acc, pC, sA, mx, kfr, vfr);    // P.V(2i+1) from V(i)[32..63]
-            if (wave_any(mx[0] > cx.thr[0] || mx[1] > cx.thr[1])) f4_rescale(cx, mx, acc);
-            toggle_v();
-            glds_wait_all();
-            block_sync();
+        for (; i < n_fast; ++i) {
+            for (int j = 0; j < 3; ++j) kfr[j] = f4_kread<1>(cx, j);
+            dm.k_lo_src = st.kb + (kt0 + i + 2) * st.ktile_bytes;
+            dm.k_up_src = st.kb + (kt0 + i + 1) * st.ktile_bytes;
+            dm.v_src = st.vb + (kt0 + i + 1) * st.vtile_bytes;
+            dm.k_lo_dst = kdst0 + (i & 1) * kF4TileBytes;
+            dm.k_up_dst = kdst0 + ((i + 1) & 1) * kF4TileBytes + 8192;
+            dm.v_dst = vdst0 + ((i + 1) & 1) * kF4TileBytes;
+            if (HAS_META) f4_meta_stage(p, cx, b, kt0 + i + 2, (i + 2) % 3);
+            LWM_F4_TILE(i, 0, 1, 2, -1);
+#ifdef LWM_PROF
+            f4p[8] += 1;
+#endif
         }
+#ifdef LWM_PROF
+        if (!HAS_META && hb == 0 && qt == nqt - 1 && lane == 0 && p.out_acc) {      // the longest q tile of head 0
+            f4p[9] = __builtin_amdgcn_s_memtime() - f4t0;
+            for (int j = 0; j < 10; ++j) ((unsigned long long*)p.out_acc)[wave * 10 + j] = f4p[j];
+        }
+#endif
+        for (; i < n_hot; ++i) {
+            for (int j = 0; j < 3; ++j) kfr[j] = f4_kread<1>(cx, j);
+            stage_iter(i);
+            LWM_F4_TILE(i, -1, -1, -1, -1);
+        }
+#undef LWM_F4_TILE
+#undef F4_LAP
         // its last tile: the second half step has no successor
         if (n_w > 0) {
-            kfr[0] = f4_kread<1>(cx, 0);
-            kfr[1] = f4_kread<1>(cx, 1);
+            for (int j = 0; j < 3; ++j) kfr[j] = f4_kread<1>(cx, j);
             stage_iter(i);
-            f4_phase1<1, true, true, 0>(cx, qf, sB, sA, pC, pb, kfr, vfr);
+            f4_phase1<1, true, true, 0, -1>(cx, qf, sB, tt, ps, pb, kfr, vfr, st, dm);
             if (needs_mask(i)) {
                 int r[2];
                 rel_of(i, r);
                 f4_mask<HAS_META, 1>(cx, sB, r, seg_q, i % 3);
             }
-            f4_phase2<0, true, true, -1>(cx, pb, acc, pC, sB, mx, kfr, vfr);
-            if (wave_any(mx[0] > cx.thr[0] || mx[1] > cx.thr[1])) f4_rescale(cx, mx, acc);
-            f4_phase1<0, false, true, 1>(cx, qf, sA, sB, pC, pb, kfr, vfr);
-            f4_phase2<1, true, false, -1>(cx, pb, acc, pC, sA, mx, kfr, vfr);
+            f4_phase2<0, true, true, -1, -1>(cx, pb, acc, ps, sB, tt, mx, kfr, vfr, st, dm);
+            if (wave_any(mx[0] > cx.thr[0] || mx[1] > cx.thr[1])) f4_rescale(cx, mx, acc, tt);
+            f4_phase1<0, false, true, 1, -1>(cx, qf, sA, tt, ps, pb, kfr, vfr, st, dm);
+            f4_phase2<1, true, false, -1, -1>(cx, pb, acc, ps, sA, tt, mx, kfr, vfr, st, dm);
             glds_wait_all();
             block_sync();
             ++i;
@@ -654,7 +768,7 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
     }
 
     // ---- epilogue: normalise, merge with the ring carry, store (per query block)
-    f4_mfma_settle();
+    f4_settle_acc(acc);
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const float l_tot = cx.lsum[qb] + xhalf(cx.lsum[qb]);

@@ -150,6 +150,24 @@ int main(int argc, char** argv) {
     const bool do_fused = strcmp(what, "two") != 0, do_two = strcmp(what, "fused") != 0;
     float ms_fused = -1, ms_dkdv = -1, ms_dq = -1, ms_delta = -1;
     const float ms_fwd = time_ms([&] { fwd(&a, nullptr); });
+    if (getenv("LWM_PROF_DUMP")) {      // -DLWM_PROF builds of the library report s_memtime laps of the forward through out_acc
+        unsigned long long* prof = nullptr;
+        CK(hipMalloc(&prof, 4 * 10 * 8));
+        CK(hipMemset(prof, 0, 4 * 10 * 8));
+        a.out_acc = (float*)prof;
+        fwd(&a, nullptr);
+        CK(hipDeviceSynchronize());
+        unsigned long long h[40];
+        CK(hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost));
+        a.out_acc = nullptr;
+        printf("forward, last q tile of head 0: cycles per tile iteration (phase1a, mask+toggle, phase2a, phase1b, mask, phase2b, dma wait, barrier | iterations, total)\n");
+        for (int w = 0; w < 4; ++w) {
+            const double n = h[w * 10 + 8] ? (double)h[w * 10 + 8] : 1.0;
+            printf("  wave %d:", w);
+            for (int i = 0; i < 8; ++i) printf(" %7.1f", (double)h[w * 10 + i] / n);
+            printf(" | %llu %llu\n", h[w * 10 + 8], h[w * 10 + 9]);
+        }
+    }
     bdelta(&a, nullptr);           // delta is an input of every backward flavour
     double cs_fused = -1, cs_two = -1, cs_dk_f = -1, cs_dk_t = -1;
     uint16_t* dq_keep = nullptr;       // the fused dq, kept for the element-wise comparison with the two-kernel dq
