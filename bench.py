@@ -156,7 +156,7 @@ def vqgan_leg(torch, frames=32, reps=3, config4_frames=1020):
     return res
 
 
-PROFILE_ROUND = "r02"      # only PMC summaries of THIS round's kernels may label this round's bench line
+PROFILE_ROUND = "r03"      # only PMC summaries of THIS round's kernels may label this round's bench line
 
 
 def pmc_traffic(kernel, S):
@@ -715,10 +715,10 @@ def main():
         doc_sq = float(sum(l * l for l in lens))
 
     class TimedOps(HipBlockOps):
-        fwd = staticmethod(lambda *a, **kw: timer.run("attn_fwd_kernel", ops.attn_fwd_block, *a, **kw))
+        fwd = staticmethod(lambda *a, **kw: timer.run("attn_fwd64_kernel", ops.attn_fwd_block, *a, **kw))
         bwd_delta = staticmethod(lambda *a, **kw: timer.run("attn_bwd_delta_kernel", ops.attn_bwd_delta, *a, **kw))
         bwd_dq = staticmethod(lambda *a, **kw: timer.run("attn_bwd_dq_kernel", ops.attn_bwd_dq_block, *a, **kw))
-        bwd_dkdv = staticmethod(lambda *a, **kw: timer.run("attn_bwd_dkdv_kernel", ops.attn_bwd_dkdv_block, *a, **kw))
+        bwd_dkdv = staticmethod(lambda *a, **kw: timer.run("attn_bwd_dkdv_kernel_w8", ops.attn_bwd_dkdv_block, *a, **kw))
         bwd_fused = staticmethod(lambda *a, **kw: timer.run("attn_bwd_fused_kernel", ops.attn_bwd_fused_block, *a, **kw))
 
     c_ring = None
@@ -853,9 +853,9 @@ def main():
             # units; the backward's 5 algorithmic units are apportioned to its two launches
             # by executed share (dkdv 4/7, dq 3/7) -- DESIGN.md "Work accounting".
             # The one-launch backward executes exactly its 5 algorithmic units.
-            algo_units = {"attn_fwd_kernel": 2.0, "attn_bwd_dkdv_kernel": 5.0 * 4 / 7,
+            algo_units = {"attn_fwd64_kernel": 2.0, "attn_bwd_dkdv_kernel_w8": 5.0 * 4 / 7,
                           "attn_bwd_dq_kernel": 5.0 * 3 / 7, "attn_bwd_fused_kernel": 5.0}
-            exec_units = {"attn_fwd_kernel": 2.0, "attn_bwd_dkdv_kernel": 4.0, "attn_bwd_dq_kernel": 3.0,
+            exec_units = {"attn_fwd64_kernel": 2.0, "attn_bwd_dkdv_kernel_w8": 4.0, "attn_bwd_dq_kernel": 3.0,
                           "attn_bwd_fused_kernel": 5.0}
             cand = {n: d for n, d in ks.items() if n in algo_units}
             dom = max(cand, key=lambda n: cand[n]["total_ms"])

@@ -167,7 +167,8 @@ LWM_DEVICE void f4_meta_stage(const AttnParams& p, const F4Ctx& cx, int b, int k
 // accumulator file), Q~ as an AGPR B operand, and every filler between them.  What hipcc still does: LDS reads
 // (builtins: it counts them and waits before the asm statement that consumes the fragment) and register allocation.
 // Hazards hipcc cannot see through asm (cdna_hip_programming.md section 5.7 item 2) are covered here:
-//   MFMA D (VGPR) -> VALU read      the score tile is first read a whole phase later; f4_mfma_settle() ends phase 1
+//   MFMA D (VGPR) -> VALU read      the fillers first read a score tile behind the next phase's first MFMA, i.e. after the
+//                                   chain has left the matrix pipe; the mask code (hipcc's) gets f4_settle_s() first
 //   v_exp (trans) -> VALU consumer  the cvt of a value comes at least one MFMA after its exp
 //   VALU write -> MFMA A/B/C        P fragments are packed a phase before the MFMA that reads them
 #ifdef LWM_EMU
@@ -340,7 +341,6 @@ LWM_DEVICE void f4_phase1(const F4Ctx& cx, const bf16x8 (&qf)[2][8], f32x16 (&sN
         ps[1][7] = f4_add2(tC[1][14], tC[1][15]);
         pb[1][1] = __builtin_bit_cast(bf16x8, u32x4{w[0], w[1], w[2], w[3]});
     }
-    if (DO_S) f4_settle_s(sN);
 }
 
 // Phase 2 (16 MFMAs): O^T += V^T P^T  ||  row sums (the pair sums ps), running max of the next half tile's scores (sN)
@@ -521,7 +521,13 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
         int smin, smax, lo, hi2;
         seg_own_range(p.segb_q + (int64_t)b * nbq * 2, nbq, qt * (kF4BQ / 32), kF4BQ / 32, smin, smax);
         seg_narrow<kF4Threads>(p.segb_k + (int64_t)b * nbk * 2, nbk, kF4BK / 32, 0, nkt, smin, smax, lds + kF4OffScan, tid, lo, hi2);
-        kt0 = lo;
+        // The walk starts ONE tile before the first tile that can meet the workgroup's documents.  The first half tile of
+        // a walk runs through a separate instruction stream (there is no P.V to put beside it), and on MI355X that stream
+        // and the steady-state stream round a row's running reference differently in the last bit (same source arithmetic,
+        // identical in the host emulation; 10 of 4.2M outputs one bf16 ulp apart at S = 8192 -- profiles/r03_fwd64.md).
+        // With the extra, fully masked tile a narrowed walk executes the SAME stream on the same tiles as the full walk:
+        // hints change the time, never a bit of the result (tests/test_gpu_attention.py::test_packed_documents_skip_is_exact).
+        kt0 = lo > 0 ? lo - 1 : 0;
         nkt = hi2;
     }
     const int n_wg = nkt > kt0 ? nkt - kt0 : 0;
@@ -591,11 +597,15 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
                 r[qb] = d > kF4BK ? kF4BK : (d < -1 ? -1 : (int)d);
             }
         };
-        auto needs_mask = [&](int rel) -> bool {
-            if (HAS_META) return true;
-            const int64_t k_pos0 = p.k_start + (int64_t)(kt0 + rel) * kF4BK;
-            return p.causal && k_pos0 + kF4BK - 1 > wq_min;
-        };
+        // a tile needs the mask code when its last key lies beyond the wave's first query (or keys can be masked for
+        // another reason than causality): from tile first_mask on -- one integer compare per half step in the loop
+        int first_mask = 0x7fffffff;
+        if (p.causal) {
+            const int64_t t = wq_min - p.k_start - (kF4BK - 1);        // k_pos0 > t  <=>  mask
+            const int64_t ft = (t >= 0 ? t / kF4BK : -((-t + kF4BK - 1) / kF4BK)) + 1 - kt0;
+            first_mask = ft < 0 ? 0 : (ft > 0x7fffffff ? 0x7fffffff : (int)ft);
+        }
+        auto needs_mask = [&](int rel) -> bool { return HAS_META || rel >= first_mask; };
 
         // ---- prologue: K(0), V(0) and the first half of K(1) in flight -> S of half tile 0, its masks, its reference
         stage_k(0, 0);
@@ -629,6 +639,7 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
         if (n_w > 0) {
             for (int j = 0; j < 3; ++j) kfr[j] = f4_kread<0>(cx, j);
             f4_phase1<0, true, false, -1, -1>(cx, qf, sA, tt, ps, pb, kfr, vfr, st, dm);
+            f4_settle_s(sA);       // (no P.V MFMA follows here: the max / exponent fillers read the scores at once)
             if (needs_mask(0)) {
                 int r[2];
                 rel_of(0, r);
@@ -680,6 +691,7 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
         if (needs_mask(i)) {                                                                                        \
             int r_[2];                                                                                              \
             rel_of(i, r_);                                                                                          \
+            f4_settle_s(sB);                                                                                        \
             f4_mask<HAS_META, 1>(cx, sB, r_, seg_q, (i) % 3);                                                       \
         }                                                                                                           \
         toggle_k();                                                                                                 \
@@ -692,6 +704,7 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
         if (needs_mask((i) + 1)) {                                                                                  \
             int r_[2];                                                                                              \
             rel_of((i) + 1, r_);                                                                                    \
+            f4_settle_s(sA);                                                                                        \
             f4_mask<HAS_META, 0>(cx, sA, r_, seg_q, ((i) + 1) % 3);                                                 \
         }                                                                                                           \
         F4_LAP(4);                                                                                                  \
@@ -749,6 +762,7 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
             if (needs_mask(i)) {
                 int r[2];
                 rel_of(i, r);
+                f4_settle_s(sB);
                 f4_mask<HAS_META, 1>(cx, sB, r, seg_q, i % 3);
             }
             f4_phase2<0, true, true, -1, -1>(cx, pb, acc, ps, sB, tt, mx, kfr, vfr, st, dm);
