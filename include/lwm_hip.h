@@ -95,15 +95,14 @@ typedef struct LwmAttnArgs {
     const int32_t* seg_blocks_k;
     /* lwm_attn_bwd_fused only: carry_in / final_out govern dk, dv; these two govern dq (a ring driver
      * finishes a q segment and a k segment at different steps).  bwd_workspace: caller-owned device
-     * memory of lwm_attn_bwd_fused_workspace_bytes() bytes (work-queue tickets + per-tile counters;
-     * the launch zeroes it on `stream`, it need not persist between launches). */
+     * memory, 256-byte aligned, bwd_workspace_bytes long (lwm_attn_bwd_fused_workspace_bytes: work-queue
+     * tickets, LSE in log2 units, and the bf16 dq partial of every (key block, query tile) pair of one group of
+     * heads; it need not persist between launches). */
     int32_t dq_carry_in, dq_final_out;
     void* bwd_workspace;
-    /* lwm_attn_bwd_dq and lwm_attn_bwd_fused: 0 = dq_acc is [B,Sq,H,D] (rows of one head 16 KiB apart),
-     * 1 = head-major [B,H,Sq,D].  The fused backward reads and rewrites a 32-query tile of dq_acc once per
-     * 256-key block; head-major makes that tile 16 KiB contiguous (whole cache lines per wave, fewer partial
-     * write-backs: 18 instead of 26 GB written per launch at S = 32768) -- give it the head-major layout. */
+    /* lwm_attn_bwd_dq and lwm_attn_bwd_fused: 0 = dq_acc is [B,Sq,H,D], 1 = head-major [B,H,Sq,D]. */
     int32_t dq_acc_head_major;
+    int64_t bwd_workspace_bytes;
 } LwmAttnArgs;
 
 int lwm_attn_fwd(const LwmAttnArgs* args, void* stream);
@@ -111,15 +110,19 @@ int lwm_attn_bwd_delta(const LwmAttnArgs* args, void* stream);
 int lwm_attn_bwd_dq(const LwmAttnArgs* args, void* stream);
 int lwm_attn_bwd_dkdv(const LwmAttnArgs* args, void* stream);
 
-/* The whole backward of one ring step in ONE launch: dq, dk and dv from S and dP computed once -- the
- * reference's 5 GEMMs per chunk pair instead of the 7 that
- * lwm_attn_bwd_dq + lwm_attn_bwd_dkdv execute between them.  Same operands and mask semantics; results
- * agree with the two-kernel path to f32 re-association (dq is accumulated per 256-key block, in ascending
- * key order -- deterministic).  dq_acc (f32; layout per dq_acc_head_major) is required unless a single key block covers Sk
- * with dq_final_out = 1 and dq_carry_in = 0: it is the accumulator the key blocks add into (and the dq
- * carry of a ring).  seg_blocks_* hints are ignored (every tile inside the causal range is visited; the
- * element mask is authoritative) -- packed batches run faster through the two-kernel path. */
-int64_t lwm_attn_bwd_fused_workspace_bytes(int32_t B, int32_t H, int32_t Sq);
+/* The whole backward of one ring step with S and dP computed ONCE -- the reference's 5 GEMMs per chunk pair
+ *  instead of the 7 that lwm_attn_bwd_dq + lwm_attn_bwd_dkdv execute between them.  Same
+ * operands and mask semantics (seg_blocks_* hints honoured).  A workgroup owns 256 keys (dk, dv as in
+ * lwm_attn_bwd_dkdv) and stores the dq contribution of its keys to each 32-query tile as a bf16 partial in the
+ * workspace; a streaming pass then sums every tile's partials in ascending key order in f32 (+ the f32 carry
+ * dq_acc when dq_carry_in), scales, and writes dq (bf16, dq_final_out = 1) or dq_acc.  Deterministic: no atomics,
+ * fixed summation order.  dq differs from the two-kernel path by the bf16 rounding of the per-256-key partials.
+ * Workspace: lwm_attn_bwd_fused_workspace_bytes(..., head_group) bytes for `head_group` (batch*head) slices per
+ * launch (0 = all at once; otherwise a multiple of 8): 8 KiB per visible (key block, query tile) pair and head,
+ * e.g. 17.2 GB for S = 32768 x 32 heads, causal.  With a smaller workspace the call runs the heads in as many
+ * groups as it has room for (bwd_workspace_bytes) and fails with LWM_EINVAL if not even 8 heads fit. */
+int64_t lwm_attn_bwd_fused_workspace_bytes(int32_t B, int32_t H, int32_t Sq, int32_t Sk, int64_t q_start,
+                                           int64_t k_start, int32_t causal, int32_t head_group);
 int lwm_attn_bwd_fused(const LwmAttnArgs* args, void* stream);
 
 /* ------------------------------------------------------------------ the sequence ring

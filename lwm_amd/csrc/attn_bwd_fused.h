@@ -17,22 +17,26 @@
 //     on v_mfma_f32_16x16x32_bf16 (both operands by ds_read_b64_tr_b16 from the [key][*] images):
 //     the reduction over the workgroup's 256 keys happens inside the MFMA accumulator, and a lane ends
 //     up holding one head dim of four query rows, so that
-//   * the partial is ADDED to the f32 dq accumulator in global memory by fire-and-forget
-//     global_atomic_add_f32: 16 consecutive lanes = 64 contiguous bytes of one (query, head) row.
-//     Nothing is read back, nothing is waited for, no key block waits for another.  The accumulator
-//     must hold zeros (or the ring's dq carry) at launch and is converted to bf16 by a separate
-//     streaming pass (lwm_attn_bwd_fused does both).  dq is therefore summed in a run-dependent order:
-//     its last f32 bits vary between runs (dk, dv do not; profiles/r03_parity_stats.json has the spread);
-//     the deterministic path is the two-kernel backward.
+//   * the partial is STORED -- not added: one 16-byte non-temporal store per lane, 8 bf16 = 4 query rows x 2 head
+//     dims, 8 KiB per (key block, query tile) -- into a partial buffer in the caller's workspace, slot
+//     (head, key block, query tile) of a causal-triangular arrangement (fb_slot).  Nothing is read back, nothing
+//     is waited for, no key block waits for another.  attn_bwd_dq_reduce_kernel then streams the buffer once and
+//     sums, per query tile, the partials of its key blocks IN ASCENDING KEY ORDER in f32 (+ the ring's dq carry),
+//     scales, and writes dq (bf16) or the f32 accumulator: dq is bit-reproducible, like dk and dv.
+//     Why stores and not adds (round 3, profiles/r03_atomic_probe.txt, r03_fused_atomic_timing.txt): f32 atomic
+//     adds are performed at the memory side at ~1.25 TB/s whatever their width or scope (4- and 8-byte integer,
+//     f32, f64, packed bf16: same BYTE rate), and a layer at S = 32768 issues 34 GB of them: 26.3 ms against 20.9
+//     for the same launch without the adds.  bf16 partials are half the bytes, ordinary write-back traffic, and
+//     one instruction per lane instead of eight; the reduction reads them back at streaming rate.
+//     Numerics: a partial (the sum over 256 keys, accumulated in f32 by the MFMA) is rounded to bf16 once
+//     (2^-9 relative, unbiased) before the f32 sum over key blocks -- the same order as the bf16 rounding of P and
+//     dS that every backward kernel here already applies, and inside the stated tolerance (tests/_parity.py).
 //
-// Where the adds are performed (MI355X: one L2 per XCD, L2s not coherent with each other --
-// MI355X_MICROARCH.md "inter-workgroup visibility"): see wave_ops.h::atomic_add_f32_at.  Work is handed
-// out through 8 queues (heads hb with hb % 8 == q); a queue is CLAIMED (atomic CAS) by the XCC id
-// (s_getreg HW_REG_XCC_ID) of the first workgroup that takes from it and only workgroups of that XCD
-// take from it afterwards; persistent workgroups drain their own XCD's queue and then claim what is
-// unclaimed.  All key blocks of one (batch, head) -- the only contributors to that head's dq rows -- are
-// therefore executed by ONE XCD whatever the dispatcher does: their Q / dO stream is shared in that L2,
-// and the adds may be performed there (LWM_ATOMIC_AGENT = 0) instead of at the memory side.
+// Work is handed out through 8 queues (heads hb with hb % 8 == q); a queue is CLAIMED (atomic CAS) by the XCC id
+// (s_getreg HW_REG_XCC_ID) of the first workgroup that takes from it and only workgroups of that XCD take from it
+// afterwards; persistent workgroups drain their own XCD's queue and then claim what is unclaimed.  All key blocks
+// of one (batch, head) are therefore executed by ONE XCD whatever the dispatcher does: their Q / dO stream is
+// shared in that L2.  Placement is a matter of speed only: no workgroup reads what another wrote.
 #pragma once
 
 namespace lwm {
@@ -50,10 +54,60 @@ constexpr int kFbOffCtl = kFbOffStats + 2 * kFbStatBytes;
 constexpr int kFbOffScan = kFbOffCtl + 64;          // seg_narrow scratch (8 waves x 8 B)
 constexpr int kFbLdsBytes = kFbOffScan + 64;
 
-// workspace (int32): [0,8) tickets | [8,16) queue owner (0 = unclaimed, xcc+1) | [16,32) unused |
-// then f32 [B,H,Sq]: LSE in log2 units (+inf where the row has no visible key), written by
-// attn_bwd_lse2_kernel before the main launch
+// workspace (int32 words): [0,8) tickets | [8,16) queue owner (0 = unclaimed, xcc+1) | [16,32) unused |
+// f32 [B,H,Sq]: LSE in log2 units (+inf where the row has no visible key), written by attn_bwd_lse2_kernel before
+// the main launch | int32 [B*H][nkb][2]: the query-tile range [lo, hi) each key block walked (written by the main
+// launch, read by the reduction) | 256-byte aligned: the partial tiles of the heads of ONE launch group.
 constexpr int kFbWsHeader = 32;
+constexpr int kFbPartBytes = kDkvBQ * kHeadDim * 2;      // one partial tile: 32 queries x 128 dims bf16 = 8 KiB
+constexpr int kFbKbPerQt = kDkvBK / kDkvBQ;              // 8 query tiles per key block along the diagonal
+
+// Where the partial tiles live.  Without hints key block j walks the query tiles [qt0(j), nqt), qt0(j) = the tile
+// holding its causal diagonal = clamp(f + 8j, 0, nqt) with f = floor((k_start - q_start) / 32) (all of them when not
+// causal).  Seen from query tile t that is the key blocks [0, count(t)), count(t) = clamp(floor((t - f) / 8) + 1, 0,
+// nkb).  The tiles are stored QUERY-TILE MAJOR: the partials of tile t are count(t) consecutive 8 KiB pieces from slot
+// prefix_q(t) = sum_{t' < t} count(t') of the head's area, key block j at + j -- so that the reduction of a tile is
+// one contiguous streaming read (key-block-major slots made it 64 reads 8 MB apart: 2.6 TB/s instead of > 5).
+struct FbGeom {
+    int64_t f;          // floor((k_start - q_start) / 32)
+    int32_t causal, nqt, nkb;
+};
+LWM_HD int fb_qt0(const FbGeom& g, int j) {
+    if (!g.causal) return 0;
+    const int64_t t = g.f + (int64_t)kFbKbPerQt * j;
+    return t < 0 ? 0 : (t > g.nqt ? g.nqt : (int)t);
+}
+LWM_HD int fb_count(const FbGeom& g, int qt) {
+    if (!g.causal) return g.nkb;
+    const int64_t u = (int64_t)qt - g.f;
+    if (u < 0) return 0;
+    const int64_t c = u / kFbKbPerQt + 1;
+    return c > g.nkb ? g.nkb : (int)c;
+}
+// sum_{u=0}^{m-1} min(nkb, floor(u / 8) + 1), m >= 0
+LWM_HD int64_t fb_sum_counts(int64_t m, int nkb) {
+    const int64_t lim = (int64_t)kFbKbPerQt * nkb;
+    const int64_t mm = m < lim ? m : lim;
+    const int64_t a = mm / kFbKbPerQt, b = mm % kFbKbPerQt;
+    int64_t s = (kFbKbPerQt / 2) * a * (a + 1) + b * (a + 1);
+    if (m > lim) s += (m - lim) * nkb;
+    return s;
+}
+LWM_HD int64_t fb_prefix_q(const FbGeom& g, int qt) {
+    if (!g.causal) return (int64_t)qt * g.nkb;
+    const int64_t u1 = (int64_t)qt - g.f;          // tiles t in [0, qt) have u = t - f in [-f, u1); only u >= 0 count
+    if (u1 <= 0) return 0;
+    const int64_t u0 = g.f < 0 ? -g.f : 0;
+    return fb_sum_counts(u1, g.nkb) - fb_sum_counts(u0, g.nkb);
+}
+struct FbPart {
+    u32x4* tiles;           // partial tiles of head hb0 (16-byte units: a tile = 512 of them)
+    int32_t* ranges;        // [B*H][nkb][2]
+    int64_t tiles_per_head; // fb_prefix_q(nqt)
+    FbGeom g;
+    int32_t hb0, hbn;       // this launch covers batch*head indices [hb0, hb0 + hbn), hb0 % 8 == 0
+    int32_t hints;          // segment-block hints given: a key block may have walked less than its causal range
+};
 
 // Per-lane state that lives across the whole tile loop is kept to a minimum (the loop runs at the
 // 256-register limit: 128 accumulator + 32 V-fragment registers are pinned): fragment addresses are
@@ -81,29 +135,96 @@ LWM_KERNEL(256) void attn_bwd_lse2_kernel(const float* lse, float* lse2, int64_t
     }
 }
 
-// dq (bf16, [B,Sq,H,D] strided) = bf16(dq_acc) -- dq_acc in either layout (AttnParams::dqa_*).
-// One thread = 8 head dims of one (b, q, h) row: 32 B in, 16 B out.
-constexpr int kFbCastThreads = 256;
-LWM_KERNEL(kFbCastThreads) void attn_bwd_dq_cast_kernel(AttnParams p) {
-    const int64_t n = (int64_t)p.B * p.Sq * p.H * (kHeadDim / 8);
-    for (int64_t i = (int64_t)block_idx_x() * kFbCastThreads + thread_idx(); i < n;
-         i += (int64_t)grid_dim_x() * kFbCastThreads) {
-        const int d8 = (int)(i & 15);
-        int64_t r = i >> 4;
-        // walk the ACCUMULATOR's layout so that the 32-byte reads of consecutive threads are contiguous
-        int64_t b, q, h;
-        if (p.dqa_sh > p.dqa_ss) {      // head-major [B,H,Sq,D]
-            q = r % p.Sq; r /= p.Sq;
-            h = r % p.H; b = r / p.H;
-        } else {                        // [B,Sq,H,D]
-            h = r % p.H; r /= p.H;
-            q = r % p.Sq; b = r / p.Sq;
+// The reduction of the partial tiles: dq[tile] = scale * sum over key blocks (ascending) of its partials
+// (+ the ring's f32 dq carry), written as bf16 dq (dq_final_out) or into the f32 accumulator.  A workgroup takes
+// one (head, 32-query tile) at a time -- its partials are contiguous (8 KiB per key block); thread (wave w, lane l)
+// owns the 16 bytes the producing lane (w, l) stored (fb_dq_partial), kFbRedBatch partials per trip, two trips in
+// flight.  The sums cross an LDS tile (row stride 132 floats) so that the carry is read and the result written in
+// whole 32- / 16-byte pieces of one (query, head) row.
+constexpr int kFbRedThreads = 512;
+constexpr int kFbRedStride = kHeadDim + 4;
+constexpr int kFbRedLdsBytes = kDkvBQ * kFbRedStride * 4;
+constexpr int kFbRedBatch = 8;
+LWM_DEVICE void fb_red_add(float (&acc)[8], u32x4 v) {
+    for (int j = 0; j < 4; ++j) {
+        acc[2 * j] += __builtin_bit_cast(float, v[j] << 16);
+        acc[2 * j + 1] += __builtin_bit_cast(float, v[j] & 0xffff0000u);
+    }
+}
+LWM_KERNEL(kFbRedThreads) void attn_bwd_dq_reduce_kernel(AttnParams p, FbPart part) {
+    const lds_t lds = dyn_lds();
+    const int tid = thread_idx(), w = tid >> 6, l = tid & 63;
+    const int nqt = part.g.nqt, nkb = part.g.nkb;
+    const int64_t items = (int64_t)part.hbn * nqt;
+    for (int64_t it = block_idx_x(); it < items; it += grid_dim_x()) {
+        const int hbl = (int)(it / nqt), qt = (int)(it % nqt);
+        const int hb = part.hb0 + hbl;
+        const int b = hb / p.H, h = hb % p.H;
+        const int cnt = fb_count(part.g, qt);
+        const u32x4* const src = part.tiles + ((int64_t)hbl * part.tiles_per_head + fb_prefix_q(part.g, qt)) * (kFbPartBytes / 16) + tid;
+        float acc[8];
+        for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+        if (!part.hints) {
+            // every key block of [0, cnt) wrote its partial: a plain stream, two trips of loads in flight
+            u32x4 va[kFbRedBatch], vb[kFbRedBatch];
+            int kb = 0;
+            const int full = cnt - cnt % (2 * kFbRedBatch);
+            if (full > 0)
+                for (int u = 0; u < kFbRedBatch; ++u) va[u] = global_load_b128(src + (int64_t)u * (kFbPartBytes / 16));
+            for (; kb < full; kb += 2 * kFbRedBatch) {
+                for (int u = 0; u < kFbRedBatch; ++u) vb[u] = global_load_b128(src + (int64_t)(kb + kFbRedBatch + u) * (kFbPartBytes / 16));
+                for (int u = 0; u < kFbRedBatch; ++u) fb_red_add(acc, va[u]);
+                if (kb + 2 * kFbRedBatch < full)
+                    for (int u = 0; u < kFbRedBatch; ++u) va[u] = global_load_b128(src + (int64_t)(kb + 2 * kFbRedBatch + u) * (kFbPartBytes / 16));
+                for (int u = 0; u < kFbRedBatch; ++u) fb_red_add(acc, vb[u]);
+            }
+            for (; kb < cnt; ++kb) fb_red_add(acc, global_load_b128(src + (int64_t)kb * (kFbPartBytes / 16)));
+        } else {
+            // packed batches: a key block walked only the tiles [lo, hi) its documents can meet
+            const int32_t* rg = part.ranges + (int64_t)hb * nkb * 2;
+            for (int kb0 = 0; kb0 < cnt; kb0 += kFbRedBatch) {
+                u32x4 v[kFbRedBatch];
+                bool ok[kFbRedBatch];
+                bool any = false;
+                for (int u = 0; u < kFbRedBatch; ++u) {
+                    const int kb = kb0 + u < cnt ? kb0 + u : cnt - 1;
+                    ok[u] = kb0 + u < cnt && rg[2 * kb] <= qt && qt < rg[2 * kb + 1];
+                    any |= ok[u];
+                }
+                if (!any) continue;
+                // (an absent partial re-reads a present slot position -- the value is discarded; the load stays
+                // unconditional so that all of a trip's loads are in flight together)
+                for (int u = 0; u < kFbRedBatch; ++u) v[u] = global_load_b128(src + (int64_t)(ok[u] ? kb0 + u : kb0) * (kFbPartBytes / 16));
+                for (int u = 0; u < kFbRedBatch; ++u)
+                    if (ok[u]) fb_red_add(acc, v[u]);
+            }
         }
-        const float* src = p.dq_acc + b * p.dqa_sb + q * p.dqa_ss + h * p.dqa_sh + d8 * 8;
-        const f32x4 lo = global_load_f32x4(src), hi = global_load_f32x4(src + 4);
-        const u32x4 o = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
-                         pack_bf16x2(hi[2], hi[3])};
-        global_store_b128(p.dq + b * p.dq_sb + q * p.dq_ss + h * p.dq_sh + d8 * 8, o);
+        // element 2r + t = dQ[row 16*(w>>2) + 4*(l>>4) + r][dim 32*(w&3) + 16t + (l&15)]
+        for (int r = 0; r < 4; ++r)
+            for (int t = 0; t < 2; ++t)
+                lds_write_f32(lds + (uint32_t)((16 * (w >> 2) + 4 * (l >> 4) + r) * kFbRedStride + 32 * (w & 3) + 16 * t + (l & 15)) * 4,
+                              acc[2 * r + t] * p.scale);
+        block_sync();
+        const int row = tid >> 4, c8 = tid & 15;
+        const int64_t q = (int64_t)qt * kDkvBQ + row;
+        if (q < p.Sq) {
+            f32x4 lo = lds_read_f32x4(lds + (uint32_t)(row * kFbRedStride + 8 * c8) * 4);
+            f32x4 hi = lds_read_f32x4(lds + (uint32_t)(row * kFbRedStride + 8 * c8 + 4) * 4);
+            float* const ap = p.dq_acc ? p.dq_acc + b * p.dqa_sb + q * p.dqa_ss + h * p.dqa_sh + c8 * 8 : nullptr;
+            if (p.dq_carry_in) {
+                lo += global_load_f32x4(ap);
+                hi += global_load_f32x4(ap + 4);
+            }
+            if (p.dq_final_out) {
+                const u32x4 o = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
+                                 pack_bf16x2(hi[2], hi[3])};
+                global_store_b128(p.dq + b * p.dq_sb + q * p.dq_ss + h * p.dq_sh + c8 * 8, o);
+            } else {
+                global_store_f32x4(ap, lo);
+                global_store_f32x4(ap + 4, hi);
+            }
+        }
+        block_sync();
     }
 }
 
@@ -262,13 +383,14 @@ LWM_DEVICE void fb_tile_c(const FusedCtx& cx, const bf16x8 (&pb)[2], const bf16x
     prio_lo();
 }
 
-// dQ[16 queries][32 head dims] of this wave = dS . K over the workgroup's 256 keys (dS^T buffer BUF), added to
-// the f32 accumulator.  Wave w owns head dims 32*(w&3) .. +31 and queries 16*(w>>2) .. +15 of tile `qt`.
+// dQ[16 queries][32 head dims] of this wave = dS . K over the workgroup's 256 keys (dS^T buffer BUF), stored as a
+// bf16 partial.  Wave w owns head dims 32*(w&3) .. +31 and queries 16*(w>>2) .. +15 of the tile.
 // MFMA 16x16x32 with A = dS (row = query l&15, k-group l>>4: 8 keys), B = K (k-group, col = head dim l&15):
-// acc[t][r] = dQ[query 4*(l>>4) + r][head dim 32*(w&3) + 16t + (l&15)] -- a 16-lane group covers 64 contiguous
-// bytes of one (query, head) row per add.
+// acc[t][r] = dQ[query 16*(w>>2) + 4*(l>>4) + r][head dim 32*(w&3) + 16t + (l&15)].  The lane's 8 values go out as
+// ONE 16-byte store at tile + 16 * (64w + l): element 2r + t (attn_bwd_dq_reduce_kernel knows the map).  Rows past
+// Sq hold zeros (dS is masked there).
 template <int BUF>
-LWM_DEVICE void fb_dq_accumulate(const AttnParams& p, const FusedCtx& cx, int b, int h, int qt) {
+LWM_DEVICE void fb_dq_partial(const FusedCtx& cx, u32x4* tile) {
     const int lane = (int)opaque((uint32_t)cx.lane);
     const int i = lane & 15, kg = lane >> 4, j = i >> 2, cc = i & 3;
     const int db = cx.wave & 3, qh = cx.wave >> 2;
@@ -308,27 +430,12 @@ LWM_DEVICE void fb_dq_accumulate(const AttnParams& p, const FusedCtx& cx, int b,
         sched_fence();
     }
     prio_lo();
-    // ---- the adds.  Row q0 + r of the tile; a row past Sq adds 0.0 to the last row that exists (branch-free:
-    // the eight adds are one asm block, wave_ops.h).
-    const int64_t row0 = (int64_t)qt * kDkvBQ;
-    float* const tile = p.dq_acc + ((int64_t)b * p.dqa_sb + row0 * p.dqa_ss + (int64_t)h * p.dqa_sh);
-    const int rows_left = (int)(p.Sq - row0 < kDkvBQ ? p.Sq - row0 : kDkvBQ);
-    const int q0 = 16 * qh + 4 * kg;
-    const uint32_t rstride = (uint32_t)p.dqa_ss * 4u;          // bytes between query rows (< 2 GiB / 32: checked by the host)
-    uint32_t voff[4];
-    f32x4 o0, o1;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const bool ok = q0 + r < rows_left;
-        const int qr = ok ? q0 + r : rows_left - 1;
-        voff[r] = (uint32_t)qr * rstride + (uint32_t)(32 * db + i) * 4u;
-        o0[r] = ok ? acc[0][r] * p.scale : 0.0f;
-        o1[r] = ok ? acc[1][r] * p.scale : 0.0f;
-    }
-#ifndef LWM_FB_NO_ATOMIC      // (timing-only builds of scripts/gpu_r3_*.sh switch parts of the step off)
-    atomic_add_f32_4x2(tile, voff, o0, o1);
+    const u32x4 o = {pack_bf16x2(acc[0][0], acc[1][0]), pack_bf16x2(acc[0][1], acc[1][1]),
+                     pack_bf16x2(acc[0][2], acc[1][2]), pack_bf16x2(acc[0][3], acc[1][3])};
+#ifndef LWM_FB_NO_STORE      // (timing-only builds switch parts of the step off)
+    global_store_b128_nt_at(tile, (uint32_t)(64 * cx.wave + lane) * 16u, o);
 #else
-    asm volatile("" ::"v"(o0), "v"(o1), "v"(voff[3]));
+    asm volatile("" ::"v"(o));
 #endif
 }
 
@@ -337,14 +444,14 @@ LWM_DEVICE void fb_dq_accumulate(const AttnParams& p, const FusedCtx& cx, int b,
 #else
 #define LWM_FB_DQ(x) x
 #endif
-LWM_KERNEL(kFbThreads) void attn_bwd_fused_kernel(AttnParams p, int32_t* ws) {
+LWM_KERNEL(kFbThreads) void attn_bwd_fused_kernel(AttnParams p, int32_t* ws, FbPart part) {
     const lds_t lds = dyn_lds();
     const int tid = thread_idx();
     const int lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = wave_uniform(tid >> 6);
     const int nkb = (p.Sk + kDkvBK - 1) / kDkvBK;
     const int nqt_all = (p.Sq + kDkvBQ - 1) / kDkvBQ;
-    const int HB = p.H * p.B;
+    const int HB = part.hbn;          // heads of this launch group (queues: local head index % 8)
     int32_t* const tickets = ws;
     int32_t* const owners = ws + kFbQueues;
     const float* const lse2 = (const float*)(ws + kFbWsHeader);
@@ -378,7 +485,8 @@ LWM_KERNEL(kFbThreads) void attn_bwd_fused_kernel(AttnParams p, int32_t* ws) {
             const int ticket = wave_uniform(lds_read_i32(ctl + 4));
             block_sync();
             if (ticket >= items) break;
-            const int hb = que + kFbQueues * (ticket / nkb);
+            const int hbl = que + kFbQueues * (ticket / nkb);      // head within the group
+            const int hb = part.hb0 + hbl;
             const int kbi = ticket % nkb;      // ascending: under a causal mask the longest walks first
             const int b = hb / p.H, h = hb % p.H;
 
@@ -429,6 +537,23 @@ LWM_KERNEL(kFbThreads) void attn_bwd_fused_kernel(AttnParams p, int32_t* ws) {
                 qt1 = hi2;
             }
             const int n = qt1 - qt0;                   // tiles to walk: loop index i -> tile qt1-1-i (walk DOWN)
+            // what the reduction will read of this key block: tiles [qt0, qt1) (empty when n <= 0)
+            if (tid == 0) {
+                int32_t* rg = part.ranges + ((int64_t)hb * nkb + kbi) * 2;
+                rg[0] = qt0;
+                rg[1] = n > 0 ? qt1 : qt0;
+            }
+            // the partial of (this key block, query tile t) goes to slot prefix_q(t) + kbi of this head's area; the walk
+            // goes DOWN from tile qt1 - 1, one partial per step, so the slot follows incrementally
+            u32x4* const ptiles = part.tiles + ((int64_t)hbl * part.tiles_per_head + kbi) * (kFbPartBytes / 16);
+            int pqt = qt1 - 1;                              // tile of the next partial
+            int64_t pslot = n > 0 ? fb_prefix_q(part.g, pqt) : 0;
+            auto next_tile = [&]() -> u32x4* {
+                u32x4* const t = ptiles + pslot * (kFbPartBytes / 16);
+                pqt -= 1;
+                pslot -= pqt >= 0 ? fb_count(part.g, pqt) : 0;
+                return t;
+            };
             auto krel_of = [&](int qt) -> int {
                 int64_t r = wk_rel - (int64_t)qt * kDkvBQ;
                 return r > 64 ? 64 : (r < -64 ? -64 : (int)r);
@@ -450,15 +575,17 @@ LWM_KERNEL(kFbThreads) void attn_bwd_fused_kernel(AttnParams p, int32_t* ws) {
                     const int left = p.Sq - qt * kDkvBQ;
                     return left < kDkvBQ ? left : kDkvBQ;
                 };
-                // step i: [the dQ of tile i-1 from the dS^T it left in LDS -> atomic adds] | staging DMA of
+                // step i: [the dQ of tile i-1 from the dS^T it left in LDS -> one partial store] | staging DMA of
                 // tile i+1 | S, dP, P, dS of tile i (dS^T -> LDS) | dV, dK | wait for the DMA | barrier.
-                // The adds are the OLDEST vector-memory operations of the step when its vmcnt(0) comes, with
-                // the whole step behind them.  Two steps per trip: the LDS buffers alternate.  Past the last
-                // tile the staging re-fetches the last tile (unconditional instruction stream).
+                // The store is the OLDEST vector-memory operation of the step when its vmcnt(0) comes, with
+                // the whole step behind it (the other order -- dQ product and store LAST in the step, vmcnt(1) at its
+                // end -- measured 26.2 vs 25.6 ms per layer, profiles/r03_fused_partials.md).  Two steps per trip: the
+                // LDS buffers alternate.  Past the last tile the staging re-fetches the last tile (unconditional
+                // instruction stream).
                 for (int i = 0; i < n; i += 2) {
                     {
                         const bool more1 = i + 1 < n;
-                        if (i > 0) LWM_FB_DQ(fb_dq_accumulate<1>(p, cx, b, h, LWM_FQT(i - 1)));
+                        if (i > 0) LWM_FB_DQ(fb_dq_partial<1>(cx, next_tile()));
                         fb_stage_issue<1>(p, cx, qb, dob, lse2, b, h, LWM_FQT(more1 ? i + 1 : i));
                         bf16x8 pb[2], dsb[2];
                         fb_tile_ab<0>(p, cx, vf, krel_of(LWM_FQT(i)), qlim_of(LWM_FQT(i)), pb, dsb);
@@ -469,7 +596,7 @@ LWM_KERNEL(kFbThreads) void attn_bwd_fused_kernel(AttnParams p, int32_t* ws) {
                     }
                     {
                         const bool more2 = i + 2 < n;
-                        LWM_FB_DQ(fb_dq_accumulate<0>(p, cx, b, h, LWM_FQT(i)));
+                        LWM_FB_DQ(fb_dq_partial<0>(cx, next_tile()));
                         fb_stage_issue<0>(p, cx, qb, dob, lse2, b, h, LWM_FQT(more2 ? i + 2 : i + 1));
                         bf16x8 pb[2], dsb[2];
                         fb_tile_ab<1>(p, cx, vf, krel_of(LWM_FQT(i + 1)), qlim_of(LWM_FQT(i + 1)), pb, dsb);
@@ -479,8 +606,8 @@ LWM_KERNEL(kFbThreads) void attn_bwd_fused_kernel(AttnParams p, int32_t* ws) {
                     }
                 }
                 // drain: the dQ of the last tile
-                if ((n - 1) & 1) LWM_FB_DQ(fb_dq_accumulate<1>(p, cx, b, h, LWM_FQT(n - 1)));
-                else LWM_FB_DQ(fb_dq_accumulate<0>(p, cx, b, h, LWM_FQT(n - 1)));
+                if ((n - 1) & 1) LWM_FB_DQ(fb_dq_partial<1>(cx, next_tile()));
+                else LWM_FB_DQ(fb_dq_partial<0>(cx, next_tile()));
             }
 #undef LWM_FQT
             // ---- dK, dV of this key block

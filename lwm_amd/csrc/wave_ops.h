@@ -21,6 +21,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 #define LWM_DEVICE __device__ __forceinline__
+#define LWM_HD __host__ __device__ inline
 #define LWM_GLOBAL __global__
 #define LWM_KERNEL(max_threads) __global__ __launch_bounds__(max_threads)
 // second argument = minimum waves per SIMD the register allocation must allow
@@ -298,39 +299,17 @@ LWM_DEVICE void global_store_b64_async(void* p, u32x2 v) {
     asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
-// Fire-and-forget f32 atomic adds (global_atomic_add_f32, no return value): the add is executed by the memory
-// system, nothing comes back, and -- issued from asm -- hipcc keeps no scoreboard entry for it.
-//   LWM_ATOMIC_AGENT = 1: sc1 -- device scope, performed at the memory side, correct under any placement.
-//   LWM_ATOMIC_AGENT = 0: no scope bits (measured on MI355X: same speed, same results -- profiles/r03_fused.md).
-#ifndef LWM_ATOMIC_AGENT
-#define LWM_ATOMIC_AGENT 1
+// 16 bytes to base + voff, fire-and-forget like the two above; `base` wave-uniform (moved to an SGPR pair here; the
+// s_nop in front covers the "VALU writes SGPR -> VMEM reads it" hazard, which hipcc does not see through asm),
+// voff a per-lane byte offset < 4 GiB.  Non-temporal: a stream that is written once and read by a later launch.
+#ifndef LWM_STORE_POLICY
+#define LWM_STORE_POLICY " nt"
 #endif
-#if LWM_ATOMIC_AGENT
-#define LWM_ATOMIC_SC " sc1"
-#else
-#define LWM_ATOMIC_SC ""
-#endif
-// Eight adds of one wave: rows r = 0..3 (byte offsets voff[r] from `base`) x two 64-byte column groups (+0, +64):
-// v0[r] to base + voff[r], v1[r] to base + voff[r] + 64.  `base` must be wave-uniform; it is moved to an SGPR pair
-// here and the s_nop covers the "VALU writes SGPR -> VMEM reads it" hazard, which hipcc does not see through asm.
-LWM_DEVICE void atomic_add_f32_4x2(float* base, const uint32_t (&voff)[4], const f32x4& v0, const f32x4& v1) {
+LWM_DEVICE void global_store_b128_nt_at(void* base, uint32_t voff, u32x4 v) {
     const uint64_t a = (uint64_t)base;
     const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
                        (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
-    asm volatile(
-        "s_nop 4\n\t"
-        "global_atomic_add_f32 %0, %4, %12" LWM_ATOMIC_SC "\n\t"
-        "global_atomic_add_f32 %0, %8, %12 offset:64" LWM_ATOMIC_SC "\n\t"
-        "global_atomic_add_f32 %1, %5, %12" LWM_ATOMIC_SC "\n\t"
-        "global_atomic_add_f32 %1, %9, %12 offset:64" LWM_ATOMIC_SC "\n\t"
-        "global_atomic_add_f32 %2, %6, %12" LWM_ATOMIC_SC "\n\t"
-        "global_atomic_add_f32 %2, %10, %12 offset:64" LWM_ATOMIC_SC "\n\t"
-        "global_atomic_add_f32 %3, %7, %12" LWM_ATOMIC_SC "\n\t"
-        "global_atomic_add_f32 %3, %11, %12 offset:64" LWM_ATOMIC_SC
-        ::"v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]),
-          "v"(v0[0]), "v"(v0[1]), "v"(v0[2]), "v"(v0[3]),
-          "v"(v1[0]), "v"(v1[1]), "v"(v1[2]), "v"(v1[3]), "s"(u)
-        : "memory");
+    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" LWM_STORE_POLICY "\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(u) : "memory");
 }
 
 // one float at base + voff + soff bytes (base and soff wave-uniform: soff rides in an SGPR, the address costs

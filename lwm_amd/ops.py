@@ -5,6 +5,7 @@ current torch stream.  There is no PyTorch / CPU fallback: tensors must be
 bf16/f32 on a ROCm device and the shared library must be present.
 """
 import ctypes as C
+import os
 import math
 
 import torch
@@ -290,35 +291,57 @@ def attn_bwd_dkdv_block(q, k, v, dout, lse, delta, *, q_start=0, k_start=0, caus
 
 
 _FUSED_WS = {}
+# Largest workspace lwm_attn_bwd_fused is given (bytes).  Its bf16 dq partials take 8 KiB per visible (256-key block,
+# 32-query tile) pair and head -- 17.2 GB for S = 32768 x 32 heads, causal; when all heads do not fit, the call runs
+# them in groups of 8 x k heads, and attn_bwd_fused_fits() says whether even 8 do (the ring driver then takes the
+# two-kernel backward).  288 GB of HBM per GPU is what makes the default comfortable.
+FUSED_WS_CAP = int(float(os.environ.get("LWM_FUSED_WS_GIB", "20")) * (1 << 30))
 
 
 def _acc_shape(B, Sq, H, D, head_major):
-    """dq accumulator: (B,Sq,H,D), or head-major (B,H,Sq,D) -- the layout the fused backward wants (a 32-query
-    tile of a head is then 16 KiB contiguous instead of 32 rows 16 KiB apart, which thrash one L2 set)."""
+    """dq accumulator / carry: (B,Sq,H,D), or head-major (B,H,Sq,D)."""
     return (B, H, Sq, D) if head_major else (B, Sq, H, D)
 
 
-def _fused_workspace(B, H, Sq, device):
-    """int32 scratch of lwm_attn_bwd_fused (work-queue tickets + the LSE in log2 units); the launch
-    initialises it itself, so one buffer per (device, stream) is reused by every call."""
+def _fused_need(B, H, Sq, Sk, q_start, k_start, causal):
+    """(bytes for all heads in one launch, bytes for the smallest group of heads)"""
     L = lib()
-    need = int(L.lwm_attn_bwd_fused_workspace_bytes(B, H, Sq))
+    f = L.lwm_attn_bwd_fused_workspace_bytes
+    return (int(f(B, H, Sq, Sk, q_start, k_start, int(bool(causal)), 0)),
+            int(f(B, H, Sq, Sk, q_start, k_start, int(bool(causal)), min(8, B * H))))
+
+
+def attn_bwd_fused_fits(B, H, Sq, Sk, q_start=0, k_start=0, causal=True):
+    """Does the fused backward's partial buffer for at least 8 heads fit under FUSED_WS_CAP?"""
+    return _fused_need(B, H, Sq, Sk, q_start, k_start, causal)[1] <= FUSED_WS_CAP
+
+
+def _fused_workspace(B, H, Sq, Sk, q_start, k_start, causal, device):
+    """Scratch of lwm_attn_bwd_fused (work-queue tickets, the LSE in log2 units, the dq partial tiles); the call
+    initialises what it needs itself, so one buffer per (device, stream) is reused by every layer."""
+    full, least = _fused_need(B, H, Sq, Sk, q_start, k_start, causal)
+    if least > FUSED_WS_CAP:
+        raise ValueError(f"attn_bwd_fused_block: the dq partials of 8 heads need {least / 2**30:.1f} GiB, more than "
+                         f"LWM_FUSED_WS_GIB = {FUSED_WS_CAP / 2**30:.1f}; use the two-kernel backward for this shard")
+    need = min(full, FUSED_WS_CAP)
     key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     ws = _FUSED_WS.get(key)
-    if ws is None or ws.numel() * 4 < need:
-        ws = _FUSED_WS[key] = torch.empty(max(need // 4, 64), dtype=torch.int32, device=device)
+    if ws is None or ws.numel() < need:
+        _FUSED_WS.pop(key, None)
+        ws = None
+        ws = _FUSED_WS[key] = torch.empty(need, dtype=torch.uint8, device=device)
     return ws
 
 
 def attn_bwd_fused_block(q, k, v, dout, lse, delta, *, q_start=0, k_start=0, causal=True, seg_q=None, seg_k=None,
                          key_valid=None, scale=None, dq=None, dk=None, dv=None, dq_acc=None, dk_acc=None,
                          dv_acc=None, dq_carry_in=False, dq_final=True, carry_in=False, final=True,
-                         acc_head_major=True):
-    """The whole backward of one ring step in one launch (lwm_attn_bwd_fused): S and dP are computed once
-    (5 GEMM units instead of 7).  `carry_in` / `final` govern dk, dv; `dq_carry_in` / `dq_final` govern dq.
-    dq_acc is the f32 accumulator the 256-key blocks ADD into (atomic adds; zeroed by the launch unless
-    dq_carry_in), head-major (B,H,Sq,D) unless acc_head_major=False -- allocated here when absent.
-    Returns (dq or dq_acc, dk or dk_acc, dv or dv_acc)."""
+                         acc_head_major=False):
+    """The whole backward of one ring step with S and dP computed once (lwm_attn_bwd_fused: 5 GEMM units instead
+    of 7).  `carry_in` / `final` govern dk, dv; `dq_carry_in` / `dq_final` govern dq.  The 256-key blocks store
+    bf16 dq partials in a workspace and a streaming pass sums them in key order (deterministic); dq_acc is only the
+    ring's f32 carry: read when dq_carry_in, written when not dq_final ((B,Sq,H,D), or (B,H,Sq,D) with
+    acc_head_major).  Returns (dq or dq_acc, dk or dk_acc, dv or dv_acc)."""
     B, Sq, H, D = q.shape
     Sk = k.shape[1]
     a = _bwd_base(q, k, v, dout, lse, delta,
@@ -335,8 +358,9 @@ def attn_bwd_fused_block(q, k, v, dout, lse, delta, *, q_start=0, k_start=0, cau
             dk_acc = torch.empty((B, Sk, H, D), dtype=torch.float32, device=q.device)
         if dv_acc is None:
             dv_acc = torch.empty((B, Sk, H, D), dtype=torch.float32, device=q.device)
-    a.dk_acc = _f32(dk_acc, "dk_acc", (B, Sk, H, D))
-    a.dv_acc = _f32(dv_acc, "dv_acc", (B, Sk, H, D))
+    if dk_acc is not None:
+        a.dk_acc = _f32(dk_acc, "dk_acc", (B, Sk, H, D))
+        a.dv_acc = _f32(dv_acc, "dv_acc", (B, Sk, H, D))
     if dq_final:
         if dq is None:
             dq = torch.empty((B, Sq, H, D), dtype=torch.bfloat16, device=q.device)
@@ -344,33 +368,19 @@ def attn_bwd_fused_block(q, k, v, dout, lse, delta, *, q_start=0, k_start=0, cau
     if dq_acc is None:
         if dq_carry_in:
             raise ValueError("attn_bwd_fused_block: dq_carry_in needs dq_acc")
-        dq_acc = _fused_dq_scratch(_acc_shape(B, Sq, H, D, acc_head_major), q.device) if dq_final else \
-            torch.empty(_acc_shape(B, Sq, H, D, acc_head_major), dtype=torch.float32, device=q.device)
-    a.dq_acc = _f32(dq_acc, "dq_acc", _acc_shape(B, Sq, H, D, acc_head_major))
+        if not dq_final:
+            dq_acc = torch.empty(_acc_shape(B, Sq, H, D, acc_head_major), dtype=torch.float32, device=q.device)
+    if dq_acc is not None:
+        a.dq_acc = _f32(dq_acc, "dq_acc", _acc_shape(B, Sq, H, D, acc_head_major))
     a.dq_acc_head_major = int(bool(acc_head_major))
     a.carry_in, a.final_out = int(bool(carry_in)), int(bool(final))
     a.dq_carry_in, a.dq_final_out = int(bool(dq_carry_in)), int(bool(dq_final))
-    ws = _fused_workspace(B, H, Sq, q.device)
+    ws = _fused_workspace(B, H, Sq, Sk, int(q_start), int(k_start), causal, q.device)
     a.bwd_workspace = ws.data_ptr()
+    a.bwd_workspace_bytes = ws.numel()
     L = lib()
     _capi.check(L, L.lwm_attn_bwd_fused(C.byref(a), _stream_ptr()), "lwm_attn_bwd_fused")
     return (dq if dq_final else dq_acc), (dk if final else dk_acc), (dv if final else dv_acc)
-
-
-_FUSED_DQ = {}
-
-
-def _fused_dq_scratch(shape, device):
-    """The f32 dq accumulator of a launch that also writes the bf16 dq (nothing reads it afterwards): one buffer
-    per (device, stream), reused by every layer -- stream order makes the reuse safe."""
-    n = 1
-    for s in shape:
-        n *= s
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
-    buf = _FUSED_DQ.get(key)
-    if buf is None or buf.numel() < n:
-        buf = _FUSED_DQ[key] = torch.empty(max(n, 1), dtype=torch.float32, device=device)
-    return buf[:n].view(shape)
 
 
 def cast_f32_to_bf16(src, dst=None):

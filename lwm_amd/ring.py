@@ -188,6 +188,7 @@ class HipBlockOps:
     bwd_dq = staticmethod(_ops.attn_bwd_dq_block)
     bwd_dkdv = staticmethod(_ops.attn_bwd_dkdv_block)
     bwd_fused = staticmethod(_ops.attn_bwd_fused_block)
+    bwd_fused_fits = staticmethod(lambda B, H, Sq, Sk: _ops.attn_bwd_fused_fits(B, H, Sq, Sk, 0, 0, False))
     cast = staticmethod(_ops.cast_f32_to_bf16)
     sum_cast = staticmethod(_ops.sum_f32_to_bf16)
     fwd_splitk = staticmethod(_ops.attn_fwd_splitk)
@@ -203,19 +204,25 @@ class HipBlockOps:
         return torch.zeros(shape, dtype=dtype, device=like.device)
 
 
-# Two backward flavours:
-#   two kernels (default)  lwm_attn_bwd_dkdv + lwm_attn_bwd_dq: 7 GEMM units executed, no atomics, every output
-#                          bit-reproducible;
-#   one launch             lwm_attn_bwd_fused (LWM_FUSED_BWD=1, bench.py --fused-bwd): S and dP computed once, 5 GEMM
-#                          units; dq accumulated by fire-and-forget f32 atomic adds, so its last bits depend on the
-#                          order in which the key blocks happen to arrive (dk, dv stay bit-reproducible).
-# LWM_DETERMINISTIC=1 forces the first whatever else is set.  DESIGN.md section 3 has both measured side by side.
+# Two backward flavours, both deterministic (no atomics, fixed summation orders):
+#   two kernels   lwm_attn_bwd_dkdv + lwm_attn_bwd_dq: 7 GEMM units executed (S and dP are recomputed by the second);
+#   fused         lwm_attn_bwd_fused: S and dP computed once, 5 GEMM units; the dq contribution of every 256-key block
+#                 is stored as a bf16 partial (8 KiB per (key block, 32-query tile) pair and head, in a workspace of up
+#                 to LWM_FUSED_WS_GIB) and summed in key order by a streaming pass.
+# LWM_FUSED_BWD=0/1 and bench.py --fused-bwd / --two-kernel-bwd select; LWM_DETERMINISTIC=1 (kept from round 2, when the
+# fused flavour used atomics) forces the two-kernel path.  A shard whose partials do not fit the workspace takes the
+# two-kernel path.  DESIGN.md section 3 has both measured side by side.
 DETERMINISTIC = os.environ.get("LWM_DETERMINISTIC", "0") == "1"
 FUSED_BACKWARD = not DETERMINISTIC and os.environ.get("LWM_FUSED_BWD", "0") == "1"
 
 
-def _use_fused(block, segment_ids):
-    return FUSED_BACKWARD and hasattr(block, "bwd_fused")
+def _use_fused(block, B, H, Sq, Sk):
+    """fused flavour wanted, offered by the backend, and its partial buffer (sized for the full Sq x Sk rectangle: an
+    upper bound over causal offsets) fits the workspace cap"""
+    if not (FUSED_BACKWARD and hasattr(block, "bwd_fused")):
+        return False
+    fits = getattr(block, "bwd_fused_fits", None)
+    return True if fits is None else bool(fits(B, H, Sq, Sk))
 
 
 # ----------------------------------------------------------------- helpers
@@ -400,7 +407,7 @@ def ring_backward(block, comm, q, k, v, out, lses, dout, *, layout, causal=True,
         sq, sk, kv = masks(qs, qs)
         kw = dict(q_start=qs[2], k_start=qs[2], causal=causal, seg_q=sq, seg_k=sk, key_valid=kv,
                   scale=scale)
-        if _use_fused(block, segment_ids):
+        if _use_fused(block, B, H, q.shape[1], k.shape[1]):
             return block.bwd_fused(q, k, v, dout, lses[0], deltas[0], dq_final=True, final=True, **kw)
         dk, dv = block.bwd_dkdv(q, k, v, dout, lses[0], deltas[0], final=True, **kw)
         dq = block.bwd_dq(q, k, v, dout, lses[0], deltas[0], final=True, **kw)
@@ -500,10 +507,9 @@ def _mesh_backward(block, comm, q, k, v, lses, dout, deltas, *, layout, causal, 
     for t in range(n):
         for qi, _ in pairs_at(t)[1]:
             n_dq[qi] += 1
-    fused = _use_fused(block, segment_ids)
-    # (the fused backward wants its dq accumulator head-major, see ops._acc_shape; the dQ kernel takes either)
-    acc_shape = (lambda ln: (B, H, ln, D)) if fused else (lambda ln: (B, ln, H, D))
-    hm = dict(acc_head_major=True) if fused else {}
+    fused = _use_fused(block, B, H, max(ln for _, ln, _ in qsegs), max(ln for _, ln, _ in layout.segments(r)))
+    acc_shape = lambda ln: (B, ln, H, D)
+    hm = {}
     dq_acc = [block.empty(acc_shape(ln), torch.float32, q) if n_dq[qi] > 1 else None
               for qi, (_, ln, _) in enumerate(qsegs)]
     done_dq = [0] * len(qsegs)
@@ -555,7 +561,7 @@ def _mesh_backward(block, comm, q, k, v, lses, dout, deltas, *, layout, causal, 
             first = ki not in part
             if first:
                 part[ki] = tuple(_xbuf(comm, block, ("part", t, ki, w), (B, ks[1], H, D), torch.float32, q) for w in (0, 1))
-            if dq_acc[qi] is None:          # a q segment with a single contribution still needs the accumulator
+            if dq_acc[qi] is None and not (fin and done_dq[qi] == 1):      # (cannot happen: n_dq > 1 allocated it)
                 dq_acc[qi] = block.empty(acc_shape(qs[1]), torch.float32, q)
             block.bwd_fused(_rows(q, qs), held[ki][0], held[ki][1], _rows(dout, qs), lses[qi], deltas[qi],
                             q_start=qs[2], k_start=ks[2], causal=causal, seg_q=sq, seg_k=sk, key_valid=kv, scale=scale,

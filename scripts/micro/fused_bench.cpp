@@ -1,5 +1,5 @@
 // fused_bench.cpp -- times the attention backward of one layer through the C ABI, without Python:
-//   fused_bench <liblwm_hip.so> [S=32768] [H=32] [reps=3] [what=all|fused|two]
+//   fused_bench <liblwm_hip.so> [S=32768] [H=32] [reps=3] [what=all|fused|two] [heads per fused launch = all]
 // One line per library: HIP-event ms per launch of lwm_attn_fwd, lwm_attn_bwd_fused and of delta + dkdv + dq,
 // checksums of dq / dk (fused vs two-kernel) and the largest element-wise dq difference, so that a timing
 // variant that breaks the result is visible.  Used by scripts/gpu_fused_ab.sh to sweep variant builds in one GPU call.
@@ -87,7 +87,7 @@ int main(int argc, char** argv) {
     attn_fn fwd = sym<attn_fn>(lib, "lwm_attn_fwd"), bdelta = sym<attn_fn>(lib, "lwm_attn_bwd_delta"),
             bdq = sym<attn_fn>(lib, "lwm_attn_bwd_dq"), bdkdv = sym<attn_fn>(lib, "lwm_attn_bwd_dkdv"),
             bfused = sym<attn_fn>(lib, "lwm_attn_bwd_fused");
-    auto ws_bytes = sym<int64_t (*)(int32_t, int32_t, int32_t)>(lib, "lwm_attn_bwd_fused_workspace_bytes");
+    auto ws_bytes = sym<int64_t (*)(int32_t, int32_t, int32_t, int32_t, int64_t, int64_t, int32_t, int32_t)>(lib, "lwm_attn_bwd_fused_workspace_bytes");
     auto last_error = sym<const char* (*)(void)>(lib, "lwm_last_error");
 
     const int D = 128;
@@ -100,7 +100,8 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&lse, (size_t)H * S * 4));
     CK(hipMalloc(&delta, (size_t)H * S * 4));
     CK(hipMalloc(&dq_acc, n * 4));
-    const int64_t wsb = ws_bytes(1, H, S);
+    const int group = argc > 6 ? atoi(argv[6]) : 0;      // (batch*head) slices per fused launch (0 = all)
+    const int64_t wsb = ws_bytes(1, H, S, S, 0, 0, 1, group);
     CK(hipMalloc(&ws, wsb));
     CK(hipMalloc(&sums, 64));
     fill_bf16<<<2048, 256>>>(q, n, 1u, 1.7f);
@@ -119,7 +120,7 @@ int main(int argc, char** argv) {
     a.scale = 1.0f / sqrtf((float)D);
     a.causal = 1; a.final_out = 1; a.dq_final_out = 1;
     a.bwd_workspace = ws;
-    a.dq_acc_head_major = 1;
+    a.bwd_workspace_bytes = wsb;
     if (fwd(&a, nullptr) != 0) {
         fprintf(stderr, "fwd: %s\n", last_error());
         return 2;

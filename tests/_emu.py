@@ -55,11 +55,11 @@ def _ptr(a):
     return None if a is None else a.ctypes.data
 
 
-def aligned(shape, dtype):
-    """16-byte aligned zero array."""
+def aligned(shape, dtype, align=16):
+    """`align`-byte aligned zero array."""
     n = int(np.prod(shape)) * np.dtype(dtype).itemsize
-    raw = np.zeros(n + 16, dtype=np.uint8)
-    off = (-raw.ctypes.data) % 16
+    raw = np.zeros(n + align, dtype=np.uint8)
+    off = (-raw.ctypes.data) % align
     return raw[off:off + n].view(dtype).reshape(shape)
 
 
@@ -164,16 +164,14 @@ def attn_bwd(q, k, v, out, lse, dout, *, causal=True, q_start=0, k_start=0, seg_
     _capi.check(L, L.lwm_attn_bwd_delta(C.byref(a), None), "lwm_attn_bwd_delta")
     if fused:
         a.dq_carry_in, a.dq_final_out = a.carry_in, a.final_out
-        # the fused kernel's accumulator layout: head-major (B,H,Sq,D); the test keeps (B,Sq,H,D) arrays
-        hm = aligned((B, H, Sq, D), np.float32)
-        hm[...] = dq_acc.transpose(0, 2, 1, 3)
-        a.dq_acc = hm.ctypes.data
-        a.dq_acc_head_major = 1
-        ws = aligned((max(L.lwm_attn_bwd_fused_workspace_bytes(B, H, Sq), 16) // 4,), np.int32)
-        ws[...] = -7     # the launch must zero it itself
+        # a workspace with room for 8 heads per launch when there are more (exercises the head groups)
+        need = L.lwm_attn_bwd_fused_workspace_bytes(B, H, Sq, Sk, int(q_start), int(k_start), int(bool(causal)),
+                                                    8 if B * H > 8 else 0)
+        ws = aligned((max(need, 256),), np.uint8, align=256)
+        ws[...] = 0xA5     # the call must initialise what it reads
         a.bwd_workspace = ws.ctypes.data
+        a.bwd_workspace_bytes = need
         _capi.check(L, L.lwm_attn_bwd_fused(C.byref(a), None), "lwm_attn_bwd_fused")
-        dq_acc[...] = hm.transpose(0, 2, 1, 3)
     else:
         _capi.check(L, L.lwm_attn_bwd_dkdv(C.byref(a), None), "lwm_attn_bwd_dkdv")
         _capi.check(L, L.lwm_attn_bwd_dq(C.byref(a), None), "lwm_attn_bwd_dq")

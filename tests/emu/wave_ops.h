@@ -30,6 +30,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 #define LWM_DEVICE static inline __attribute__((always_inline))
+#define LWM_HD static inline
 #define LWM_GLOBAL static
 #define LWM_KERNEL(max_threads) static
 #define LWM_KERNEL_OCC(max_threads, waves_per_simd) static
@@ -409,23 +410,8 @@ LWM_DEVICE f32x4 global_load_f32x4_l2(const float* base, uint32_t byte_off) {
     return v;
 }
 
-LWM_DEVICE void emu_atomic_add_f32(float* q, float v) {   // blocks run on different host threads
-    uint32_t* p = (uint32_t*)q;
-    uint32_t old = __atomic_load_n(p, __ATOMIC_RELAXED), want;
-    do {
-        float f;
-        memcpy(&f, &old, 4);
-        f += v;
-        memcpy(&want, &f, 4);
-    } while (!__atomic_compare_exchange_n(p, &old, want, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
-}
-LWM_DEVICE void atomic_add_f32_4x2(float* base, const uint32_t (&voff)[4], const f32x4& v0, const f32x4& v1) {
-    for (int r = 0; r < 4; ++r) {
-        emu_atomic_add_f32((float*)((char*)base + voff[r]), v0[r]);
-        emu_atomic_add_f32((float*)((char*)base + voff[r] + 64), v1[r]);
-    }
-}
 LWM_DEVICE void global_store_f32x4_async(float* p, f32x4 v) { memcpy(p, &v, 16); }
+LWM_DEVICE void global_store_b128_nt_at(void* base, uint32_t voff, u32x4 v) { memcpy((char*)base + voff, &v, 16); }
 LWM_DEVICE void global_store_b64_async(void* p, u32x2 v) { memcpy(p, &v, 8); }
 
 LWM_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
