@@ -47,6 +47,9 @@ constexpr int kF4LdsBytes = kF4OffScan + 64;
 #define LWM_F4_PRESCALE 0
 #endif
 constexpr bool kF4Prescale = LWM_F4_PRESCALE != 0;
+// gaps (MFMA index inside a phase) after which the hot loop issues its LDS-DMA pieces (odd gaps only -- the ones
+// without an LDS read -- measured the same: 7.40 - 7.51 vs 7.37 - 7.43 ms)
+constexpr int kF4G0a = 2, kF4G0b = 8, kF4G1a = 2, kF4G1b = 7, kF4G1c = 12, kF4G2a = 1, kF4G2b = 5, kF4G2c = 9;
 
 struct F4Ctx {
     uint32_t ka[8];             // K row-fragment addresses, tile 0, keys 0..31, per 16-wide d step
@@ -118,11 +121,12 @@ LWM_DEVICE void f4_dma1(uint32_t voff, const char* src, lds_t dst) {
     const uint64_t a = (uint64_t)src;
     const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
                        (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_nop 3\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(u), "s"(dst)
-                 : "memory");
+    // M0 is written and left: nothing else in the kernel reads it (LDS instructions do not on gfx9+, and the f4_dma<N>
+    // blocks of the slow paths save and restore it themselves).  `src` is wave-uniform and, in the hot loop, produced
+    // by scalar adds well before this point: no "VALU writes SGPR -> VMEM reads it" wait states are needed here.
+    // Measured against the save / 4 wait states / write / load / restore form: 7.37 - 7.43 vs 7.55 - 7.70 ms per
+    // layer (profiles/r03_fwd64_dma.txt: the three pieces of a P.V phase cost 76 cycles there and ~0 here).
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(u), "s"(dst) : "memory");
 #endif
 }
 // the pieces one tile iteration issues inside its four phases (all wave-uniform but the offsets)
@@ -316,11 +320,11 @@ LWM_DEVICE void f4_phase1(const F4Ctx& cx, const bf16x8 (&qf)[2][8], f32x16 (&sN
         }
         // LDS-DMA pieces of this phase (measured: a piece needs ~1000 cycles from issue to landed under load, so the
         // last one leaves in the first half of the iteration's third phase; what is needed first goes first)
-        if (DMA == 0 && g == 2) f4_dma1(st.voff_k[2], dm.k_up_src, dm.k_up_dst);            // K(i+1), keys 32..63
-        if (DMA == 0 && g == 8) f4_dma1(st.voff_k[3], dm.k_up_src, dm.k_up_dst + 4096);
-        if (DMA == 2 && g == 1) f4_dma1(st.voff_v[3], dm.v_src, dm.v_dst + 12288);         // V(i+1), last piece
-        if (DMA == 2 && g == 5) f4_dma1(st.voff_k[0], dm.k_lo_src, dm.k_lo_dst);            // K(i+2), keys 0..31
-        if (DMA == 2 && g == 9) f4_dma1(st.voff_k[1], dm.k_lo_src, dm.k_lo_dst + 4096);
+        if (DMA == 0 && g == kF4G0a) f4_dma1(st.voff_k[2], dm.k_up_src, dm.k_up_dst);            // K(i+1), keys 32..63
+        if (DMA == 0 && g == kF4G0b) f4_dma1(st.voff_k[3], dm.k_up_src, dm.k_up_dst + 4096);
+        if (DMA == 2 && g == kF4G2a) f4_dma1(st.voff_v[3], dm.v_src, dm.v_dst + 12288);         // V(i+1), last piece
+        if (DMA == 2 && g == kF4G2b) f4_dma1(st.voff_k[0], dm.k_lo_src, dm.k_lo_dst);            // K(i+2), keys 0..31
+        if (DMA == 2 && g == kF4G2c) f4_dma1(st.voff_k[1], dm.k_lo_src, dm.k_lo_dst + 4096);
         if (DO_FIN) {
             // finish-softmax slice: elements 2g, 2g+1 of the finished half tile, flattened [qb][r]; the pair of the
             // PREVIOUS gap is packed and summed here (a transcendental's result is not read by the very next instruction)
@@ -363,9 +367,9 @@ LWM_DEVICE void f4_phase2(F4Ctx& cx, const bf16x8 (&pb)[2][2], f32x16 (&acc)[2][
         if (KNEXT >= 0 && h == 15) kfr[2] = f4_kread<KNEXT < 0 ? 0 : KNEXT>(cx, 2);
         sched_fence();
         if (DO_PV) f4_mfma_o(acc[qb][db], vfr[f & 3], pb[qb][t]);
-        if (DMA == 1 && h == 2) f4_dma1(st.voff_v[0], dm.v_src, dm.v_dst);                  // V(i+1)
-        if (DMA == 1 && h == 7) f4_dma1(st.voff_v[1], dm.v_src, dm.v_dst + 4096);
-        if (DMA == 1 && h == 12) f4_dma1(st.voff_v[2], dm.v_src, dm.v_dst + 8192);
+        if (DMA == 1 && h == kF4G1a) f4_dma1(st.voff_v[0], dm.v_src, dm.v_dst);                  // V(i+1)
+        if (DMA == 1 && h == kF4G1b) f4_dma1(st.voff_v[1], dm.v_src, dm.v_dst + 4096);
+        if (DMA == 1 && h == kF4G1c) f4_dma1(st.voff_v[2], dm.v_src, dm.v_dst + 8192);
         const int e = 2 * h, fq = e >> 4, r = e & 15;
         if (DO_PV) f4_add(ls[fq], ps[fq][r >> 1]);
         if (DO_MAX) {
