@@ -167,8 +167,25 @@ typedef struct LwmRingArgs {
     int32_t B, c, H, D;      /* c = local sequence length = S_global / n */
     float scale;
     int32_t causal;
-    void* workspace;         /* lwm_ring_workspace_bytes(B, c, H, D, backward) bytes, 256-byte aligned */
+    void* workspace;         /* lwm_ring_workspace_bytes(B, c, H, D, backward, n, schedule) bytes, 256-byte aligned */
+    int32_t layout;          /* LWM_RING_LAYOUT_*: which positions a rank owns */
+    int32_t schedule;        /* LWM_RING_SCHEDULE_*: how K/V and the dK/dV contributions move */
 } LwmRingArgs;
+
+/* Ownership.  CONTIGUOUS = the reference's: rank r holds positions [r*c, (r+1)*c) (lwm/llama.py:560-562).
+ * ZIGZAG: rank r holds the half-chunks r and 2n-1-r (c/2 positions each, local rows [0,c/2) and [c/2,c)) -- the
+ * permutation applied at the boundary that balances causal work: under contiguous ownership rank n-1 computes n
+ * blocks and rank 0 one.  With two segments lse is two dense [B,H,c/2] pieces, one per segment (an opaque residual
+ * between lwm_ring_attn_fwd and _bwd); everything else keeps its [B,c,H,D] shape in local row order. */
+enum { LWM_RING_LAYOUT_CONTIGUOUS = 0, LWM_RING_LAYOUT_ZIGZAG = 1 };
+/* Exchange.  RING = the reference's (lax.ppermute i -> i+1): the K/V block, and in the backward its f32 dK/dV
+ * carry, hop to the next rank once per step -- every byte crosses ONE link per step, n-1 (n) times.
+ * DIRECT: MI355X's xGMI is a full mesh, so nothing is forwarded: one grouped exchange brings every rank exactly
+ * the K/V segments its queries can see from their owners (all 7 links busy at once; zigzag + causal: 1/4 fewer
+ * bytes than rotating whole blocks), and in the backward the f32 dK/dV partial of each remote block goes straight
+ * back to its owner, which sums the <= n partials in a fixed order (lwm_sum_f32_to_bf16).  Results agree with RING
+ * up to the f32 association of that sum. */
+enum { LWM_RING_SCHEDULE_RING = 0, LWM_RING_SCHEDULE_DIRECT = 1 };
 
 int lwm_ring_create(void* nccl_comm, int32_t rank, int32_t n, void* side_stream, LwmRing** out);
 int lwm_ring_unique_id(void* id128);   /* 128 bytes = ncclUniqueId */
@@ -176,7 +193,8 @@ int lwm_ring_create_from_id(const void* id128, int32_t rank, int32_t n, void* si
 int lwm_ring_create_transport(const LwmRingTransport* transport, int32_t rank, int32_t n, void* side_stream,
                               LwmRing** out);
 int lwm_ring_destroy(LwmRing* ring);
-int64_t lwm_ring_workspace_bytes(int32_t B, int32_t c, int32_t H, int32_t D, int32_t backward);
+int64_t lwm_ring_workspace_bytes(int32_t B, int32_t c, int32_t H, int32_t D, int32_t backward, int32_t n,
+                                 int32_t schedule);
 int lwm_ring_attn_fwd(LwmRing* ring, const LwmRingArgs* args, void* compute_stream);
 int lwm_ring_attn_bwd(LwmRing* ring, const LwmRingArgs* args, void* compute_stream);
 /* bytes this ring object has sent since creation (diagnostic) */

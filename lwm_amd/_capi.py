@@ -46,7 +46,12 @@ class LwmRingArgs(C.Structure):
         ("segment_ids", C.c_void_p), ("key_valid", C.c_void_p),
         ("B", C.c_int32), ("c", C.c_int32), ("H", C.c_int32), ("D", C.c_int32),
         ("scale", C.c_float), ("causal", C.c_int32), ("workspace", C.c_void_p),
+        ("layout", C.c_int32), ("schedule", C.c_int32),
     ]
+
+
+RING_LAYOUT = {"contiguous": 0, "zigzag": 1}
+RING_SCHEDULE = {"ring": 0, "direct": 1, "mesh": 1}
 
 
 RING_GROUP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
@@ -80,7 +85,7 @@ PROTOTYPES = {
     "lwm_ring_create_transport": (C.c_int, [C.POINTER(LwmRingTransport), C.c_int32, C.c_int32, C.c_void_p,
                                             C.POINTER(C.c_void_p)]),
     "lwm_ring_destroy": (C.c_int, [C.c_void_p]),
-    "lwm_ring_workspace_bytes": (C.c_int64, [C.c_int32] * 5),
+    "lwm_ring_workspace_bytes": (C.c_int64, [C.c_int32] * 7),
     "lwm_ring_attn_fwd": (C.c_int, [C.c_void_p, C.POINTER(LwmRingArgs), C.c_void_p]),
     "lwm_ring_attn_bwd": (C.c_int, [C.c_void_p, C.POINTER(LwmRingArgs), C.c_void_p]),
     "lwm_ring_bytes_sent": (C.c_int64, [C.c_void_p]),

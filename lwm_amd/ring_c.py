@@ -5,10 +5,12 @@ lax.ppermute under `ringattention` (lwm/llama.py:539-569, SURVEY.md Appendix A.1
 Python.  This module is the thin torch caller: it creates the ring object, owns the workspace tensor and
 wraps the two entry points in an autograd Function.
 
-Ownership is the reference's contiguous one (rank r holds positions [r*c, (r+1)*c), lwm/llama.py:560-562)
-and the schedule is the reference's ring.  The Python driver (lwm_amd/ring.py) additionally offers the
-zigzag ownership and the full-mesh schedule; `ring_attention_c` is the C-ABI path with the same results
-as ring.py's (layout="contiguous", schedule="ring")."""
+Ownership: "contiguous" = the reference's (rank r holds positions [r*c, (r+1)*c), lwm/llama.py:560-562) or
+"zigzag" (half-chunks r and 2n-1-r: balanced causal work; the caller shards with SeqLayout.global_index).
+Schedule: "ring" = the reference's neighbour rotation, or "direct" (alias "mesh"): every rank fetches the K/V
+segments its queries can see straight from their owners in one grouped exchange and returns f32 dK/dV partials
+to the owners -- lwm_amd/ring.py's mesh schedule, driven from C.  Same results as ring.py with the same layout and
+schedule."""
 from __future__ import annotations
 
 import ctypes as C
@@ -24,7 +26,8 @@ class CRing:
     """One ring object per (process group, device).  transport: None = RCCL (a communicator is created from
     an ncclUniqueId broadcast over `group`), or a _capi.LwmRingTransport (tests)."""
 
-    def __init__(self, group=None, *, rank=None, size=None, transport=None, device=None):
+    def __init__(self, group=None, *, rank=None, size=None, transport=None, device=None, layout="contiguous",
+                 schedule="ring"):
         import torch.distributed as dist
         L = lib()
         if rank is None:
@@ -54,6 +57,7 @@ class CRing:
         _capi.check(L, rc, "lwm_ring_create")
         self._h = h
         self._ws = None
+        self.layout, self.schedule = _capi.RING_LAYOUT[layout], _capi.RING_SCHEDULE[schedule]
 
     def close(self):
         if getattr(self, "_h", None):
@@ -71,7 +75,7 @@ class CRing:
         return int(lib().lwm_ring_bytes_sent(self._h))
 
     def _workspace(self, B, c, H, D, backward):
-        need = int(lib().lwm_ring_workspace_bytes(B, c, H, D, int(backward)))
+        need = int(lib().lwm_ring_workspace_bytes(B, c, H, D, int(backward), self.size, self.schedule))
         if self._ws is None or self._ws.numel() < need + 256:
             self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
         off = (-self._ws.data_ptr()) % 256
@@ -95,6 +99,7 @@ class CRing:
                 raise ValueError(f"key_valid: expected contiguous uint8 {(B, Sg)} (replicated, full length)")
             a.key_valid = key_valid.data_ptr()
         a.workspace = self._workspace(B, c, H, D, backward)
+        a.layout, a.schedule = self.layout, self.schedule
         return a
 
     def forward(self, q, k, v, *, causal=True, segment_ids=None, key_valid=None, scale=None):

@@ -27,11 +27,17 @@ def test_ring_symbols_sizes_and_validation():
     # the double-buffered f32 dK/dV carries.  All pieces 256-byte aligned.
     B, c, H, D = 1, 16384, 32, 128
     blk16, blk32 = B * c * H * D * 2, B * c * H * D * 4
-    fwd = L.lwm_ring_workspace_bytes(B, c, H, D, 0)
-    bwd = L.lwm_ring_workspace_bytes(B, c, H, D, 1)
+    fwd = L.lwm_ring_workspace_bytes(B, c, H, D, 0, 8, 0)
+    bwd = L.lwm_ring_workspace_bytes(B, c, H, D, 1, 8, 0)
     assert fwd >= 4 * blk16 + blk32 and fwd < 4 * blk16 + blk32 + (1 << 22)
     assert bwd - fwd >= 5 * blk32 and bwd % 256 == 0
-    assert L.lwm_ring_workspace_bytes(0, c, H, D, 0) == 0
+    assert L.lwm_ring_workspace_bytes(0, c, H, D, 0, 8, 0) == 0
+    # direct schedule: the K/V of the 7 peers stay resident; the backward adds a sent and a received f32 dK/dV
+    # partial per peer and the local one
+    dfwd = L.lwm_ring_workspace_bytes(B, c, H, D, 0, 8, 1)
+    dbwd = L.lwm_ring_workspace_bytes(B, c, H, D, 1, 8, 1)
+    assert dfwd >= 14 * blk16 + blk32 and dfwd < 14 * blk16 + blk32 + (1 << 22)
+    assert dbwd - dfwd >= (1 + 28 + 2) * blk32 and dbwd % 256 == 0
     h = C.c_void_p()
     for rank, n in ((2, 2), (-1, 2), (0, 0), (0, 65)):
         assert L.lwm_ring_create(None, rank, n, None, C.byref(h)) == cap.LWM_EINVAL and not h.value
@@ -98,14 +104,17 @@ class _Mailbox:
         return t
 
 
-def _run_c_ring(n, S, H, causal, packed, padded, B=1):
+def _run_c_ring(n, S, H, causal, packed, padded, B=1, layout="contiguous", schedule="ring"):
     import torch
+    from lwm_amd.ring import SeqLayout
     from lwm_amd.ring_c import CRing
     g = torch.Generator().manual_seed(7)
     mk = lambda: torch.randn(B, S, H, 128, generator=g).to(torch.bfloat16).cuda()
     q, k, v, do = mk(), mk(), mk(), mk()
     seg = kv = None
-    if packed:
+    if callable(packed):
+        seg = packed(S).to(torch.int32)[None].expand(B, S).contiguous().cuda()
+    elif packed:
         seg = torch.zeros(B, S, dtype=torch.int32)
         seg[:, S // 3:] = 1
         seg[:, (5 * S) // 8:] = 2
@@ -114,19 +123,19 @@ def _run_c_ring(n, S, H, causal, packed, padded, B=1):
         kv = torch.ones(B, S, dtype=torch.uint8)
         kv[:, 5:40] = 0
         kv = kv.cuda()
-    c = S // n
+    lay = SeqLayout(layout, n, S)
     box = _Mailbox(n)
     res, errs = [None] * n, []
 
     def worker(r):
         try:
-            ring = CRing(rank=r, size=n, transport=box.transport(r) if n > 1 else None)
-            sl = slice(r * c, (r + 1) * c)
-            ql, kl, vl, dol = (t[:, sl].contiguous() for t in (q, k, v, do))
+            ring = CRing(rank=r, size=n, transport=box.transport(r) if n > 1 else None, layout=layout, schedule=schedule)
+            idx = lay.global_index(r).cuda()
+            ql, kl, vl, dol = (t[:, idx].contiguous() for t in (q, k, v, do))
             out, lse = ring.forward(ql, kl, vl, causal=causal, segment_ids=seg, key_valid=kv)
             dq, dk, dv = ring.backward(ql, kl, vl, out, lse, dol, causal=causal, segment_ids=seg, key_valid=kv)
             torch.cuda.synchronize()
-            res[r] = (out, dq, dk, dv, ring.bytes_sent)
+            res[r] = (idx, out, dq, dk, dv, ring.bytes_sent)
             ring.close()
         except Exception as e:  # pragma: no cover
             import traceback
@@ -137,22 +146,30 @@ def _run_c_ring(n, S, H, causal, packed, padded, B=1):
     for t in ths:
         t.start()
     for t in ths:
-        t.join(timeout=300)
+        t.join(timeout=600)
     assert not errs, errs
-    got = [torch.cat([res[r][i] for r in range(n)], 1) for i in range(4)]
-    return got, (q, k, v, do, seg, kv), [r[4] for r in res]
+    got = [torch.zeros_like(q) for _ in range(4)]
+    for idx, *parts, _ in res:
+        for dst, src in zip(got, parts):
+            dst[:, idx] = src
+    return got, (q, k, v, do, seg, kv), [r[5] for r in res]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,causal,packed,padded", [(1, True, True, True), (2, True, False, False), (4, True, True, True),
-                                                    (4, False, False, True), (8, True, True, False)])
-def test_c_ring_schedule_vs_oracle_and_python_driver(n, causal, packed, padded):
+@pytest.mark.parametrize("n,causal,packed,padded,layout,schedule", [
+    (1, True, True, True, "contiguous", "ring"), (2, True, False, False, "contiguous", "ring"),
+    (4, True, True, True, "contiguous", "ring"), (4, False, False, True, "contiguous", "ring"),
+    (8, True, True, False, "contiguous", "ring"),
+    (4, True, True, True, "zigzag", "ring"), (2, True, False, False, "zigzag", "direct"),
+    (4, True, True, True, "zigzag", "direct"), (4, False, False, True, "zigzag", "direct"),
+    (8, True, True, False, "zigzag", "direct"), (4, True, False, True, "contiguous", "direct")])
+def test_c_ring_schedule_vs_oracle_and_python_driver(n, causal, packed, padded, layout, schedule):
     import torch
     from oracle import attention_ref as R
     from lwm_amd.ring import ring_attention
     from tests._parity import check
     S, H = 512 * max(n // 2, 1) if n > 1 else 640, 2
-    got, (q, k, v, do, seg, kv), sent = _run_c_ring(n, S, H, causal, packed, padded)
+    got, (q, k, v, do, seg, kv), sent = _run_c_ring(n, S, H, causal, packed, padded, layout=layout, schedule=schedule)
     f = lambda t: t.float().cpu().numpy()
     sg = None if seg is None else seg.cpu().numpy()
     kvn = None if kv is None else kv.cpu().numpy()
@@ -161,18 +178,91 @@ def test_c_ring_schedule_vs_oracle_and_python_driver(n, causal, packed, padded):
     from tests._parity import dq_row_slack
     slack = dq_row_slack(f(do), ro, f(k))
     for name, a, b in zip(("out", "dq", "dk", "dv"), got, (ro, rq, rk, rv)):
-        check(f"{name} c-ring n={n}", f(a), b, row_slack=slack if name == "dq" else None)
+        check(f"{name} c-ring n={n} {layout} {schedule}", f(a), b, row_slack=slack if name == "dq" else None)
     # the single-device Python driver on the same data (same kernels, other association order at most)
     q1, k1, v1 = (t.clone().requires_grad_(True) for t in (q, k, v))
     o1 = ring_attention(q1, k1, v1, causal=causal, segment_ids=seg, key_valid=kv)
     o1.backward(do)
     for name, a, b in zip(("out", "dq", "dk", "dv"), got, (o1.detach(), q1.grad, k1.grad, v1.grad)):
         assert ((a.float() - b.float()).abs().max() / b.float().abs().max()).item() <= 8e-3, name
-    if n > 1:
+    if n > 1 and schedule == "ring":
         # forward: n-1 rotations of K and V; backward: n-1 of K and V + n of the two f32 carries
         c = S // n
         blk = c * H * 128
         assert all(s == (n - 1) * 2 * blk * 2 * 2 + n * 2 * blk * 4 for s in sent), sent
+    if n > 1 and schedule == "direct" and not causal:
+        # every rank ships its whole K/V shard to every peer twice (forward, backward) and one f32 dK/dV partial of a
+        # whole shard back to every peer
+        c = S // n
+        blk = c * H * 128
+        assert all(s == (n - 1) * (2 * 2 * blk * 2 + 2 * blk * 4) for s in sent), sent
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout,schedule", [("contiguous", "ring"), ("zigzag", "ring"), ("zigzag", "direct")])
+def test_c_ring_batch_2(layout, schedule):
+    """B = 2: segments of a [B,c,H,D] shard are not contiguous over the batch -- the carries and the direct
+    schedule's buffers are segment-major, K/V pieces travel per batch row."""
+    import torch
+    from lwm_amd.ring import ring_attention
+    n, S, H = 4, 1024, 2
+    got, (q, k, v, do, seg, kv), _ = _run_c_ring(n, S, H, True, True, True, B=2, layout=layout, schedule=schedule)
+    q1, k1, v1 = (t.clone().requires_grad_(True) for t in (q, k, v))
+    o1 = ring_attention(q1, k1, v1, causal=True, segment_ids=seg, key_valid=kv)
+    o1.backward(do)
+    for name, a, b in zip(("out", "dq", "dk", "dv"), got, (o1.detach(), q1.grad, k1.grad, v1.grad)):
+        assert ((a.float() - b.float()).abs().max() / b.float().abs().max()).item() <= 8e-3, name
+
+
+@pytest.mark.gpu
+def test_c_ring_direct_moves_fewer_bytes_than_the_ring():
+    """zigzag + causal: a rank's early half-chunk is invisible to every earlier rank's queries and its late
+    half-chunk to every later rank's early queries, so the direct schedule ships ~3/4 of the K/V bytes the rotating
+    ring does, and no f32 carry is forwarded through bystanders (the verdict's bar: < 0.8x)."""
+    n, S, H = 8, 2048, 2
+    _, _, ring_sent = _run_c_ring(n, S, H, True, False, False, layout="zigzag", schedule="ring")
+    _, _, direct_sent = _run_c_ring(n, S, H, True, False, False, layout="zigzag", schedule="direct")
+    assert sum(direct_sent) < 0.8 * sum(ring_sent), (sum(direct_sent), sum(ring_sent))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("schedule,packed", [("direct", False), ("direct", True), ("ring", False)])
+def test_c_ring8_at_config3_shard_shapes_vs_oracle(schedule, packed):
+    """BASELINE configs[2] through the C driver: S = 131072 over an 8-rank zigzag ring, c = 16384 per rank (two
+    half-chunks of 8192 at global offsets r*8192 and (15-r)*8192), thread-played ranks, the real kernels, events and
+    workspace arithmetic; checked against the fp64 oracle in windows on the first, a middle and the last rank (as
+    tests/test_gpu_ring_sim.py does for the Python driver)."""
+    import torch
+    from oracle import attention_ref as R
+    from tests._parity import check, dq_row_slack
+    n, S, H = 8, 131072, 2
+    bounds = [0, 40000, 70000, 100000, S]
+    seg_fn = (lambda S_: torch.bucketize(torch.arange(S_), torch.tensor(bounds[1:-1]), right=True)) if packed else False
+    got, (q, k, v, do, seg, kv), sent = _run_c_ring(n, S, H, True, seg_fn, False, layout="zigzag", schedule=schedule)
+    f = lambda t, rows, h: t[:, rows, h:h + 1].float().cpu().numpy()
+    out, dq, dk, dv = got
+    if not packed:
+        for h, r0 in ((0, 96), (1, 65408), (0, S - 256), (1, 36000)):
+            rows, keys = slice(r0, r0 + 256), slice(0, r0 + 256)
+            ro, _ = R.dense_attention(f(q, rows, h), f(k, keys, h), f(v, keys, h), causal=True, q_start=r0)
+            rq, _, _ = R.dense_attention_bwd(f(q, rows, h), f(k, keys, h), f(v, keys, h), f(do, rows, h), causal=True, q_start=r0)
+            check(f"out c-ring8 {schedule} row {r0}", f(out, rows, h), ro)
+            check(f"dq c-ring8 {schedule} row {r0}", f(dq, rows, h), rq, row_slack=dq_row_slack(f(do, rows, h), ro, f(k, keys, h)))
+        K0, h = S - 512, 1
+        rows, allk = slice(K0, S), slice(0, S)
+        _, rk, rv = R.dense_attention_bwd(f(q, rows, h), f(k, allk, h), f(v, allk, h), f(do, rows, h), causal=True, q_start=K0)
+        check(f"dk c-ring8 {schedule} last keys", f(dk, slice(K0, K0 + 256), h), rk[:, K0:K0 + 256])
+        check(f"dv c-ring8 {schedule} last keys", f(dv, slice(K0 + 256, S), h), rv[:, K0 + 256:])
+        return
+    for i, (a, b) in enumerate(zip(bounds[:-1], bounds[1:])):
+        h, qa, w0 = i & 1, b - 2048, b - 256
+        rows, keys, win = slice(qa, b), slice(a, b), slice(w0, b)
+        ro, _ = R.dense_attention(f(q, rows, h), f(k, keys, h), f(v, keys, h), causal=True, q_start=qa - a)
+        rq, rk, rv = R.dense_attention_bwd(f(q, rows, h), f(k, keys, h), f(v, keys, h), f(do, rows, h), causal=True, q_start=qa - a)
+        check(f"out c-ring8 doc {i}", f(out, win, h), ro[:, w0 - qa:])
+        check(f"dq c-ring8 doc {i}", f(dq, win, h), rq[:, w0 - qa:], row_slack=dq_row_slack(f(do, win, h), ro[:, w0 - qa:], f(k, keys, h)))
+        check(f"dk c-ring8 doc {i}", f(dk, win, h), rk[:, w0 - a:])
+        check(f"dv c-ring8 doc {i}", f(dv, win, h), rv[:, w0 - a:])
 
 
 _RCCL_FIRST_CONTACT = r'''
