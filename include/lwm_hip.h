@@ -206,6 +206,24 @@ int64_t lwm_ring_bytes_sent(const LwmRing* ring);
  * table, the by-value ncclUniqueId, ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on a non-default stream. */
 int lwm_ring_selftest(LwmRing* ring, const void* src, void* dst, int64_t bytes, void* compute_stream);
 
+/* A transport that needs neither RCCL nor compute units: every rank owns a mailbox (device memory) that its peers map
+ * through hipIpcMemHandles; a message is one hipMemcpyAsync into the receiver's mailbox (SDMA over xGMI between GPUs)
+ * followed by a stream memory operation on an uncached flag word (hipStreamWriteValue32 / hipStreamWaitValue32), and
+ * one local copy out of the mailbox on the receiving side.  All 256 CUs stay with the attention kernels, and because
+ * IPC also works between processes sharing ONE GPU the complete multi-process driver can run on a single-GPU box.
+ *   1. every rank: lwm_ring_ipc_export(rank, n, slot_bytes, slots, info, &ipc) -- allocates mailbox + flags on the
+ *      current device; info receives lwm_ring_ipc_info_bytes() bytes to publish.  slot_bytes >= the largest message
+ *      (a K/V or f32 dK/dV piece: B * c * H * D * 4 bytes covers everything the driver sends), slots >= 4 * B
+ *      messages per ordered pair and group (8 is a good default); memory = n * slots * slot_bytes per rank.
+ *   2. the host all-gathers the n info blobs by its own means (rank-major) -> lwm_ring_ipc_connect(ipc, all_infos).
+ *   3. lwm_ring_create_ipc(ipc, side_stream, &ring) -- a ring object like any other; destroy the ring, then the ipc. */
+typedef struct LwmRingIpc LwmRingIpc;
+int64_t lwm_ring_ipc_info_bytes(void);
+int lwm_ring_ipc_export(int32_t rank, int32_t n, int64_t slot_bytes, int32_t slots, void* info_out, LwmRingIpc** out);
+int lwm_ring_ipc_connect(LwmRingIpc* ipc, const void* all_infos);
+int lwm_ring_create_ipc(LwmRingIpc* ipc, void* side_stream, LwmRing** out);
+int lwm_ring_ipc_destroy(LwmRingIpc* ipc);
+
 /* (min, max) of segment_ids over each block of 32 rows, excluding rows whose valid[] is 0
  * (valid may be NULL); an all-invalid block gets (INT32_MAX, INT32_MIN).
  * blocks: [B][ceil(S/32)][2] int32. */

@@ -90,6 +90,11 @@ PROTOTYPES = {
     "lwm_ring_attn_bwd": (C.c_int, [C.c_void_p, C.POINTER(LwmRingArgs), C.c_void_p]),
     "lwm_ring_bytes_sent": (C.c_int64, [C.c_void_p]),
     "lwm_ring_selftest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "lwm_ring_ipc_info_bytes": (C.c_int64, []),
+    "lwm_ring_ipc_export": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "lwm_ring_ipc_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lwm_ring_create_ipc": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "lwm_ring_ipc_destroy": (C.c_int, [C.c_void_p]),
     "lwm_attn_segment_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "lwm_attn_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, LwmTensor4, C.c_void_p, C.c_void_p,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

@@ -3,6 +3,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <unistd.h>
 #include "wave_ops.h"
 #include "launch.h"
 #include "lwm_hip.h"
@@ -17,3 +18,4 @@
 #include "gemv.h"
 #include "api.inc"
 #include "ring_driver.inc"
+#include "ring_ipc.inc"

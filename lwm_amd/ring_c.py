@@ -23,11 +23,14 @@ from .ops import _t4
 
 
 class CRing:
-    """One ring object per (process group, device).  transport: None = RCCL (a communicator is created from
-    an ncclUniqueId broadcast over `group`), or a _capi.LwmRingTransport (tests)."""
+    """One ring object per (process group, device).  transport: None / "rccl" = RCCL (a communicator is created
+    from an ncclUniqueId broadcast over `group`); "ipc" = the library's CU-free transport (peer mailboxes mapped through
+    hipIpcMemHandles, hipMemcpyAsync + stream memory operations; `ipc_slot_bytes` must cover the largest message:
+    B * c * H * D * 4 bytes, the f32 dK/dV piece of a whole shard, covers everything); or a _capi.LwmRingTransport
+    (tests).  `group` may be a gloo group: only the bootstrap (id / handle exchange) goes through it."""
 
     def __init__(self, group=None, *, rank=None, size=None, transport=None, device=None, layout="contiguous",
-                 schedule="ring"):
+                 schedule="ring", ipc_slot_bytes=None, ipc_slots=8):
         import torch.distributed as dist
         L = lib()
         if rank is None:
@@ -41,9 +44,26 @@ class CRing:
         side_ptr = C.c_void_p(self.side.cuda_stream) if self.side is not None else None
         h = C.c_void_p()
         self._transport = transport           # keep the callbacks alive
+        self._ipc = None
         if self.size == 1:
             rc = L.lwm_ring_create(None, 0, 1, None, C.byref(h))
-        elif transport is not None:
+        elif transport == "ipc":
+            if not ipc_slot_bytes:
+                raise ValueError("CRing(transport='ipc') needs ipc_slot_bytes (>= B*c*H*D*4 covers every message)")
+            nb = int(L.lwm_ring_ipc_info_bytes())
+            info = (C.c_char * nb)()
+            ipc = C.c_void_p()
+            with torch.cuda.device(self.device):
+                _capi.check(L, L.lwm_ring_ipc_export(self.rank, self.size, int(ipc_slot_bytes), int(ipc_slots), info, C.byref(ipc)),
+                            "lwm_ring_ipc_export")
+            self._ipc = ipc
+            blobs = [None] * self.size
+            dist.all_gather_object(blobs, bytes(info), group=group)
+            allinfo = (C.c_char * (nb * self.size)).from_buffer_copy(b"".join(blobs))
+            with torch.cuda.device(self.device):
+                _capi.check(L, L.lwm_ring_ipc_connect(ipc, allinfo), "lwm_ring_ipc_connect")
+            rc = L.lwm_ring_create_ipc(ipc, side_ptr, C.byref(h))
+        elif transport is not None and transport != "rccl":
             rc = L.lwm_ring_create_transport(C.byref(transport), self.rank, self.size, side_ptr, C.byref(h))
         else:
             ident = (C.c_char * 128)()
@@ -63,6 +83,9 @@ class CRing:
         if getattr(self, "_h", None):
             lib().lwm_ring_destroy(self._h)
             self._h = None
+        if getattr(self, "_ipc", None):
+            lib().lwm_ring_ipc_destroy(self._ipc)
+            self._ipc = None
 
     def __del__(self):
         try:
