@@ -616,9 +616,17 @@ def main():
                     help="A/B: run the backward as the one-launch lwm_attn_bwd_fused (5 GEMM units executed) instead "
                          "of lwm_attn_bwd_dkdv + lwm_attn_bwd_dq (7); also LWM_FUSED_BWD=1")
     ap.add_argument("--two-kernel-bwd", action="store_true", help="(default) the two-kernel backward")
-    ap.add_argument("--c-ring", action="store_true",
-                    help="N > 1: run the exchange through the C-ABI ring driver (lwm_ring_attn_fwd/bwd: RCCL send/recv on a "
-                         "side HIP stream, contiguous ownership, the reference's ring schedule) instead of lwm_amd/ring.py")
+    ap.add_argument("--driver", default=None, choices=["c", "python"],
+                    help="N > 1: who drives the exchange.  c (default on GPUs) = the C-ABI ring driver (lwm_ring_attn_fwd/bwd: "
+                         "RCCL send/recv or the IPC transport on a side HIP stream, zigzag / contiguous ownership, ring / direct "
+                         "schedule); python = lwm_amd/ring.py over torch.distributed (the only choice for --backend gloo without "
+                         "--transport ipc)")
+    ap.add_argument("--c-ring", action="store_true", help="same as --driver c")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "ipc"],
+                    help="C driver only: rccl = ncclSend/ncclRecv; ipc = the library's CU-free transport (peer mailboxes mapped "
+                         "through hipIpcMemHandles + hipMemcpyAsync + stream memory operations).  With --backend gloo the ranks may "
+                         "share GPUs: `--gpus 4 --backend gloo --transport ipc` runs the whole C-driver path on a 1-GPU box")
+    ap.add_argument("--no-configs2", action="store_true", help="N > 1: skip the S = 131072 leg (BASELINE configs[2]) of the line")
     ap.add_argument("--init-timeout", type=int, default=180,
                     help="seconds before a stuck RCCL rendezvous / first collective is reported as an error line")
     ap.add_argument("--no-full-model", action="store_true", help="skip the N=1 leg `model_full` (all 32 layers of LWM-7B)")
@@ -647,13 +655,20 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus "
                          f"must agree (plain `python bench.py --gpus {args.gpus}` launches the ranks itself)")
-    dry = args.backend == "gloo"
+    shared = args.backend == "gloo"             # the ranks may share devices
+    dry = shared and args.transport != "ipc"    # ... and stage their messages through host memory (Python driver)
+    if args.c_ring:
+        args.driver = "c"
+    if args.driver is None:
+        args.driver = "python" if dry else "c"
+    if args.driver == "c" and dry:
+        raise SystemExit("--driver c needs a GPU transport: --backend nccl, or --backend gloo --transport ipc")
     n_dev = torch.cuda.device_count()
-    if n_dev == 0 or (not dry and local_rank >= n_dev):
+    if n_dev == 0 or (not shared and local_rank >= n_dev):
         fail_line(args, "devices", RuntimeError(f"rank {rank} (local {local_rank}) sees {n_dev} GPU(s); "
                                                 f"--gpus {args.gpus} needs one GPU per rank (--backend gloo is the dry run)"))
         sys.exit(3)
-    dev_index = local_rank % n_dev if dry else local_rank
+    dev_index = local_rank % n_dev if shared else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     rccl_ranks_seen = None
@@ -668,15 +683,18 @@ def main():
             if dry:
                 dist.init_process_group("gloo", timeout=tmo)
                 comm = HostStagedComm(torch, dist, TorchRingComm, args.schedule)
+            elif shared:
+                dist.init_process_group("gloo", timeout=tmo)      # bootstrap only: the data moves through the IPC transport
+                comm = None
             else:
                 dist.init_process_group("nccl", device_id=dev, timeout=tmo)
                 comm = TorchRingComm(dist.group.WORLD, schedule=args.schedule)
             # first contact: every rank contributes 1 through the backend that will carry the exchange
             # (RCCL over xGMI, or gloo in the dry run) and one neighbour send/recv goes round the ring
-            one = torch.ones(1, dtype=torch.float32, device="cpu" if dry else dev)
+            one = torch.ones(1, dtype=torch.float32, device="cpu" if shared else dev)
             dist.all_reduce(one)
             rccl_ranks_seen = int(one.item())
-            if not dry:
+            if not shared:
                 tok = torch.full((1,), float(rank), device=dev)
                 got = torch.empty(1, device=dev)
                 for r_ in dist.batch_isend_irecv([dist.P2POp(dist.isend, tok, (rank + 1) % world),
@@ -722,22 +740,35 @@ def main():
         bwd_fused = staticmethod(lambda *a, **kw: timer.run("attn_bwd_fused_kernel", ops.attn_bwd_fused_block, *a, **kw))
 
     c_ring = None
-    if args.c_ring and world > 1 and not dry:
+    sched_c = "ring" if args.schedule == "ring" else "direct"
+    S2 = 131072                     # BASELINE configs[2]'s sequence: a second leg of every N > 1 line
+    if args.driver == "c" and world > 1:
         from lwm_amd.ring_c import CRing
-        if args.layout != "contiguous":
-            args.layout = "contiguous"
-            layout = SeqLayout("contiguous", world, S)
-        c_ring = CRing(dist.group.WORLD)
+        c_max = max(c, S2 // world if not args.no_configs2 else 0)
+        c_ring = CRing(dist.group.WORLD, transport=args.transport, layout=args.layout, schedule=sched_c,
+                       ipc_slot_bytes=c_max * N_HEADS * HEAD_DIM * 4)
 
-    def step():
+    def step(ring=None, ten=None, lay=None, seg=None):
+        ring = c_ring if ring is None else ring
+        q_, k_, v_, do_ = (q, k, v, do) if ten is None else ten
+        lay = layout if lay is None else lay
+        seg = segment_ids if ten is None else seg
         for _ in range(args.layers):
-            if c_ring is not None:
-                o_, l_ = c_ring.forward(q, k, v, causal=True, segment_ids=segment_ids)
-                c_ring.backward(q, k, v, o_, l_, do, causal=True, segment_ids=segment_ids)
+            if ring is not None:
+                o_, l_ = ring.forward(q_, k_, v_, causal=True, segment_ids=seg)
+                ring.backward(q_, k_, v_, o_, l_, do_, causal=True, segment_ids=seg)
                 continue
-            out, lses = ring_forward(TimedOps, comm, q, k, v, layout=layout, causal=True, segment_ids=segment_ids)
-            ring_backward(TimedOps, comm, q, k, v, out, lses, do, layout=layout, causal=True,
-                          segment_ids=segment_ids)
+            out, lses = ring_forward(TimedOps, comm, q_, k_, v_, layout=lay, causal=True, segment_ids=seg)
+            ring_backward(TimedOps, comm, q_, k_, v_, out, lses, do_, layout=lay, causal=True, segment_ids=seg)
+
+    def null_ring():
+        """the same C driver with a transport that moves nothing (buffers left as allocated): what the step costs when
+        every transfer is free"""
+        from lwm_amd import _capi
+        from lwm_amd.ring_c import CRing
+        ok = lambda *a: 0
+        t = _capi.LwmRingTransport(None, _capi.RING_GROUP_FN(ok), _capi.RING_SEND_FN(ok), _capi.RING_SEND_FN(ok), _capi.RING_GROUP_FN(ok))
+        return CRing(rank=rank, size=world, transport=t, layout=args.layout, schedule=sched_c)
 
     def barrier():
         torch.cuda.synchronize()
@@ -748,7 +779,7 @@ def main():
     def max_over_ranks(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cpu" if dry else dev)
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if shared else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -780,7 +811,20 @@ def main():
                             "exposed_ms_per_step": (elapsed / args.steps - compute_only) * 1e3,
                             "overlap_efficiency": compute_only / (elapsed / args.steps)}
             else:
-                exchange = {"schedule": "ring (C-ABI driver)", "bytes_sent_per_rank": c_ring.bytes_sent}
+                sent = c_ring.bytes_sent
+                nr = null_ring()
+                step(nr)
+                barrier()
+                t0 = time.perf_counter()
+                step(nr)
+                torch.cuda.synchronize()
+                compute_only = max_over_ranks(time.perf_counter() - t0)
+                nr.close()
+                exchange = {"schedule": f"{sched_c} (C-ABI driver, {args.transport})", "transport": args.transport,
+                            "bytes_sent_per_rank_per_step": sent / (args.steps + args.warmup),
+                            "compute_only_ms_per_step": compute_only * 1e3,
+                            "exposed_ms_per_step": (elapsed / args.steps - compute_only) * 1e3,
+                            "overlap_efficiency": compute_only / (elapsed / args.steps)}
             # The N=1 line of this bench is BASELINE configs[1] (S=32768); attention cost is quadratic
             # in S, so tokens/s at different S do not compare.  For a like-for-like strong-scaling
             # figure every rank also times ONE layer of THIS problem (same S) on its GPU alone.
@@ -813,6 +857,60 @@ def main():
         except Exception as e:      # the main line must still be printed
             exchange = dict(exchange or {}, error=repr(e))
 
+    configs2 = None
+    if world > 1 and not args.no_configs2 and S != S2 and not args.packed:
+        # BASELINE configs[2] (S = 131072 over the ring) at THIS N, in the same line: `value` stays the S = 32768 strong-scaling
+        # series, this object is the configuration the metric names.
+        try:
+            lay2 = SeqLayout(args.layout, world, S2)
+            c2 = lay2.local_len
+            g2 = torch.Generator(device=dev).manual_seed(4321 + rank)
+            ten2 = [torch.randn(1, c2, N_HEADS, HEAD_DIM, generator=g2, device=dev, dtype=torch.float32).to(torch.bfloat16)
+                    for _ in range(4)]
+            sent0 = c_ring.bytes_sent if c_ring is not None else None
+            step(ten=ten2, lay=lay2)
+            barrier()
+            t0 = time.perf_counter()
+            n2 = 2
+            for _ in range(n2):
+                step(ten=ten2, lay=lay2)
+            barrier()
+            el2 = max_over_ranks(time.perf_counter() - t0)
+            configs2 = {
+                "workload": f"LWM-7B attention fwd+bwd, {args.layers} layers, B=1, S={S2}, H=32, D=128, causal, ring={world}, "
+                            f"layout={lay2.kind} [BASELINE configs[2]" + ("" if world == 8 else f" at N={world}") + "]",
+                "seq_len": S2, "steps": n2, "ms_per_step": el2 * 1e3 / n2, "tokens_per_s": S2 * n2 / el2,
+                "tokens_per_s_per_gpu": S2 * n2 / el2 / world,
+                "path_algorithmic_tflops_per_gpu": 7.0 * gemm_unit_flops(S2) * args.layers / (el2 / n2) / 1e12 / world,
+                "exchange": ({"schedule": f"{sched_c} (C-ABI driver, {args.transport})",
+                              "bytes_sent_per_rank_per_step": (c_ring.bytes_sent - sent0) / (n2 + 1)} if c_ring is not None
+                             else {"schedule": getattr(comm, "schedule", None)}),
+            }
+            del ten2
+            # the same problem on one GPU, one layer
+            g1 = torch.Generator(device=dev).manual_seed(98)
+            t1 = [torch.randn(1, S2, N_HEADS, HEAD_DIM, generator=g1, device=dev, dtype=torch.float32).to(torch.bfloat16)
+                  for _ in range(4)]
+            lay1 = SeqLayout("contiguous", 1, S2)
+
+            def one_layer2():
+                o, l = ring_forward(HipBlockOps, SingleComm(), t1[0], t1[1], t1[2], layout=lay1, causal=True)
+                ring_backward(HipBlockOps, SingleComm(), t1[0], t1[1], t1[2], o, l, t1[3], layout=lay1, causal=True)
+
+            one_layer2()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            one_layer2()
+            torch.cuda.synchronize()
+            tl = max_over_ranks(time.perf_counter() - t0)
+            tps1 = S2 / (tl * args.layers)
+            configs2["same_problem_on_1_gpu"] = {"ms_per_layer": tl * 1e3, "tokens_per_s": tps1,
+                                                 "speedup": configs2["tokens_per_s"] / tps1,
+                                                 "strong_scaling_efficiency": configs2["tokens_per_s"] / tps1 / world}
+            del t1
+        except Exception as e:
+            configs2 = dict(configs2 or {}, error=repr(e))
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         tokens_per_s = S * args.steps / elapsed
@@ -837,13 +935,15 @@ def main():
                              + (" [BASELINE configs[2] problem]" if world > 1 and S == 131072 else "")
                              + (" [BASELINE configs[1] problem, ring-sharded]" if world > 1 and S == 32768 else "")),
                 "seq_len": S, "ring": world, "layers": args.layers,
-                "exchange_schedule": ("ring (C-ABI driver, RCCL on a side stream)" if c_ring is not None else
+                "exchange_schedule": (f"{sched_c} (C-ABI driver, {args.transport} on a side stream)" if c_ring is not None else
                                       getattr(comm, "schedule", None)) if world > 1 else None,
             },
             "tokens_per_s_per_gpu": tokens_per_s / world,
             "exchange": exchange,
+            "configs2": configs2,
             "rccl_ranks_seen": rccl_ranks_seen,
-            "dry_run": "ranks share devices, messages staged through host memory; timings are not xGMI" if dry else None,
+            "dry_run": ("ranks share devices, messages staged through host memory; timings are not xGMI" if dry else
+                        "ranks share devices (IPC transport inside one GPU); timings are not xGMI" if shared and world > 1 else None),
             "path_algorithmic_tflops_per_gpu": algo_flops_step / (ms_per_step * 1e-3) / 1e12 / world,
         }
         if world == 1:

@@ -629,6 +629,28 @@ class _RingAttention(torch.autograd.Function):
         return dq, dk, dv, None, None, None
 
 
+_C_RINGS = {}
+
+
+def _c_driver_wanted(group, block_ops):
+    if block_ops is not None or os.environ.get("LWM_RING_DRIVER", "c") != "c":
+        return False
+    try:
+        return dist.get_backend(group) == "nccl" and dist.get_world_size(group) > 1
+    except Exception:
+        return False
+
+
+def _c_ring_for(group, layout_kind, schedule):
+    """one C ring object (communicator, side stream, workspace) per (group, layout, schedule), reused by every layer"""
+    from .ring_c import CRing
+    key = (id(group), layout_kind, schedule, torch.cuda.current_device())
+    ring = _C_RINGS.get(key)
+    if ring is None:
+        ring = _C_RINGS[key] = CRing(group, layout=layout_kind, schedule=schedule)
+    return ring
+
+
 def ring_attention(q, k, v, *, group=None, causal=True, segment_ids=None, key_valid=None,
                    scale=None, layout="contiguous", block_ops=None, comm=None):
     """Differentiable ring attention on the local (B, S/n, H, D) shards.
@@ -646,6 +668,15 @@ def ring_attention(q, k, v, *, group=None, causal=True, segment_ids=None, key_va
             # never default to WORLD: a data-parallel job would silently ring its replicas
             raise RuntimeError("ring_attention in a multi-process job needs the sequence-parallel group "
                                "(group=... or comm=...; torch.distributed.group.WORLD for a pure ring)")
+        elif _c_driver_wanted(group, block_ops):
+            # N > 1 on GPUs: the exchange is driven by the C-ABI ring driver (lwm_ring_attn_fwd / _bwd: RCCL on a side HIP
+            # stream, the same layouts, the direct schedule = this module's "mesh"); this module stays the reference
+            # implementation of the schedule and the gloo / stand-in path of the CPU tests.  LWM_RING_DRIVER=python opts out.
+            from .ring_c import ring_attention_c
+            kind = layout.kind if isinstance(layout, SeqLayout) else layout
+            sched = os.environ.get("LWM_RING_SCHEDULE") or "mesh"
+            return ring_attention_c(q, k, v, _c_ring_for(group, kind, sched), causal=causal, segment_ids=segment_ids,
+                                    key_valid=key_valid, scale=scale)
         else:
             comm = TorchRingComm(group)
     block = block_ops if block_ops is not None else HipBlockOps
