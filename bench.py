@@ -45,50 +45,102 @@ def gemm_unit_flops(S):
     return float(S) * S * D_MODEL
 
 
-def cpu_baseline(S_target):
-    """Port of the reference's blockwise attention on PyTorch-CPU fp32, timed on
-    a bounded sample (S=4096, 8 heads, 1 layer, fwd+bwd) and scaled to the
-    workload by the algorithmic FLOP count (7*S^2*d_model per layer)."""
+def _cpu_threads():
+    """The one `cores` convention of this file: the threads a CPU leg actually computes with (torch's intra-op pool;
+    the OpenMP oracle is given the same number)."""
+    import torch
+    return int(torch.get_num_threads())
+
+
+def cpu_config1():
+    """BASELINE configs[0] end to end on the host cores: the fp32 CPU model (oracle/llama_model_ref.py) as a 2-layer slice
+    of LWM-7B (d_model 4096, 32 heads, FFN 11008, vocab 32000), B = 1, S = 4096, loss forward + backward, random weights
+    N(0, 0.02^2).  One pass (~15-30 s).  FLOPs: 6 x (matmul parameters of the slice) x tokens + the causal attention's
+    7 * S^2 * d_model per layer."""
+    import types
+    import torch
+    from oracle import llama_model_ref as M
+    S, d, H, F, V, L = 4096, D_MODEL, N_HEADS, 11008, 32000, 2
+    cfg = types.SimpleNamespace(num_attention_heads=H, hidden_size=d, theta=1e4, max_sequence_length=S,
+                                num_hidden_layers=L, rms_norm_eps=1e-6)
+    g = torch.Generator().manual_seed(0)
+    w = lambda *shape: (torch.randn(*shape, generator=g) * 0.02).requires_grad_(True)
+    st = {"wte": w(V, d), "lm_head": w(d, V), "ln_f.kernel": torch.ones(d, requires_grad=True)}
+    for i in range(L):
+        p = f"h.{i}."
+        st.update({p + "attention_norm.kernel": torch.ones(d, requires_grad=True), p + "ffn_norm.kernel": torch.ones(d, requires_grad=True),
+                   p + "attention.wq": w(d, d), p + "attention.wk": w(d, d), p + "attention.wv": w(d, d), p + "attention.wo": w(d, d),
+                   p + "feed_forward.w1": w(d, F), p + "feed_forward.w3": w(d, F), p + "feed_forward.w2": w(F, d)})
+    tok = torch.randint(0, V, (1, S + 1), generator=g)
+    t0 = time.perf_counter()
+    loss, _ = M.forward_loss(st, cfg, tok[:, :-1], tok[:, 1:])
+    loss.backward()
+    dt = time.perf_counter() - t0
+    matmul_params = L * (4 * d * d + 3 * d * F) + d * V
+    flops = 6.0 * matmul_params * S + 7.0 * S * S * d * L
+    return {"workload": "LWM-7B 2-layer slice + lm_head, B=1, S=4096, fp32, loss fwd+bwd on the host cores [BASELINE configs[0]]",
+            "seconds": dt, "tokens_per_s": S / dt, "gflops": flops / dt / 1e9, "loss": float(loss.detach()),
+            "kind": "port", "cores": _cpu_threads(), "sample": "oracle/llama_model_ref.forward_loss + backward, 1 pass"}
+
+
+def cpu_baseline(S_target, full=True):
+    """Port of the reference's blockwise attention on PyTorch-CPU fp32 (oracle/attention_torch_cpu.py), timed on bounded
+    samples: the headline figure from S = 4096 x 8 heads (fwd+bwd, 1 layer), scaled to the workload by the algorithmic
+    FLOP count (7*S^2*d_model per layer, labelled as extrapolated); op points at S = 8192 (2 heads) and 16384 (1 head)
+    show that the rate holds as S grows; `config1` is BASELINE configs[0] end to end."""
     import torch
     from oracle.attention_torch_cpu import blockwise_fwd_bwd
-    S, H = 4096, 8
     g = torch.Generator().manual_seed(0)
-    q, k, v, do = (torch.randn(1, S, H, HEAD_DIM, generator=g) for _ in range(4))
-    blockwise_fwd_bwd(q[:, :1024], k[:, :1024], v[:, :1024], do[:, :1024])  # warm the BLAS threads
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        blockwise_fwd_bwd(q, k, v, do)
-        reps += 1
-        if time.perf_counter() - t0 > 10.0 or reps >= 8:
-            break
-    dt = (time.perf_counter() - t0) / reps
-    flops_sample = 7.0 * S * S * (H * HEAD_DIM)
-    flops_per_s = flops_sample / dt
+
+    def op_point(S, H, budget_s, max_reps):
+        q, k, v, do = (torch.randn(1, S, H, HEAD_DIM, generator=g) for _ in range(4))
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            blockwise_fwd_bwd(q, k, v, do)
+            reps += 1
+            if time.perf_counter() - t0 > budget_s or reps >= max_reps:
+                break
+        dt = (time.perf_counter() - t0) / reps
+        return {"S": S, "heads": H, "reps": reps, "seconds_per_pass": dt, "gflops": 7.0 * S * S * (H * HEAD_DIM) / dt / 1e9}
+
+    w = (torch.randn(1, 1024, 8, HEAD_DIM, generator=g) for _ in range(4))
+    blockwise_fwd_bwd(*w)  # warm the BLAS threads
+    p4 = op_point(4096, 8, 8.0, 4)
+    flops_per_s = p4["gflops"] * 1e9
     flops_workload = 7.0 * gemm_unit_flops(S_target) * N_LAYERS
-    return {
+    res = {
         "value": S_target / (flops_workload / flops_per_s),
         "unit": "tokens/s",
-        "cores": torch.get_num_threads(),
+        "cores": _cpu_threads(),
         "kind": "port",
-        "gflops": flops_per_s / 1e9,
-        "sample": f"oracle/attention_torch_cpu.blockwise_fwd_bwd fp32, S={S}, {H} heads, 1 layer, "
-                  f"chunks 1024/1024, {reps} reps of {dt:.2f}s; scaled to S={S_target}, 32 heads, "
-                  f"32 layers by the 7*S^2*d_model FLOP law (extrapolated)",
+        "gflops": p4["gflops"],
+        "sample": f"oracle/attention_torch_cpu.blockwise_fwd_bwd fp32, S=4096, 8 heads, 1 layer, chunks 1024/1024, "
+                  f"{p4['reps']} reps of {p4['seconds_per_pass']:.2f}s; scaled to S={S_target}, 32 heads, 32 layers by the "
+                  f"7*S^2*d_model FLOP law (extrapolated)",
     }
+    if full:
+        try:
+            res["op_points"] = [p4, op_point(8192, 2, 6.0, 2), op_point(16384, 1, 6.0, 1)]
+            res["config1"] = cpu_config1()
+        except Exception as e:      # a baseline leg must not cost the bench line
+            res["error"] = repr(e)
+    return res
 
 
 VQGAN_ENC_GFLOP, VQGAN_DEC_GFLOP = 216.6, 477.4   # per 256x256 frame, SURVEY.md Appendix B
 MFMA_F32_PEAK_TFLOPS = 157.3                      # exact-f32 MFMA, MI355X_MICROARCH.md
 
 
-def vqgan_leg(torch, frames=32, reps=3, config4_frames=1020):
+def vqgan_leg(torch, frames=64, reps=3, config4_frames=1020):
     """Secondary leg (not part of `value`): VQGAN encode/decode of synthetic
     256x256 frames U(-1,1), random weights of the default VQGANConfig
     (lwm/vqgan.py:62-77), frames resident in HBM; plus the C oracle on the host
-    cores for one frame (cpu_baseline of this leg).  32 frames per call: frames are independent
+    cores for one frame (cpu_baseline of this leg).  64 frames per call: frames are independent
     (BASELINE configs[3] tokenises 1020 of them) and the late-encoder / early-decoder layers have
-    only 256-4096 output pixels per frame (round 2, 32 frames: 438 / 209 frames/s)."""
+    only 256-4096 output pixels per frame -- at 32 frames their 384 tiles of 128 x 128 fill 256 CUs 1.5 times, at 64
+    exactly 3 times (round 3 sweep, same box: 32 / 64 / 128 frames = 439 / 457 / 461 encode, 209 / 213 / 214 decode
+    frames/s; profiles/r03_vqgan_frames.txt)."""
     import numpy as np
     from lwm_amd.vqgan import VQGAN, VQGANConfig, random_params
     cfg = VQGANConfig.get_default_config()
@@ -140,6 +192,7 @@ def vqgan_leg(torch, frames=32, reps=3, config4_frames=1020):
                      "kernel": "conv_patch_c256 / conv_patch_c128 / conv_igemm (decode pass)"},
     }
     try:
+        os.environ.setdefault("OMP_NUM_THREADS", str(_cpu_threads()))     # the one `cores` convention (set before the library loads)
         from oracle import vqgan_ref as R
         x1 = px[:1].cpu().numpy()
         t0 = time.perf_counter()
@@ -148,7 +201,7 @@ def vqgan_leg(torch, frames=32, reps=3, config4_frames=1020):
         R.decode(params, ridx, cfg.as_dict())
         t2 = time.perf_counter()
         res["cpu_baseline"] = {"encode_frames_per_s": 1.0 / (t1 - t0), "decode_frames_per_s": 1.0 / (t2 - t1),
-                               "cores": os.cpu_count(), "kind": "port",
+                               "cores": int(os.environ.get("OMP_NUM_THREADS", _cpu_threads())), "kind": "port",
                                "sample": "oracle/vqgan_ref (C, OpenMP) encode+decode of 1 frame"}
         res["indices_match_oracle"] = bool((idx[0].cpu().numpy() == ridx[0]).all())
     except Exception as e:  # the oracle is a checker; its absence must not break the bench line
