@@ -226,7 +226,7 @@ def test_c_ring_direct_moves_fewer_bytes_than_the_ring():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("schedule,packed", [("direct", False), ("direct", True), ("ring", False)])
+@pytest.mark.parametrize("schedule,packed", [("direct", True), ("ring", False)])
 def test_c_ring8_at_config3_shard_shapes_vs_oracle(schedule, packed):
     """BASELINE configs[2] through the C driver: S = 131072 over an 8-rank zigzag ring, c = 16384 per rank (two
     half-chunks of 8192 at global offsets r*8192 and (15-r)*8192), thread-played ranks, the real kernels, events and
