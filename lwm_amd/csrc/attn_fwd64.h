@@ -47,6 +47,17 @@ constexpr int kF4LdsBytes = kF4OffScan + 64;
 #define LWM_F4_PRESCALE 0
 #endif
 constexpr bool kF4Prescale = LWM_F4_PRESCALE != 0;
+// LDS fragments (K row fragments for S, V transposed fragments for P.V: eight of each per half tile) are requested
+// kF4Ahead MFMA pairs before the MFMA that consumes them, through register rings of eight (index = fragment): with ONE
+// wave on the SIMD nothing else covers the LDS latency, and 512 registers leave room for the deeper ring.  The first
+// kF4Ahead fragments of a phase are requested during the last gaps of the phase before it.  Measured (profiles/
+// r03_fwd64_dma.txt): distance 3 / 5 / 6 / 7 = 7.50 / 7.40 / 7.40 / 7.36 ms per layer.
+#ifndef LWM_F4_AHEAD
+#define LWM_F4_AHEAD 7
+#endif
+constexpr int kF4Ahead = LWM_F4_AHEAD;
+static_assert(kF4Ahead >= 1 && kF4Ahead <= 7, "prefetch distance in fragments");
+constexpr int f4_pre_gap(int j) { return 17 - 2 * kF4Ahead + 2 * j; }      // the odd gap in which fragment j < kF4Ahead of the NEXT phase is requested
 // gaps (MFMA index inside a phase) after which the hot loop issues its LDS-DMA pieces (odd gaps only -- the ones
 // without an LDS read -- measured the same: 7.40 - 7.51 vs 7.37 - 7.43 ms)
 constexpr int kF4G0a = 2, kF4G0b = 8, kF4G1a = 2, kF4G1b = 7, kF4G1c = 12, kF4G2a = 1, kF4G2b = 5, kF4G2c = 9;
@@ -299,24 +310,24 @@ LWM_DEVICE bf16x8 f4_vread(const F4Ctx& cx, int f) {
 // Phase 1 (16 MFMAs): S(next) = K Q^T  ||  p = exp2(t), P -> bf16, pair sums.  t = s*c - m*c of the half tile being
 // finished was left in tC by the phase 2 before (so that the two phases carry about the same number of fillers);
 // ps receives p[2j] + p[2j+1].  KHALF = key half of the NEXT half tile inside the K buffer cx.ka points at; its
-// fragments 0..2 are ALREADY in kfr[0..2] (requested by whoever ran before: with one wave on the SIMD nothing else
+// fragments 0..kF4Ahead-1 are ALREADY in kfr (requested by whoever ran before: with one wave on the SIMD nothing else
 // covers the LDS latency at the head of a phase).  VNEXT >= 0: request the first three V fragments of the phase 2 that
 // follows (key half VNEXT) during the last gaps.  DMA: which LDS-DMA pieces of `dm` go out in this phase (-1 none).
 template <int KHALF, bool DO_S, bool DO_FIN, int VNEXT, int DMA>
 LWM_DEVICE void f4_phase1(const F4Ctx& cx, const bf16x8 (&qf)[2][8], f32x16 (&sN)[2], float (&tC)[2][16], float (&ps)[2][8],
-                          bf16x8 (&pb)[2][2], bf16x8 (&kfr)[4], bf16x8 (&vfr)[4], const F4Stage& st, const F4Dma& dm) {
+                          bf16x8 (&pb)[2][2], bf16x8 (&kfr)[8], bf16x8 (&vfr)[8], const F4Stage& st, const F4Dma& dm) {
     uint32_t w[4];
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
         const int s = g >> 1, qb = g & 1;
-        if (DO_S && qb == 0 && s + 3 < 8) kfr[(s + 3) & 3] = f4_kread<KHALF>(cx, s + 3);
-        if (VNEXT >= 0 && g == 11) vfr[0] = f4_vread<VNEXT < 0 ? 0 : VNEXT>(cx, 0);
-        if (VNEXT >= 0 && g == 13) vfr[1] = f4_vread<VNEXT < 0 ? 0 : VNEXT>(cx, 1);
-        if (VNEXT >= 0 && g == 15) vfr[2] = f4_vread<VNEXT < 0 ? 0 : VNEXT>(cx, 2);
+        if (DO_S && qb == 0 && s + kF4Ahead < 8) kfr[s + kF4Ahead] = f4_kread<KHALF>(cx, s + kF4Ahead);
+#pragma unroll
+        for (int j = 0; j < kF4Ahead; ++j)
+            if (VNEXT >= 0 && g == f4_pre_gap(j)) vfr[j] = f4_vread<VNEXT < 0 ? 0 : VNEXT>(cx, j);
         sched_fence();
         if (DO_S) {
             if (s == 0) f4_mfma_s_first(sN[qb], kfr[0], qf[qb][0]);
-            else f4_mfma_s(sN[qb], kfr[s & 3], qf[qb][s]);
+            else f4_mfma_s(sN[qb], kfr[s], qf[qb][s]);
         }
         // LDS-DMA pieces of this phase (measured: a piece needs ~1000 cycles from issue to landed under load, so the
         // last one leaves in the first half of the iteration's third phase; what is needed first goes first)
@@ -349,24 +360,24 @@ LWM_DEVICE void f4_phase1(const F4Ctx& cx, const bf16x8 (&qf)[2][8], f32x16 (&sN
 
 // Phase 2 (16 MFMAs): O^T += V^T P^T  ||  row sums (the pair sums ps), running max of the next half tile's scores (sN)
 // and its exponents tN = s*c - m*c (one fma per score; a subtract when Q is prescaled: c = 1).
-// VHALF = key half of the half tile being finished inside the V buffer; its fragments 0..2 are already in vfr[0..2].
+// VHALF = key half of the half tile being finished inside the V buffer; its fragments 0..kF4Ahead-1 are already in vfr.
 // KNEXT >= 0: request the first three K fragments of the phase 1 that follows (key half KNEXT of the buffer cx.ka
 // points at NOW) during the last gaps.
 template <int VHALF, bool DO_PV, bool DO_MAX, int KNEXT, int DMA>
 LWM_DEVICE void f4_phase2(F4Ctx& cx, const bf16x8 (&pb)[2][2], f32x16 (&acc)[2][4], const float (&ps)[2][8],
-                          const f32x16 (&sN)[2], float (&tN)[2][16], float (&mx)[2], bf16x8 (&kfr)[4], bf16x8 (&vfr)[4],
+                          const f32x16 (&sN)[2], float (&tN)[2][16], float (&mx)[2], bf16x8 (&kfr)[8], bf16x8 (&vfr)[8],
                           const F4Stage& st, const F4Dma& dm) {
     float ls[2] = {0.f, 0.f};
     float mp[2] = {-INFINITY, -INFINITY};
 #pragma unroll
     for (int h = 0; h < 16; ++h) {
         const int f = h >> 1, qb = h & 1, t = f >> 2, db = f & 3;
-        if (DO_PV && qb == 0 && f + 3 < 8) vfr[(f + 3) & 3] = f4_vread<VHALF>(cx, f + 3);
-        if (KNEXT >= 0 && h == 11) kfr[0] = f4_kread<KNEXT < 0 ? 0 : KNEXT>(cx, 0);
-        if (KNEXT >= 0 && h == 13) kfr[1] = f4_kread<KNEXT < 0 ? 0 : KNEXT>(cx, 1);
-        if (KNEXT >= 0 && h == 15) kfr[2] = f4_kread<KNEXT < 0 ? 0 : KNEXT>(cx, 2);
+        if (DO_PV && qb == 0 && f + kF4Ahead < 8) vfr[f + kF4Ahead] = f4_vread<VHALF>(cx, f + kF4Ahead);
+#pragma unroll
+        for (int j = 0; j < kF4Ahead; ++j)
+            if (KNEXT >= 0 && h == f4_pre_gap(j)) kfr[j] = f4_kread<KNEXT < 0 ? 0 : KNEXT>(cx, j);
         sched_fence();
-        if (DO_PV) f4_mfma_o(acc[qb][db], vfr[f & 3], pb[qb][t]);
+        if (DO_PV) f4_mfma_o(acc[qb][db], vfr[f], pb[qb][t]);
         if (DMA == 1 && h == kF4G1a) f4_dma1(st.voff_v[0], dm.v_src, dm.v_dst);                  // V(i+1)
         if (DMA == 1 && h == kF4G1b) f4_dma1(st.voff_v[1], dm.v_src, dm.v_dst + 4096);
         if (DMA == 1 && h == kF4G1c) f4_dma1(st.voff_v[2], dm.v_src, dm.v_dst + 8192);
@@ -634,14 +645,14 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
             for (int r = 0; r < 8; ++r) ps[qb][r] = 0.0f;
             for (int t = 0; t < 2; ++t) pb[qb][t] = zero_bf16x8();
         }
-        bf16x8 kfr[4], vfr[4];
-        for (int j = 0; j < 4; ++j) {
+        bf16x8 kfr[8], vfr[8];
+        for (int j = 0; j < 8; ++j) {
             kfr[j] = zero_bf16x8();
             vfr[j] = zero_bf16x8();
         }
         F4Dma dm = {};
         if (n_w > 0) {
-            for (int j = 0; j < 3; ++j) kfr[j] = f4_kread<0>(cx, j);
+            for (int j = 0; j < kF4Ahead; ++j) kfr[j] = f4_kread<0>(cx, j);
             f4_phase1<0, true, false, -1, -1>(cx, qf, sA, tt, ps, pb, kfr, vfr, st, dm);
             f4_settle_s(sA);       // (no P.V MFMA follows here: the max / exponent fillers read the scores at once)
             if (needs_mask(0)) {
@@ -732,7 +743,7 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
 #endif
         int i = 0;
         for (; i < n_fast; ++i) {
-            for (int j = 0; j < 3; ++j) kfr[j] = f4_kread<1>(cx, j);
+            for (int j = 0; j < kF4Ahead; ++j) kfr[j] = f4_kread<1>(cx, j);
             dm.k_lo_src = st.kb + (kt0 + i + 2) * st.ktile_bytes;
             dm.k_up_src = st.kb + (kt0 + i + 1) * st.ktile_bytes;
             dm.v_src = st.vb + (kt0 + i + 1) * st.vtile_bytes;
@@ -752,7 +763,7 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
         }
 #endif
         for (; i < n_hot; ++i) {
-            for (int j = 0; j < 3; ++j) kfr[j] = f4_kread<1>(cx, j);
+            for (int j = 0; j < kF4Ahead; ++j) kfr[j] = f4_kread<1>(cx, j);
             stage_iter(i);
             LWM_F4_TILE(i, -1, -1, -1, -1);
         }
@@ -760,7 +771,7 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
 #undef F4_LAP
         // its last tile: the second half step has no successor
         if (n_w > 0) {
-            for (int j = 0; j < 3; ++j) kfr[j] = f4_kread<1>(cx, j);
+            for (int j = 0; j < kF4Ahead; ++j) kfr[j] = f4_kread<1>(cx, j);
             stage_iter(i);
             f4_phase1<1, true, true, 0, -1>(cx, qf, sB, tt, ps, pb, kfr, vfr, st, dm);
             if (needs_mask(i)) {

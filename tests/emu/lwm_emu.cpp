@@ -30,9 +30,14 @@ LWM_EMU_NO_RING(int, lwm_ring_unique_id, void*)
 LWM_EMU_NO_RING(int, lwm_ring_create_from_id, const void*, int32_t, int32_t, void*, LwmRing**)
 LWM_EMU_NO_RING(int, lwm_ring_create_transport, const LwmRingTransport*, int32_t, int32_t, void*, LwmRing**)
 LWM_EMU_NO_RING(int, lwm_ring_destroy, LwmRing*)
-LWM_EMU_NO_RING(int64_t, lwm_ring_workspace_bytes, int32_t, int32_t, int32_t, int32_t, int32_t)
+LWM_EMU_NO_RING(int64_t, lwm_ring_workspace_bytes, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t)
 LWM_EMU_NO_RING(int, lwm_ring_attn_fwd, LwmRing*, const LwmRingArgs*, void*)
 LWM_EMU_NO_RING(int, lwm_ring_attn_bwd, LwmRing*, const LwmRingArgs*, void*)
 LWM_EMU_NO_RING(int64_t, lwm_ring_bytes_sent, const LwmRing*)
 LWM_EMU_NO_RING(int, lwm_ring_selftest, LwmRing*, const void*, void*, int64_t, void*)
+LWM_EMU_NO_RING(int64_t, lwm_ring_ipc_info_bytes, void)
+LWM_EMU_NO_RING(int, lwm_ring_ipc_export, int32_t, int32_t, int64_t, int32_t, void*, LwmRingIpc**)
+LWM_EMU_NO_RING(int, lwm_ring_ipc_connect, LwmRingIpc*, const void*)
+LWM_EMU_NO_RING(int, lwm_ring_create_ipc, LwmRingIpc*, void*, LwmRing**)
+LWM_EMU_NO_RING(int, lwm_ring_ipc_destroy, LwmRingIpc*)
 }
