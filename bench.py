@@ -801,6 +801,27 @@ def main():
         c_ring = CRing(dist.group.WORLD, transport=args.transport, layout=args.layout, schedule=sched_c,
                        ipc_slot_bytes=c_max * N_HEADS * HEAD_DIM * 4)
 
+    driver_fallback = None
+    if c_ring is not None:
+        # The C driver has met RCCL on one GPU and real processes over IPC, never several GPUs: its first layer runs under a
+        # collective vote, and a rank that fails takes everybody to the torch.distributed driver instead of killing the line.
+        ok, why = 1, ""
+        try:
+            o_, l_ = c_ring.forward(q, k, v, causal=True, segment_ids=segment_ids)
+            c_ring.backward(q, k, v, o_, l_, do, causal=True, segment_ids=segment_ids)
+            torch.cuda.synchronize()
+        except Exception as e:      # noqa: BLE001
+            ok, why = 0, repr(e)[:500]
+        vote = torch.tensor([ok], dtype=torch.int32, device="cpu" if shared else dev)
+        dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+        if int(vote.item()) == 0:
+            if comm is None:
+                fail_line(args, "C ring driver, first layer", RuntimeError(why or "another rank failed"), {"transport": args.transport})
+                os._exit(5)
+            driver_fallback = {"from": f"C driver ({args.transport}, {sched_c})", "to": "lwm_amd/ring.py over torch.distributed",
+                               "first_error_on_this_rank": why or None}
+            c_ring = None
+
     def step(ring=None, ten=None, lay=None, seg=None):
         ring = c_ring if ring is None else ring
         q_, k_, v_, do_ = (q, k, v, do) if ten is None else ten
@@ -840,11 +861,13 @@ def main():
         step()
     barrier()
     timer.enabled = world == 1
+    sent_before = c_ring.bytes_sent if c_ring is not None else 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
+    sent_timed = (c_ring.bytes_sent - sent_before) if c_ring is not None else 0
 
     exchange = None
     if world > 1:
@@ -864,7 +887,6 @@ def main():
                             "exposed_ms_per_step": (elapsed / args.steps - compute_only) * 1e3,
                             "overlap_efficiency": compute_only / (elapsed / args.steps)}
             else:
-                sent = c_ring.bytes_sent
                 nr = null_ring()
                 step(nr)
                 barrier()
@@ -874,7 +896,7 @@ def main():
                 compute_only = max_over_ranks(time.perf_counter() - t0)
                 nr.close()
                 exchange = {"schedule": f"{sched_c} (C-ABI driver, {args.transport})", "transport": args.transport,
-                            "bytes_sent_per_rank_per_step": sent / (args.steps + args.warmup),
+                            "bytes_sent_per_rank_per_step": sent_timed / args.steps,
                             "compute_only_ms_per_step": compute_only * 1e3,
                             "exposed_ms_per_step": (elapsed / args.steps - compute_only) * 1e3,
                             "overlap_efficiency": compute_only / (elapsed / args.steps)}
@@ -994,6 +1016,7 @@ def main():
             "tokens_per_s_per_gpu": tokens_per_s / world,
             "exchange": exchange,
             "configs2": configs2,
+            "driver_fallback": driver_fallback,
             "rccl_ranks_seen": rccl_ranks_seen,
             "dry_run": ("ranks share devices, messages staged through host memory; timings are not xGMI" if dry else
                         "ranks share devices (IPC transport inside one GPU); timings are not xGMI" if shared and world > 1 else None),

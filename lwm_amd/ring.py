@@ -644,7 +644,7 @@ def _c_driver_wanted(group, block_ops):
 def _c_ring_for(group, layout_kind, schedule):
     """one C ring object (communicator, side stream, workspace) per (group, layout, schedule), reused by every layer"""
     from .ring_c import CRing
-    key = (id(group), layout_kind, schedule, torch.cuda.current_device())
+    key = (group, layout_kind, schedule, torch.cuda.current_device())      # (the group object itself: an id() can be recycled)
     ring = _C_RINGS.get(key)
     if ring is None:
         ring = _C_RINGS[key] = CRing(group, layout=layout_kind, schedule=schedule)
