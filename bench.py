@@ -799,7 +799,7 @@ def main():
         from lwm_amd.ring_c import CRing
         c_max = max(c, S2 // world if not args.no_configs2 else 0)
         c_ring = CRing(dist.group.WORLD, transport=args.transport, layout=args.layout, schedule=sched_c,
-                       ipc_slot_bytes=c_max * N_HEADS * HEAD_DIM * 4)
+                       ipc_slot_bytes=c_max * N_HEADS * HEAD_DIM * 4, ipc_slots=4)      # (B = 1: at most 4 messages per pair and group)
 
     driver_fallback = None
     if c_ring is not None:
