@@ -38,6 +38,10 @@ def test_committed_bench_line_follows_the_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+    # round 3: BASELINE configs[0] end to end and the op points ride in the same object, one `cores` convention
+    assert c["config1"]["tokens_per_s"] > 0 and "configs[0]" in c["config1"]["workload"] and c["config1"]["cores"] == c["cores"]
+    assert [p["S"] for p in c["op_points"]] == [4096, 8192, 16384]
+    assert d["vqgan"]["cpu_baseline"]["cores"] == c["cores"]
 
 
 def test_bench_cli_contract_without_a_gpu():
@@ -65,5 +69,5 @@ def test_bench_cli_contract_without_a_gpu():
     else:
         assert r.returncode == 0 and lines[-1]["n_gpus"] == 2 and lines[-1]["rccl_ranks_seen"] == 2
     h = subprocess.run([sys.executable, bench, "--help"], capture_output=True, text=True, timeout=300)
-    for flag in ("--gpus", "--steps", "--warmup"):
+    for flag in ("--gpus", "--steps", "--warmup", "--driver", "--transport", "--schedule", "--layout", "--no-configs2"):
         assert flag in h.stdout
