@@ -308,6 +308,24 @@ int lwm_gemv_bf16(const void* x, int64_t ldx, const void* w, void* y, int64_t ld
 int lwm_gemv_multi_bf16(const void* x, int64_t ldx, int32_t nmat, const void* const* w, void* const* y, const int64_t* ldy,
                         float* const* y_f32, const int32_t* N, void* workspace, int32_t rows, int32_t K, void* stream);
 
+/* The same launch pair with the small launches either side of a decode-step projection riding along (every field but
+ * the first block optional, zero = off):
+ *   RMSNorm on load  (lwm/llama.py:320-341 in front of wq|wk|wv, w1|w3, lm_head): x is normalised as it is read,
+ *     bf16(bf16(x * rstd) * norm_weight[k]) with rstd = 1/sqrt(sum(ss_in[r][0..ss_n)) / K + eps) -- ss_in are partial
+ *     sums of squares of x's rows, e.g. the ss_out of the launch that produced x (or one total and zeros);
+ *   residual add     (lwm/llama.py:719, :737 behind wo, w2): y = bf16(bf16(x . W) + residual), and
+ *   ss_out           [rows][N/128] partial sums of squares of y's rows (one matrix, N % 128 == 0) for the next norm.
+ * Results equal the separate launches' (same roundings); rstd may differ in its last bit (other summation order). */
+typedef struct LwmGemvArgs {
+    const void* x; int64_t ldx; int32_t nmat; int32_t rows, K;
+    const void* w[3]; void* y[3]; int64_t ldy[3]; float* y_f32[3]; int32_t N[3];
+    void* workspace;
+    const void* norm_weight; const float* ss_in; int32_t ss_n; float eps;
+    const void* residual[3]; int64_t ldres[3];
+    float* ss_out;
+} LwmGemvArgs;
+int lwm_gemv_fused_bf16(const LwmGemvArgs* args, void* stream);
+
 /* tux.cross_entropy_loss_and_accuracy as used at lwm/train.py:177-181, :192-201, per row of
  * bf16 logits [rows, V] (V % 8 == 0, V <= 32768): nll[r] = logsumexp(row) - row[target[r]] in
  * f32; correct[r] = (first argmax == target[r]) (may be NULL); and, if dlogits != NULL, the

@@ -54,6 +54,17 @@ RING_LAYOUT = {"contiguous": 0, "zigzag": 1}
 RING_SCHEDULE = {"ring": 0, "direct": 1, "mesh": 1}
 
 
+class LwmGemvArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int64), ("nmat", C.c_int32), ("rows", C.c_int32), ("K", C.c_int32),
+        ("w", C.c_void_p * 3), ("y", C.c_void_p * 3), ("ldy", C.c_int64 * 3), ("y_f32", C.c_void_p * 3), ("N", C.c_int32 * 3),
+        ("workspace", C.c_void_p),
+        ("norm_weight", C.c_void_p), ("ss_in", C.c_void_p), ("ss_n", C.c_int32), ("eps", C.c_float),
+        ("residual", C.c_void_p * 3), ("ldres", C.c_int64 * 3),
+        ("ss_out", C.c_void_p),
+    ]
+
+
 RING_GROUP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 RING_SEND_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)
 
@@ -116,6 +127,7 @@ PROTOTYPES = {
     "lwm_gemv_multi_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                       C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_void_p,
                                       C.c_int32, C.c_int32, C.c_void_p]),
+    "lwm_gemv_fused_bf16": (C.c_int, [C.POINTER(LwmGemvArgs), C.c_void_p]),
     "lwm_cast_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "lwm_sum_f32_to_bf16": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "lwm_conv2d_nhwc_f32": (C.c_int, [C.POINTER(LwmConvArgs), C.c_void_p]),

@@ -10,7 +10,14 @@
 //   * the four waves' sums meet in LDS in wave order, the workgroup writes f32 partials [K/128][R][N];
 //   * gemv_reduce_kernel adds the K/128 partials of an output along a FIXED tree (deterministic; no atomics) and
 //     writes bf16 and / or f32;
-//   * up to three matrices that share x (wq | wk | wv, w1 | w3) ride in ONE pair of launches.
+//   * up to three matrices that share x (wq | wk | wv, w1 | w3) ride in ONE pair of launches;
+//   * the small launches either side of a projection can ride along (lwm_gemv_fused_bf16; a decode step is a dozen
+//     3-5 us launches per layer next to ~90 us of weight streaming):
+//       - RMSNorm ON LOAD: x is normalised as it is read -- bf16(bf16(x * rstd) * gamma), the arithmetic of
+//         rmsnorm_fwd_kernel (lwm/llama.py:320-341) -- with rstd from partial sums of squares that the reduction
+//         which PRODUCED x left behind (ss_in: a few dozen floats per row, summed along a fixed tree by every wave);
+//       - RESIDUAL ADD in the reduction: y = bf16(bf16(x . W) + residual), the bf16 add the block would launch next
+//         (lwm/llama.py:719, :737), and the partial sums of squares of y for the next norm (ss_out).
 // R <= 4 rows, N % 8 == 0, K % 32 == 0, K <= 12288 (LWM-7B: 4096, 11008, 32000 all qualify).
 #pragma once
 
@@ -33,7 +40,17 @@ struct GemvParams {
     int64_t ldx, ldy[kGemvMaxMats], part_off[kGemvMaxMats];
     int32_t N[kGemvMaxMats], blk0[kGemvMaxMats + 1], quad0[kGemvMaxMats + 1];   // first workgroup / first reduce quad of matrix i
     int32_t R, K, KS, nmat;
+    // fused neighbours (all optional)
+    const bf16_t* gamma;              // RMSNorm weight [K]: x is normalised on load
+    const float* ss_in;               // [R][ss_n] partial sums of squares of x's rows (their sum = sum_k x[r,k]^2)
+    int32_t ss_n;                     // <= 64
+    float eps;
+    const bf16_t* res[kGemvMaxMats];  // residual [R, N_i] (row stride ldres[i]) added in the reduction
+    int64_t ldres[kGemvMaxMats];
+    float* ss_out;                    // [R][N_0 / 128]: partial sums of squares of matrix 0's bf16 output rows (N_0 % 128 == 0)
 };
+
+constexpr int kGemvSsCols = 128;      // output columns per reduce workgroup = per ss_out partial
 
 LWM_DEVICE float bf16_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
 LWM_DEVICE float bf16_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
@@ -57,8 +74,18 @@ LWM_DEVICE void gemv_body(const GemvParams& p) {
     float xv[R];
     for (int r = 0; r < R; ++r) {
         const int k = k0 + (lane & (kGemvRPW - 1));
-        const bf16_t raw = p.x[(int64_t)r * p.ldx + (k < p.K ? k : p.K - 1)];
-        xv[r] = k < p.K ? bf16_lo((uint32_t)__builtin_bit_cast(uint16_t, raw)) : 0.0f;
+        const int kc = k < p.K ? k : p.K - 1;
+        const bf16_t raw = p.x[(int64_t)r * p.ldx + kc];
+        float xf = bf16_lo((uint32_t)__builtin_bit_cast(uint16_t, raw));
+        if (p.gamma) {
+            // rstd of row r from the partials (every wave sums the same <= 64 numbers along the same tree)
+            float t = lane < p.ss_n ? p.ss_in[(int64_t)r * p.ss_n + lane] : 0.0f;
+            for (int m = 1; m < 64; m <<= 1) t += shfl_xor_f(t, m);
+            const float rstd = 1.0f / sqrtf(t / (float)p.K + p.eps);
+            const float g = bf16_lo((uint32_t)__builtin_bit_cast(uint16_t, p.gamma[kc]));
+            xf = (float)(bf16_t)((float)(bf16_t)(xf * rstd) * g);
+        }
+        xv[r] = k < p.K ? xf : 0.0f;
     }
     float acc[R][8];
     for (int r = 0; r < R; ++r)
@@ -146,9 +173,33 @@ LWM_KERNEL(256) void gemv_reduce_kernel(GemvParams p) {
         if (sub + 8 * u < p.KS) s = s + v[u];
     for (int m = 1; m < 8; m <<= 1)
         for (int j = 0; j < 4; ++j) s[j] = s[j] + shfl_xor_f(s[j], m);
-    if (!live || sub != 0) return;
-    if (p.y_f32[mi]) global_store_f32x4(p.y_f32[mi] + (int64_t)r * N + n, s);
-    if (p.y[mi]) global_store_b64(p.y[mi] + (int64_t)r * p.ldy[mi] + n, u32x2{pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], s[3])});
+    const bool writer = live && sub == 0;
+    float sq = 0.0f;
+    if (writer) {
+        if (p.y_f32[mi]) global_store_f32x4(p.y_f32[mi] + (int64_t)r * N + n, s);
+        if (p.y[mi]) {
+            float o[4];
+            for (int j = 0; j < 4; ++j) o[j] = (float)(bf16_t)s[j];
+            if (p.res[mi]) {
+                const u32x2 rr = *(const u32x2*)(p.res[mi] + (int64_t)r * p.ldres[mi] + n);
+                o[0] = (float)(bf16_t)(o[0] + bf16_lo(rr[0]));
+                o[1] = (float)(bf16_t)(o[1] + bf16_hi(rr[0]));
+                o[2] = (float)(bf16_t)(o[2] + bf16_lo(rr[1]));
+                o[3] = (float)(bf16_t)(o[3] + bf16_hi(rr[1]));
+            }
+            global_store_b64(p.y[mi] + (int64_t)r * p.ldy[mi] + n, u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])});
+            for (int j = 0; j < 4; ++j) sq = fmaf(o[j], o[j], sq);
+        }
+    }
+    if (p.ss_out) {
+        // one partial per workgroup = per 128 output columns of one row (N_0 % 128 == 0, one matrix: checked by the host)
+        const float tot = block_sum_256(sq, dyn_lds(), thread_idx());
+        if (thread_idx() == 0) {
+            const int64_t wg = block_idx_x();
+            const int per_row = p.N[0] / kGemvSsCols;
+            if (wg < (int64_t)p.R * per_row) p.ss_out[wg] = tot;        // [r][wg % per_row], r = wg / per_row
+        }
+    }
 }
 
 }  // namespace lwm

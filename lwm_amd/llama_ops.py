@@ -290,6 +290,51 @@ def gemv(x, kernel, out_dtype=torch.bfloat16):
     return gemv_multi(x, [kernel], out_dtype)[0]
 
 
+def gemv_fused(x, kernels, *, norm=None, residual=None, want_ss=False, out_dtype=torch.bfloat16):
+    """lwm_gemv_fused_bf16: gemv_multi with the neighbouring launches of a decode step riding along.
+    norm = (ss (rows, n <= 64) f32 partial sums of squares of x's rows, weight (K,) bf16, eps): RMSNorm on load;
+    residual (rows, N) bf16 (one kernel): y = bf16(bf16(x @ W) + residual); want_ss: also return the (rows, N / 128)
+    partial sums of squares of y for the next norm.  -> [y_i] or ([y_i], ss)."""
+    rows, K = x.shape
+    if x.dtype != torch.bfloat16 or x.stride(1) != 1 or any(
+            k.dtype != torch.bfloat16 or not k.is_contiguous() or k.shape[0] != K for k in kernels):
+        raise ValueError("gemv: expected bf16 x (contiguous rows) and contiguous bf16 (K, N) kernels")
+    L = lib()
+    n = len(kernels)
+    Ns = [int(k.shape[1]) for k in kernels]
+    key = (x.device, rows, K, tuple(Ns))
+    ws = _GEMV_WS.get(key)
+    if ws is None:
+        need = sum(L.lwm_gemv_workspace_bytes(rows, K, N) for N in Ns)
+        ws = _GEMV_WS[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
+    ys = [torch.empty(rows, N, dtype=out_dtype, device=x.device) for N in Ns]
+    a = _capi.LwmGemvArgs()
+    a.x, a.ldx, a.nmat, a.rows, a.K = x.data_ptr(), x.stride(0), n, rows, K
+    a.workspace = ws.data_ptr()
+    for i in range(n):
+        a.w[i], a.N[i] = kernels[i].data_ptr(), Ns[i]
+        if out_dtype == torch.float32:
+            a.y_f32[i] = ys[i].data_ptr()
+        else:
+            a.y[i], a.ldy[i] = ys[i].data_ptr(), Ns[i]
+    if norm is not None:
+        ss, w, eps = norm
+        if ss.dtype != torch.float32 or not ss.is_contiguous() or ss.shape[0] != rows or ss.shape[1] > 64 or \
+                w.dtype != torch.bfloat16 or not w.is_contiguous() or w.numel() != K:
+            raise ValueError("gemv_fused: norm = (ss (rows, n <= 64) f32 contiguous, weight (K,) bf16, eps)")
+        a.norm_weight, a.ss_in, a.ss_n, a.eps = w.data_ptr(), ss.data_ptr(), ss.shape[1], float(eps)
+    if residual is not None:
+        if n != 1 or residual.dtype != torch.bfloat16 or tuple(residual.shape) != (rows, Ns[0]) or residual.stride(1) != 1:
+            raise ValueError("gemv_fused: residual goes with ONE kernel and has its output's shape")
+        a.residual[0], a.ldres[0] = residual.data_ptr(), residual.stride(0)
+    ss_out = None
+    if want_ss:
+        ss_out = torch.empty(rows, Ns[0] // 128, dtype=torch.float32, device=x.device)
+        a.ss_out = ss_out.data_ptr()
+    _capi.check(L, L.lwm_gemv_fused_bf16(C.byref(a), _stream_ptr()), "lwm_gemv_fused_bf16")
+    return (ys, ss_out) if want_ss else ys
+
+
 def _decode_rows(x, kernels):
     rows = x.numel() // x.shape[-1]
     ok = rows <= 4 and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 32 == 0 and x.shape[-1] <= 12288 and \

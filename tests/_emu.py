@@ -380,3 +380,47 @@ def gemv_multi(x, ws, want_f32=False):
                                          (C.c_int64 * n)(*Ns), y_arr if want_f32 else None, (C.c_int32 * n)(*Ns),
                                          work.ctypes.data, rows, K, None), "lwm_gemv_multi_bf16")
     return [y.copy() if want_f32 else from_bf16_bits(y) for y in ys]
+
+
+def gemv_fused(x, ws, *, norm=None, residual=None, want_ss=False, want_f32=False):
+    """lwm_gemv_fused_bf16: 1..3 kernels that share x; norm = (ss_in (rows, n) f32, weight (K,), eps) normalises x on
+    load; residual (rows, N) is added in the reduction (one kernel); want_ss returns the (rows, N/128) partial sums of
+    squares of the output."""
+    import ctypes as C
+    L = lib()
+    xb = bf16_array(x)
+    wbs = [bf16_array(w) for w in ws]
+    rows, K = x.shape
+    Ns = [w.shape[1] for w in ws]
+    n = len(ws)
+    wsz = sum(max(L.lwm_gemv_workspace_bytes(rows, K, N), 16) for N in Ns)
+    work = aligned((wsz // 4,), np.float32)
+    ys = [aligned((rows, N), np.float32 if want_f32 else np.uint16) for N in Ns]
+    a = _capi.LwmGemvArgs()
+    a.x, a.ldx, a.nmat, a.rows, a.K = xb.ctypes.data, K, n, rows, K
+    a.workspace = work.ctypes.data
+    for i in range(n):
+        a.w[i], a.N[i] = wbs[i].ctypes.data, Ns[i]
+        if want_f32:
+            a.y_f32[i] = ys[i].ctypes.data
+        else:
+            a.y[i], a.ldy[i] = ys[i].ctypes.data, Ns[i]
+    keep = []
+    if norm is not None:
+        ss, w, eps = norm
+        ssa = aligned(ss.shape, np.float32)
+        ssa[...] = ss
+        wb = bf16_array(w)
+        keep += [ssa, wb]
+        a.norm_weight, a.ss_in, a.ss_n, a.eps = wb.ctypes.data, ssa.ctypes.data, ss.shape[1], eps
+    if residual is not None:
+        rb = bf16_array(residual)
+        keep.append(rb)
+        a.residual[0], a.ldres[0] = rb.ctypes.data, Ns[0]
+    sso = None
+    if want_ss:
+        sso = aligned((rows, Ns[0] // 128), np.float32)
+        a.ss_out = sso.ctypes.data
+    _capi.check(L, L.lwm_gemv_fused_bf16(C.byref(a), None), "lwm_gemv_fused_bf16")
+    out = [y.copy() if want_f32 else from_bf16_bits(y) for y in ys]
+    return (out, sso.copy()) if want_ss else out

@@ -101,6 +101,44 @@ def test_gemv_multi_shares_x():
     assert np.array_equal(gb[0], _emu.gemv(x, ws[0])) and np.array_equal(gb[1], _emu.gemv(x, ws[1]))
 
 
+def test_gemv_fused_neighbours_equal_the_separate_launches():
+    """lwm_gemv_fused_bf16: RMSNorm on load (rstd from partial sums of squares), residual add in the reduction and the
+    partial sums of squares of the result, against rmsnorm_fwd -> gemv -> bf16 add run one by one: identical bits when
+    rstd is identical (one partial = the kernel's own total), and the partials sum to the row's sum of squares."""
+    rng = np.random.default_rng(5)
+    rows, K, N = 2, 256, 384
+    x = R.round_bf16(rng.standard_normal((rows, K)).astype(np.float32))
+    gam = R.round_bf16((1.0 + 0.1 * rng.standard_normal(K)).astype(np.float32))
+    w1, w2 = (R.round_bf16((rng.standard_normal((K, n)) * 0.05).astype(np.float32)) for n in (N, 128))
+    res = R.round_bf16(rng.standard_normal((rows, N)).astype(np.float32))
+    eps = 1e-6
+    xn, rstd = _emu.rmsnorm_fwd(x, gam, eps)
+    # partials whose tree sum reproduces the standalone kernel's total exactly: the total itself + zeros
+    tot = (1.0 / rstd.astype(np.float64) ** 2 - eps) * K
+    ss = np.zeros((rows, 32), np.float32)
+    ss[:, 0] = tot.astype(np.float32)
+    (y1, y2) = _emu.gemv_fused(x, [w1, w2], norm=(ss, gam, eps))
+    r1, r2 = _emu.gemv(xn, w1), _emu.gemv(xn, w2)
+    rstd_f = 1.0 / np.sqrt(ss.sum(1) / np.float32(K) + np.float32(eps), dtype=np.float32)
+    if np.array_equal(rstd_f, rstd):        # (the f64 -> f32 round trip of the total may move rstd by an ulp)
+        assert np.array_equal(y1, r1) and np.array_equal(y2, r2)
+    else:
+        assert np.abs(y1 - r1).max() <= 2.0 ** -7 * np.abs(r1).max()
+    # residual + partial sums of squares
+    (z,), sso = _emu.gemv_fused(x, [w1], residual=res, want_ss=True)
+    want = R.round_bf16(_emu.gemv(x, w1) + res)
+    assert np.array_equal(z, want)
+    assert sso.shape == (rows, N // 128)
+    assert np.allclose(sso.sum(1), (want.astype(np.float64) ** 2).sum(1), rtol=1e-5)
+    # the two together: a whole "x + wo(attn)" -> "norm -> w1" hand-off
+    w3 = R.round_bf16((rng.standard_normal((N, 128)) * 0.05).astype(np.float32))
+    ones = np.ones(N, np.float32)
+    (q,) = _emu.gemv_fused(z, [w3], norm=(sso, ones, eps))
+    zn, _ = _emu.rmsnorm_fwd(z, ones, eps)
+    ref = _emu.gemv(zn, w3)
+    assert np.abs(q - ref).max() <= 2.0 ** -7 * np.abs(ref).max()       # (rstd: other summation order, at most an ulp)
+
+
 def test_gemv_validation():
     import ctypes as C
     L = _emu.lib()

@@ -104,3 +104,25 @@ def test_graph_captured_decode_matches_hf_and_eager():
     graph, lg = model.generate(seq[:, :PL], attention_mask=mask, max_new_tokens=NEW, return_logits=True, graph=True)
     assert torch.equal(graph, eager) and torch.equal(graph.cpu(), seq.cpu())
     assert (lg - le).abs().max().item() <= 1e-3 * le.abs().max().item()
+
+
+def test_fused_decode_layers_match_hf_and_the_separate_launches(monkeypatch):
+    """The cached one-token step with RMSNorm folded into the projections' x load and the residual adds into their
+    reductions (lwm_gemv_fused_bf16; the default) -- same greedy tokens as HF transformers and as the launches issued
+    one by one (LWM_DECODE_FUSED=0), eager and captured in a hipGraph; logits within bf16 noise of the unfused path."""
+    import torch
+    F, cfg, model = _model()
+    gold = np.load(os.path.join(HERE, "golden", "hf_llama_tiny.npz"))
+    seq = torch.from_numpy(gold["gen_tokens"]).cuda()
+    mask = torch.from_numpy(gold["gen_mask"]).cuda()
+    PL, NEW = mask.shape[1], gold["gen_scores"].shape[1]
+    monkeypatch.setenv("LWM_DECODE_FUSED", "0")
+    base, lb = model.generate(seq[:, :PL], attention_mask=mask, max_new_tokens=NEW, return_logits=True)
+    monkeypatch.setenv("LWM_DECODE_FUSED", "1")
+    with torch.no_grad():      # (generate() runs under no_grad: the fused path must engage for this model there)
+        assert model._fused_decode_ok(torch.empty(1, 1, cfg.hidden_size, dtype=torch.bfloat16, device="cuda"), 1)
+    eager, le = model.generate(seq[:, :PL], attention_mask=mask, max_new_tokens=NEW, return_logits=True)
+    graph, lg = model.generate(seq[:, :PL], attention_mask=mask, max_new_tokens=NEW, return_logits=True, graph=True)
+    assert torch.equal(eager, base) and torch.equal(graph, base) and torch.equal(eager.cpu(), seq.cpu())
+    for l in (le, lg):
+        assert (l - lb).abs().max().item() <= 2e-2 * lb.abs().max().item()

@@ -168,6 +168,32 @@ def test_gemv_decode_projection_7b_shapes(rows, K, N):
     assert torch.equal(gemv(x, w, torch.float32), yf)                # deterministic
 
 
+def test_gemv_fused_neighbours_equal_the_separate_launches_on_gpu():
+    """lwm_gemv_fused_bf16 at LWM-7B's shapes: norm on load + residual in the reduction + the partial sums of squares,
+    against RMSNorm kernel -> gemv -> bf16 add launched one by one."""
+    import torch
+    from lwm_amd.llama_ops import RMSNorm, gemv, gemv_fused, gemv_multi
+    g = torch.Generator(device="cuda").manual_seed(9)
+    rows, d, F = 2, 4096, 11008
+    x = torch.randn(rows, d, generator=g, device="cuda").to(torch.bfloat16)
+    res = torch.randn(rows, d, generator=g, device="cuda").to(torch.bfloat16)
+    wo = (torch.randn(d, d, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    w1, w3 = ((torch.randn(d, F, generator=g, device="cuda") * 0.02).to(torch.bfloat16) for _ in range(2))
+    norm = RMSNorm(d, 1e-6).cuda()
+    with torch.no_grad():
+        norm.kernel.copy_(1.0 + 0.1 * torch.randn(d, generator=g, device="cuda"))
+        # x2 = res + x @ wo, then norm -> w1 | w3
+        (x2,), ss = gemv_fused(x, (wo,), residual=res, want_ss=True)
+        want_x2 = gemv(x, wo) + res
+        assert torch.equal(x2, want_x2)
+        assert torch.allclose(ss.sum(-1), x2.float().pow(2).sum(-1), rtol=1e-5)
+        a, b = gemv_fused(x2, (w1, w3), norm=(ss, norm.kernel.to(torch.bfloat16), 1e-6))
+        ra, rb = gemv_multi(norm(x2[:, None])[:, 0].contiguous(), [w1, w3])
+        for got, ref in ((a, ra), (b, rb)):      # rstd sums in another order: at most one bf16 ulp on a few inputs
+            assert (got.float() - ref.float()).abs().max() <= 2 ** -7 * ref.float().abs().max()
+        assert torch.equal(gemv_fused(x2, (w1, w3), norm=(ss, norm.kernel.to(torch.bfloat16), 1e-6))[0], a)    # deterministic
+
+
 def test_dense_routes_decode_rows_through_gemv():
     """`dense` = flax nn.Dense without bias: <= 4 rows without autograd take lwm_gemv_bf16, anything else the
     library GEMM; both agree to bf16 rounding."""
