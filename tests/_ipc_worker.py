@@ -74,7 +74,7 @@ def main():
             # windows: the last rows of every document against that document alone (complete for out / dq of the rows and
             # dk / dv of the keys in the window)
             for i, (a, b) in enumerate(zip(bounds[:-1], bounds[1:])):
-                h, qa, w0 = i % H, max(a, b - 2048), b - 256
+                h, qa, w0 = i % H, b - 256, b - 256      # (the window's own rows are all the queries its out / dq / dk / dv need)
                 rows, keys, win = slice(qa, b), slice(a, b), slice(w0, b)
                 ro, _ = R.dense_attention(f(q, rows, h), f(k, keys, h), f(v, keys, h), causal=True, q_start=qa - a)
                 rq, rk, rv = R.dense_attention_bwd(f(q, rows, h), f(k, keys, h), f(v, keys, h), f(do, rows, h), causal=True, q_start=qa - a)
