@@ -197,6 +197,11 @@ int64_t lwm_ring_workspace_bytes(int32_t B, int32_t c, int32_t H, int32_t D, int
                                  int32_t schedule);
 int lwm_ring_attn_fwd(LwmRing* ring, const LwmRingArgs* args, void* compute_stream);
 int lwm_ring_attn_bwd(LwmRing* ring, const LwmRingArgs* args, void* compute_stream);
+/* What ONE call of lwm_ring_attn_fwd (backward = 0) or lwm_ring_attn_bwd (backward = 1) makes rank `rank` send, in
+ * bytes, under the given ownership and schedule -- a pure function of the geometry (no device is touched): the
+ * forward's K/V, and in the backward the K/V again plus the f32 dK/dV carries (ring) or partials (direct). */
+int64_t lwm_ring_planned_bytes(int32_t layout, int32_t schedule, int32_t n, int32_t rank, int32_t B, int32_t c, int32_t H,
+                               int32_t D, int32_t causal, int32_t backward);
 /* bytes this ring object has sent since creation (diagnostic) */
 int64_t lwm_ring_bytes_sent(const LwmRing* ring);
 /* Diagnostic: ONE grouped exchange with ourselves through the ring's transport -- send `bytes` bytes at src to

@@ -53,6 +53,41 @@ def test_ring_symbols_sizes_and_validation():
     assert L.lwm_ring_unique_id(None) == cap.LWM_EINVAL
 
 
+def test_planned_bytes_follow_the_schedules():
+    """lwm_ring_planned_bytes (a pure function of the geometry, CPU): the neighbour ring rotates whole blocks -- K and V
+    n-1 times, the f32 carries n times -- whatever the ownership; the direct schedule ships exactly the (segment, peer)
+    pairs lwm_amd/ring.py's mesh schedule ships (same visibility rule), which under zigzag + causal is under 0.8x the
+    ring's bytes at n = 8 and equals 'everything to everybody' without a causal mask."""
+    from lwm_amd.ring import SeqLayout, _needed_ksegs
+    L, cap = _lib()
+    B, H, D = 1, 4, 128
+    for n in (2, 4, 8):
+        c = 512 * 2
+        row = H * D
+        for layout in ("contiguous", "zigzag"):
+            lay = SeqLayout(layout, n, c * n)
+            for causal in (1, 0):
+                for bwd in (0, 1):
+                    ring = [L.lwm_ring_planned_bytes(cap.RING_LAYOUT[layout], 0, n, r, B, c, H, D, causal, bwd) for r in range(n)]
+                    assert all(x == (n - 1) * 2 * c * row * 2 + bwd * n * 2 * c * row * 4 for x in ring)
+                    direct = [L.lwm_ring_planned_bytes(cap.RING_LAYOUT[layout], 1, n, r, B, c, H, D, causal, bwd) for r in range(n)]
+                    for r in range(n):
+                        want = 0
+                        for t in range(1, n):
+                            dst, owner = (r + t) % n, (r - t) % n
+                            want += sum(2 * lay.segments(r)[ki][1] * row * 2 for ki in _needed_ksegs(lay, dst, r, bool(causal)))
+                            if bwd:
+                                want += sum(2 * lay.segments(owner)[ki][1] * row * 4 for ki in _needed_ksegs(lay, r, owner, bool(causal)))
+                        assert direct[r] == want, (n, layout, causal, bwd, r)
+                    if not causal:
+                        assert all(x == (n - 1) * (2 * c * row * 2 + bwd * 2 * c * row * 4) for x in direct)
+        zz = lambda sched: sum(L.lwm_ring_planned_bytes(1, sched, n, r, B, c, H, D, 1, 0) + L.lwm_ring_planned_bytes(1, sched, n, r, B, c, H, D, 1, 1)
+                               for r in range(n))
+        if n == 8:
+            assert zz(1) < 0.8 * zz(0)
+    assert L.lwm_ring_planned_bytes(0, 0, 1, 0, 1, 64, 1, 128, 1, 1) == 0 and L.lwm_ring_planned_bytes(0, 0, 2, 2, 1, 64, 1, 128, 1, 1) == -1
+
+
 # ---------------------------------------------------------------- GPU
 class _Mailbox:
     """send/recv as the C driver wants them (enqueue on the given stream), implemented with one FIFO per
@@ -185,6 +220,14 @@ def test_c_ring_schedule_vs_oracle_and_python_driver(n, causal, packed, padded, 
     o1.backward(do)
     for name, a, b in zip(("out", "dq", "dk", "dv"), got, (o1.detach(), q1.grad, k1.grad, v1.grad)):
         assert ((a.float() - b.float()).abs().max() / b.float().abs().max()).item() <= 8e-3, name
+    if n > 1:
+        # what every rank sent = what the schedule plans for one forward + one backward (lwm_ring_planned_bytes, checked
+        # against lwm_amd/ring.py's visibility rule on CPU)
+        from lwm_amd import _capi
+        from lwm_amd._lib import lib
+        plan = lambda r, b: lib().lwm_ring_planned_bytes(_capi.RING_LAYOUT[layout], _capi.RING_SCHEDULE[schedule], n, r, 1, S // n, H, 128,
+                                                         int(causal), b)
+        assert sent == [plan(r, 0) + plan(r, 1) for r in range(n)], (sent, [plan(r, 0) + plan(r, 1) for r in range(n)])
     if n > 1 and schedule == "ring":
         # forward: n-1 rotations of K and V; backward: n-1 of K and V + n of the two f32 carries
         c = S // n
