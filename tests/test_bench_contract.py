@@ -39,9 +39,11 @@ def test_committed_bench_line_follows_the_contract():
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
     # round 3: BASELINE configs[0] end to end and the op points ride in the same object, one `cores` convention
-    assert c["config1"]["tokens_per_s"] > 0 and "configs[0]" in c["config1"]["workload"] and c["config1"]["cores"] == c["cores"]
+    # (`cores` = the threads a leg computed with: the blockwise port runs at the best of a thread sweep, the dense model
+    # and the OpenMP VQGAN oracle on every thread)
+    assert c["config1"]["tokens_per_s"] > 0 and "configs[0]" in c["config1"]["workload"] and c["config1"]["cores"] >= c["cores"]
     assert [p["S"] for p in c["op_points"]] == [4096, 8192, 16384]
-    assert d["vqgan"]["cpu_baseline"]["cores"] == c["cores"]
+    assert d["vqgan"]["cpu_baseline"]["cores"] == c["config1"]["cores"]
 
 
 def test_bench_cli_contract_without_a_gpu():
