@@ -327,8 +327,8 @@ def _fused_workspace(B, H, Sq, Sk, q_start, k_start, causal, device):
     key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     ws = _FUSED_WS.get(key)
     if ws is None or ws.numel() < need:
-        _FUSED_WS.pop(key, None)
-        ws = None
+        _FUSED_WS.pop(key, None)       # (drop the smaller buffer before the larger one is allocated)
+        del ws
         ws = _FUSED_WS[key] = torch.empty(need, dtype=torch.uint8, device=device)
     return ws
 
