@@ -224,7 +224,7 @@ def vqgan_leg(torch, frames=64, reps=3, config4_frames=1020):
     return res
 
 
-PROFILE_ROUND = "r03"      # only PMC summaries of THIS round's kernels may label this round's bench line
+PROFILE_ROUND = "r04"      # only PMC summaries of THIS round's kernels may label this round's bench line
 
 
 def pmc_traffic(kernel, S):
@@ -680,10 +680,6 @@ def main():
     ap.add_argument("--packed", action="store_true",
                     help="masked sequence packing (BASELINE config #5 style): documents log-uniform in "
                          "[S/256, S/4]; FLOPs are counted over visible pairs only")
-    ap.add_argument("--fused-bwd", action="store_true",
-                    help="A/B: run the backward as the one-launch lwm_attn_bwd_fused (5 GEMM units executed) instead "
-                         "of lwm_attn_bwd_dkdv + lwm_attn_bwd_dq (7); also LWM_FUSED_BWD=1")
-    ap.add_argument("--two-kernel-bwd", action="store_true", help="(default) the two-kernel backward")
     ap.add_argument("--driver", default=None, choices=["c", "python"],
                     help="N > 1: who drives the exchange.  c (default on GPUs) = the C-ABI ring driver (lwm_ring_attn_fwd/bwd: "
                          "RCCL send/recv or the IPC transport on a side HIP stream, zigzag / contiguous ownership, ring / direct "
@@ -712,11 +708,6 @@ def main():
     from lwm_amd.ring import (HipBlockOps, SeqLayout, SingleComm, TorchRingComm, ring_backward,
                               ring_forward)
 
-    import lwm_amd.ring as _ring
-    if args.fused_bwd:
-        _ring.FUSED_BACKWARD = True
-    if args.two_kernel_bwd:
-        _ring.FUSED_BACKWARD = False
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -804,8 +795,7 @@ def main():
         fwd = staticmethod(lambda *a, **kw: timer.run("attn_fwd64_kernel", ops.attn_fwd_block, *a, **kw))
         bwd_delta = staticmethod(lambda *a, **kw: timer.run("attn_bwd_delta_kernel", ops.attn_bwd_delta, *a, **kw))
         bwd_dq = staticmethod(lambda *a, **kw: timer.run("attn_bwd_dq_kernel", ops.attn_bwd_dq_block, *a, **kw))
-        bwd_dkdv = staticmethod(lambda *a, **kw: timer.run("attn_bwd_dkdv_kernel_w8", ops.attn_bwd_dkdv_block, *a, **kw))
-        bwd_fused = staticmethod(lambda *a, **kw: timer.run("attn_bwd_fused_kernel", ops.attn_bwd_fused_block, *a, **kw))
+        bwd_dkdv = staticmethod(lambda *a, **kw: timer.run("attn_bwd_dkdv4_kernel", ops.attn_bwd_dkdv_block, *a, **kw))
 
     c_ring = None
     sched_c = "ring" if args.schedule == "ring" else "direct"
@@ -1043,11 +1033,8 @@ def main():
             # dominant kernel by total time; algorithmic FLOPs per launch: fwd = 2 GEMM
             # units; the backward's 5 algorithmic units are apportioned to its two launches
             # by executed share (dkdv 4/7, dq 3/7) -- DESIGN.md "Work accounting".
-            # The one-launch backward executes exactly its 5 algorithmic units.
-            algo_units = {"attn_fwd64_kernel": 2.0, "attn_bwd_dkdv_kernel_w8": 5.0 * 4 / 7,
-                          "attn_bwd_dq_kernel": 5.0 * 3 / 7, "attn_bwd_fused_kernel": 5.0}
-            exec_units = {"attn_fwd64_kernel": 2.0, "attn_bwd_dkdv_kernel_w8": 4.0, "attn_bwd_dq_kernel": 3.0,
-                          "attn_bwd_fused_kernel": 5.0}
+            algo_units = {"attn_fwd64_kernel": 2.0, "attn_bwd_dkdv4_kernel": 5.0 * 4 / 7, "attn_bwd_dq_kernel": 5.0 * 3 / 7}
+            exec_units = {"attn_fwd64_kernel": 2.0, "attn_bwd_dkdv4_kernel": 4.0, "attn_bwd_dq_kernel": 3.0}
             cand = {n: d for n, d in ks.items() if n in algo_units}
             dom = max(cand, key=lambda n: cand[n]["total_ms"])
             avg_s = cand[dom]["avg_ms"] * 1e-3
@@ -1056,6 +1043,7 @@ def main():
                 "kernel": dom, "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
                 "traffic": pmc_traffic(dom, S)[0], "traffic_profile": pmc_traffic(dom, S)[1],
+                "traffic_source": "committed rocprofv3 --pmc profile of the same command (bench.py cannot collect counters)",
                 "avg_launch_ms": cand[dom]["avg_ms"],
                 "executed_tflops": exec_units[dom] * unit / avg_s / 1e12,
                 "all_kernels_algorithmic_tflops": {

@@ -60,7 +60,9 @@ typedef struct LwmAttnArgs {
     float* lse_acc;        /* [B,H,Sq]   f32 ring carry */
     LwmTensor4 dout;       /* bf16 in (bwd) */
     LwmTensor4 dq, dk, dv; /* bf16 out (bwd, when final_out) */
-    float* delta;          /* [B,H,Sq] f32: rowsum(dout*out); written by lwm_attn_bwd_delta */
+    float* delta;          /* backward row statistics, lwm_attn_bwd_delta_bytes(B,H,Sq) bytes, written by
+                            * lwm_attn_bwd_delta from out, dout and lse, read by lwm_attn_bwd_dq / _dkdv: per (b,h)
+                            * [-lse*log2(e) | -rowsum(dout*out)], each row padded to a multiple of 64 queries */
     float* dq_acc;         /* [B,Sq,H,D] f32 dense carry */
     float* dk_acc;         /* [B,Sk,H,D] f32 dense carry (travels with the K/V block) */
     float* dv_acc;
@@ -93,37 +95,22 @@ typedef struct LwmAttnArgs {
      * Results are unchanged (the per-element mask is still applied).  NULL = no skipping. */
     const int32_t* seg_blocks_q;
     const int32_t* seg_blocks_k;
-    /* lwm_attn_bwd_fused only: carry_in / final_out govern dk, dv; these two govern dq (a ring driver
-     * finishes a q segment and a k segment at different steps).  bwd_workspace: caller-owned device
-     * memory, 256-byte aligned, bwd_workspace_bytes long (lwm_attn_bwd_fused_workspace_bytes: work-queue
-     * tickets, LSE in log2 units, and the bf16 dq partial of every (key block, query tile) pair of one group of
-     * heads; it need not persist between launches). */
-    int32_t dq_carry_in, dq_final_out;
-    void* bwd_workspace;
-    /* lwm_attn_bwd_dq and lwm_attn_bwd_fused: 0 = dq_acc is [B,Sq,H,D], 1 = head-major [B,H,Sq,D]. */
+    /* lwm_attn_bwd_dq: 0 = dq_acc is [B,Sq,H,D], 1 = head-major [B,H,Sq,D]. */
     int32_t dq_acc_head_major;
-    int64_t bwd_workspace_bytes;
 } LwmAttnArgs;
 
 int lwm_attn_fwd(const LwmAttnArgs* args, void* stream);
+/* The backward of one ring step = three launches (no atomics, bit-reproducible): the row statistics once per query
+ * block, then dq (a workgroup owns 256 queries and streams K/V: 3 GEMM units) and dk, dv (a workgroup owns 128 keys
+ * and streams Q/dO: 4 units) per (query block, K/V block) pair, chained through the f32 carries.  [A form that
+ * computed S and dP once and summed bf16 dq partials -- 5 units -- was measured in rounds 2-3 and retired in round 4:
+ * profiles/r04_backward.md.] */
 int lwm_attn_bwd_delta(const LwmAttnArgs* args, void* stream);
 int lwm_attn_bwd_dq(const LwmAttnArgs* args, void* stream);
 int lwm_attn_bwd_dkdv(const LwmAttnArgs* args, void* stream);
 
-/* The whole backward of one ring step with S and dP computed ONCE -- the reference's 5 GEMMs per chunk pair
- *  instead of the 7 that lwm_attn_bwd_dq + lwm_attn_bwd_dkdv execute between them.  Same
- * operands and mask semantics (seg_blocks_* hints honoured).  A workgroup owns 256 keys (dk, dv as in
- * lwm_attn_bwd_dkdv) and stores the dq contribution of its keys to each 32-query tile as a bf16 partial in the
- * workspace; a streaming pass then sums every tile's partials in ascending key order in f32 (+ the f32 carry
- * dq_acc when dq_carry_in), scales, and writes dq (bf16, dq_final_out = 1) or dq_acc.  Deterministic: no atomics,
- * fixed summation order.  dq differs from the two-kernel path by the bf16 rounding of the per-256-key partials.
- * Workspace: lwm_attn_bwd_fused_workspace_bytes(..., head_group) bytes for `head_group` (batch*head) slices per
- * launch (0 = all at once; otherwise a multiple of 8): 8 KiB per visible (key block, query tile) pair and head,
- * e.g. 17.2 GB for S = 32768 x 32 heads, causal.  With a smaller workspace the call runs the heads in as many
- * groups as it has room for (bwd_workspace_bytes) and fails with LWM_EINVAL if not even 8 heads fit. */
-int64_t lwm_attn_bwd_fused_workspace_bytes(int32_t B, int32_t H, int32_t Sq, int32_t Sk, int64_t q_start,
-                                           int64_t k_start, int32_t causal, int32_t head_group);
-int lwm_attn_bwd_fused(const LwmAttnArgs* args, void* stream);
+/* Bytes of the backward's row statistics (LwmAttnArgs::delta) for a [B, Sq, H, D] query block. */
+int64_t lwm_attn_bwd_delta_bytes(int32_t B, int32_t H, int32_t Sq);
 
 /* ------------------------------------------------------------------ the sequence ring
  * The exchange that lax.ppermute performs under ringattention (lwm/llama.py:539-569, SURVEY.md Appendix

@@ -33,9 +33,7 @@ class LwmAttnArgs(C.Structure):
         ("dense_mask", C.c_void_p), ("mask_stride_b", C.c_int64), ("mask_stride_q", C.c_int64),
         ("k_splits", C.c_int32),
         ("seg_blocks_q", C.c_void_p), ("seg_blocks_k", C.c_void_p),
-        ("dq_carry_in", C.c_int32), ("dq_final_out", C.c_int32), ("bwd_workspace", C.c_void_p),
         ("dq_acc_head_major", C.c_int32),
-        ("bwd_workspace_bytes", C.c_int64),
     ]
 
 
@@ -87,9 +85,7 @@ PROTOTYPES = {
     "lwm_attn_bwd_delta": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
     "lwm_attn_bwd_dq": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
     "lwm_attn_bwd_dkdv": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
-    "lwm_attn_bwd_fused": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
-    "lwm_attn_bwd_fused_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
-                                                      C.c_int32, C.c_int32]),
+    "lwm_attn_bwd_delta_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "lwm_ring_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "lwm_ring_unique_id": (C.c_int, [C.c_void_p]),
     "lwm_ring_create_from_id": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -1,0 +1,657 @@
+// attn_bwd64.h -- blockwise attention backward, ONE WAVE PER SIMD (the structure of attn_fwd64.h): the dK/dV kernel
+// of the two-kernel backward for one (q block, kv block) ring step on gfx950.  Requires wave_ops.h, attn_common.h,
+// attn_fwd.h, attn_fwd64.h (f4_* instruction helpers) and attn_bwd.h (the delta kernel).
+//
+// Replaces the dk / dv part of the custom-VJP backward of `ringattention` (call site lwm/llama.py:539-569; SURVEY.md
+// Appendix A.1): p from the saved LSE, dv += p^T do, dp = do v^T, ds = p * (dp - rowsum(do * o)), dk += ds^T q * scale.
+// Same contract, operands, masks, carries and segment-block hints as attn_bwd_dkdv_kernel_w8 (attn_bwd.h), which
+// stays as the 8-wave reference build (-DLWM_DKDV_OLD).
+//
+// Workgroup = 4 waves = 128 keys; a wave owns 32 keys and the SIMD's whole register file: its K and V fragments (B
+// operands, 32 + 32 registers) and the f32 dK^T / dV^T accumulators (64 + 64) live in the accumulator file -- the
+// forward's budget of 192 AGPRs -- so the only LDS traffic of the tile loop is the streamed operand: Q / dO row
+// fragments for S and dP, Q^T / dO^T transposed fragments for dK and dV, one fragment per MFMA, every address
+// register-resident (no v_xor).  Q / dO arrive by LDS-DMA in steps of 64 queries through a ring of four 32-KiB
+// slots: the pieces of step i+2 are issued in the first phase of step i and have landed, for every wave, at the
+// barrier that ends step i -- a whole step before their first reader, which is what lets the last phase of step
+// i+1 request the first fragments of step i+2 across the barrier.  The row statistics (attn_bwd.h: -lse * log2 e,
+// -delta, padded) travel the same way, one dword per lane.
+//
+// A unit = 32 queries x the wave's 32 keys = two phases of 16 MFMAs, written as `asm volatile` statements in program
+// order (attn_fwd64.h explains why), with the vector work placed in the gaps:
+//
+//   phase   matrix pipe (consecutive MFMAs never share an accumulator)      vector pipe (same wave)
+//   X(u)    S(u) = Q(u) K^T  and  dP'(u) = dO(u) V^T - delta, alternating   P(u-1) -> bf16, dS(u-1) = p dP'(u-1) -> bf16
+//   Y(u)    dV^T += dO(u-1)^T P(u-1), dK^T += Q(u-1)^T dS(u-1), 8 tuples    t = S(u) c - lse2, p(u) = exp2(t)
+//
+// The products lag one unit, so every phase has fillers -- 32 VALU per 16 MFMAs -- and S needs one register tile (dP'
+// two: the multiply of unit u-1 runs beside the chain of unit u).  -delta enters as the initial value of the dP
+// accumulator (the wave that carries the statistics negates it on its way to LDS; the unit before requests it into
+// the tuple), so the chain leaves dP' = dP - delta and dS is ONE multiply: 64 VALU per 32 MFMAs.
+//
+// LDS map: slot 0..3 = [Q tile 64 rows | dO tile 64 rows] (16 KiB each) | stats 0..3 = [nl2 64 | -delta 64 | seg_q 64]
+#pragma once
+
+namespace lwm {
+
+constexpr int kD4BK = 128;      // keys per workgroup
+constexpr int kD4BQ = 64;       // queries per step (two units of 32)
+constexpr int kD4Threads = 256;
+constexpr int kD4Slots = 4;
+constexpr int kD4TileBytes = kD4BQ * kRowBytes;          // 16 KiB
+constexpr int kD4SlotBytes = 2 * kD4TileBytes;           // Q | dO
+constexpr int kD4OffStat = kD4Slots * kD4SlotBytes;      // 128 KiB
+constexpr int kD4StatBytes = 3 * kD4BQ * 4;              // nl2 | delta | seg_q
+constexpr int kD4LdsBytes = kD4OffStat + kD4Slots * kD4StatBytes;
+// LDS fragments are requested kD4Ahead MFMAs before the MFMA that consumes them, through ONE register ring of eight
+// that all four phases share (fragment m of a unit lives in ring[m % 8]).
+#ifndef LWM_D4_AHEAD
+#define LWM_D4_AHEAD 6
+#endif
+constexpr int kD4Ahead = LWM_D4_AHEAD;
+static_assert(kD4Ahead >= 1 && kD4Ahead <= 7, "prefetch distance in fragments");
+// timing experiments only (wrong results): -DLWM_D4X_NODMA / _NOFILL / _NOBAR / _NOSTAT / _NOSLOAD drop one ingredient of the loop
+#ifdef LWM_D4X_NOFILL
+constexpr bool kD4xFill = false;
+#else
+constexpr bool kD4xFill = true;
+#endif
+#ifdef LWM_D4X_NOSLOAD
+constexpr bool kD4xSload = false;
+#else
+constexpr bool kD4xSload = true;
+#endif
+#ifdef LWM_D4X_NOSTAT
+constexpr bool kD4xStat = false;
+#else
+constexpr bool kD4xStat = true;
+#endif
+
+struct D4Ctx {
+    uint32_t qa[8];             // Q row-fragment addresses (d step s), rows 0..31 of the CURRENT step's Q tile
+    uint32_t tlo[4], tup[4];    // transposed-fragment addresses (d block), rows 0..15 of the current step's Q tile
+    uint32_t plo[4], pup[4];    // the same in the PREVIOUS step's slot (the lagging dK of a step's first unit)
+    uint32_t stat;              // this step's statistics + 16 * hi
+    float c;                    // scale * log2(e)
+    int hi;
+};
+
+#ifdef LWM_EMU
+LWM_DEVICE void d4_mfma_p_first(f32x16& d, bf16x8 a, bf16x8 b) { d = mfma_32x32x16(a, b, d); }
+LWM_DEVICE void d4_mfma_o_first(f32x16& d, bf16x8 a, bf16x8 b) { d = mfma_32x32x16(a, b, zero_f32x16()); }
+LWM_DEVICE float d4_mul(float a, float b) { return a * b; }
+LWM_DEVICE void d4_dma_b32(uint32_t voff, const char* src, lds_t dst) { glds_load_b32(src + voff, dst); }
+LWM_DEVICE void d4_settle_t(f32x16&) {}
+LWM_DEVICE void d4_settle_acc(f32x16 (&)[4], f32x16 (&)[4]) {}
+#else
+// What hipcc does not know about an asm MFMA (cdna_hip_programming.md section 5.7 item 2): a register it has just
+// written itself -- a copy that moves a tuple into place, a zero it materialises late -- needs two wait states before
+// an MFMA reads it.  The two statements below are used where that can happen:
+//   * the first MFMA of a dP chain: its accumulator was filled with -delta by compiler-visible LDS loads, which hipcc
+//     may route through copies (it does in the prologue): the wait states stand in front of the MFMA;
+//   * the first product of the walk into each dK^T / dV^T tuple: C = 0 and an OUTPUT-only operand, so that no
+//     compiler-made zero is read at all.
+LWM_DEVICE void d4_mfma_p_first(f32x16& d, bf16x8 a, bf16x8 b) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
+}
+LWM_DEVICE void d4_mfma_o_first(f32x16& d, bf16x8 a, bf16x8 b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&a"(d) : "v"(a), "v"(b));
+}
+LWM_DEVICE float d4_mul(float a, float b) {
+    float y;
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(y) : "v"(a), "v"(b));
+    return y;
+}
+// one LDS-DMA dword per lane (64 floats of row statistics), M0 written bare as f4_dma1 does
+LWM_DEVICE void d4_dma_b32(uint32_t voff, const char* src, lds_t dst) {
+    const uint64_t a = (uint64_t)src;
+    const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(u), "s"(dst) : "memory");
+}
+LWM_DEVICE void d4_settle_t(f32x16& s) { asm volatile("s_nop 7\n\ts_nop 7" : "+v"(s)); }
+LWM_DEVICE void d4_settle_acc(f32x16 (&a)[4], f32x16 (&b)[4]) {
+    asm volatile("s_nop 7\n\ts_nop 7"
+                 : "+a"(a[0]), "+a"(a[1]), "+a"(a[2]), "+a"(a[3]), "+a"(b[0]), "+a"(b[1]), "+a"(b[2]), "+a"(b[3]));
+}
+#endif
+
+// per-lane byte offsets of the wave's four pieces of a 64-row tile (piece = 4 rows = 1 KiB; wave w moves pieces
+// w, w+4, w+8, w+12: rows 4w + 16j + (l>>4)) relative to the step's first row, rows clamped to Sq-1 (rows past Sq
+// get nl2 = -inf through the statistics).  Lane l writes physical slot l&15 of its row, so it fetches logical slot
+// (l&15) ^ swz(row) -- the XOR swizzle applied on the SOURCE column.
+LWM_DEVICE void d4_stage_offsets(const AttnParams& p, int wave, int lane, int st, uint32_t (&vq)[4], uint32_t (&vdo)[4]) {
+    const int slot = lane & 15;
+    for (int j = 0; j < 4; ++j) {
+        const int row = 4 * (wave + 4 * j) + (lane >> 4);
+        int qrow = st * kD4BQ + row;
+        qrow = qrow < p.Sq ? qrow : p.Sq - 1;
+        const int rel = qrow - st * kD4BQ;
+        const int col = (slot ^ swz(row)) << 3;
+        vq[j] = (uint32_t)(((int64_t)rel * p.q_ss + col) * 2);
+        vdo[j] = (uint32_t)(((int64_t)rel * p.do_ss + col) * 2);
+    }
+}
+
+// fragment f of a unit (f = MFMA index 0..31; 32.. = the first fragments of the unit that follows):
+//   0..15   phase X: d step f>>1; even = Q row fragment (S), odd = dO row fragment (dP)
+//   16..31  phase Y: j = f-16, (q step (j>>3)&1, d block (j>>1)&3) of the PREVIOUS unit; even = dO^T (dV), odd = Q^T (dK)
+// cx.qa points at the step's slot for HALF = 0 and for the X phase of HALF = 1; it has moved on to the next step's slot
+// when the Y phase of HALF = 1 requests f >= 32.
+template <int HALF>
+LWM_DEVICE bf16x8 d4_frag(const D4Ctx& cx, int f) {
+    if (f >= 32) {
+        const int g = f - 32;
+        return lds_read_b128(cx.qa[g >> 1] + (g & 1) * kD4TileBytes + (HALF == 0 ? 32 * kRowBytes : 0));
+    }
+    if (f < 16) return lds_read_b128(cx.qa[f >> 1] + (f & 1) * kD4TileBytes + HALF * 32 * kRowBytes);
+    const int j = f - 16, t = (j >> 3) & 1, db = (j >> 1) & 3;
+    // the previous unit: the second half of the previous step's tiles for HALF = 0, the first half of this step's
+    const uint32_t alo = HALF == 0 ? cx.plo[db] : cx.tlo[db];
+    const uint32_t aup = HALF == 0 ? cx.pup[db] : cx.tup[db];
+    const uint32_t off = ((j & 1) ? 0 : kD4TileBytes) + (HALF == 0 ? 32 * kRowBytes : 0) + 16 * t * kRowBytes;
+    bf16x4 lo = lds_read_tr16(alo + off);
+    bf16x4 up = lds_read_tr16(aup + off);
+    bf16x8 o;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+    o[4] = up[0]; o[5] = up[1]; o[6] = up[2]; o[7] = up[3];
+    return o;
+}
+
+// the LDS-DMA pieces one step issues (all wave-uniform but the offsets): Q and dO of the step two ahead
+struct D4Dma {
+    const char* q_src;
+    const char* do_src;
+    lds_t dst;          // the slot's Q tile + wave * 1024
+};
+
+// Live state of a wave across units.
+struct D4Regs {
+    f32x16 s;               // S tile (MFMA result, read-only for the vector pipe)
+    f32x16 dp[2];           // dP' tiles by unit parity: preloaded with -delta (in C/D register order), then the dP chain
+    float nl[16];           // -lse * log2(e) of the unit's rows, C/D register order
+    float t[16];            // exponents, then p
+    float ds[16];           // dS = p * dP'
+    bf16x8 pb[2], dsb[2];   // P / dS as B operands (q steps of 16)
+    bf16x8 fr[8];           // the fragment ring
+};
+
+// -delta of a unit's rows -> the dP tuple that unit's chain will accumulate into (stat = statistics slot + 16 hi)
+template <int HALF>
+LWM_DEVICE void d4_load_ndelta(uint32_t stat, f32x16& dp, int g) {
+    const f32x4 v = lds_read_f32x4(stat + kD4BQ * 4 + HALF * 32 * 4 + 8 * g * 4);
+    dp[4 * g + 0] = v[0]; dp[4 * g + 1] = v[1]; dp[4 * g + 2] = v[2]; dp[4 * g + 3] = v[3];
+}
+
+// Phase X of unit u (16 MFMAs): S(u) = Q K^T and dP'(u) = dO V^T - delta, the two chains ALTERNATING -- a dependent
+// MFMA that does not follow its predecessor back to back waits for the whole chain before it (MI355X_MICROARCH.md,
+// per-instruction constants: +43 cycles for the first instruction in between), an independent MFMA in between hides
+// that -- || the second half of unit u-1's vector work: P -> bf16, dS = p dP', dS -> bf16.
+// The first kD4Ahead fragments are ALREADY in the ring; the dP tuple holds -delta.
+template <int HALF, bool HAS_PREV, bool DMA>
+LWM_DEVICE void d4_x(const D4Ctx& cx, D4Regs& rg, const bf16x8 (&kf)[8], const bf16x8 (&vf)[8], const uint32_t (&vq)[4],
+                     const uint32_t (&vdo)[4], const D4Dma& dm) {
+    uint32_t w[4];
+    f32x16& dpn = rg.dp[HALF];            // this unit's dP'
+    const f32x16& dpo = rg.dp[HALF ^ 1];  // the previous unit's
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        rg.fr[(m + kD4Ahead) & 7] = d4_frag<HALF>(cx, m + kD4Ahead);
+        if (kD4xStat && (m & 3) == 2) {      // the unit's -lse * log2 e (needed from gap 1 of phase Y)
+            const int g = m >> 2;
+            const f32x4 v = lds_read_f32x4(cx.stat + HALF * 32 * 4 + 8 * g * 4);
+            rg.nl[4 * g + 0] = v[0]; rg.nl[4 * g + 1] = v[1]; rg.nl[4 * g + 2] = v[2]; rg.nl[4 * g + 3] = v[3];
+        }
+        sched_fence();
+        if (m == 0) f4_mfma_s_first(rg.s, rg.fr[0], kf[0]);
+        else if ((m & 1) == 0) f4_mfma_s(rg.s, rg.fr[m & 7], kf[m >> 1]);
+        else if (m == 1) d4_mfma_p_first(dpn, rg.fr[1], vf[0]);
+        else f4_mfma_s(dpn, rg.fr[m & 7], vf[m >> 1]);
+#ifndef LWM_D4X_NODMA
+        if (DMA && (m & 1)) {         // the wave's 4 Q and 4 dO pieces of the step two ahead, all in the step's first phase
+            const int j = m >> 2;
+            if ((m & 2) == 0) f4_dma1(vq[j], dm.q_src, dm.dst + 4096 * j);
+            else f4_dma1(vdo[j], dm.do_src, dm.dst + kD4TileBytes + 4096 * j);
+        }
+#endif
+        if (HAS_PREV && kD4xFill) {
+            if (m < 8) {
+                w[m & 3] = f4_cvt_pk(rg.t[2 * m], rg.t[2 * m + 1]);
+                if ((m & 3) == 3) rg.pb[m >> 2] = __builtin_bit_cast(bf16x8, u32x4{w[0], w[1], w[2], w[3]});
+                rg.ds[2 * m] = d4_mul(rg.t[2 * m], dpo[2 * m]);
+                rg.ds[2 * m + 1] = d4_mul(rg.t[2 * m + 1], dpo[2 * m + 1]);
+            } else {
+                const int i = m - 8;
+                w[i & 3] = f4_cvt_pk(rg.ds[2 * i], rg.ds[2 * i + 1]);
+                if ((i & 3) == 3) rg.dsb[i >> 2] = __builtin_bit_cast(bf16x8, u32x4{w[0], w[1], w[2], w[3]});
+            }
+        }
+        sched_fence();
+    }
+}
+
+// masks of a unit on its scores (lwm/llama.py:572-592): query row (r&3) + 8 (r>>2) + 4 hi of the unit sees this lane's
+// key iff it is not before it (rel = key position - position of the unit's row 0 - 4 hi, clamped) and, with key meta,
+// shares its segment (kseg = kSegInvalid for a padded / out-of-range key)
+template <int HALF, bool HAS_META>
+LWM_DEVICE void d4_mask(const D4Ctx& cx, D4Regs& rg, int rel, int32_t kseg) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (HAS_META) {
+            const u32x4 sg = lds_read_u32x4(cx.stat + 2 * kD4BQ * 4 + HALF * 32 * 4 + 8 * g * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool vis = ((int32_t)sg[j] == kseg) && (8 * g + j >= rel);
+                rg.s[4 * g + j] = vis ? rg.s[4 * g + j] : -INFINITY;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rg.s[4 * g + j] = (8 * g + j >= rel) ? rg.s[4 * g + j] : -INFINITY;
+        }
+    }
+}
+
+// Phase Y of unit u (16 MFMAs): dV^T += dO(u-1)^T P(u-1) and dK^T += Q(u-1)^T dS(u-1), eight accumulators in turn  ||
+// the first half of unit u's vector work: t = S c - lse2 (from gap 1: the chains have left the pipe), p = exp2(t).
+// The last gaps request the first fragments of the unit that follows and its -delta (statn = the statistics slot
+// of that unit + 16 hi).
+// INIT: these are the first products of the walk (C = 0: the tuples are defined here).
+template <int HALF, bool HAS_PREV, bool NEXT, bool INIT>
+LWM_DEVICE void d4_y(const D4Ctx& cx, D4Regs& rg, f32x16 (&dk)[4], f32x16 (&dv)[4], uint32_t statn) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int m = 16 + j;
+        if (m + kD4Ahead < 32 || NEXT) rg.fr[(m + kD4Ahead) & 7] = d4_frag<HALF>(cx, m + kD4Ahead);
+        if (kD4xStat && NEXT && j >= 12) d4_load_ndelta<HALF ^ 1>(statn, rg.dp[HALF ^ 1], j - 12);
+        sched_fence();
+        if (HAS_PREV) {
+            if (INIT && j < 8) {
+                if ((j & 1) == 0) d4_mfma_o_first(dv[(j >> 1) & 3], rg.fr[m & 7], rg.pb[0]);
+                else d4_mfma_o_first(dk[(j >> 1) & 3], rg.fr[m & 7], rg.dsb[0]);
+            } else {
+                if ((j & 1) == 0) f4_mfma_o(dv[(j >> 1) & 3], rg.fr[m & 7], rg.pb[j >> 3]);
+                else f4_mfma_o(dk[(j >> 1) & 3], rg.fr[m & 7], rg.dsb[j >> 3]);
+            }
+        }
+        if (kD4xFill) {
+            if (j >= 1 && j <= 8) {
+                const int e = 2 * (j - 1);
+                rg.t[e] = f4_fma(rg.s[e], cx.c, rg.nl[e]);
+                rg.t[e + 1] = f4_fma(rg.s[e + 1], cx.c, rg.nl[e + 1]);
+            }
+            // exponentials: every element at least one gap behind its fma
+            if (j == 2) rg.t[0] = f4_exp2(rg.t[0]);
+            if (j == 3) rg.t[1] = f4_exp2(rg.t[1]);
+            if (j == 4) { rg.t[2] = f4_exp2(rg.t[2]); rg.t[3] = f4_exp2(rg.t[3]); }
+            if (j == 5) rg.t[4] = f4_exp2(rg.t[4]);
+            if (j == 6) rg.t[5] = f4_exp2(rg.t[5]);
+            if (j == 7) { rg.t[6] = f4_exp2(rg.t[6]); rg.t[7] = f4_exp2(rg.t[7]); }
+            if (j == 8) rg.t[8] = f4_exp2(rg.t[8]);
+            if (j >= 9 && j <= 11) { rg.t[2 * j - 9] = f4_exp2(rg.t[2 * j - 9]); rg.t[2 * j - 8] = f4_exp2(rg.t[2 * j - 8]); }
+            if (j == 12) rg.t[15] = f4_exp2(rg.t[15]);
+        }
+        sched_fence();
+    }
+}
+
+// the pipeline's tail: the second half of the last unit's vector work, then its dV / dK products (no fillers left).
+// PAR = the parity of the last unit (its dP' tuple); its tiles are addressed as the "previous unit" of a HALF = 0 unit.
+template <int PAR>
+LWM_DEVICE void d4_drain(const D4Ctx& cx, D4Regs& rg, f32x16 (&dk)[4], f32x16 (&dv)[4]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        w[m & 3] = f4_cvt_pk(rg.t[2 * m], rg.t[2 * m + 1]);
+        if ((m & 3) == 3) rg.pb[m >> 2] = __builtin_bit_cast(bf16x8, u32x4{w[0], w[1], w[2], w[3]});
+        rg.ds[2 * m] = d4_mul(rg.t[2 * m], rg.dp[PAR][2 * m]);
+        rg.ds[2 * m + 1] = d4_mul(rg.t[2 * m + 1], rg.dp[PAR][2 * m + 1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        w[i & 3] = f4_cvt_pk(rg.ds[2 * i], rg.ds[2 * i + 1]);
+        if ((i & 3) == 3) rg.dsb[i >> 2] = __builtin_bit_cast(bf16x8, u32x4{w[0], w[1], w[2], w[3]});
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rg.fr[j] = d4_frag<0>(cx, 16 + 8 * h + j);
+        sched_fence();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int jj = 8 * h + j;
+            if ((jj & 1) == 0) f4_mfma_o(dv[(jj >> 1) & 3], rg.fr[j], rg.pb[jj >> 3]);
+            else f4_mfma_o(dk[(jj >> 1) & 3], rg.fr[j], rg.dsb[jj >> 3]);
+        }
+        sched_fence();
+    }
+}
+
+template <bool HAS_META>
+LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
+    const lds_t lds = dyn_lds();
+    const int tid = thread_idx();
+    const int wave = wave_uniform(tid >> 6), lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+
+    // ---- block -> (key block, head, batch): all key blocks of one (b,h) on one XCD, longest walks first
+    const int nkb = (p.Sk + kD4BK - 1) / kD4BK;
+    const int HB = p.H * p.B;
+    int lin = block_idx_x(), kbi, hb;
+    if ((HB & 7) == 0) {
+        int xcd = lin & 7, i = lin >> 3;
+        hb = xcd + 8 * (i / nkb);
+        kbi = i % nkb;
+    } else {
+        hb = lin / nkb;
+        kbi = lin % nkb;
+    }
+    const int b = hb / p.H, h = hb % p.H;
+    const bf16_t* qb = p.q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
+    const bf16_t* kb = p.k + (int64_t)b * p.k_sb + (int64_t)h * p.k_sh;
+    const bf16_t* vb = p.v + (int64_t)b * p.v_sb + (int64_t)h * p.v_sh;
+    const bf16_t* dob = p.dout + (int64_t)b * p.do_sb + (int64_t)h * p.do_sh;
+
+    // ---- this lane's key: fragments straight into the accumulator file (a row past Sk re-reads the last row: its
+    // results are never stored)
+    const int k_row = kbi * kD4BK + wave * 32 + l31;
+    const bool k_ok = k_row < p.Sk;
+    const int kr = k_ok ? k_row : p.Sk - 1;
+    bf16x8 kf[8], vf[8];
+    for (int s = 0; s < 8; ++s) kf[s] = f4_load_agpr(kb + (int64_t)kr * p.k_ss + 16 * s + 8 * hi);
+    for (int s = 0; s < 8; ++s) vf[s] = f4_load_agpr(vb + (int64_t)kr * p.v_ss + 16 * s + 8 * hi);
+    const int64_t k_pos = p.k_start + k_row;
+    int32_t kseg = 0;
+    if (HAS_META) {
+        kseg = kSegInvalid;
+        if (k_ok) {
+            const bool valid = p.key_valid ? (p.key_valid[(int64_t)b * p.Sk + k_row] != 0) : true;
+            if (valid) kseg = p.seg_k ? p.seg_k[(int64_t)b * p.Sk + k_row] : 0;
+        }
+    }
+
+    // ---- step range of the walk (steps of 64 queries; causal: skip steps wholly before this key block)
+    int nst = (p.Sq + kD4BQ - 1) / kD4BQ;
+    int st0 = 0;
+    if (p.causal) {
+        const int64_t d = p.k_start + (int64_t)kbi * kD4BK - p.q_start;   // first q row that can see key 0
+        if (d > 0) st0 = (int)(d / kD4BQ < nst ? d / kD4BQ : nst);
+    }
+    if (HAS_META && p.segb_q && p.segb_k && st0 < nst) {     // packed sequences: skip other documents' query steps
+        const int nbq = (p.Sq + 31) >> 5, nbk = (p.Sk + 31) >> 5;
+        int smin, smax, lo, hi2;
+        seg_own_range(p.segb_k + (int64_t)b * nbk * 2, nbk, kbi * (kD4BK / 32), kD4BK / 32, smin, smax);
+        seg_narrow<kD4Threads>(p.segb_q + (int64_t)b * nbq * 2, nbq, kD4BQ / 32, st0, nst, smin, smax, lds + kD4OffStat, tid, lo, hi2);
+        st0 = lo;
+        nst = hi2;
+    }
+    const int n = nst > st0 ? nst - st0 : 0;       // steps of the walk; walk index i -> step nst - 1 - i (descending:
+                                                   // the key blocks resident on an XCD read the same tile at the same time)
+
+    f32x16 dk[4], dv[4];       // defined by the first products of the walk (d4_y<.., INIT>), or zero when there is no walk
+    if (n == 0)
+        for (int i = 0; i < 4; ++i) {
+            dk[i] = zero_f32x16();
+            dv[i] = zero_f32x16();
+        }
+    f4_load_agpr_wait8(kf);
+    f4_load_agpr_wait8(vf);
+
+    if (n > 0) {
+        D4Ctx cx;
+        cx.hi = hi;
+        cx.c = p.scale * kLog2e;
+        for (int s = 0; s < 8; ++s) cx.qa[s] = lds + tile_off(l31, 2 * s + hi);
+        {
+            const TrFragAddr t = frag_tr_addr(lds, lane);
+            for (int db = 0; db < 4; ++db) {
+                cx.tlo[db] = t.lo[db];
+                cx.tup[db] = t.up[db];
+                cx.plo[db] = t.lo[db];
+                cx.pup[db] = t.up[db];
+            }
+        }
+        cx.stat = lds + kD4OffStat + 16 * hi;
+
+        const int64_t q_step_bytes = (int64_t)kD4BQ * p.q_ss * 2, do_step_bytes = (int64_t)kD4BQ * p.do_ss * 2;
+        uint32_t vq[4], vdo[4];
+        d4_stage_offsets(p, wave, lane, 0, vq, vdo);      // full steps: nothing is clamped
+        // The row statistics travel like the tiles: ONE LDS-DMA dword instruction moves the 64 floats of a step's nl2 row
+        // (wave 0), of its nd row (wave 1) and -- with key meta -- of its query segment ids (wave 2), first thing in the
+        // step, so that the counted wait at the bottom (all but the 8 tile pieces of the step) covers them.
+        const int64_t Sqp = bwd_stat_pad(p.Sq);
+        const char* stat_src = (const char*)(p.delta + bwd_stat_row((int64_t)b * p.H + h, Sqp) + (wave == 1 ? Sqp : 0));
+        bool stat_on = wave < 2;
+        if (HAS_META && wave == 2 && p.seg_q) {
+            stat_src = (const char*)(p.seg_q + (int64_t)b * p.Sq);
+            stat_on = true;
+        }
+        const lds_t stat_dst = lds + kD4OffStat + (uint32_t)(wave < 3 ? wave : 0) * kD4BQ * 4;
+        const uint32_t vstat = (uint32_t)lane * 4;
+        if (HAS_META && !p.seg_q)                          // no query segments: every slot's ids read as 0
+            for (int sl = 0; sl < kD4Slots; ++sl)
+                if (tid < kD4BQ) lds_write_i32(lds + kD4OffStat + sl * kD4StatBytes + 2 * kD4BQ * 4 + tid * 4, 0);
+        // staging of walk index i from the slow path (prologue; the ragged top step has its own offsets, and its
+        // segment ids stop at Sq: the statistics rows are padded, the caller's ids are not)
+        auto stage_step = [&](int i) {
+            const int st = nst - 1 - i;
+            const lds_t dst = lds + (i & 3) * kD4SlotBytes + (uint32_t)wave * 1024;
+            const char* qs = (const char*)qb + st * q_step_bytes;
+            const char* ds = (const char*)dob + st * do_step_bytes;
+            if (stat_on) {
+                int row = st * kD4BQ + lane;
+                if (HAS_META && wave == 2) row = row < p.Sq ? row : p.Sq - 1;
+                glds_load_b32(stat_src + (int64_t)row * 4, stat_dst + (i & 3) * kD4StatBytes);
+            }
+            if (st * kD4BQ + kD4BQ > p.Sq) {
+                uint32_t v2[4], d2[4];
+                d4_stage_offsets(p, wave, lane, st, v2, d2);
+                f4_dma<4>(v2, qs, dst);
+                f4_dma<4>(d2, ds, dst + kD4TileBytes);
+            } else {
+                f4_dma<4>(vq, qs, dst);
+                f4_dma<4>(vdo, ds, dst + kD4TileBytes);
+            }
+        };
+
+        // ---- prologue: steps 0 and 1 in flight
+        stage_step(0);
+        if (n > 1) stage_step(1);
+        glds_wait_all();
+        block_sync();
+
+        // A unit needs the mask code when its first query lies before the wave's last key (or keys can be masked for
+        // another reason than causality).  Units are named by the row of their first query inside the q block,
+        // ub = 64 * step + 32 * half (steps descend, the halves of a step ascend); everything is clamped to 32 bits once.
+        auto clamp32 = [](int64_t x) -> int { return x > (1 << 30) ? (1 << 30) : (x < -(1 << 30) ? -(1 << 30) : (int)x); };
+        const int wk_rel = clamp32(p.k_start + (int64_t)kbi * kD4BK + wave * 32 + 31 - p.q_start);   // the wave's last key
+        const int k_rel = clamp32(k_pos - p.q_start) - 4 * hi;                                      // this lane's key
+        auto needs_mask = [&](int ub) -> bool { return HAS_META || (p.causal && ub < wk_rel); };
+        auto rel_of = [&](int ub) -> int {
+            if (!p.causal) return -64;
+            const int d = k_rel - ub;
+            return d > 64 ? 64 : (d < -64 ? -64 : d);
+        };
+
+        D4Regs rg;
+        rg.s = zero_f32x16();
+        rg.dp[0] = zero_f32x16();
+        rg.dp[1] = zero_f32x16();
+        for (int r = 0; r < 16; ++r) {
+            rg.nl[r] = 0.0f;
+            rg.t[r] = 0.0f;
+            rg.ds[r] = 0.0f;
+        }
+        for (int t = 0; t < 2; ++t) {
+            rg.pb[t] = zero_bf16x8();
+            rg.dsb[t] = zero_bf16x8();
+        }
+        for (int j = 0; j < 8; ++j) rg.fr[j] = zero_bf16x8();
+        D4Dma dm = {};
+        // the first unit's fragments and -delta (every later unit finds them requested by the unit before it)
+        for (int j = 0; j < kD4Ahead; ++j) rg.fr[j] = d4_frag<0>(cx, j);
+        for (int g = 0; g < 4; ++g) d4_load_ndelta<0>(cx.stat, rg.dp[0], g);
+
+        // Step i of the walk.  Its tiles are in slot i & 3; the address registers in cx point there and move on to the slot
+        // of step i+1 (wrapping) as the step ends: the row-fragment addresses behind the last X phase (the Y phase after
+        // it already requests the next step's first fragments: that step's tiles became visible at the barrier before
+        // this one), the others behind the barrier.  Top: the statistics piece and, inside the first X phase, the
+        // LDS-DMA pieces of step i+2 -> slot (i+2) & 3 (last read by the lagging products at the head of step i-1).
+        // Bottom: this wave's pieces have landed (they were issued >= 2000 cycles ago), one barrier.
+#ifdef LWM_D4X_NOBAR
+#define LWM_D4_BAR()
+#else
+#define LWM_D4_BAR() block_sync_lds()
+#endif
+#define LWM_D4_MASK(HALF_, HAS_PREV_, ub_)                                                                          \
+    do {                                                                                                            \
+        /* (the wait states sit in ONE statement on every path that needs them: with two, hipcc merges the tuples */ \
+        /* of the two paths by copies placed right behind the last MFMA)                                         */ \
+        if (!(HAS_PREV_)) d4_settle_t(rg.s);     /* no MFMA stands between the S chain and its first reader */       \
+        if (needs_mask(ub_)) {                                                                                      \
+            if (HAS_PREV_) d4_settle_t(rg.s);                                                                       \
+            d4_mask<HALF_, HAS_META>(cx, rg, rel_of(ub_), kseg);                                                    \
+        }                                                                                                           \
+    } while (0)
+        // (-DLWM_PROF builds, scripts/micro/attn_bench with LWM_PROF_DUMP=1: s_memtime laps of the pipelined steps of the
+        // longest key block of head 0 -- 0 X(0), 1 mask, 2 Y(0), 3 X(1), 4 mask, 5 Y(1), 6 counted wait, 7 barrier,
+        // 8 address registers; 9 steps, 10 total.  LWM_PROF = 1 stamps only 5..8: a stamp drains lgkmcnt, i.e. the
+        // fragments requested across a phase boundary)
+#ifdef LWM_PROF
+        unsigned long long d4p[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, d4t = __builtin_amdgcn_s_memtime();
+        const unsigned long long d4t0 = d4t;
+#define D4_LAP(slot)                                                  \
+    do {                                                              \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        d4p[slot] += now_ - d4t;                                      \
+        d4t = now_;                                                   \
+    } while (0)
+#if LWM_PROF > 1
+#define D4_LAP2(slot) D4_LAP(slot)
+#else
+#define D4_LAP2(slot)
+#endif
+#else
+#define D4_LAP(slot)
+#define D4_LAP2(slot)
+#endif
+        // `ub` = first row of the running step, `src` pointers = the step two ahead (they walk down with the steps)
+        int ub = (nst - 1) * kD4BQ;
+        const char* q_src2 = (const char*)qb + (int64_t)(nst - 3) * q_step_bytes;
+        const char* do_src2 = (const char*)dob + (int64_t)(nst - 3) * do_step_bytes;
+        const char* st_src2 = stat_src + (int64_t)(nst - 3) * kD4BQ * 4;
+#define LWM_D4_STEP(i, FIRST, PIPE)                                                                                 \
+    do {                                                                                                            \
+        if (PIPE) {                                                                                                 \
+            if (kD4xSload && stat_on) d4_dma_b32(vstat, st_src2, stat_dst + (((i) + 2) & 3) * kD4StatBytes);        \
+            dm.q_src = q_src2;                                                                                      \
+            dm.do_src = do_src2;                                                                                    \
+            dm.dst = lds + (((i) + 2) & 3) * kD4SlotBytes + (uint32_t)wave * 1024;                                  \
+            q_src2 -= q_step_bytes;                                                                                 \
+            do_src2 -= do_step_bytes;                                                                               \
+            st_src2 -= kD4BQ * 4;                                                                                   \
+        }                                                                                                           \
+        const uint32_t d_ = (((i) & 3) == 3) ? (uint32_t)(-3 * kD4SlotBytes) : (uint32_t)kD4SlotBytes;             \
+        const uint32_t e_ = (((i) & 3) == 3) ? (uint32_t)(-3 * kD4StatBytes) : (uint32_t)kD4StatBytes;             \
+        d4_x<0, !(FIRST), PIPE>(cx, rg, kf, vf, vq, vdo, dm);                                                       \
+        D4_LAP2(0);                                                                                                 \
+        LWM_D4_MASK(0, !(FIRST), ub);                                                                               \
+        D4_LAP2(1);                                                                                                 \
+        d4_y<0, !(FIRST), true, false>(cx, rg, dk, dv, cx.stat);                                                           \
+        D4_LAP2(2);                                                                                                 \
+        d4_x<1, true, false>(cx, rg, kf, vf, vq, vdo, dm);                                                           \
+        for (int s_ = 0; s_ < 8; ++s_) cx.qa[s_] += d_;                                                             \
+        D4_LAP2(3);                                                                                                 \
+        LWM_D4_MASK(1, true, ub + 32);                                                                              \
+        D4_LAP2(4);                                                                                                 \
+        d4_y<1, true, true, FIRST>(cx, rg, dk, dv, cx.stat + e_);                                                          \
+        D4_LAP(5);                                                                                                  \
+        ub -= kD4BQ;                                                                                                \
+        /* wherever control flow merges behind a step (loop entry, loop exit, the short-walk branch) hipcc may */  \
+        /* reconcile the accumulator tuples of the two paths by copies: they must find the last MFMAs retired  */  \
+        if ((FIRST) || !(PIPE)) d4_settle_acc(dk, dv);                                                              \
+        glds_wait_all();                                                                                            \
+        D4_LAP(6);                                                                                                  \
+        LWM_D4_BAR();                                                                                               \
+        D4_LAP(7);                                                                                                  \
+        for (int db_ = 0; db_ < 4; ++db_) {                                                                         \
+            cx.plo[db_] = cx.tlo[db_];                                                                              \
+            cx.pup[db_] = cx.tup[db_];                                                                              \
+            cx.tlo[db_] += d_;                                                                                      \
+            cx.tup[db_] += d_;                                                                                      \
+        }                                                                                                           \
+        cx.stat += e_;                                                                                              \
+        D4_LAP(8);                                                                                                  \
+    } while (0)
+
+        int i = 0;
+        if (n > 2) {
+            LWM_D4_STEP(0, true, true);
+#ifdef LWM_PROF
+            for (int j = 0; j < 12; ++j) d4p[j] = 0;
+            d4t = __builtin_amdgcn_s_memtime();
+#endif
+            for (i = 1; i + 2 < n; ++i) {
+                LWM_D4_STEP(i, false, true);
+#ifdef LWM_PROF
+                d4p[9] += 1;
+#endif
+            }
+#ifdef LWM_PROF
+            if (!HAS_META && hb == 0 && kbi == 0 && lane == 0 && p.out_acc) {
+                d4p[10] = __builtin_amdgcn_s_memtime() - d4t0;
+                for (int j = 0; j < 12; ++j) ((unsigned long long*)p.out_acc)[wave * 12 + j] = d4p[j];
+            }
+#endif
+            for (; i < n; ++i) LWM_D4_STEP(i, false, false);
+        } else {
+            LWM_D4_STEP(0, true, false);
+            if (n > 1) LWM_D4_STEP(1, false, false);
+        }
+#undef LWM_D4_STEP
+#undef D4_LAP
+#undef D4_LAP2
+#undef LWM_D4_MASK
+#undef LWM_D4_BAR
+        // the last unit's products: its tiles are the second half of the PREVIOUS slot now (the registers moved on)
+        d4_drain<1>(cx, rg, dk, dv);
+        d4_settle_acc(dk, dv);      // before the paths merge (hipcc reconciles the tuples by copies at the merge)
+    }
+
+    // ---- epilogue: scale, merge with the ring carries, store
+    d4_settle_acc(dk, dv);
+    if (k_ok) {
+        const float ksc = p.scale;
+        const int64_t krow_o = (int64_t)b * p.dk_sb + (int64_t)k_row * p.dk_ss + (int64_t)h * p.dk_sh;
+        const int64_t vrow_o = (int64_t)b * p.dv_sb + (int64_t)k_row * p.dv_ss + (int64_t)h * p.dv_sh;
+        const int64_t arow = (((int64_t)b * p.Sk + k_row) * p.H + h) * kHeadDim;
+        for (int db = 0; db < 4; ++db)
+            for (int rq = 0; rq < 4; ++rq) {
+                const int d0 = 32 * db + 8 * rq + 4 * hi;
+                float k0 = dk[db][4 * rq + 0] * ksc, k1 = dk[db][4 * rq + 1] * ksc;
+                float k2 = dk[db][4 * rq + 2] * ksc, k3 = dk[db][4 * rq + 3] * ksc;
+                float v0 = dv[db][4 * rq + 0], v1 = dv[db][4 * rq + 1];
+                float v2 = dv[db][4 * rq + 2], v3 = dv[db][4 * rq + 3];
+                if (p.carry_in) {
+                    const float* ka = p.dk_acc + arow + d0;
+                    const float* va = p.dv_acc + arow + d0;
+                    k0 += ka[0]; k1 += ka[1]; k2 += ka[2]; k3 += ka[3];
+                    v0 += va[0]; v1 += va[1]; v2 += va[2]; v3 += va[3];
+                }
+                if (p.final_out) {
+                    global_store_b64(p.dk + krow_o + d0, u32x2{pack_bf16x2(k0, k1), pack_bf16x2(k2, k3)});
+                    global_store_b64(p.dv + vrow_o + d0, u32x2{pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)});
+                } else {
+                    global_store_b128(p.dk_acc + arow + d0,
+                                      u32x4{__builtin_bit_cast(uint32_t, k0), __builtin_bit_cast(uint32_t, k1),
+                                            __builtin_bit_cast(uint32_t, k2), __builtin_bit_cast(uint32_t, k3)});
+                    global_store_b128(p.dv_acc + arow + d0,
+                                      u32x4{__builtin_bit_cast(uint32_t, v0), __builtin_bit_cast(uint32_t, v1),
+                                            __builtin_bit_cast(uint32_t, v2), __builtin_bit_cast(uint32_t, v3)});
+                }
+            }
+    }
+}
+
+LWM_KERNEL(kD4Threads) void attn_bwd_dkdv4_kernel(AttnParams p) { attn_bwd_dkdv4_body<false>(p); }
+LWM_KERNEL(kD4Threads) void attn_bwd_dkdv4_meta_kernel(AttnParams p) { attn_bwd_dkdv4_body<true>(p); }
+
+}  // namespace lwm

@@ -36,7 +36,7 @@ struct AttnParams {
     float* lse_acc;     // f32 carry [B,H,Sq]
     // backward operands
     const bf16_t* dout;
-    const float* delta;  // [B,H,Sq] rowsum(dO*O)
+    const float* delta;  // backward row statistics (attn_bwd.h): per (b,h) [-lse*log2e | -rowsum(dO*O)], rows padded to 64
     bf16_t* dq;
     bf16_t* dk;
     bf16_t* dv;
@@ -62,8 +62,6 @@ struct AttnParams {
     int32_t causal;
     int32_t carry_in;          // merge with *_acc before writing
     int32_t final_out;         // write bf16 results (else f32 *_acc)
-    int32_t dq_carry_in;       // fused backward only: the same two switches for dq (carry_in /
-    int32_t dq_final_out;      // final_out then govern dk, dv)
     int64_t dqa_sb, dqa_ss, dqa_sh;   // element strides of dq_acc: [B,Sq,H,D] or head-major [B,H,Sq,D]
     // forward only: dense boolean mask and split-K (see include/lwm_hip.h)
     const uint8_t* dense_mask;

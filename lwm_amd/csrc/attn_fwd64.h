@@ -203,6 +203,7 @@ LWM_DEVICE void f4_max3(float& m, float a, float b) { m = fmaxf(fmaxf(m, a), b);
 LWM_DEVICE bf16x8 f4_to_agpr(bf16x8 x) { return x; }
 LWM_DEVICE bf16x8 f4_load_agpr(const bf16_t* g) { return __builtin_bit_cast(bf16x8, global_load_b128(g)); }
 LWM_DEVICE void f4_load_agpr_wait(bf16x8 (&)[2][8]) {}
+LWM_DEVICE void f4_load_agpr_wait8(bf16x8 (&)[8]) {}
 LWM_DEVICE void f4_scale_acc(f32x16& d, float alpha) { d *= alpha; }
 #else
 LWM_DEVICE void f4_mfma_s_first(f32x16& d, bf16x8 a, bf16x8 b) {
@@ -272,6 +273,12 @@ LWM_DEVICE void f4_load_agpr_wait(bf16x8 (&q)[2][8]) {
     asm volatile("s_waitcnt vmcnt(0)"
                  : "+a"(q[0][0]), "+a"(q[0][1]), "+a"(q[0][2]), "+a"(q[0][3]), "+a"(q[0][4]), "+a"(q[0][5]), "+a"(q[0][6]), "+a"(q[0][7]),
                    "+a"(q[1][0]), "+a"(q[1][1]), "+a"(q[1][2]), "+a"(q[1][3]), "+a"(q[1][4]), "+a"(q[1][5]), "+a"(q[1][6]), "+a"(q[1][7])
+                 :
+                 : "memory");
+}
+LWM_DEVICE void f4_load_agpr_wait8(bf16x8 (&q)[8]) {
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+a"(q[0]), "+a"(q[1]), "+a"(q[2]), "+a"(q[3]), "+a"(q[4]), "+a"(q[5]), "+a"(q[6]), "+a"(q[7])
                  :
                  : "memory");
 }

@@ -11,7 +11,7 @@
 #include "attn_fwd.h"
 #include "attn_fwd64.h"
 #include "attn_bwd.h"
-#include "attn_bwd_fused.h"
+#include "attn_bwd64.h"
 #include "attn_decode.h"
 #include "misc_kernels.h"
 #include "llama_elem.h"

@@ -48,9 +48,9 @@ LWM_DEVICE lds_t dyn_lds() {
 
 LWM_DEVICE void block_sync() { __syncthreads(); }
 // Workgroup barrier that orders LDS traffic ONLY: __syncthreads() carries a workgroup-scope release fence,
-// which on gfx950 is an s_waitcnt vmcnt(0) -- every global store still in flight is waited for at every
-// barrier.  A kernel that keeps global stores in flight across its tile barrier (attn_bwd_fused.h) and
-// hands global data over by its own protocol uses this one: LDS writes retired (lgkmcnt(0)), s_barrier.
+// which on gfx950 is an s_waitcnt vmcnt(0) -- every vector-memory operation still in flight is waited for at
+// every barrier.  A kernel that keeps LDS-DMA pieces in flight across its step barrier behind a counted vmcnt
+// (attn_bwd64.h) uses this one: LDS operations retired (lgkmcnt(0)), s_barrier.
 LWM_DEVICE void block_sync_lds() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0); vmcnt and expcnt left alone
@@ -64,14 +64,6 @@ LWM_DEVICE void block_sync_lds() {
 //   C/D: lane l, reg r holds C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
 LWM_DEVICE f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-
-// D = A(16x32) * B(32x16) + C(16x16), bf16 in / f32 accumulate (v_mfma_f32_16x16x32_bf16).
-//   A: lane l holds A[row = l&15][k-group l>>4, 8 values];  B: lane l holds B[k-group l>>4][col = l&15]
-//   C/D: lane l, reg r holds C[row = 4*(l>>4) + r][col = l&15]
-// (A and B must use the SAME (k-group, j) -> k assignment; which k that is does not matter.)
-LWM_DEVICE f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
 // ds_read_b64_tr_b16.  Per 16-lane group: lanes 4j..4j+3 each point at 4
@@ -137,27 +129,6 @@ LWM_DEVICE void glds_load_b32(const void* g, lds_t wave_base) {
         : "v"(g), "s"(wave_base)
         : "memory");
 }
-// 16-byte form with agent scope (sc1: bypasses this CU's L1, served by the XCD's L2)
-LWM_DEVICE void glds_load_b128_l2(const void* g, lds_t wave_base) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(g), "s"(wave_base)
-        : "memory");
-}
-// the same with agent scope (sc1: the load bypasses this CU's L1) -- a flag poll whose answer lands in LDS, so
-// that no VGPR and no compiler-inserted s_waitcnt is involved until the wave decides to look at it
-LWM_DEVICE void glds_load_b32_l2(const void* g, lds_t wave_base) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-        "global_load_lds_dword %1, off sc1\n\ts_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(g), "s"(wave_base)
-        : "memory");
-}
 // wait until at most N of this wave's vector-memory operations are outstanding (they retire in issue order)
 template <int N>
 LWM_DEVICE void wait_vmem_le() {
@@ -165,17 +136,8 @@ LWM_DEVICE void wait_vmem_le() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");   // asm: hipcc neither merges nor drops it
 }
 LWM_DEVICE void glds_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// The same wait as an instruction the compiler SEES (it updates hipcc's own scoreboard: no second,
-// badly placed vmcnt(0) for operations this one already covered).  gfx9 encoding: vmcnt = bits 3:0 and
-// 15:14, expcnt = 6:4, lgkmcnt = 11:8; everything but vmcnt left at "no wait".
-LWM_DEVICE void wait_vmem_all() { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); }
 // Make a value that IS the same in every lane provably uniform (SGPR).
 LWM_DEVICE int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
-
-// Require a value to EXIST at this point of the instruction stream (no instruction is emitted): keeps LLVM
-// from sinking its computation -- and with it the retirement of the loads it depends on -- into a later
-// conditional block.
-LWM_DEVICE void pin_value(float x) { asm volatile("" ::"v"(x)); }
 
 // Make a value opaque to the optimiser at this point (no instruction is emitted):
 // address arithmetic derived from it cannot be hoisted out of the enclosing loop
@@ -184,24 +146,6 @@ LWM_DEVICE uint32_t opaque(uint32_t x) {
     asm volatile("" : "+v"(x));
     return x;
 }
-// Scheduler hint (LLVM sched_group_barrier): emit n_mfma MFMAs, then n_ds LDS reads,
-// at this point of the instruction stream.  Repeating it N times over a region that
-// holds N*n_mfma MFMAs and N*n_ds independent ds_reads yields the interleave
-// "MFMA, reads for a LATER step, MFMA, ..." -- i.e. software-pipelined fragment
-// loads -- without pinning anything else.
-template <int N_MFMA, int N_DS>
-LWM_DEVICE void sched_mfma_dsread() {
-    __builtin_amdgcn_sched_group_barrier(0x008, N_MFMA, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, N_DS, 0);
-}
-// One group of a scheduling pipeline (LLVM sched_group_barrier): "N instructions of class MASK come next".  A
-// sequence of these at the end of a scheduling region describes the interleave the machine scheduler is to build.
-// MASK: 0x002 VALU (not MFMA, not transcendental), 0x008 MFMA, 0x100 LDS read, 0x200 LDS write, 0x400 transcendental.
-template <int MASK, int N>
-LWM_DEVICE void sched_group() { __builtin_amdgcn_sched_group_barrier(MASK, N, 0); }
-// s_sleep: park this wave for ~64*n cycles (n a compile-time constant 1..127).
-template <int N>
-LWM_DEVICE void sleep_cycles64() { __builtin_amdgcn_s_sleep(N); }
 // Scheduling fence: the compiler may not move instructions across it.
 LWM_DEVICE void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // Raise/lower this wave's issue priority around an MFMA cluster (T5).
@@ -216,8 +160,6 @@ LWM_DEVICE void prio_lo() {
     if (LWM_PRIO_MODE == 1) __builtin_amdgcn_s_setprio(0);
     if (LWM_PRIO_MODE == 2) __builtin_amdgcn_s_setprio(1);
 }
-template <int N>
-LWM_DEVICE void set_prio() { __builtin_amdgcn_s_setprio(N); }
 
 // value held by lane (l ^ 32)
 LWM_DEVICE float xhalf(float x) {
@@ -242,75 +184,14 @@ LWM_DEVICE void global_store_b64(void* p, u32x2 v) { *(u32x2*)p = v; }
 LWM_DEVICE f32x4 global_load_f32x4(const float* p) { return *(const f32x4*)p; }
 LWM_DEVICE void global_store_f32x4(float* p, f32x4 v) { *(f32x4*)p = v; }
 
-// ---- inter-workgroup hand-off inside ONE XCD (attn_bwd_fused.h; MI355X_MICROARCH.md "Workgroup dispatch,
-// XCD placement & inter-workgroup visibility").  The XCD's L2 is the point of coherence:
-//   writer: plain stores (L1 writes through, L2 acknowledges) -> s_waitcnt vmcnt(0) -> barrier ->
-//           store_i32_plain(flag)            (plain: the line STAYS in this L2; an sc1 store would drop it)
-//   reader: load_i32_l2(flag) until set -> global_load_f32x4_l2(data)   (sc1: miss in L1, served by L2)
-// XCC id of the executing CU (0..7): the truth about placement, not blockIdx % 8.
+// XCC id of the executing CU (0..7): the truth about placement, not blockIdx % 8 (tests/test_gpu_probe.py checks that
+// the two agree closely enough for the kernels' "one head per XCD" block mappings to share an L2)
 LWM_DEVICE int xcc_id() {
     int x;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
     return x & 15;
 }
-// "L2" loads: agent-scope relaxed loads (sc1: miss-always in the CU's L1, served by the XCD's L2).  The
-// non-temporal form (nt, -DLWM_L2_NT) behaves the same in this kernel (28.5 vs 28.4 ms).
-#ifdef LWM_L2_NT
-LWM_DEVICE int load_i32_l2(const int32_t* p) { return __builtin_nontemporal_load(p); }
-#else
-LWM_DEVICE int load_i32_l2(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#endif
-// A PLAIN global store (no sc bits), from asm: a C++ `volatile` store is compiled as a system-scope
-// write-through flat store followed by s_waitcnt vmcnt(0) -- a full trip to memory on every publication
-// (measured: 12 ms of a 30 ms launch).  Not waited for; the line stays in this XCD's L2.
-LWM_DEVICE void store_i32_plain(int32_t* p, int32_t v) {
-    asm volatile("global_store_dword %0, %1, off\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
-}
-// device-scope atomics on the work queues (shared by all XCDs: executed at memory, ~0.3-1 us each)
 LWM_DEVICE int atomic_add_i32(int32_t* p, int32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-LWM_DEVICE int atomic_cas_i32(int32_t* p, int32_t expected, int32_t desired) {
-    __hip_atomic_compare_exchange_strong(p, &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return expected;   // the value found
-}
-LWM_DEVICE void spin_pause() { __builtin_amdgcn_s_sleep(2); }
-// 16 bytes at base + byte_off, agent scope (L1 miss-always); `base` must be wave-uniform (it becomes the buffer
-// descriptor), byte_off < 4 GiB.  A compiler-visible buffer load: hipcc tracks its vmcnt.
-LWM_DEVICE f32x4 global_load_f32x4_l2(const float* base, uint32_t byte_off) {
-    const uint64_t a = (uint64_t)base;
-    const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
-                       (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
-    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, 0x7fffffff, 0x00020000);
-#ifdef LWM_L2_NT
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 2 /* nt */));
-#else
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16 /* sc1 */));
-#endif
-}
-
-// Fire-and-forget global stores, issued from inline asm so that hipcc does not enter them in its vmcnt
-// scoreboard (it otherwise guards the data registers of a pending store with an s_waitcnt vmcnt at their next
-// redefinition -- which, the counter being shared, also waits for every younger load).  The hardware reads a
-// store's registers at issue; the s_nop covers the ISA's "VMEM store data then overwritten" wait states.
-// Completion is the caller's business: wait_vmem_all() before publishing.
-LWM_DEVICE void global_store_f32x4_async(float* p, f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-}
-LWM_DEVICE void global_store_b64_async(void* p, u32x2 v) {
-    asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-}
-
-// 16 bytes to base + voff, fire-and-forget like the two above; `base` wave-uniform (moved to an SGPR pair here; the
-// s_nop in front covers the "VALU writes SGPR -> VMEM reads it" hazard, which hipcc does not see through asm),
-// voff a per-lane byte offset < 4 GiB.  Non-temporal: a stream that is written once and read by a later launch.
-#ifndef LWM_STORE_POLICY
-#define LWM_STORE_POLICY " nt"
-#endif
-LWM_DEVICE void global_store_b128_nt_at(void* base, uint32_t voff, u32x4 v) {
-    const uint64_t a = (uint64_t)base;
-    const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
-                       (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
-    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" LWM_STORE_POLICY "\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(u) : "memory");
-}
 
 // one float at base + voff + soff bytes (base and soff wave-uniform: soff rides in an SGPR, the address costs
 // no VALU); plain cache policy

@@ -218,15 +218,22 @@ def kv_cache_write_at(cache, src, index_dev, *, row_offset=0, src_row0=0, nrows=
     return cache
 
 
-def attn_bwd_delta(out, dout, delta=None):
-    """delta[b,h,q] = sum_d dout*out (lwm_attn_bwd_delta)."""
+def bwd_stats_shape(B, H, Sq):
+    """Shape of the backward's row statistics for a (B, Sq, H, D) query block: per (b, h) the rows
+    [-lse * log2 e | -rowsum(dout * out)], padded to a multiple of 64 queries (lwm_attn_bwd_delta_bytes)."""
+    return (B, H, 2, (Sq + 63) // 64 * 64)
+
+
+def attn_bwd_delta(out, dout, lse, delta=None):
+    """The row statistics the backward kernels consume (lwm_attn_bwd_delta), from out, dout and the forward's lse."""
     B, Sq, H, D = out.shape
     if delta is None:
-        delta = torch.empty((B, H, Sq), dtype=torch.float32, device=out.device)
+        delta = torch.empty(bwd_stats_shape(B, H, Sq), dtype=torch.float32, device=out.device)
     a = _capi.LwmAttnArgs()
     a.out, a.dout = _t4(out, "out"), _t4(dout, "dout")
     a.B, a.H, a.Sq, a.Sk, a.D = B, H, Sq, 0, D
-    a.delta = _f32(delta, "delta", (B, H, Sq))
+    a.lse = _f32(lse, "lse", (B, H, Sq))
+    a.delta = _f32(delta, "delta", bwd_stats_shape(B, H, Sq))
     L = lib()
     _capi.check(L, L.lwm_attn_bwd_delta(C.byref(a), _stream_ptr()), "lwm_attn_bwd_delta")
     return delta
@@ -237,8 +244,13 @@ def _bwd_base(q, k, v, dout, lse, delta, kw):
     a = _base(q, k, v, **kw)
     a.dout = _t4(dout, "dout")
     a.lse = _f32(lse, "lse", (B, H, Sq))
-    a.delta = _f32(delta, "delta", (B, H, Sq))
+    a.delta = _f32(delta, "delta", bwd_stats_shape(B, H, Sq))
     return a
+
+
+def _acc_shape(B, Sq, H, D, head_major):
+    """dq accumulator / carry: (B,Sq,H,D), or head-major (B,H,Sq,D)."""
+    return (B, H, Sq, D) if head_major else (B, Sq, H, D)
 
 
 def attn_bwd_dq_block(q, k, v, dout, lse, delta, *, q_start=0, k_start=0, causal=True,
@@ -288,99 +300,6 @@ def attn_bwd_dkdv_block(q, k, v, dout, lse, delta, *, q_start=0, k_start=0, caus
     L = lib()
     _capi.check(L, L.lwm_attn_bwd_dkdv(C.byref(a), _stream_ptr()), "lwm_attn_bwd_dkdv")
     return (dk, dv) if final else (dk_acc, dv_acc)
-
-
-_FUSED_WS = {}
-# Largest workspace lwm_attn_bwd_fused is given (bytes).  Its bf16 dq partials take 8 KiB per visible (256-key block,
-# 32-query tile) pair and head -- 17.2 GB for S = 32768 x 32 heads, causal; when all heads do not fit, the call runs
-# them in groups of 8 x k heads, and attn_bwd_fused_fits() says whether even 8 do (the ring driver then takes the
-# two-kernel backward).  288 GB of HBM per GPU is what makes the default comfortable.
-FUSED_WS_CAP = int(float(os.environ.get("LWM_FUSED_WS_GIB", "20")) * (1 << 30))
-
-
-def _acc_shape(B, Sq, H, D, head_major):
-    """dq accumulator / carry: (B,Sq,H,D), or head-major (B,H,Sq,D)."""
-    return (B, H, Sq, D) if head_major else (B, Sq, H, D)
-
-
-def _fused_need(B, H, Sq, Sk, q_start, k_start, causal):
-    """(bytes for all heads in one launch, bytes for the smallest group of heads)"""
-    L = lib()
-    f = L.lwm_attn_bwd_fused_workspace_bytes
-    return (int(f(B, H, Sq, Sk, q_start, k_start, int(bool(causal)), 0)),
-            int(f(B, H, Sq, Sk, q_start, k_start, int(bool(causal)), min(8, B * H))))
-
-
-def attn_bwd_fused_fits(B, H, Sq, Sk, q_start=0, k_start=0, causal=True):
-    """Does the fused backward's partial buffer for at least 8 heads fit under FUSED_WS_CAP?"""
-    return _fused_need(B, H, Sq, Sk, q_start, k_start, causal)[1] <= FUSED_WS_CAP
-
-
-def _fused_workspace(B, H, Sq, Sk, q_start, k_start, causal, device):
-    """Scratch of lwm_attn_bwd_fused (work-queue tickets, the LSE in log2 units, the dq partial tiles); the call
-    initialises what it needs itself, so one buffer per (device, stream) is reused by every layer."""
-    full, least = _fused_need(B, H, Sq, Sk, q_start, k_start, causal)
-    if least > FUSED_WS_CAP:
-        raise ValueError(f"attn_bwd_fused_block: the dq partials of 8 heads need {least / 2**30:.1f} GiB, more than "
-                         f"LWM_FUSED_WS_GIB = {FUSED_WS_CAP / 2**30:.1f}; use the two-kernel backward for this shard")
-    need = min(full, FUSED_WS_CAP)
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
-    ws = _FUSED_WS.get(key)
-    if ws is None or ws.numel() < need:
-        _FUSED_WS.pop(key, None)       # (drop the smaller buffer before the larger one is allocated)
-        del ws
-        ws = _FUSED_WS[key] = torch.empty(need, dtype=torch.uint8, device=device)
-    return ws
-
-
-def attn_bwd_fused_block(q, k, v, dout, lse, delta, *, q_start=0, k_start=0, causal=True, seg_q=None, seg_k=None,
-                         key_valid=None, scale=None, dq=None, dk=None, dv=None, dq_acc=None, dk_acc=None,
-                         dv_acc=None, dq_carry_in=False, dq_final=True, carry_in=False, final=True,
-                         acc_head_major=False):
-    """The whole backward of one ring step with S and dP computed once (lwm_attn_bwd_fused: 5 GEMM units instead
-    of 7).  `carry_in` / `final` govern dk, dv; `dq_carry_in` / `dq_final` govern dq.  The 256-key blocks store
-    bf16 dq partials in a workspace and a streaming pass sums them in key order (deterministic); dq_acc is only the
-    ring's f32 carry: read when dq_carry_in, written when not dq_final ((B,Sq,H,D), or (B,H,Sq,D) with
-    acc_head_major).  Returns (dq or dq_acc, dk or dk_acc, dv or dv_acc)."""
-    B, Sq, H, D = q.shape
-    Sk = k.shape[1]
-    a = _bwd_base(q, k, v, dout, lse, delta,
-                  dict(q_start=q_start, k_start=k_start, causal=causal, seg_q=seg_q, seg_k=seg_k,
-                       key_valid=key_valid, scale=scale))
-    if final:
-        if dk is None:
-            dk = torch.empty((B, Sk, H, D), dtype=torch.bfloat16, device=q.device)
-        if dv is None:
-            dv = torch.empty((B, Sk, H, D), dtype=torch.bfloat16, device=q.device)
-        a.dk, a.dv = _t4(dk, "dk"), _t4(dv, "dv")
-    else:
-        if dk_acc is None:
-            dk_acc = torch.empty((B, Sk, H, D), dtype=torch.float32, device=q.device)
-        if dv_acc is None:
-            dv_acc = torch.empty((B, Sk, H, D), dtype=torch.float32, device=q.device)
-    if dk_acc is not None:
-        a.dk_acc = _f32(dk_acc, "dk_acc", (B, Sk, H, D))
-        a.dv_acc = _f32(dv_acc, "dv_acc", (B, Sk, H, D))
-    if dq_final:
-        if dq is None:
-            dq = torch.empty((B, Sq, H, D), dtype=torch.bfloat16, device=q.device)
-        a.dq = _t4(dq, "dq")
-    if dq_acc is None:
-        if dq_carry_in:
-            raise ValueError("attn_bwd_fused_block: dq_carry_in needs dq_acc")
-        if not dq_final:
-            dq_acc = torch.empty(_acc_shape(B, Sq, H, D, acc_head_major), dtype=torch.float32, device=q.device)
-    if dq_acc is not None:
-        a.dq_acc = _f32(dq_acc, "dq_acc", _acc_shape(B, Sq, H, D, acc_head_major))
-    a.dq_acc_head_major = int(bool(acc_head_major))
-    a.carry_in, a.final_out = int(bool(carry_in)), int(bool(final))
-    a.dq_carry_in, a.dq_final_out = int(bool(dq_carry_in)), int(bool(dq_final))
-    ws = _fused_workspace(B, H, Sq, Sk, int(q_start), int(k_start), causal, q.device)
-    a.bwd_workspace = ws.data_ptr()
-    a.bwd_workspace_bytes = ws.numel()
-    L = lib()
-    _capi.check(L, L.lwm_attn_bwd_fused(C.byref(a), _stream_ptr()), "lwm_attn_bwd_fused")
-    return (dq if dq_final else dq_acc), (dk if final else dk_acc), (dv if final else dv_acc)
 
 
 def cast_f32_to_bf16(src, dst=None):

@@ -187,8 +187,6 @@ class HipBlockOps:
     bwd_delta = staticmethod(_ops.attn_bwd_delta)
     bwd_dq = staticmethod(_ops.attn_bwd_dq_block)
     bwd_dkdv = staticmethod(_ops.attn_bwd_dkdv_block)
-    bwd_fused = staticmethod(_ops.attn_bwd_fused_block)
-    bwd_fused_fits = staticmethod(lambda B, H, Sq, Sk: _ops.attn_bwd_fused_fits(B, H, Sq, Sk, 0, 0, False))
     cast = staticmethod(_ops.cast_f32_to_bf16)
     sum_cast = staticmethod(_ops.sum_f32_to_bf16)
     fwd_splitk = staticmethod(_ops.attn_fwd_splitk)
@@ -204,25 +202,9 @@ class HipBlockOps:
         return torch.zeros(shape, dtype=dtype, device=like.device)
 
 
-# Two backward flavours, both deterministic (no atomics, fixed summation orders):
-#   two kernels   lwm_attn_bwd_dkdv + lwm_attn_bwd_dq: 7 GEMM units executed (S and dP are recomputed by the second);
-#   fused         lwm_attn_bwd_fused: S and dP computed once, 5 GEMM units; the dq contribution of every 256-key block
-#                 is stored as a bf16 partial (8 KiB per (key block, 32-query tile) pair and head, in a workspace of up
-#                 to LWM_FUSED_WS_GIB) and summed in key order by a streaming pass.
-# LWM_FUSED_BWD=0/1 and bench.py --fused-bwd / --two-kernel-bwd select; LWM_DETERMINISTIC=1 (kept from round 2, when the
-# fused flavour used atomics) forces the two-kernel path.  A shard whose partials do not fit the workspace takes the
-# two-kernel path.  DESIGN.md section 3 has both measured side by side.
-DETERMINISTIC = os.environ.get("LWM_DETERMINISTIC", "0") == "1"
-FUSED_BACKWARD = not DETERMINISTIC and os.environ.get("LWM_FUSED_BWD", "0") == "1"
-
-
-def _use_fused(block, B, H, Sq, Sk):
-    """fused flavour wanted, offered by the backend, and its partial buffer (sized for the full Sq x Sk rectangle: an
-    upper bound over causal offsets) fits the workspace cap"""
-    if not (FUSED_BACKWARD and hasattr(block, "bwd_fused")):
-        return False
-    fits = getattr(block, "bwd_fused_fits", None)
-    return True if fits is None else bool(fits(B, H, Sq, Sk))
+# The backward is deterministic: lwm_attn_bwd_delta + lwm_attn_bwd_dkdv + lwm_attn_bwd_dq, no atomics, fixed summation
+# orders (7 GEMM units executed: S and dP are recomputed by the dq kernel).  A 5-unit form that stored bf16 dq partials
+# was measured in rounds 2-3 and retired in round 4 (profiles/r04_backward.md).
 
 
 # ----------------------------------------------------------------- helpers
@@ -399,7 +381,7 @@ def ring_backward(block, comm, q, k, v, out, lses, dout, *, layout, causal=True,
     masks = _MaskSlices(segment_ids, key_valid)
     if not dout.is_contiguous():
         dout = dout.contiguous()
-    deltas = [block.bwd_delta(_rows(out, qs), _rows(dout, qs)) for qs in qsegs]
+    deltas = [block.bwd_delta(_rows(out, qs), _rows(dout, qs), lses[qi]) for qi, qs in enumerate(qsegs)]
 
     if n == 1 and len(qsegs) == 1:
         # single block: write bf16 results straight from the accumulators
@@ -407,8 +389,6 @@ def ring_backward(block, comm, q, k, v, out, lses, dout, *, layout, causal=True,
         sq, sk, kv = masks(qs, qs)
         kw = dict(q_start=qs[2], k_start=qs[2], causal=causal, seg_q=sq, seg_k=sk, key_valid=kv,
                   scale=scale)
-        if _use_fused(block, B, H, q.shape[1], k.shape[1]):
-            return block.bwd_fused(q, k, v, dout, lses[0], deltas[0], dq_final=True, final=True, **kw)
         dk, dv = block.bwd_dkdv(q, k, v, dout, lses[0], deltas[0], final=True, **kw)
         dq = block.bwd_dq(q, k, v, dout, lses[0], deltas[0], final=True, **kw)
         return dq, dk, dv
@@ -507,9 +487,7 @@ def _mesh_backward(block, comm, q, k, v, lses, dout, deltas, *, layout, causal, 
     for t in range(n):
         for qi, _ in pairs_at(t)[1]:
             n_dq[qi] += 1
-    fused = _use_fused(block, B, H, max(ln for _, ln, _ in qsegs), max(ln for _, ln, _ in layout.segments(r)))
     acc_shape = lambda ln: (B, ln, H, D)
-    hm = {}
     dq_acc = [block.empty(acc_shape(ln), torch.float32, q) if n_dq[qi] > 1 else None
               for qi, (_, ln, _) in enumerate(qsegs)]
     done_dq = [0] * len(qsegs)
@@ -527,7 +505,7 @@ def _mesh_backward(block, comm, q, k, v, lses, dout, deltas, *, layout, causal, 
             block.bwd_dq(_rows(q, qs), held[ki][0], held[ki][1], _rows(dout, qs), lses[qi], deltas[qi],
                          q_start=qs[2], k_start=ks[2], causal=causal, seg_q=sq, seg_k=sk, key_valid=kv,
                          scale=scale, dq=_rows(dq, qs) if fin else None, dq_acc=dq_acc[qi],
-                         carry_in=done_dq[qi] > 1, final=fin, **hm)
+                         carry_in=done_dq[qi] > 1, final=fin)
 
     def run_dkdv(t, held):
         """-> {ki: (dk_part, dv_part)} f32, for the key segments that got a contribution."""
@@ -549,36 +527,13 @@ def _mesh_backward(block, comm, q, k, v, lses, dout, deltas, *, layout, causal, 
                            final=False)
         return part
 
-    def run_fused(t, held):
-        """dq (chained) and the dk/dv partial of a REMOTE block in one launch per (q segment, k segment)."""
-        ksegs, pairs = pairs_at(t)
-        part = {}
-        for qi, ki in pairs:
-            qs, ks = qsegs[qi], ksegs[ki]
-            sq, sk, kv = masks(qs, ks)
-            done_dq[qi] += 1
-            fin = done_dq[qi] == n_dq[qi]
-            first = ki not in part
-            if first:
-                part[ki] = tuple(_xbuf(comm, block, ("part", t, ki, w), (B, ks[1], H, D), torch.float32, q) for w in (0, 1))
-            if dq_acc[qi] is None and not (fin and done_dq[qi] == 1):      # (cannot happen: n_dq > 1 allocated it)
-                dq_acc[qi] = block.empty(acc_shape(qs[1]), torch.float32, q)
-            block.bwd_fused(_rows(q, qs), held[ki][0], held[ki][1], _rows(dout, qs), lses[qi], deltas[qi],
-                            q_start=qs[2], k_start=ks[2], causal=causal, seg_q=sq, seg_k=sk, key_valid=kv, scale=scale,
-                            dq=_rows(dq, qs) if fin else None, dq_acc=dq_acc[qi], dq_carry_in=done_dq[qi] > 1,
-                            dq_final=fin, dk_acc=part[ki][0], dv_acc=part[ki][1], carry_in=not first, final=False)
-        return part
-
     own = layout.segments(r)
     run_dq(0, mesh.get(0))
     returned = {}     # t -> ({ki: (dk, dv)} received from rank r+t for MY segments, handle)
     for t in range(1, n):
         held = mesh.get(t)
-        if fused:
-            part = run_fused(t, held)
-        else:
-            run_dq(t, held)
-            part = run_dkdv(t, held)
+        run_dq(t, held)
+        part = run_dkdv(t, held)
         owner, giver = (r - t) % n, (r + t) % n
         sends = []
         for ki in _needed_ksegs(layout, r, owner, causal):   # == sorted(part)

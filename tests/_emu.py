@@ -129,14 +129,9 @@ def attn_fwd(q, k, v, *, causal=True, q_start=0, k_start=0, seg_q=None, seg_k=No
     return out_acc, lse_acc
 
 
-FUSED_BWD = False   # module default for attn_bwd(fused=None): the emulated tests flip it to run both paths
-
-
 def attn_bwd(q, k, v, out, lse, dout, *, causal=True, q_start=0, k_start=0, seg_q=None,
-             seg_k=None, key_valid=None, scale=None, carry=None, final=True, fused=None):
-    """Returns (dq, dk, dv) as f32 (bf16-rounded when final).  fused: lwm_attn_bwd_fused (one launch,
-    5 GEMM units) instead of lwm_attn_bwd_dkdv + lwm_attn_bwd_dq."""
-    fused = FUSED_BWD if fused is None else fused
+             seg_k=None, key_valid=None, scale=None, carry=None, final=True):
+    """Returns (dq, dk, dv) as f32 (bf16-rounded when final): lwm_attn_bwd_delta + lwm_attn_bwd_dkdv + lwm_attn_bwd_dq."""
     L = lib()
     qb, kb, vb = bf16_array(q), bf16_array(k), bf16_array(v)
     ob, dob = bf16_array(out), bf16_array(dout)
@@ -146,7 +141,8 @@ def attn_bwd(q, k, v, out, lse, dout, *, causal=True, q_start=0, k_start=0, seg_
                         seg_k=seg_k, key_valid=key_valid, scale=scale)
     lse_a = aligned((B, H, Sq), np.float32)
     lse_a[...] = lse
-    delta = aligned((B, H, Sq), np.float32)
+    delta = aligned((L.lwm_attn_bwd_delta_bytes(B, H, Sq) // 4,), np.float32)
+    delta[...] = np.nan      # the call must write everything the kernels read
     dq, dk, dv = (aligned((B, Sq, H, D), np.uint16), aligned((B, Sk, H, D), np.uint16),
                   aligned((B, Sk, H, D), np.uint16))
     if carry is not None:
@@ -162,19 +158,8 @@ def attn_bwd(q, k, v, out, lse, dout, *, causal=True, q_start=0, k_start=0, seg_
     a.dq_acc, a.dk_acc, a.dv_acc = dq_acc.ctypes.data, dk_acc.ctypes.data, dv_acc.ctypes.data
     a.final_out = int(final)
     _capi.check(L, L.lwm_attn_bwd_delta(C.byref(a), None), "lwm_attn_bwd_delta")
-    if fused:
-        a.dq_carry_in, a.dq_final_out = a.carry_in, a.final_out
-        # a workspace with room for 8 heads per launch when there are more (exercises the head groups)
-        need = L.lwm_attn_bwd_fused_workspace_bytes(B, H, Sq, Sk, int(q_start), int(k_start), int(bool(causal)),
-                                                    8 if B * H > 8 else 0)
-        ws = aligned((max(need, 256),), np.uint8, align=256)
-        ws[...] = 0xA5     # the call must initialise what it reads
-        a.bwd_workspace = ws.ctypes.data
-        a.bwd_workspace_bytes = need
-        _capi.check(L, L.lwm_attn_bwd_fused(C.byref(a), None), "lwm_attn_bwd_fused")
-    else:
-        _capi.check(L, L.lwm_attn_bwd_dkdv(C.byref(a), None), "lwm_attn_bwd_dkdv")
-        _capi.check(L, L.lwm_attn_bwd_dq(C.byref(a), None), "lwm_attn_bwd_dq")
+    _capi.check(L, L.lwm_attn_bwd_dkdv(C.byref(a), None), "lwm_attn_bwd_dkdv")
+    _capi.check(L, L.lwm_attn_bwd_dq(C.byref(a), None), "lwm_attn_bwd_dq")
     if final:
         return from_bf16_bits(dq), from_bf16_bits(dk), from_bf16_bits(dv)
     return dq_acc, dk_acc, dv_acc

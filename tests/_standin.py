@@ -76,7 +76,7 @@ class OracleBlockOps:
         return out_acc, lse_acc
 
     @staticmethod
-    def bwd_delta(out, dout, delta=None):
+    def bwd_delta(out, dout, lse=None, delta=None):      # (the stand-in keeps plain delta: its own kernels consume it)
         d = torch.einsum("bqhd,bqhd->bhq", out.double(), dout.double()).float()
         if delta is not None:
             delta.copy_(d)

@@ -231,29 +231,6 @@ LWM_DEVICE f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
     return d;
 }
 
-// v_mfma_f32_16x16x32_bf16: A[row = l&15][k = 8*(l>>4) + j], B[k][col = l&15], C[row = 4*(l>>4) + r][col = l&15]
-LWM_DEVICE f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
-    emu::Wave& w = emu::g_blk->waves[emu::g_lane->tid >> 6];
-    int l = emu::g_lane->tid & 63;
-    w.a[l] = a;
-    w.b[l] = b;
-    emu::wave_sync();
-    f32x4 d;
-    int col = l & 15, g = l >> 4;
-    for (int r = 0; r < 4; ++r) {
-        int row = 4 * g + r;
-        float s = c[r];
-        for (int k = 0; k < 32; ++k) {
-            float av = (float)w.a[(k >> 3) * 16 + row][k & 7];
-            float bv = (float)w.b[(k >> 3) * 16 + col][k & 7];
-            s += av * bv;
-        }
-        d[r] = s;
-    }
-    emu::wave_sync();
-    return d;
-}
-
 // v_mfma_f32_32x32x2_f32: exact f32, k = 0 (lanes 0-31) then k = 1 (lanes 32-63).
 LWM_DEVICE f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) {
     emu::Wave& w = emu::g_blk->waves[emu::g_lane->tid >> 6];
@@ -308,30 +285,14 @@ LWM_DEVICE void glds_load_b32(const void* g, lds_t wave_base) {
     int l = emu::g_lane->tid & 63;
     memcpy(emu::lds_ptr(wave_base + 4 * l, 4, 4), g, 4);
 }
-LWM_DEVICE void glds_load_b128_l2(const void* g, lds_t wave_base) { glds_load_b128(g, wave_base); }
-LWM_DEVICE void glds_load_b32_l2(const void* g, lds_t wave_base) {
-    int l = emu::g_lane->tid & 63;
-    int32_t v = __atomic_load_n((const int32_t*)g, __ATOMIC_ACQUIRE);
-    memcpy(emu::lds_ptr(wave_base + 4 * l, 4, 4), &v, 4);
-}
 template <int N>
 LWM_DEVICE void wait_vmem_le() {}
 LWM_DEVICE void glds_wait_all() {}
-LWM_DEVICE void wait_vmem_all() {}
 LWM_DEVICE int wave_uniform(int x) { return x; }
 LWM_DEVICE void sched_fence() {}
-template <int A, int B>
-LWM_DEVICE void sched_mfma_dsread() {}
-template <int MASK, int N>
-LWM_DEVICE void sched_group() {}
-template <int N>
-LWM_DEVICE void sleep_cycles64() {}
 LWM_DEVICE uint32_t opaque(uint32_t x) { return x; }
-LWM_DEVICE void pin_value(float) {}
 LWM_DEVICE void prio_hi() {}
 LWM_DEVICE void prio_lo() {}
-template <int N>
-LWM_DEVICE void set_prio() {}
 
 LWM_DEVICE float shfl_xor_f(float x, int m) {
     emu::Wave& w = emu::g_blk->waves[emu::g_lane->tid >> 6];
@@ -385,35 +346,13 @@ LWM_DEVICE void global_store_b64(void* p, u32x2 v) { memcpy(p, &v, 8); }
 LWM_DEVICE f32x4 global_load_f32x4(const float* p) { f32x4 v; memcpy(&v, p, 16); return v; }
 LWM_DEVICE void global_store_f32x4(float* p, f32x4 v) { memcpy(p, &v, 16); }
 
-// inter-workgroup hand-off: blocks run on different host threads, so the flag is a release/acquire pair and
-// the "XCC id" is the block index modulo 8 (what the hardware does in practice; the kernel must not rely on it)
 LWM_DEVICE int xcc_id() { return emu::g_blk->bx & 7; }
-LWM_DEVICE int load_i32_l2(const int32_t* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
-LWM_DEVICE void store_i32_plain(int32_t* p, int32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 LWM_DEVICE int atomic_add_i32(int32_t* p, int32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
-LWM_DEVICE int atomic_cas_i32(int32_t* p, int32_t expected, int32_t desired) {
-    __atomic_compare_exchange_n(p, &expected, desired, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
-    return expected;
-}
-LWM_DEVICE void spin_pause() {
-    emu::g_blk->progress++;     // waiting on ANOTHER block is not a deadlock of this one
-    emu::yield();
-}
 LWM_DEVICE float global_load_f32_at(const float* base, uint32_t voff, uint32_t soff) {
     float v;
     memcpy(&v, (const char*)base + voff + soff, 4);
     return v;
 }
-LWM_DEVICE f32x4 global_load_f32x4_l2(const float* base, uint32_t byte_off) {
-    f32x4 v;
-    memcpy(&v, (const char*)base + byte_off, 16);
-    return v;
-}
-
-LWM_DEVICE void global_store_f32x4_async(float* p, f32x4 v) { memcpy(p, &v, 16); }
-LWM_DEVICE void global_store_b128_nt_at(void* base, uint32_t voff, u32x4 v) { memcpy((char*)base + voff, &v, 16); }
-LWM_DEVICE void global_store_b64_async(void* p, u32x2 v) { memcpy(p, &v, 8); }
-
 LWM_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
     union { bf16_t h[2]; uint32_t u; } x;
     x.h[0] = (bf16_t)lo;

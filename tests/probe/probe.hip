@@ -91,18 +91,3 @@ extern "C" int probe_run_xcc(int* out, int* per_xcc, int blocks, int lds_bytes, 
     return (int)hipGetLastError();
 }
 
-// v_mfma_f32_16x16x32_bf16 with the operand maps attn_bwd_fused.h assumes: A[16][32], B[32][16] row-major.
-__global__ __launch_bounds__(64) void probe_mfma16(const bf16_t* A, const bf16_t* Bm, float* Cm) {
-    int l = thread_idx(), i = l & 15, kg = l >> 4;
-    bf16x8 a, b;
-    for (int j = 0; j < 8; ++j) {
-        a[j] = A[i * 32 + 8 * kg + j];
-        b[j] = Bm[(8 * kg + j) * 16 + i];
-    }
-    f32x4 c = mfma_16x16x32(a, b, f32x4{0.f, 0.f, 0.f, 0.f});
-    for (int r = 0; r < 4; ++r) Cm[(4 * kg + r) * 16 + i] = c[r];
-}
-extern "C" int probe_run_mfma16(const void* A, const void* B, float* C, void* stream) {
-    hipLaunchKernelGGL(probe_mfma16, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)A, (const bf16_t*)B, C);
-    return (int)hipGetLastError();
-}

@@ -67,10 +67,9 @@ def test_fwd_bwd_vs_oracle(B, Sq, Sk, H, causal, seg, kv):
               key_valid=t(key_valid, torch.uint8))
     qd, kd, vd, dod = q.cuda(), k.cuda(), v.cuda(), do.cuda()
     out, lse = ops.attn_fwd_block(qd, kd, vd, **kw)
-    delta = ops.attn_bwd_delta(out, dod)
+    delta = ops.attn_bwd_delta(out, dod, lse)
     dk, dv = ops.attn_bwd_dkdv_block(qd, kd, vd, dod, lse, delta, **kw)
     dq = ops.attn_bwd_dq_block(qd, kd, vd, dod, lse, delta, **kw)
-    fq, fk, fv = ops.attn_bwd_fused_block(qd, kd, vd, dod, lse, delta, **kw)     # one launch, S and dP once
     torch.cuda.synchronize()
     okw = dict(causal=causal, seg_q=seg_q, seg_k=seg_k, key_valid=key_valid)
     ro, rl = R.dense_attention(_np(q), _np(k), _np(v), **okw)
@@ -85,64 +84,51 @@ def test_fwd_bwd_vs_oracle(B, Sq, Sk, H, causal, seg, kv):
     _check("dq", _np(dq), rq, row_slack=slack)
     _check("dk", _np(dk), rk)
     _check("dv", _np(dv), rv)
-    _check("dq fused", _np(fq), rq, row_slack=slack)
-    _check("dk fused", _np(fk), rk)
-    _check("dv fused", _np(fv), rv)
-    # dk, dv: the same sums in the same order as the two-kernel path -> identical bits
-    assert torch.equal(fk, dk) and torch.equal(fv, dv)
 
 
-def test_fused_backward_is_deterministic_and_carries():
-    """lwm_attn_bwd_fused stores the dq partial of every (256-key block, 32-query tile) pair as bf16 and sums them in
-    key order in a second pass: dq, dk and dv are all bit-reproducible.  Many key blocks per head, more work items
-    than CUs, uneven head count (queues of different length), a workspace that only takes 8 of the 10 (batch*head)
-    slices per launch (head groups), carries in and out: repeated launches give identical bits, equal to the oracle;
-    and the f32 carry path (dq_carry_in / not final) adds onto what is there."""
+def test_backward_is_deterministic_and_carries():
+    """The backward has no atomics and fixed summation orders: dq, dk and dv are bit-reproducible.  Many key blocks per
+    head, more workgroups than CUs, an uneven (batch*head) count (the non-XCD-aware block mapping): repeated launches give
+    identical bits, equal to the oracle; the f32 carry path (carry_in / not final) adds onto what is there, and the
+    head-major dq accumulator gives the same numbers."""
     import torch
     from lwm_amd import ops
     B, S, H = 2, 4096, 5
     q, k, v, do = (_rand((B, S, H, 128), s).cuda() for s in (61, 62, 63, 64))
     out, lse = ops.attn_fwd_block(q, k, v, causal=True)
-    delta = ops.attn_bwd_delta(out, do)
-    ref = [t.clone() for t in ops.attn_bwd_fused_block(q, k, v, do, lse, delta, causal=True)]
-    dk2, dv2 = ops.attn_bwd_dkdv_block(q, k, v, do, lse, delta, causal=True)
-    assert torch.equal(ref[1], dk2) and torch.equal(ref[2], dv2)
+    delta = ops.attn_bwd_delta(out, do, lse)
+
+    def run(**kw):
+        dk, dv = ops.attn_bwd_dkdv_block(q, k, v, do, lse, delta, causal=True, **{k_: v_ for k_, v_ in kw.items() if k_ != "dq_kw"})
+        dq = ops.attn_bwd_dq_block(q, k, v, do, lse, delta, causal=True, **kw.get("dq_kw", {}))
+        return [dq, dk, dv]
+
+    ref = [t.clone() for t in run()]
     for _ in range(4):
-        got = ops.attn_bwd_fused_block(q, k, v, do, lse, delta, causal=True)
+        got = run()
         torch.cuda.synchronize()
         assert all(torch.equal(a, b) for a, b in zip(got, ref))
-    # head groups: room for 8 slices only -> two launches; same bits
-    full, least = ops._fused_need(B, H, S, S, 0, 0, True)
-    cap, ops.FUSED_WS_CAP = ops.FUSED_WS_CAP, least
-    try:
-        ops._FUSED_WS.clear()
-        got = ops.attn_bwd_fused_block(q, k, v, do, lse, delta, causal=True)
-        torch.cuda.synchronize()
-        assert least < full and all(torch.equal(a, b) for a, b in zip(got, ref))
-    finally:
-        ops.FUSED_WS_CAP = cap
-        ops._FUSED_WS.clear()
     f = lambda t: _np(t[:1, :, 2:3])
     rq, rk, rv = R.dense_attention_bwd(f(q), f(k), f(v), f(do), causal=True)
-    _check("dq fused 4096", f(ref[0]), rq, row_slack=_slack(f(do), f(out), f(k)))
-    _check("dk fused 4096", f(ref[1]), rk)
-    _check("dv fused 4096", f(ref[2]), rv)
-    # carries: start from a known f32 dq carry, leave the result in f32
-    carry = torch.randn(B, S, H, 128, device="cuda")
-    acc = carry.clone()
-    dqa, dka, dva = ops.attn_bwd_fused_block(q, k, v, do, lse, delta, causal=True, dq_acc=acc, dq_carry_in=True,
-                                             dq_final=False, final=False)
-    plain = ops.attn_bwd_fused_block(q, k, v, do, lse, delta, causal=True, dq_final=False, final=False)
+    _check("dq 4096", f(ref[0]), rq, row_slack=_slack(f(do), f(out), f(k)))
+    _check("dk 4096", f(ref[1]), rk)
+    _check("dv 4096", f(ref[2]), rv)
+    # carries: start from known f32 carries, leave the results in f32
+    cq, ck, cv = (torch.randn(B, S, H, 128, device="cuda") for _ in range(3))
+    aq, ak, av = cq.clone(), ck.clone(), cv.clone()
+    dka, dva = ops.attn_bwd_dkdv_block(q, k, v, do, lse, delta, causal=True, dk_acc=ak, dv_acc=av, carry_in=True, final=False)
+    dqa = ops.attn_bwd_dq_block(q, k, v, do, lse, delta, causal=True, dq_acc=aq, carry_in=True, final=False)
+    pk, pv = ops.attn_bwd_dkdv_block(q, k, v, do, lse, delta, causal=True, final=False)
+    pq = ops.attn_bwd_dq_block(q, k, v, do, lse, delta, causal=True, final=False)
     torch.cuda.synchronize()
-    assert dqa.data_ptr() == acc.data_ptr()
-    pmax = plain[0].abs().max().item()
-    assert ((dqa - carry) - plain[0]).abs().max().item() <= 1e-4 * pmax
-    assert torch.equal(dka, plain[1]) and torch.equal(dva, plain[2])
-    assert torch.equal(ops.cast_f32_to_bf16(plain[0]), ref[0])       # the same f32 sums, rounded once
-    # the head-major accumulator layout gives the same numbers
-    alt = ops.attn_bwd_fused_block(q, k, v, do, lse, delta, causal=True, dq_final=False, final=False,
-                                   acc_head_major=True)
-    assert torch.equal(alt[0], plain[0].transpose(1, 2))
+    assert dqa.data_ptr() == aq.data_ptr() and dka.data_ptr() == ak.data_ptr()
+    for acc, carry, plain in ((dqa, cq, pq), (dka, ck, pk), (dva, cv, pv)):
+        assert ((acc - carry) - plain).abs().max().item() <= 1e-4 * plain.abs().max().item()
+    for plain, r in zip((pq, pk, pv), ref):
+        assert torch.equal(ops.cast_f32_to_bf16(plain), r)       # the same f32 sums, rounded once
+    # the head-major dq accumulator layout gives the same numbers
+    alt = ops.attn_bwd_dq_block(q, k, v, do, lse, delta, causal=True, final=False, acc_head_major=True)
+    assert torch.equal(alt, pq.transpose(1, 2))
 
 
 def test_softmax_rescale_branch_is_exercised():
@@ -184,7 +170,7 @@ def test_cast_and_backward_carries():
     x = torch.randn(1000, 129, device="cuda")[:, :128].contiguous()
     assert torch.equal(ops.cast_f32_to_bf16(x), x.to(torch.bfloat16))
     out, lse = ops.attn_fwd_block(q, k, v, causal=True)
-    delta = ops.attn_bwd_delta(out, do)
+    delta = ops.attn_bwd_delta(out, do, lse)
     dq1 = ops.attn_bwd_dq_block(q, k, v, do, lse, delta, causal=True)
     dk1, dv1 = ops.attn_bwd_dkdv_block(q, k, v, do, lse, delta, causal=True)
     z = lambda: torch.zeros(1, 512, 2, 128, dtype=torch.float32, device="cuda")
@@ -216,7 +202,7 @@ def test_packed_documents_skip_is_exact():
 
     def run():
         out, lse = ops.attn_fwd_block(q, k, v, causal=True, seg_q=segd, seg_k=segd)
-        delta = ops.attn_bwd_delta(out, do)
+        delta = ops.attn_bwd_delta(out, do, lse)
         dk, dv = ops.attn_bwd_dkdv_block(q, k, v, do, lse, delta, causal=True, seg_q=segd, seg_k=segd)
         dq = ops.attn_bwd_dq_block(q, k, v, do, lse, delta, causal=True, seg_q=segd, seg_k=segd)
         return out, lse, dq, dk, dv
@@ -250,11 +236,6 @@ def test_packed_documents_skip_is_exact():
     _check("dq", _np(dq[:, :, sl]), rq, row_slack=slack)
     _check("dk", _np(dk[:, :, sl]), rk)
     _check("dv", _np(dv[:, :, sl]), rv)
-    # the one-launch backward honours the hints too: dk, dv bit-identical, dq (atomic adds) within tolerance
-    delta = ops.attn_bwd_delta(out, do)
-    fq, fk, fv = ops.attn_bwd_fused_block(q, k, v, do, res[True][1], delta, causal=True, seg_q=segd, seg_k=segd)
-    assert torch.equal(fk, dk) and torch.equal(fv, dv)
-    _check("dq fused packed", _np(fq[:, :, sl]), rq, row_slack=slack)
 
 
 def test_autograd_ring1_matches_oracle():
@@ -326,7 +307,7 @@ def test_full_size_properties(full):
     assert np.abs(_np(lse[:, h:h + 1, r0:r0 + 512]) - rl).max() <= 2e-3
     # (6) backward identities: sum_k dv[k] == sum_q do[q] when V-gradient weights sum to 1;
     #     and ring-split (two kv halves with carries) == single shot
-    delta = ops.attn_bwd_delta(out, do)
+    delta = ops.attn_bwd_delta(out, do, lse)
     dk, dv = ops.attn_bwd_dkdv_block(q, k, v, do, lse, delta, causal=True)
     dq = ops.attn_bwd_dq_block(q, k, v, do, lse, delta, causal=True)
     sdv = dv.float().sum(dim=1)
@@ -366,17 +347,6 @@ def test_full_size_properties(full):
                                      _np(do[:, r0:, h:h + 1]), causal=True, q_start=r0, k_start=0)
     slack_2 = _slack(_np(do[:, r0:, h:h + 1]), _np(out[:, r0:, h:h + 1]), _np(k[:, :, h:h + 1]))
     _check("dq window 2", _np(dq[:, r0:, h:h + 1]), rq, row_slack=slack_2)
-    # (10) the one-launch backward at full size: dk, dv bit-identical to the two-kernel path, dq (atomic adds)
-    #      against the same oracle windows
-    fq, fk, fv = ops.attn_bwd_fused_block(q, k, v, do, lse, delta, causal=True)
-    assert torch.equal(fk, dk) and torch.equal(fv, dv)
-    _check("dq fused window 2", _np(fq[:, r0:, h:h + 1]), rq, row_slack=slack_2)
-    h, r0, w = 5, 2048, 256
-    sl = slice(0, r0 + w)
-    rq, _, _ = R.dense_attention_bwd(_np(q[:, sl, h:h + 1]), _np(k[:, sl, h:h + 1]), _np(v[:, sl, h:h + 1]),
-                                     _np(do[:, sl, h:h + 1]), causal=True)
-    _check("dq fused window", _np(fq[:, r0:r0 + w, h:h + 1]), rq[:, r0:r0 + w], row_slack=slack_w)
-    assert ((fq.float() - dq.float()).abs().max() / dq.float().abs().max()).item() <= 8e-3
 
 
 def test_addressing_beyond_4g_elements_at_1m_tokens():

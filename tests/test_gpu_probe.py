@@ -105,26 +105,11 @@ def test_plain_c_program_runs_the_forward():
     assert r.returncode == 0 and r.stdout.startswith("ok"), (r.returncode, r.stdout, r.stderr)
 
 
-def test_mfma_16x16x32_layout(probe):
-    """Operand / result lane maps of v_mfma_f32_16x16x32_bf16 as lwm_amd/csrc/wave_ops.h states them
-    (the dQ product of attn_bwd_fused.h); asymmetric operands so that a transposed result cannot pass."""
-    import torch
-    g = torch.Generator().manual_seed(5)
-    A = torch.randn(16, 32, generator=g).to(torch.bfloat16).cuda()
-    B = torch.randn(32, 16, generator=g).to(torch.bfloat16).cuda()
-    Cm = torch.zeros(16, 16, device="cuda")
-    probe.probe_run_mfma16.argtypes = [C.c_void_p] * 4
-    assert probe.probe_run_mfma16(A.data_ptr(), B.data_ptr(), Cm.data_ptr(), None) == 0
-    torch.cuda.synchronize()
-    ref = A.float() @ B.float()
-    assert (Cm - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
-
-
 def test_xcc_id_register_and_persistent_grid_placement(probe):
-    """attn_bwd_fused.h keys its work queues on s_getreg(HW_REG_XCC_ID).  The register must report all 8
-    XCDs of an MI355X, and a persistent grid of one 512-thread workgroup per CU (131 KB of LDS each, so one
-    per CU) must put workgroups on every XCD -- the kernel stays correct on any placement (queues are
-    claimed), but its speed assumes the 256 workgroups spread 32 per XCD."""
+    """The attention kernels map all tiles of one (batch, head) onto one XCD by block index modulo 8, so that its K/V
+    (or Q/dO) stream is shared in that XCD's L2.  s_getreg(HW_REG_XCC_ID) must report all 8 XCDs of an MI355X, and a
+    grid of one workgroup per CU (131 KB of LDS each, so one per CU) must put workgroups on every XCD, 32 each -- the
+    kernels are correct on any placement, their speed assumes this one."""
     import torch
     n = torch.cuda.get_device_properties(0).multi_processor_count
     out = torch.full((n,), -1, dtype=torch.int32, device="cuda")

@@ -129,27 +129,6 @@ def test_ring_n_equals_ring_1_on_gpu(n, layout_kind, packed, schedule):
         _check(f"{name} ring{n}", f(a), b, row_slack=slack if name == "dq" else None)
 
 
-@pytest.mark.parametrize("n,schedule", [(1, "ring"), (4, "mesh"), (4, "ring")])
-def test_fused_backward_flavour_through_the_drivers(n, schedule):
-    """LWM_FUSED_BWD=1 (lwm_attn_bwd_fused: bf16 dq partials + reduction) through the ring drivers: single block, the
-    mesh schedule's dq-carry + remote dK/dV partial launches, and the ring schedule (which keeps the two kernels)."""
-    import lwm_amd.ring as ring
-    old = ring.FUSED_BACKWARD
-    ring.FUSED_BACKWARD = True
-    try:
-        S, H = 512 * n, 2
-        got, ref, (q, k, v, do, seg) = _run_ring(n, "zigzag" if n > 1 else "contiguous", S, H, True, schedule)
-    finally:
-        ring.FUSED_BACKWARD = old
-    f = lambda t: t.float().cpu().numpy()
-    sg = seg.cpu().numpy()
-    ro, _ = R.dense_attention(f(q), f(k), f(v), causal=True, seg_q=sg, seg_k=sg)
-    rq, rk, rv = R.dense_attention_bwd(f(q), f(k), f(v), f(do), causal=True, seg_q=sg, seg_k=sg)
-    slack = _slack(f(do), ro, f(k))
-    for name, a, b in zip(("out", "dq", "dk", "dv"), got, (ro, rq, rk, rv)):
-        _check(f"{name} fused flavour ring{n} {schedule}", f(a), b, row_slack=slack if name == "dq" else None)
-
-
 def _doc_windows(bounds, w=256):
     """[(doc_start, doc_end, window_start)]: the last `w` rows of every document."""
     return [(a, b, b - w) for a, b in zip(bounds[:-1], bounds[1:])]
