@@ -68,7 +68,9 @@ def torch_dtype(name: str):
     """--dtype (fp32 | bf16 | fp16, tux.get_float_dtype_by_name; the reference's default and every launcher's value
     is fp32, lwm/train.py:36, scripts/run_train_text.sh:21).  The MI355X hot path exists for bf16 operands only
     (f32 logits / softmax / accumulation, i.e. the reference's bf16 run with float32_logits=True, BASELINE configs
-    2-5); anything else is REFUSED rather than silently computed in a different precision than the command line says."""
+    2-5).  The entry points here therefore DEFAULT to bf16 (a documented divergence from the reference's default:
+    README.md), and an explicit --dtype=fp32 / fp16 is REFUSED rather than silently
+    computed in a different precision than the command line says."""
     if name not in ("fp32", "bf16", "fp16", "float32", "bfloat16", "float16"):
         raise SystemExit(f"unknown --dtype {name!r}")
     if name not in ("bf16", "bfloat16"):

@@ -17,7 +17,7 @@ from . import _common as C
 from ._flags import parse
 
 DEFAULTS = dict(
-    modality="text", use_data_sharded_loader=True, seed=42, mesh_dim="1,-1,1,1", dtype="fp32", total_steps=10000,
+    modality="text", use_data_sharded_loader=True, seed=42, mesh_dim="1,-1,1,1", dtype="bf16", total_steps=10000,
     load_llama_config="", update_llama_config="", load_checkpoint="", load_dataset_state="", log_freq=50,
     save_model_freq=0, save_milestone_freq=0, eval_steps=0, tokenizer="LargeWorldModel/LWM-Text-1M",
     log_all_worker=False, autoresume=False)

@@ -13,7 +13,7 @@ from . import _common as C
 from ._flags import parse
 
 DEFAULTS = dict(prompt="", input_file="", vqgan_checkpoint="", temperature=0.2, max_n_frames=8, seed=1234,
-                mesh_dim="1,-1,1,1", dtype="fp32", load_llama_config="", update_llama_config="", load_checkpoint="",
+                mesh_dim="1,-1,1,1", dtype="bf16", load_llama_config="", update_llama_config="", load_checkpoint="",
                 tokenizer="LargeWorldModel/LWM-Text-1M")
 GROUPS = ("llama", "jax_distributed")
 

@@ -13,7 +13,7 @@ from ._flags import parse
 
 DEFAULTS = dict(prompt="Fireworks over the city", output_file="", temperature_image=1.0, temperature_video=1.0,
                 top_k_image=8192, top_k_video=100, cfg_scale_image=1.0, cfg_scale_video=1.0, vqgan_checkpoint="",
-                n_frames=1, seed=1234, mesh_dim="1,-1,1,1", dtype="fp32", load_llama_config="", update_llama_config="",
+                n_frames=1, seed=1234, mesh_dim="1,-1,1,1", dtype="bf16", load_llama_config="", update_llama_config="",
                 load_checkpoint="", tokenizer="LargeWorldModel/LWM-Text-1M")
 GROUPS = ("llama", "jax_distributed")
 TOKENS_PER_FRAME = 257

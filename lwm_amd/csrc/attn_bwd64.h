@@ -50,6 +50,14 @@ constexpr int kD4LdsBytes = kD4OffStat + kD4Slots * kD4StatBytes;
 #endif
 constexpr int kD4Ahead = LWM_D4_AHEAD;
 static_assert(kD4Ahead >= 1 && kD4Ahead <= 7, "prefetch distance in fragments");
+// Fragments are requested and consumed in PAIRS (the two chains of X, the two products of Y): both requests go out in
+// the even gap, and the pair's YOUNGER fragment is consumed first -- the s_waitcnt hipcc puts in front of that MFMA
+// covers the older one too, so there is one wait per two MFMAs.  (0: one fragment per gap, consumed in request order.)
+#ifndef LWM_D4_PAIR
+#define LWM_D4_PAIR 1
+#endif
+constexpr bool kD4Pair = LWM_D4_PAIR != 0;
+static_assert(!kD4Pair || (kD4Ahead % 2) == 0, "paired requests need an even distance");
 // timing experiments only (wrong results): -DLWM_D4X_NODMA / _NOFILL / _NOBAR / _NOSTAT / _NOSLOAD drop one ingredient of the loop
 #ifdef LWM_D4X_NOFILL
 constexpr bool kD4xFill = false;
@@ -158,6 +166,70 @@ LWM_DEVICE bf16x8 d4_frag(const D4Ctx& cx, int f) {
     return o;
 }
 
+// ---- where the vector work of a unit u goes.  Gaps are numbered over the two phases that host it: G = 0..15 = the
+// gaps of Y(u) (its S and dP' tiles are complete), G = 16..31 = the gaps of X(u+1).  Per element e (16 per lane) /
+// per pair i (8 per lane):
+//   F(e)  t = S c - lse2          needs S(u): G >= 1 (the chains have left the pipe), G <= 15 (X(u+1) overwrites S)
+//   E(e)  p = exp2(t)             >= 1 gap behind F(e) (and a transcendental's result is not read in the next slot)
+//   M(e)  dS = p dP'              >= 1 gap behind E(e)
+//   P(i)  P words -> bf16         >= 1 gap behind E(2i), E(2i+1); the products of Y(u) still read the OLD P: word i of
+//   D(i)  dS words -> bf16           the first half (i < 4) from G = 8, of the second from G = 16; D(i) likewise, >= 1 gap
+//                                    behind M(2i), M(2i+1); everything done by G = 29 (Y(u+1) reads them at G = 32)
+// d4_sched_ok() checks a table at compile time.  LWM_D4_SCHED selects (A/B in profiles/r04_backward.md).
+struct D4Sched {
+    int F[16], E[16], M[16], P[8], D[8];
+};
+constexpr bool d4_sched_ok(const D4Sched& c) {
+    for (int e = 0; e < 16; ++e) {
+        if (c.F[e] < 1 || c.F[e] > 15) return false;
+        if (c.E[e] <= c.F[e] || c.M[e] <= c.E[e] || c.M[e] > 29) return false;
+    }
+    for (int i = 0; i < 8; ++i) {
+        const int lo = i < 4 ? 8 : 16;
+        if (c.P[i] < lo || c.P[i] > 29 || c.P[i] <= c.E[2 * i] || c.P[i] <= c.E[2 * i + 1]) return false;
+        if (c.D[i] < lo || c.D[i] > 29 || c.D[i] <= c.M[2 * i] || c.D[i] <= c.M[2 * i + 1]) return false;
+    }
+    return true;
+}
+#ifndef LWM_D4_SCHED
+#define LWM_D4_SCHED 0
+#endif
+#if LWM_D4_SCHED == 0
+// exponentials in Y (beside the transposed reads), multiplies and packs in X
+constexpr D4Sched kD4Sched = {
+    /* F */ {1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8},
+    /* E */ {2, 3, 4, 4, 5, 6, 7, 7, 8, 9, 9, 10, 10, 11, 11, 12},
+    /* M */ {16, 16, 17, 17, 18, 18, 19, 19, 20, 20, 21, 21, 22, 22, 23, 23},
+    /* P */ {16, 17, 18, 19, 20, 21, 22, 23},
+    /* D */ {24, 25, 26, 27, 28, 29, 29, 29}};
+#elif LWM_D4_SCHED == 1
+// one exponential per gap from G = 9 on (7 beside the transposed reads of Y, 9 beside the row reads of X), each
+// followed by its multiply and the packs as they become possible
+constexpr D4Sched kD4Sched = {
+    /* F */ {1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8},
+    /* E */ {9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24},
+    /* M */ {10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25},
+    /* P */ {11, 13, 15, 17, 19, 21, 23, 25},
+    /* D */ {12, 14, 16, 18, 20, 22, 24, 26}};
+#elif LWM_D4_SCHED == 2
+// every exponential in X: Y keeps the 16 fmas only
+constexpr D4Sched kD4Sched = {
+    /* F */ {1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8},
+    /* E */ {16, 16, 17, 17, 18, 18, 19, 19, 20, 20, 21, 21, 22, 22, 23, 23},
+    /* M */ {17, 17, 18, 18, 19, 19, 20, 20, 21, 21, 22, 22, 23, 23, 24, 24},
+    /* P */ {17, 18, 19, 20, 21, 22, 23, 24},
+    /* D */ {18, 19, 20, 21, 22, 23, 24, 25}};
+#elif LWM_D4_SCHED == 3
+// fmas and exponentials spread over all of Y (1 + 1 per gap), the rest in X
+constexpr D4Sched kD4Sched = {
+    /* F */ {1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 14},
+    /* E */ {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 15, 16},
+    /* M */ {16, 16, 17, 17, 18, 18, 19, 19, 20, 20, 21, 21, 22, 22, 23, 23},
+    /* P */ {16, 17, 18, 19, 20, 21, 22, 23},
+    /* D */ {24, 25, 26, 27, 28, 29, 29, 29}};
+#endif
+static_assert(d4_sched_ok(kD4Sched), "filler schedule violates a dependency");
+
 // the LDS-DMA pieces one step issues (all wave-uniform but the offsets): Q and dO of the step two ahead
 struct D4Dma {
     const char* q_src;
@@ -173,8 +245,45 @@ struct D4Regs {
     float t[16];            // exponents, then p
     float ds[16];           // dS = p * dP'
     bf16x8 pb[2], dsb[2];   // P / dS as B operands (q steps of 16)
+    uint32_t pw[8], dw[8];  // their words as they are packed (a half is handed over when its fourth word is in)
     bf16x8 fr[8];           // the fragment ring
 };
+
+// the vector work scheduled in gap G; dpu = the dP' tile of the unit being finished
+template <int G>
+LWM_DEVICE void d4_fillers(const D4Ctx& cx, D4Regs& rg, const f32x16& dpu) {
+    if (!kD4xFill) return;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        if (kD4Sched.F[e] == G) rg.t[e] = f4_fma(rg.s[e], cx.c, rg.nl[e]);
+        if (kD4Sched.E[e] == G) rg.t[e] = f4_exp2(rg.t[e]);
+        if (kD4Sched.M[e] == G) rg.ds[e] = d4_mul(rg.t[e], dpu[e]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (kD4Sched.P[i] == G) rg.pw[i] = f4_cvt_pk(rg.t[2 * i], rg.t[2 * i + 1]);
+        if (kD4Sched.D[i] == G) rg.dw[i] = f4_cvt_pk(rg.ds[2 * i], rg.ds[2 * i + 1]);
+    }
+    // hand a half over behind its last word
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        int lp = 0, ld = 0;
+        for (int i = 4 * h; i < 4 * h + 4; ++i) {
+            lp = kD4Sched.P[i] > lp ? kD4Sched.P[i] : lp;
+            ld = kD4Sched.D[i] > ld ? kD4Sched.D[i] : ld;
+        }
+        if (lp == G) rg.pb[h] = __builtin_bit_cast(bf16x8, u32x4{rg.pw[4 * h], rg.pw[4 * h + 1], rg.pw[4 * h + 2], rg.pw[4 * h + 3]});
+        if (ld == G) rg.dsb[h] = __builtin_bit_cast(bf16x8, u32x4{rg.dw[4 * h], rg.dw[4 * h + 1], rg.dw[4 * h + 2], rg.dw[4 * h + 3]});
+    }
+}
+// dispatch a loop index to the compile-time gap (the loops are fully unrolled: the chain folds to one call)
+template <int G0, int N>
+LWM_DEVICE void d4_fill_at(int g, const D4Ctx& cx, D4Regs& rg, const f32x16& dpu) {
+    if constexpr (N > 0) {
+        if (g == G0) d4_fillers<G0>(cx, rg, dpu);
+        else d4_fill_at<G0 + 1, N - 1>(g, cx, rg, dpu);
+    }
+}
 
 // -delta of a unit's rows -> the dP tuple that unit's chain will accumulate into (stat = statistics slot + 16 hi)
 template <int HALF>
@@ -191,22 +300,29 @@ LWM_DEVICE void d4_load_ndelta(uint32_t stat, f32x16& dp, int g) {
 template <int HALF, bool HAS_PREV, bool DMA>
 LWM_DEVICE void d4_x(const D4Ctx& cx, D4Regs& rg, const bf16x8 (&kf)[8], const bf16x8 (&vf)[8], const uint32_t (&vq)[4],
                      const uint32_t (&vdo)[4], const D4Dma& dm) {
-    uint32_t w[4];
     f32x16& dpn = rg.dp[HALF];            // this unit's dP'
     const f32x16& dpo = rg.dp[HALF ^ 1];  // the previous unit's
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
-        rg.fr[(m + kD4Ahead) & 7] = d4_frag<HALF>(cx, m + kD4Ahead);
+        if (!kD4Pair) {
+            rg.fr[(m + kD4Ahead) & 7] = d4_frag<HALF>(cx, m + kD4Ahead);
+        } else if ((m & 1) == 0) {
+            rg.fr[(m + kD4Ahead) & 7] = d4_frag<HALF>(cx, m + kD4Ahead);
+            rg.fr[(m + kD4Ahead + 1) & 7] = d4_frag<HALF>(cx, m + kD4Ahead + 1);
+        }
         if (kD4xStat && (m & 3) == 2) {      // the unit's -lse * log2 e (needed from gap 1 of phase Y)
             const int g = m >> 2;
             const f32x4 v = lds_read_f32x4(cx.stat + HALF * 32 * 4 + 8 * g * 4);
             rg.nl[4 * g + 0] = v[0]; rg.nl[4 * g + 1] = v[1]; rg.nl[4 * g + 2] = v[2]; rg.nl[4 * g + 3] = v[3];
         }
         sched_fence();
-        if (m == 0) f4_mfma_s_first(rg.s, rg.fr[0], kf[0]);
-        else if ((m & 1) == 0) f4_mfma_s(rg.s, rg.fr[m & 7], kf[m >> 1]);
-        else if (m == 1) d4_mfma_p_first(dpn, rg.fr[1], vf[0]);
-        else f4_mfma_s(dpn, rg.fr[m & 7], vf[m >> 1]);
+        {
+            const int f = kD4Pair ? (m ^ 1) : m;      // the fragment this gap's MFMA consumes: even = Q (S), odd = dO (dP')
+            if (f == 0) f4_mfma_s_first(rg.s, rg.fr[0], kf[0]);
+            else if ((f & 1) == 0) f4_mfma_s(rg.s, rg.fr[f & 7], kf[f >> 1]);
+            else if (f == 1) d4_mfma_p_first(dpn, rg.fr[1], vf[0]);
+            else f4_mfma_s(dpn, rg.fr[f & 7], vf[f >> 1]);
+        }
 #ifndef LWM_D4X_NODMA
         if (DMA && (m & 1)) {         // the wave's 4 Q and 4 dO pieces of the step two ahead, all in the step's first phase
             const int j = m >> 2;
@@ -214,18 +330,7 @@ LWM_DEVICE void d4_x(const D4Ctx& cx, D4Regs& rg, const bf16x8 (&kf)[8], const b
             else f4_dma1(vdo[j], dm.do_src, dm.dst + kD4TileBytes + 4096 * j);
         }
 #endif
-        if (HAS_PREV && kD4xFill) {
-            if (m < 8) {
-                w[m & 3] = f4_cvt_pk(rg.t[2 * m], rg.t[2 * m + 1]);
-                if ((m & 3) == 3) rg.pb[m >> 2] = __builtin_bit_cast(bf16x8, u32x4{w[0], w[1], w[2], w[3]});
-                rg.ds[2 * m] = d4_mul(rg.t[2 * m], dpo[2 * m]);
-                rg.ds[2 * m + 1] = d4_mul(rg.t[2 * m + 1], dpo[2 * m + 1]);
-            } else {
-                const int i = m - 8;
-                w[i & 3] = f4_cvt_pk(rg.ds[2 * i], rg.ds[2 * i + 1]);
-                if ((i & 3) == 3) rg.dsb[i >> 2] = __builtin_bit_cast(bf16x8, u32x4{w[0], w[1], w[2], w[3]});
-            }
-        }
+        if (HAS_PREV) d4_fill_at<16, 16>(16 + m, cx, rg, dpo);
         sched_fence();
     }
 }
@@ -261,35 +366,25 @@ LWM_DEVICE void d4_y(const D4Ctx& cx, D4Regs& rg, f32x16 (&dk)[4], f32x16 (&dv)[
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int m = 16 + j;
-        if (m + kD4Ahead < 32 || NEXT) rg.fr[(m + kD4Ahead) & 7] = d4_frag<HALF>(cx, m + kD4Ahead);
+        if (!kD4Pair) {
+            if (m + kD4Ahead < 32 || NEXT) rg.fr[(m + kD4Ahead) & 7] = d4_frag<HALF>(cx, m + kD4Ahead);
+        } else if ((j & 1) == 0 && (m + kD4Ahead < 32 || NEXT)) {
+            rg.fr[(m + kD4Ahead) & 7] = d4_frag<HALF>(cx, m + kD4Ahead);
+            rg.fr[(m + kD4Ahead + 1) & 7] = d4_frag<HALF>(cx, m + kD4Ahead + 1);
+        }
         if (kD4xStat && NEXT && j >= 12) d4_load_ndelta<HALF ^ 1>(statn, rg.dp[HALF ^ 1], j - 12);
         sched_fence();
         if (HAS_PREV) {
-            if (INIT && j < 8) {
-                if ((j & 1) == 0) d4_mfma_o_first(dv[(j >> 1) & 3], rg.fr[m & 7], rg.pb[0]);
-                else d4_mfma_o_first(dk[(j >> 1) & 3], rg.fr[m & 7], rg.dsb[0]);
+            const int jf = kD4Pair ? (j ^ 1) : j;      // the fragment consumed: even = dO^T (dV), odd = Q^T (dK)
+            if (INIT && jf < 8) {
+                if ((jf & 1) == 0) d4_mfma_o_first(dv[(jf >> 1) & 3], rg.fr[(16 + jf) & 7], rg.pb[0]);
+                else d4_mfma_o_first(dk[(jf >> 1) & 3], rg.fr[(16 + jf) & 7], rg.dsb[0]);
             } else {
-                if ((j & 1) == 0) f4_mfma_o(dv[(j >> 1) & 3], rg.fr[m & 7], rg.pb[j >> 3]);
-                else f4_mfma_o(dk[(j >> 1) & 3], rg.fr[m & 7], rg.dsb[j >> 3]);
+                if ((jf & 1) == 0) f4_mfma_o(dv[(jf >> 1) & 3], rg.fr[(16 + jf) & 7], rg.pb[jf >> 3]);
+                else f4_mfma_o(dk[(jf >> 1) & 3], rg.fr[(16 + jf) & 7], rg.dsb[jf >> 3]);
             }
         }
-        if (kD4xFill) {
-            if (j >= 1 && j <= 8) {
-                const int e = 2 * (j - 1);
-                rg.t[e] = f4_fma(rg.s[e], cx.c, rg.nl[e]);
-                rg.t[e + 1] = f4_fma(rg.s[e + 1], cx.c, rg.nl[e + 1]);
-            }
-            // exponentials: every element at least one gap behind its fma
-            if (j == 2) rg.t[0] = f4_exp2(rg.t[0]);
-            if (j == 3) rg.t[1] = f4_exp2(rg.t[1]);
-            if (j == 4) { rg.t[2] = f4_exp2(rg.t[2]); rg.t[3] = f4_exp2(rg.t[3]); }
-            if (j == 5) rg.t[4] = f4_exp2(rg.t[4]);
-            if (j == 6) rg.t[5] = f4_exp2(rg.t[5]);
-            if (j == 7) { rg.t[6] = f4_exp2(rg.t[6]); rg.t[7] = f4_exp2(rg.t[7]); }
-            if (j == 8) rg.t[8] = f4_exp2(rg.t[8]);
-            if (j >= 9 && j <= 11) { rg.t[2 * j - 9] = f4_exp2(rg.t[2 * j - 9]); rg.t[2 * j - 8] = f4_exp2(rg.t[2 * j - 8]); }
-            if (j == 12) rg.t[15] = f4_exp2(rg.t[15]);
-        }
+        d4_fill_at<0, 16>(j, cx, rg, rg.dp[HALF]);
         sched_fence();
     }
 }
@@ -298,19 +393,8 @@ LWM_DEVICE void d4_y(const D4Ctx& cx, D4Regs& rg, f32x16 (&dk)[4], f32x16 (&dv)[
 // PAR = the parity of the last unit (its dP' tuple); its tiles are addressed as the "previous unit" of a HALF = 0 unit.
 template <int PAR>
 LWM_DEVICE void d4_drain(const D4Ctx& cx, D4Regs& rg, f32x16 (&dk)[4], f32x16 (&dv)[4]) {
-    uint32_t w[4];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        w[m & 3] = f4_cvt_pk(rg.t[2 * m], rg.t[2 * m + 1]);
-        if ((m & 3) == 3) rg.pb[m >> 2] = __builtin_bit_cast(bf16x8, u32x4{w[0], w[1], w[2], w[3]});
-        rg.ds[2 * m] = d4_mul(rg.t[2 * m], rg.dp[PAR][2 * m]);
-        rg.ds[2 * m + 1] = d4_mul(rg.t[2 * m + 1], rg.dp[PAR][2 * m + 1]);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        w[i & 3] = f4_cvt_pk(rg.ds[2 * i], rg.ds[2 * i + 1]);
-        if ((i & 3) == 3) rg.dsb[i >> 2] = __builtin_bit_cast(bf16x8, u32x4{w[0], w[1], w[2], w[3]});
-    }
+    for (int g = 16; g < 32; ++g) d4_fill_at<16, 16>(g, cx, rg, rg.dp[PAR]);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll

@@ -585,10 +585,14 @@ class _RingAttention(torch.autograd.Function):
 
 
 _C_RINGS = {}
+_C_RING_REFUSED = set()     # groups whose first contact with the C driver failed on some rank: they stay on this module's driver
 
 
 def _c_driver_wanted(group, block_ops):
-    if block_ops is not None or os.environ.get("LWM_RING_DRIVER", "c") != "c":
+    """The C-ABI ring driver (lwm_ring_attn_fwd / _bwd) is OPT-IN for the library entry point: LWM_RING_DRIVER=c.  It has
+    run between real processes (IPC transport, one GPU) and against RCCL at n = 1, never across GPUs, so the default stays
+    this module's driver over torch.distributed; bench.py asks for it explicitly (--driver c) under the same vote."""
+    if block_ops is not None or os.environ.get("LWM_RING_DRIVER", "python") != "c" or group in _C_RING_REFUSED:
         return False
     try:
         return dist.get_backend(group) == "nccl" and dist.get_world_size(group) > 1
@@ -597,12 +601,31 @@ def _c_driver_wanted(group, block_ops):
 
 
 def _c_ring_for(group, layout_kind, schedule):
-    """one C ring object (communicator, side stream, workspace) per (group, layout, schedule), reused by every layer"""
+    """One C ring object (communicator, side stream, workspace) per (group, layout, schedule), reused by every layer; None
+    when the first contact fails on ANY rank (collective vote: every rank then takes this module's driver).  The direct
+    schedule's owner-side reduction takes at most 16 sources (lwm_sum_f32_to_bf16): larger groups get the neighbour ring."""
     from .ring_c import CRing
+    if schedule in ("mesh", "direct") and dist.get_world_size(group) > 16:
+        schedule = "ring"
     key = (group, layout_kind, schedule, torch.cuda.current_device())      # (the group object itself: an id() can be recycled)
     ring = _C_RINGS.get(key)
     if ring is None:
-        ring = _C_RINGS[key] = CRing(group, layout=layout_kind, schedule=schedule)
+        ok, err = 1, None
+        try:
+            ring = CRing(group, layout=layout_kind, schedule=schedule)
+        except Exception as e:       # noqa: BLE001 -- whatever it is, the vote decides
+            ok, err = 0, e
+        vote = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(vote, op=dist.ReduceOp.MIN, group=group)
+        if int(vote.item()) == 0:
+            import warnings
+            warnings.warn(f"lwm_amd.ring: the C ring driver could not be set up on every rank of this group ({err!r} here); "
+                          "falling back to the torch.distributed driver")
+            _C_RING_REFUSED.add(group)
+            if ring is not None:
+                ring.close()
+            return None
+        _C_RINGS[key] = ring
     return ring
 
 
@@ -624,14 +647,16 @@ def ring_attention(q, k, v, *, group=None, causal=True, segment_ids=None, key_va
             raise RuntimeError("ring_attention in a multi-process job needs the sequence-parallel group "
                                "(group=... or comm=...; torch.distributed.group.WORLD for a pure ring)")
         elif _c_driver_wanted(group, block_ops):
-            # N > 1 on GPUs: the exchange is driven by the C-ABI ring driver (lwm_ring_attn_fwd / _bwd: RCCL on a side HIP
-            # stream, the same layouts, the direct schedule = this module's "mesh"); this module stays the reference
-            # implementation of the schedule and the gloo / stand-in path of the CPU tests.  LWM_RING_DRIVER=python opts out.
+            # LWM_RING_DRIVER=c, N > 1 on GPUs: the exchange is driven by the C-ABI ring driver (lwm_ring_attn_fwd / _bwd:
+            # RCCL on a side HIP stream, the same layouts, the direct schedule = this module's "mesh").
             from .ring_c import ring_attention_c
             kind = layout.kind if isinstance(layout, SeqLayout) else layout
             sched = os.environ.get("LWM_RING_SCHEDULE") or "mesh"
-            return ring_attention_c(q, k, v, _c_ring_for(group, kind, sched), causal=causal, segment_ids=segment_ids,
-                                    key_valid=key_valid, scale=scale)
+            c_ring = _c_ring_for(group, kind, sched)
+            if c_ring is not None:
+                return ring_attention_c(q, k, v, c_ring, causal=causal, segment_ids=segment_ids,
+                                        key_valid=key_valid, scale=scale)
+            comm = TorchRingComm(group)
         else:
             comm = TorchRingComm(group)
     block = block_ops if block_ops is not None else HipBlockOps

@@ -84,10 +84,13 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&lse, (size_t)H * S * 4));
     CK(hipMalloc(&delta, (size_t)stat_bytes(1, H, S)));
     CK(hipMalloc(&sums, 64));
-    fill_bf16<<<2048, 256>>>(q, n, 1u, 1.7f);
-    fill_bf16<<<2048, 256>>>(k, n, 2u, 1.7f);
-    fill_bf16<<<2048, 256>>>(v, n, 3u, 1.7f);
-    fill_bf16<<<2048, 256>>>(dout, n, 4u, 1.7f);
+    // LWM_BENCH_AMP=0: all-zero operands (the matrix pipe then draws less power and the chip clocks higher: the gap to
+    // the random-data time is what DVFS costs, MI355X_MICROARCH.md "DVFS give-back")
+    const float amp = getenv("LWM_BENCH_AMP") ? (float)atof(getenv("LWM_BENCH_AMP")) : 1.7f;
+    fill_bf16<<<2048, 256>>>(q, n, 1u, amp);
+    fill_bf16<<<2048, 256>>>(k, n, 2u, amp);
+    fill_bf16<<<2048, 256>>>(v, n, 3u, amp);
+    fill_bf16<<<2048, 256>>>(dout, n, 4u, amp);
     CK(hipDeviceSynchronize());
 
     LwmAttnArgs a;

@@ -159,6 +159,10 @@ def test_dtype_flag_refuses_what_the_kernels_do_not_compute():
         assert "--dtype=bf16" in str(e.value)
     with pytest.raises(SystemExit):
         torch_dtype("int8")
+    # ... and an invocation WITHOUT --dtype must run: the entry points default to what the kernels compute
+    from lwm_amd.cli import train, vision_chat, vision_generation
+    for mod in (train, vision_chat, vision_generation):
+        assert torch_dtype(mod.DEFAULTS["dtype"]) is torch.bfloat16, mod.__name__
 
 
 def test_vision_checkpoint_round_trip_through_load_checkpoint(tmp_path):
