@@ -264,9 +264,12 @@ class LLaMAForCausalLM(torch.nn.Module):
         """One token per batch row through the KV cache, bf16, no autograd, one rank: the layers can run as GEMV launch
         pairs that carry their neighbours (lwm_gemv_fused_bf16; LWM_DECODE_FUSED=0 issues every launch on its own)."""
         d = self.cfg.hidden_size
+        # (d / 128 partial sums of squares per row ride along: lwm_gemv_fused_bf16 takes at most 64 of them; the weights
+        # must be what the GEMV streams -- contiguous bf16 -- or the per-block path runs)
         return (os.environ.get("LWM_DECODE_FUSED", "1") == "1" and x.shape[1] == 1 and x.shape[0] <= 4 and n_sp == 1
                 and x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled() and d % 128 == 0
-                and d <= 12288 and self.cfg.intermediate_size % 32 == 0 and self.cfg.intermediate_size <= 12288)
+                and d <= 8192 and self.cfg.intermediate_size % 32 == 0 and self.cfg.intermediate_size <= 12288
+                and all(p.dtype == torch.bfloat16 and p.is_contiguous() for p in self.h[0].parameters() if p.dim() == 2))
 
     @staticmethod
     def _norm_weight_bf16(norm):

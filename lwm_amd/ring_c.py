@@ -45,6 +45,7 @@ class CRing:
         h = C.c_void_p()
         self._transport = transport           # keep the callbacks alive
         self._ipc = None
+        self._ipc_slots = int(ipc_slots) if transport == "ipc" else None
         if self.size == 1:
             rc = L.lwm_ring_create(None, 0, 1, None, C.byref(h))
         elif transport == "ipc":
@@ -77,6 +78,7 @@ class CRing:
         _capi.check(L, rc, "lwm_ring_create")
         self._h = h
         self._ws = None
+        self._parked = []
         self.layout, self.schedule = _capi.RING_LAYOUT[layout], _capi.RING_SCHEDULE[schedule]
 
     def close(self):
@@ -98,13 +100,24 @@ class CRing:
         return int(lib().lwm_ring_bytes_sent(self._h))
 
     def _workspace(self, B, c, H, D, backward):
-        need = int(lib().lwm_ring_workspace_bytes(B, c, H, D, int(backward), self.size, self.schedule))
+        # One buffer for the forward AND the backward of a shape (the larger of the two), so that the backward never
+        # replaces the buffer a forward still in flight works in: the side stream's transfers into a workspace are not
+        # known to torch's caching allocator, which would hand a freed block to the next allocation (another rank's
+        # tensor, a staging buffer) while they are pending.  A buffer that has to grow is parked, not freed.
+        L = lib()
+        need = max(int(L.lwm_ring_workspace_bytes(B, c, H, D, bw, self.size, self.schedule)) for bw in (0, 1))
         if self._ws is None or self._ws.numel() < need + 256:
+            if self._ws is not None:
+                self._parked.append(self._ws)
             self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
         off = (-self._ws.data_ptr()) % 256
         return self._ws.data_ptr() + off
 
     def _args(self, q, k, v, out, lse, segment_ids, key_valid, scale, causal, backward):
+        if self._ipc_slots is not None and 4 * q.shape[0] > self._ipc_slots:
+            # the direct schedule posts (2 segments x {K, V} x B) messages per pair in one group: more than `slots` of
+            # them would make a send wait for an acknowledgement of its own group (the transport refuses that)
+            raise ValueError(f"CRing(transport='ipc', ipc_slots={self._ipc_slots}): batch {q.shape[0]} needs ipc_slots >= {4 * q.shape[0]}")
         B, c, H, D = q.shape
         a = _capi.LwmRingArgs()
         a.q, a.k, a.v, a.out = _t4(q, "q"), _t4(k, "k"), _t4(v, "v"), _t4(out, "out")

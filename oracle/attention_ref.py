@@ -87,8 +87,15 @@ def dense_attention(q, k, v, *, causal=True, q_start=0, k_start=0, seg_q=None, s
 
 
 def dense_attention_bwd(q, k, v, dout, *, causal=True, q_start=0, k_start=0, seg_q=None,
-                        seg_k=None, key_valid=None, scale=None, dtype=np.float64):
-    """Analytic gradients of dense_attention w.r.t. q, k, v (float64 by default)."""
+                        seg_k=None, key_valid=None, scale=None, dtype=np.float64, out_saved=None):
+    """Analytic gradients of dense_attention w.r.t. q, k, v (float64 by default): (dq, dk, dv).
+
+    out_saved: the forward output AS THE IMPLEMENTATION SAVED IT (bf16, the reference saves `out` cast to v.dtype for
+    its custom VJP too -- SURVEY.md Appendix A.1).  With it the call returns (dq_saved, dk, dv, dq): dq_saved takes
+    delta = rowsum(dout * out_saved), i.e. the residual every implementation of this VJP really has, so that a dq row
+    can be checked against its own scale with no allowance for the rounding of `out` (in rows that see few keys
+    dp - delta cancels almost completely and that rounding is the whole gradient); dq, dk, dv differentiate the exact
+    function."""
     q = np.asarray(q, dtype=dtype)
     k = np.asarray(k, dtype=dtype)
     v = np.asarray(v, dtype=dtype)
@@ -111,7 +118,13 @@ def dense_attention_bwd(q, k, v, dout, *, causal=True, q_start=0, k_start=0, seg
     ds = p * (dp - delta) * dtype(scale)
     dq = np.einsum("bhqk,bkhd->bqhd", ds, k)
     dk = np.einsum("bhqk,bqhd->bkhd", ds, q)
-    return dq, dk, dv
+    if out_saved is None:
+        return dq, dk, dv
+    delta_s = np.einsum("bqhd,bqhd->bhq", dout, np.asarray(out_saved, dtype=dtype))[..., None]
+    # dq_saved = dq - scale * (delta_saved - delta) * (P K): no second pass over the scores
+    pk = np.einsum("bhqk,bkhd->bqhd", p, k)
+    dq_saved = dq - dtype(scale) * np.moveaxis(delta_s - delta, 1, 2) * pk
+    return dq_saved, dk, dv, dq
 
 
 def decode_mask(B, Q, K, cache_index, attention_mask=None):

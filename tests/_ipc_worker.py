@@ -59,17 +59,17 @@ def main():
             err = ((a.float() - b.float().cpu()).abs().max() / b.float().abs().max()).item()
             assert err <= 8e-3, (name, err)
         from oracle import attention_ref as R
-        from tests._parity import check, dq_row_slack
+        from tests._parity import check, check_dq
         f = lambda t, rows, h: t[:, rows, h:h + 1].float().numpy()
         out, dq, dk, dv = full
         if not big:
             fa = lambda t: t.float().numpy()
             sg = None if seg is None else seg.numpy()
             ro, _ = R.dense_attention(fa(q), fa(k), fa(v), causal=True, seg_q=sg, seg_k=sg)
-            rq, rk, rv = R.dense_attention_bwd(fa(q), fa(k), fa(v), fa(do), causal=True, seg_q=sg, seg_k=sg)
-            slack = dq_row_slack(fa(do), ro, fa(k))
-            for name, a, b in zip(("out", "dq", "dk", "dv"), full, (ro, rq, rk, rv)):
-                check(f"{name} ipc ring n={world}", fa(a), b, row_slack=slack if name == "dq" else None)
+            rq, rk, rv, rqx = R.dense_attention_bwd(fa(q), fa(k), fa(v), fa(do), causal=True, seg_q=sg, seg_k=sg, out_saved=fa(out))
+            for name, a, b in zip(("out", "dk", "dv"), (out, dk, dv), (ro, rk, rv)):
+                check(f"{name} ipc ring n={world}", fa(a), b)
+            check_dq(f"dq ipc ring n={world}", fa(dq), rq, rqx)
         else:
             # windows: the last rows of every document against that document alone (complete for out / dq of the rows and
             # dk / dv of the keys in the window)
@@ -77,9 +77,10 @@ def main():
                 h, qa, w0 = i % H, b - 256, b - 256      # (the window's own rows are all the queries its out / dq / dk / dv need)
                 rows, keys, win = slice(qa, b), slice(a, b), slice(w0, b)
                 ro, _ = R.dense_attention(f(q, rows, h), f(k, keys, h), f(v, keys, h), causal=True, q_start=qa - a)
-                rq, rk, rv = R.dense_attention_bwd(f(q, rows, h), f(k, keys, h), f(v, keys, h), f(do, rows, h), causal=True, q_start=qa - a)
+                rq, rk, rv, rqx = R.dense_attention_bwd(f(q, rows, h), f(k, keys, h), f(v, keys, h), f(do, rows, h), causal=True, q_start=qa - a,
+                                                        out_saved=f(out, rows, h))
                 check(f"out ipc doc {i}", f(out, win, h), ro[:, w0 - qa:])
-                check(f"dq ipc doc {i}", f(dq, win, h), rq[:, w0 - qa:], row_slack=dq_row_slack(f(do, win, h), ro[:, w0 - qa:], f(k, keys, h)))
+                check_dq(f"dq ipc doc {i}", f(dq, win, h), rq[:, w0 - qa:], rqx[:, w0 - qa:])
                 check(f"dk ipc doc {i}", f(dk, win, h), rk[:, w0 - a:])
                 check(f"dv ipc doc {i}", f(dv, win, h), rv[:, w0 - a:])
         print(f"IPC_RING_OK n={world} S={S} c={c} H={H} {layout} {schedule} packed={packed} bytes_sent_per_rank={sent_all}", flush=True)

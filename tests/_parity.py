@@ -7,17 +7,14 @@ oracle.  Stated tolerances (north_star: "within a stated fp tolerance"):
            -- a wrong SMALL-magnitude row fails this one although it passes a max-normalised test
   lse    : max|err| <= 2e-3 (absolute, natural log)
 
-The dq slack.  ds = p * (dp - delta) with delta = rowsum(dO * O) taken from the SAVED output, which is bf16 (the
-reference saves `out` cast to v.dtype too).  Rounding O to bf16 moves delta by at most
-e = 2^-9 * sum_d |dO_d| |O_d| (round-to-nearest: 2^-9 relative per element), every ds_k of the row by p_k * e, and the
-row of dq = scale * sum_k ds_k k_k by at most
-
-      slack_row = scale * 2^-9 * (sum_d |dO_d| |O_d|) * max|k|        (sum_k p_k = 1)
-
--- an error that scales with the row's own operands, not with its (possibly vanishing) gradient: in rows that see few
-keys (the first rows of a sequence or of a packed document) dp - delta cancels almost completely and the exact dq is
-~0.  `dq_row_slack` computes that bound from the row's dO and O; dq checks must pass it (round 2 used a blanket floor of
-25 % of the tensor's largest value instead, which hid dq errors below ~0.6 % of it).
+dq and the saved output.  ds = p * (dp - delta) with delta = rowsum(dO * O) taken from the SAVED output, which is bf16
+(the reference saves `out` cast to v.dtype too).  In rows that see few keys (the first rows of a
+sequence or of a packed document) dp - delta cancels almost completely, the exact dq is ~0 and the rounding of O is the
+whole row.  Rounds 2-3 subtracted a bound on that effect (`dq_row_slack`) before the row test -- sound, but never
+reached: the row criterion measured nothing for dq.  Since round 4 the oracle takes the implementation's saved output
+(`dense_attention_bwd(..., out_saved=)`) and dq is checked TWICE: per row, with no allowance, against the gradient for
+that residual (`check("dq", got, dq_saved)`), and globally against the exact function's gradient
+(`check("dq exact-delta", got, dq_exact, row_tol=None)`).
 
 Every call records what it measured; the session writes the worst figures per quantity to
 gpurun_out/parity_stats.json (tests/conftest.py) so the bounds above can be compared with what the
@@ -28,43 +25,38 @@ TOL, ROW_TOL, ROW_FLOOR, COS = 8e-3, 2.5e-2, 0.02, 0.9999
 STATS = []   # (name, global_rel_err, row_rel_err, cosine)
 
 
-def dq_row_slack(dout, out, k, scale=None):
-    """(B,S,H) bound on the dq error that the bf16 rounding of the saved output causes (see the module docstring).
-    dout, out: (B,S,H,D) of the query rows checked; k: (B,Sk,H,D) of the keys they can see."""
-    dout, out, k = (np.asarray(t, np.float64) for t in (dout, out, k))
-    scale = 1.0 / np.sqrt(dout.shape[-1]) if scale is None else scale
-    kmax = np.abs(k).max(axis=(1, 3))[:, None, :]                 # (B,1,H)
-    return scale * 2.0 ** -9 * (np.abs(dout) * np.abs(out)).sum(-1) * kmax
-
-
-def check(name, got, ref, tol=TOL, row_tol=ROW_TOL, row_slack=None):
+def check(name, got, ref, tol=TOL, row_tol=ROW_TOL):
+    """row_tol=None: the global and cosine criteria only."""
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
-    if name.startswith("dq") and row_slack is None:
-        raise ValueError(f"{name}: dq checks take row_slack=dq_row_slack(dout, out, k) (tests/_parity.py)")
     gmax = max(np.abs(ref).max(), 1e-9)
     diff = np.abs(got - ref)
     err = diff.max() / gmax
     cos = (got * ref).sum() / max(np.sqrt((got ** 2).sum() * (ref ** 2).sum()), 1e-30)
-    rowdiff = diff.max(axis=-1)
-    if row_slack is not None:
-        rowdiff = np.maximum(rowdiff - np.asarray(row_slack, np.float64), 0.0)
-    row = (rowdiff / np.maximum(np.abs(ref).max(axis=-1), ROW_FLOOR * gmax)).max()
-    STATS.append((name, float(err), float(row), float(cos)))
+    row = (diff.max(axis=-1) / np.maximum(np.abs(ref).max(axis=-1), ROW_FLOOR * gmax)).max()
+    STATS.append((name, float(err), float(row) if row_tol is not None else None, float(cos)))
     assert err <= tol, f"{name}: max|err| / max|ref| = {err:.3e} > {tol}"
-    assert row <= row_tol, f"{name}: worst row error relative to its own scale = {row:.3e} > {row_tol}"
+    assert row_tol is None or row <= row_tol, f"{name}: worst row error relative to its own scale = {row:.3e} > {row_tol}"
     assert cos >= COS, f"{name}: cosine {cos}"
+
+
+def check_dq(name, got, dq_saved, dq_exact):
+    """the two dq checks of the module docstring"""
+    check(name, got, dq_saved)
+    check(name + " exact-delta", got, dq_exact, row_tol=None)
 
 
 def summary():
     out = {}
     for name, err, row, cos in STATS:
-        key = name.split(" ")[0].split("(")[0]
+        key = name.split(" ")[0].split("(")[0] + ("_exact_delta" if name.endswith("exact-delta") else "")
         s = out.setdefault(key, {"n": 0, "max_global_rel_err": 0.0, "max_row_rel_err": 0.0, "min_cosine": 1.0})
         s["n"] += 1
         s["max_global_rel_err"] = max(s["max_global_rel_err"], err)
-        s["max_row_rel_err"] = max(s["max_row_rel_err"], row)
+        if row is not None:
+            s["max_row_rel_err"] = max(s["max_row_rel_err"], row)
         s["min_cosine"] = min(s["min_cosine"], cos)
     return {"bounds": {"global": TOL, "row": ROW_TOL, "row_floor": ROW_FLOOR,
-                       "dq_row_slack": "scale * 2^-9 * sum_d|dO||O| * max|k| (tests/_parity.py)", "cosine": COS},
+                       "dq": "per row against the gradient for the SAVED (bf16) output, no allowance; globally against the exact one",
+                       "cosine": COS},
             "measured": out}

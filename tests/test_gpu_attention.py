@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from oracle import attention_ref as R
-from tests._parity import check as _check, dq_row_slack as _slack
+from tests._parity import check as _check, check_dq as _check_dq
 
 pytestmark = pytest.mark.gpu
 
@@ -79,9 +79,8 @@ def test_fwd_bwd_vs_oracle(B, Sq, Sk, H, causal, seg, kv):
     if fin.any():
         assert np.abs(_np(lse)[fin] - rl[fin]).max() <= 2e-3
     # gradients: the oracle differentiates the exact function at the bf16 inputs
-    rq, rk, rv = R.dense_attention_bwd(_np(q), _np(k), _np(v), _np(do), **okw)
-    slack = _slack(_np(do), ro, _np(k))
-    _check("dq", _np(dq), rq, row_slack=slack)
+    rq, rk, rv, rqx = R.dense_attention_bwd(_np(q), _np(k), _np(v), _np(do), out_saved=_np(out), **okw)
+    _check_dq("dq", _np(dq), rq, rqx)
     _check("dk", _np(dk), rk)
     _check("dv", _np(dv), rv)
 
@@ -109,8 +108,8 @@ def test_backward_is_deterministic_and_carries():
         torch.cuda.synchronize()
         assert all(torch.equal(a, b) for a, b in zip(got, ref))
     f = lambda t: _np(t[:1, :, 2:3])
-    rq, rk, rv = R.dense_attention_bwd(f(q), f(k), f(v), f(do), causal=True)
-    _check("dq 4096", f(ref[0]), rq, row_slack=_slack(f(do), f(out), f(k)))
+    rq, rk, rv, rqx = R.dense_attention_bwd(f(q), f(k), f(v), f(do), causal=True, out_saved=f(out))
+    _check_dq("dq 4096", f(ref[0]), rq, rqx)
     _check("dk 4096", f(ref[1]), rk)
     _check("dv 4096", f(ref[2]), rv)
     # carries: start from known f32 carries, leave the results in f32
@@ -157,8 +156,11 @@ def test_ring_carry_equals_single_shot():
     out, lse = ops.attn_fwd_block(q, k[:, h:], v[:, h:], causal=False, k_start=h, out_acc=acc[0],
                                   lse_acc=acc[1], carry_in=True, final=True)
     torch.cuda.synchronize()
-    assert (out.float() - ref.float()).abs().max().item() <= 2e-2
-    assert (lse - rlse).abs().max().item() <= 1e-4
+    # both are bf16 roundings of (nearly) the same f32 sums, and both meet the oracle at the stated tolerances
+    _check("out two steps vs one", _np(out), _np(ref))
+    ro, rl = R.dense_attention(_np(q), _np(k), _np(v), causal=False)
+    _check("out two steps", _np(out), ro)
+    assert (lse - rlse).abs().max().item() <= 1e-4 and np.abs(_np(lse) - rl).max() <= 2e-3
 
 
 def test_cast_and_backward_carries():
@@ -228,12 +230,11 @@ def test_packed_documents_skip_is_exact():
     h = 2
     sl = slice(h, h + 1)
     ro, _ = R.dense_attention(_np(q[:, :, sl]), _np(k[:, :, sl]), _np(v[:, :, sl]), causal=True, seg_q=seg, seg_k=seg)
-    rq, rk, rv = R.dense_attention_bwd(_np(q[:, :, sl]), _np(k[:, :, sl]), _np(v[:, :, sl]), _np(do[:, :, sl]),
-                                       causal=True, seg_q=seg, seg_k=seg)
     out, _, dq, dk, dv = res[True]
+    rq, rk, rv, rqx = R.dense_attention_bwd(_np(q[:, :, sl]), _np(k[:, :, sl]), _np(v[:, :, sl]), _np(do[:, :, sl]),
+                                            causal=True, seg_q=seg, seg_k=seg, out_saved=_np(out[:, :, sl]))
     _check("out", _np(out[:, :, sl]), ro)
-    slack = _slack(_np(do[:, :, sl]), ro, _np(k[:, :, sl]))
-    _check("dq", _np(dq[:, :, sl]), rq, row_slack=slack)
+    _check_dq("dq", _np(dq[:, :, sl]), rq, rqx)
     _check("dk", _np(dk[:, :, sl]), rk)
     _check("dv", _np(dv[:, :, sl]), rv)
 
@@ -251,10 +252,11 @@ def test_autograd_ring1_matches_oracle():
                         blockwise_kwargs=dict(causal_block_size=1, query_chunk_size=128,
                                               key_chunk_size=128))
     out.backward(do.cuda())
-    rq, rk, rv = R.dense_attention_bwd(_np(q), _np(k), _np(v), _np(do), causal=True, seg_q=seg, seg_k=seg)
+    rq, rk, rv, rqx = R.dense_attention_bwd(_np(q), _np(k), _np(v), _np(do), causal=True, seg_q=seg, seg_k=seg,
+                                            out_saved=_np(out.detach()))
     ro, _ = R.dense_attention(_np(q), _np(k), _np(v), causal=True, seg_q=seg, seg_k=seg)
     _check("out", _np(out), ro)
-    _check("dq", _np(qd.grad), rq, row_slack=_slack(_np(do), ro, _np(k)))
+    _check_dq("dq", _np(qd.grad), rq, rqx)
     _check("dk", _np(kd.grad), rk)
     _check("dv", _np(vd.grad), rv)
 
@@ -320,10 +322,9 @@ def test_full_size_properties(full):
     # sampled window of dq against the oracle (needs all keys <= window end)
     h, r0, w = 5, 2048, 256
     sl = slice(0, r0 + w)
-    rq, rk, rv = R.dense_attention_bwd(_np(q[:, sl, h:h + 1]), _np(k[:, sl, h:h + 1]), _np(v[:, sl, h:h + 1]),
-                                       _np(do[:, sl, h:h + 1]), causal=True)
-    slack_w = _slack(_np(do[:, r0:r0 + w, h:h + 1]), _np(out[:, r0:r0 + w, h:h + 1]), _np(k[:, sl, h:h + 1]))
-    _check("dq window", _np(dq[:, r0:r0 + w, h:h + 1]), rq[:, r0:r0 + w], row_slack=slack_w)
+    rq, rk, rv, rqx = R.dense_attention_bwd(_np(q[:, sl, h:h + 1]), _np(k[:, sl, h:h + 1]), _np(v[:, sl, h:h + 1]),
+                                            _np(do[:, sl, h:h + 1]), causal=True, out_saved=_np(out[:, sl, h:h + 1]))
+    _check_dq("dq window", _np(dq[:, r0:r0 + w, h:h + 1]), rq[:, r0:r0 + w], rqx[:, r0:r0 + w])
     # (7) a second out window, early rows of another head (short softmax rows, first key tiles)
     h, r0 = 3, 96
     ro, rl = R.dense_attention(_np(q[:, r0:r0 + 512, h:h + 1]), _np(k[:, :r0 + 512, h:h + 1]),
@@ -343,10 +344,10 @@ def test_full_size_properties(full):
         _check("dv window", _np(dv[:, ks, h:h + 1]), rv[:, ks])
     # (9) dq of the LAST rows (longest key loops; the diagonal key block is the last contributor)
     h, r0, w = 23, S - 256, 256
-    rq, _, _ = R.dense_attention_bwd(_np(q[:, r0:, h:h + 1]), _np(k[:, :, h:h + 1]), _np(v[:, :, h:h + 1]),
-                                     _np(do[:, r0:, h:h + 1]), causal=True, q_start=r0, k_start=0)
-    slack_2 = _slack(_np(do[:, r0:, h:h + 1]), _np(out[:, r0:, h:h + 1]), _np(k[:, :, h:h + 1]))
-    _check("dq window 2", _np(dq[:, r0:, h:h + 1]), rq, row_slack=slack_2)
+    rq, _, _, rqx = R.dense_attention_bwd(_np(q[:, r0:, h:h + 1]), _np(k[:, :, h:h + 1]), _np(v[:, :, h:h + 1]),
+                                          _np(do[:, r0:, h:h + 1]), causal=True, q_start=r0, k_start=0,
+                                          out_saved=_np(out[:, r0:, h:h + 1]))
+    _check_dq("dq window 2", _np(dq[:, r0:, h:h + 1]), rq, rqx)
 
 
 def test_addressing_beyond_4g_elements_at_1m_tokens():

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from oracle import attention_ref as R
-from tests._parity import check as _check, dq_row_slack as _slack
+from tests._parity import check as _check, check_dq as _check_dq
 
 pytestmark = pytest.mark.gpu
 
@@ -118,15 +118,17 @@ def test_ring_n_equals_ring_1_on_gpu(n, layout_kind, packed, schedule):
     S, H = 256 * n, 2
     got, ref, (q, k, v, do, seg) = _run_ring(n, layout_kind, S, H, packed, schedule)
     f = lambda t: t.float().cpu().numpy()
-    slack = _slack(f(do), f(ref[0]), f(k))
     for name, a, b in zip(("out", "dq", "dk", "dv"), got, ref):     # both are bf16 roundings of the same sums
-        _check(f"{name} ring{n} vs ring1", f(a), f(b), row_slack=slack if name == "dq" else None)
+        # (dq globally only: the two runs save outputs that differ in a last bit here and there, and a row whose
+        # gradient cancels is made of exactly that; its own row check follows, against the oracle)
+        _check(f"{name} ring{n} vs ring1", f(a), f(b), **({"row_tol": None} if name == "dq" else {}))
     # and against the fp64 oracle
     sg = None if seg is None else seg.cpu().numpy()
     ro, _ = R.dense_attention(f(q), f(k), f(v), causal=True, seg_q=sg, seg_k=sg)
-    rq, rk, rv = R.dense_attention_bwd(f(q), f(k), f(v), f(do), causal=True, seg_q=sg, seg_k=sg)
-    for name, a, b in zip(("out", "dq", "dk", "dv"), got, (ro, rq, rk, rv)):
-        _check(f"{name} ring{n}", f(a), b, row_slack=slack if name == "dq" else None)
+    rq, rk, rv, rqx = R.dense_attention_bwd(f(q), f(k), f(v), f(do), causal=True, seg_q=sg, seg_k=sg, out_saved=f(got[0]))
+    for name, a, b in zip(("out", "dk", "dv"), (got[0], got[2], got[3]), (ro, rk, rv)):
+        _check(f"{name} ring{n}", f(a), b)
+    _check_dq(f"dq ring{n}", f(got[1]), rq, rqx)
 
 
 def _doc_windows(bounds, w=256):
@@ -160,10 +162,10 @@ def test_ring8_at_config3_shard_shapes_vs_oracle(schedule, packed):
         for h, r0 in ((0, 96), (1, 65408), (0, S - 256), (1, 36000)):
             rows, keys = slice(r0, r0 + 256), slice(0, r0 + 256)
             ro, _ = R.dense_attention(f(q, rows, h), f(k, keys, h), f(v, keys, h), causal=True, q_start=r0)
-            rq, _, _ = R.dense_attention_bwd(f(q, rows, h), f(k, keys, h), f(v, keys, h), f(do, rows, h),
-                                             causal=True, q_start=r0)
+            rq, _, _, rqx = R.dense_attention_bwd(f(q, rows, h), f(k, keys, h), f(v, keys, h), f(do, rows, h),
+                                                  causal=True, q_start=r0, out_saved=f(out, rows, h))
             _check(f"out ring8 row {r0}", f(out, rows, h), ro)
-            _check(f"dq ring8 row {r0}", f(dq, rows, h), rq, row_slack=_slack(f(do, rows, h), ro, f(k, keys, h)))
+            _check_dq(f"dq ring8 row {r0}", f(dq, rows, h), rq, rqx)
         K0, h = S - 512, 1
         rows, allk = slice(K0, S), slice(0, S)
         _, rk, rv = R.dense_attention_bwd(f(q, rows, h), f(k, allk, h), f(v, allk, h), f(do, rows, h),
@@ -179,12 +181,11 @@ def test_ring8_at_config3_shard_shapes_vs_oracle(schedule, packed):
         qa = w0          # (the window's own rows are all the queries its out / dq / dk / dv need: 8x less oracle time)
         rows, keys = slice(qa, b), slice(a, b)
         ro, _ = R.dense_attention(f(q, rows, h), f(k, keys, h), f(v, keys, h), causal=True, q_start=qa - a)
-        rq, rk, rv = R.dense_attention_bwd(f(q, rows, h), f(k, keys, h), f(v, keys, h), f(do, rows, h),
-                                           causal=True, q_start=qa - a)
+        rq, rk, rv, rqx = R.dense_attention_bwd(f(q, rows, h), f(k, keys, h), f(v, keys, h), f(do, rows, h),
+                                                causal=True, q_start=qa - a, out_saved=f(out, rows, h))
         win = slice(w0, b)
         _check(f"out ring8 doc {i}", f(out, win, h), ro[:, w0 - qa:])
-        _check(f"dq ring8 doc {i}", f(dq, win, h), rq[:, w0 - qa:],
-               row_slack=_slack(f(do, win, h), ro[:, w0 - qa:], f(k, keys, h)))
+        _check_dq(f"dq ring8 doc {i}", f(dq, win, h), rq[:, w0 - qa:], rqx[:, w0 - qa:])
         _check(f"dk ring8 doc {i}", f(dk, win, h), rk[:, w0 - a:])
         _check(f"dv ring8 doc {i}", f(dv, win, h), rv[:, w0 - a:])
 
@@ -203,10 +204,11 @@ def test_mesh8_at_1m_token_offsets_vs_oracle():
     for d0 in (0, (S // 2) - doc, S // 2, 131072 * 5 + 8 * doc, S - doc):
         rows = slice(d0, d0 + doc)
         ro, _ = R.dense_attention(f(q, rows), f(k, rows), f(v, rows), causal=True)
-        rq, rk, rv = R.dense_attention_bwd(f(q, rows), f(k, rows), f(v, rows), f(do, rows), causal=True)
-        for name, a, b in zip(("out", "dq", "dk", "dv"), got, (ro, rq, rk, rv)):
-            _check(f"{name} mesh8@1M doc {d0 // doc}", f(a, rows), b,
-                   row_slack=_slack(f(do, rows), ro, f(k, rows)) if name == "dq" else None)
+        rq, rk, rv, rqx = R.dense_attention_bwd(f(q, rows), f(k, rows), f(v, rows), f(do, rows), causal=True,
+                                                out_saved=f(got[0], rows))
+        for name, a, b in zip(("out", "dk", "dv"), (got[0], got[2], got[3]), (ro, rk, rv)):
+            _check(f"{name} mesh8@1M doc {d0 // doc}", f(a, rows), b)
+        _check_dq(f"dq mesh8@1M doc {d0 // doc}", f(got[1], rows), rq, rqx)
 
 
 @pytest.mark.parametrize("schedule", ["ring", "mesh"])
@@ -214,9 +216,8 @@ def test_ring_batch_2_on_gpu(schedule):
     """B = 2: every per-segment view handed to the kernels is strided in the batch dimension."""
     got, ref, (q, k, v, do, seg) = _run_ring(4, "zigzag", 1024, 2, True, schedule, B=2)
     f = lambda t: t.float().cpu().numpy()
-    slack = _slack(f(do), f(ref[0]), f(k))
     for name, a, b in zip(("out", "dq", "dk", "dv"), got, ref):
-        _check(f"{name} ring4 B=2", f(a), f(b), row_slack=slack if name == "dq" else None)
+        _check(f"{name} ring4 B=2", f(a), f(b), **({"row_tol": None} if name == "dq" else {}))
 
 
 def test_mesh_schedule_moves_fewer_bytes_than_the_ring():
