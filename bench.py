@@ -85,9 +85,9 @@ def cpu_config1():
 
 def cpu_baseline(S_target, full=True):
     """Port of the reference's blockwise attention on PyTorch-CPU fp32 (oracle/attention_torch_cpu.py), timed on bounded
-    samples: the headline figure from S = 4096 x 8 heads (fwd+bwd, 1 layer), scaled to the workload by the algorithmic
-    FLOP count (7*S^2*d_model per layer, labelled as extrapolated); op points at S = 8192 (2 heads) and 16384 (1 head)
-    show that the rate holds as S grows; `config1` is BASELINE configs[0] end to end."""
+    samples: op points at S = 4096 (8 heads), 8192 (2 heads) and 16384 (1 head), fwd+bwd of 1 layer; the headline
+    figure takes the FASTEST of them (the port's best) and scales it to the workload by the algorithmic FLOP count
+    (7*S^2*d_model per layer, labelled as extrapolated); `config1` is BASELINE configs[0] end to end."""
     import torch
     from oracle.attention_torch_cpu import blockwise_fwd_bwd
     g = torch.Generator().manual_seed(0)
@@ -108,33 +108,37 @@ def cpu_baseline(S_target, full=True):
     blockwise_fwd_bwd(*w)  # warm the BLAS threads
     # The port is many small batched matmuls and elementwise passes over 1024 x 1024 tiles: on a many-core host it runs
     # SLOWER with every thread than with a few (30 GFLOP/s on 128 threads, 130 on 8).  The baseline is what the host
-    # does at its best setting: one pass per candidate thread count, then the timed passes at the winner.  `cores` =
-    # the threads the leg computed with.
+    # does at its BEST: one timed sample per candidate thread count at S = 4096 x 8 heads (`thread_sweep_gflops` -- the
+    # winner's entry IS op_points[0], same reps, same heads), then S = 8192 and 16384 at the winning thread count; `value`
+    # is extrapolated from the op point with the highest measured rate.  `cores` = the threads the leg computed with.
     all_threads = _cpu_threads()
     sweep = {}
     for t in sorted({min(8, all_threads), min(32, all_threads), all_threads}):
         torch.set_num_threads(t)
         blockwise_fwd_bwd(*w)
-        sweep[t] = op_point(4096, 8, 0.0, 1)["gflops"]
-    best = max(sweep, key=sweep.get)
+        sweep[t] = op_point(4096, 8, 3.0, 2)
+    best = max(sweep, key=lambda t: sweep[t]["gflops"])
     torch.set_num_threads(best)
-    p4 = op_point(4096, 8, 8.0, 4)
-    flops_per_s = p4["gflops"] * 1e9
+    points = [sweep[best]]
+    if full:
+        points += [op_point(8192, 2, 6.0, 2), op_point(16384, 1, 6.0, 1)]
+    top = max(points, key=lambda p_: p_["gflops"])
+    flops_per_s = top["gflops"] * 1e9
     flops_workload = 7.0 * gemm_unit_flops(S_target) * N_LAYERS
     res = {
         "value": S_target / (flops_workload / flops_per_s),
         "unit": "tokens/s",
         "cores": best,
         "kind": "port",
-        "gflops": p4["gflops"],
-        "thread_sweep_gflops": {str(t): round(v, 1) for t, v in sweep.items()},
-        "sample": f"oracle/attention_torch_cpu.blockwise_fwd_bwd fp32, S=4096, 8 heads, 1 layer, chunks 1024/1024, "
-                  f"{p4['reps']} reps of {p4['seconds_per_pass']:.2f}s on {best} of {all_threads} threads (the best of the sweep); scaled "
-                  f"to S={S_target}, 32 heads, 32 layers by the 7*S^2*d_model FLOP law (extrapolated)",
+        "gflops": top["gflops"],
+        "thread_sweep_gflops": {str(t): round(v["gflops"], 1) for t, v in sweep.items()},
+        "op_points": points,
+        "sample": f"oracle/attention_torch_cpu.blockwise_fwd_bwd fp32, 1 layer, chunks 1024/1024, on {best} of {all_threads} threads "
+                  f"(the best of the sweep); the fastest op point (S={top['S']}, {top['heads']} heads, {top['reps']} reps of "
+                  f"{top['seconds_per_pass']:.2f}s) scaled to S={S_target}, 32 heads, 32 layers by the 7*S^2*d_model FLOP law (extrapolated)",
     }
     if full:
         try:
-            res["op_points"] = [p4, op_point(8192, 2, 6.0, 2), op_point(16384, 1, 6.0, 1)]
             torch.set_num_threads(all_threads)       # the dense model is large GEMMs: every thread
             res["config1"] = cpu_config1()
         except Exception as e:      # a baseline leg must not cost the bench line
@@ -694,8 +698,11 @@ def main():
     ap.add_argument("--init-timeout", type=int, default=180,
                     help="seconds before a stuck RCCL rendezvous / first collective is reported as an error line")
     ap.add_argument("--no-full-model", action="store_true", help="skip the N=1 leg `model_full` (all 32 layers of LWM-7B)")
-    ap.add_argument("--packed-1m", action="store_true",
-                    help="also run the 1M-token packed-documents leg (BASELINE configs[4]'s problem on one GPU, ~25 s)")
+    ap.add_argument("--packed-1m", action="store_true", help="(default since round 4; kept for old command lines)")
+    ap.add_argument("--no-packed-1m", action="store_true",
+                    help="N = 1: skip the 1M-token packed-documents leg (BASELINE configs[4]'s problem on one GPU, ~25 s)")
+    ap.add_argument("--no-configs34", action="store_true",
+                    help="N > 1: skip the S = 262144 (BASELINE configs[3]) and packed S = 1048576 (configs[4]) legs of the line")
     args = ap.parse_args()
 
     under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
@@ -802,7 +809,7 @@ def main():
     S2 = 131072                     # BASELINE configs[2]'s sequence: a second leg of every N > 1 line
     if args.driver == "c" and world > 1:
         from lwm_amd.ring_c import CRing
-        c_max = max(c, S2 // world if not args.no_configs2 else 0)
+        c_max = max(c, S2 // world if not args.no_configs2 else 0)      # (configs3 / configs4 do not run over the IPC transport)
         c_ring = CRing(dist.group.WORLD, transport=args.transport, layout=args.layout, schedule=sched_c,
                        ipc_slot_bytes=c_max * N_HEADS * HEAD_DIM * 4, ipc_slots=4)      # (B = 1: at most 4 messages per pair and group)
 
@@ -827,12 +834,12 @@ def main():
                                "first_error_on_this_rank": why or None}
             c_ring = None
 
-    def step(ring=None, ten=None, lay=None, seg=None):
+    def step(ring=None, ten=None, lay=None, seg=None, layers=None):
         ring = c_ring if ring is None else ring
         q_, k_, v_, do_ = (q, k, v, do) if ten is None else ten
         lay = layout if lay is None else lay
         seg = segment_ids if ten is None else seg
-        for _ in range(args.layers):
+        for _ in range(args.layers if layers is None else layers):
             if ring is not None:
                 o_, l_ = ring.forward(q_, k_, v_, causal=True, segment_ids=seg)
                 ring.backward(q_, k_, v_, o_, l_, do_, causal=True, segment_ids=seg)
@@ -991,6 +998,59 @@ def main():
         except Exception as e:
             configs2 = dict(configs2 or {}, error=repr(e))
 
+    def other_config(tag, Sx, layers_x, packed_docs):
+        """One more configuration of BASELINE.json in the same N > 1 line: the sequence ring at S = Sx over these N GPUs,
+        `layers_x` layers (scaled to 32 and labelled), one warm-up step + one timed step."""
+        try:
+            layx = SeqLayout(args.layout, world, Sx)
+            cx = layx.local_len
+            gx = torch.Generator(device=dev).manual_seed(8765 + rank)
+            tenx = [torch.randn(1, cx, N_HEADS, HEAD_DIM, generator=gx, device=dev, dtype=torch.float32).to(torch.bfloat16)
+                    for _ in range(4)]
+            segx, pair_units = None, 0.5 * float(Sx) * Sx       # causal: half the square
+            if packed_docs:
+                import numpy as np
+                rng = np.random.default_rng(0)
+                sg = np.zeros((1, Sx), np.int32)
+                pos, d, lens = 0, 0, []
+                while pos < Sx:
+                    ln = min(int(np.exp(rng.uniform(np.log(4096), np.log(262144)))), Sx - pos)
+                    sg[:, pos:pos + ln] = d
+                    lens.append(ln)
+                    pos, d = pos + ln, d + 1
+                segx = torch.from_numpy(sg).to(dev)
+                pair_units = 0.5 * sum(float(l) * l for l in lens)
+            sent0 = c_ring.bytes_sent if c_ring is not None else None
+            step(ten=tenx, lay=layx, seg=segx, layers=layers_x)
+            barrier()
+            t0 = time.perf_counter()
+            step(ten=tenx, lay=layx, seg=segx, layers=layers_x)
+            barrier()
+            el = max_over_ranks(time.perf_counter() - t0)
+            out = {
+                "workload": f"LWM-7B attention fwd+bwd, B=1, S={Sx}, H=32, D=128, causal" +
+                            (f", {len(lens)} packed documents (4096..262144 tokens)" if packed_docs else "") +
+                            f", ring={world}, layout={layx.kind}; {layers_x} layers timed, scaled to 32 [BASELINE {tag}" +
+                            ("" if world == 8 else f" at N={world}") + "]",
+                "seq_len": Sx, "layers_timed": layers_x, "steps": 1, "ms_per_layer": el * 1e3 / layers_x,
+                "tokens_per_s": Sx / (el / layers_x * N_LAYERS), "tokens_per_s_per_gpu": Sx / (el / layers_x * N_LAYERS) / world,
+                "path_algorithmic_tflops_per_gpu": 7.0 * 2.0 * pair_units * D_MODEL / (el / layers_x) / 1e12 / world,
+                "exchange": ({"schedule": f"{sched_c} (C-ABI driver, {args.transport})",
+                              "bytes_sent_per_rank_per_layer": (c_ring.bytes_sent - sent0) / (2 * layers_x)} if c_ring is not None
+                             else {"schedule": getattr(comm, "schedule", None)}),
+            }
+            del tenx
+            return out
+        except Exception as e:      # noqa: BLE001 -- a secondary leg must not cost the line
+            return {"error": repr(e)[:500]}
+
+    configs3 = configs4 = None
+    if world > 1 and not args.no_configs34 and not args.packed and not shared:
+        torch.cuda.empty_cache()
+        configs3 = other_config("configs[3] sequence (262144 tokens; its VQGAN tokenisation is the `vqgan` leg of the N = 1 line)", 262144, 2, False)
+        torch.cuda.empty_cache()
+        configs4 = other_config("configs[4]", 1 << 20, 2, True)
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         tokens_per_s = S * args.steps / elapsed
@@ -1021,6 +1081,8 @@ def main():
             "tokens_per_s_per_gpu": tokens_per_s / world,
             "exchange": exchange,
             "configs2": configs2,
+            "configs3": configs3,
+            "configs4": configs4,
             "driver_fallback": driver_fallback,
             "rccl_ranks_seen": rccl_ranks_seen,
             "dry_run": ("ranks share devices, messages staged through host memory; timings are not xGMI" if dry else
@@ -1057,7 +1119,7 @@ def main():
                 res["model_slice"] = model_slice_leg(torch)
                 if not args.no_full_model:
                     res["model_full"] = model_full_leg(torch)
-                if args.packed_1m:
+                if not args.no_packed_1m:
                     res["packed_1m"] = packed_1m_leg(torch)
                 res["decode"] = decode_leg(torch)
                 res["generate"] = generate_leg(torch)

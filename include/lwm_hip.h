@@ -191,6 +191,16 @@ int64_t lwm_ring_planned_bytes(int32_t layout, int32_t schedule, int32_t n, int3
                                int32_t D, int32_t causal, int32_t backward);
 /* bytes this ring object has sent since creation (diagnostic) */
 int64_t lwm_ring_bytes_sent(const LwmRing* ring);
+/* Direct schedule: the K/V fetch of a call goes out as `groups` grouped exchanges over contiguous ranges of rank distance,
+ * nearest first, each with its own arrival event; step t of the schedule waits only for the group that holds distance t.
+ * 1 (default with RCCL: one bulk-synchronous group keeps all xGMI links busy) ... n - 1 (default of the IPC transport,
+ * whose copies are serial anyway: every block is handed over as it lands).  Values above n - 1 mean n - 1. */
+int lwm_ring_set_fetch_groups(LwmRing* ring, int32_t groups);
+/* Diagnostic (rings created with LWM_RING_TIMING=1 in the environment: their events then carry timestamps): after the
+ * last lwm_ring_attn_fwd / _bwd call has completed, the milliseconds from the call's entry to (kv_ms[t]) the arrival of
+ * the K/V block of rank distance t (direct schedule, t >= 1) and to (kernels_ms[t]) the end of the kernels of step t;
+ * count >= n entries each, -1 where undefined.  Blocks on the call's completion. */
+int lwm_ring_fetch_timeline(LwmRing* ring, float* kv_ms, float* kernels_ms, int32_t count);
 /* Diagnostic: ONE grouped exchange with ourselves through the ring's transport -- send `bytes` bytes at src to
  * our own ring rank and receive them into dst -- enqueued on the ring's side stream and handed over by the same
  * events an attention step uses (compute stream -> side stream -> compute stream).  With a ring made by

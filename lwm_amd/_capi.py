@@ -98,6 +98,8 @@ PROTOTYPES = {
     "lwm_ring_bytes_sent": (C.c_int64, [C.c_void_p]),
     "lwm_ring_planned_bytes": (C.c_int64, [C.c_int32] * 10),
     "lwm_ring_selftest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "lwm_ring_set_fetch_groups": (C.c_int, [C.c_void_p, C.c_int32]),
+    "lwm_ring_fetch_timeline": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32]),
     "lwm_ring_ipc_info_bytes": (C.c_int64, []),
     "lwm_ring_ipc_export": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "lwm_ring_ipc_connect": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -99,6 +99,16 @@ class CRing:
     def bytes_sent(self):
         return int(lib().lwm_ring_bytes_sent(self._h))
 
+    def set_fetch_groups(self, groups):
+        """direct schedule: grouped exchanges of the K/V fetch (lwm_ring_set_fetch_groups)"""
+        _capi.check(lib(), lib().lwm_ring_set_fetch_groups(self._h, int(groups)), "lwm_ring_set_fetch_groups")
+
+    def fetch_timeline(self):
+        """(kv_ms, kernels_ms) of the last call -- rings created under LWM_RING_TIMING=1 (lwm_ring_fetch_timeline)"""
+        kv, ke = (C.c_float * self.size)(), (C.c_float * self.size)()
+        _capi.check(lib(), lib().lwm_ring_fetch_timeline(self._h, kv, ke, self.size), "lwm_ring_fetch_timeline")
+        return list(kv), list(ke)
+
     def _workspace(self, B, c, H, D, backward):
         # One buffer for the forward AND the backward of a shape (the larger of the two), so that the backward never
         # replaces the buffer a forward still in flight works in: the side stream's transfers into a workspace are not

@@ -36,6 +36,8 @@ LWM_EMU_NO_RING(int, lwm_ring_attn_bwd, LwmRing*, const LwmRingArgs*, void*)
 LWM_EMU_NO_RING(int64_t, lwm_ring_bytes_sent, const LwmRing*)
 LWM_EMU_NO_RING(int64_t, lwm_ring_planned_bytes, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t)
 LWM_EMU_NO_RING(int, lwm_ring_selftest, LwmRing*, const void*, void*, int64_t, void*)
+LWM_EMU_NO_RING(int, lwm_ring_set_fetch_groups, LwmRing*, int32_t)
+LWM_EMU_NO_RING(int, lwm_ring_fetch_timeline, LwmRing*, float*, float*, int32_t)
 LWM_EMU_NO_RING(int64_t, lwm_ring_ipc_info_bytes, void)
 LWM_EMU_NO_RING(int, lwm_ring_ipc_export, int32_t, int32_t, int64_t, int32_t, void*, LwmRingIpc**)
 LWM_EMU_NO_RING(int, lwm_ring_ipc_connect, LwmRingIpc*, const void*)

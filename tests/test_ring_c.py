@@ -94,8 +94,10 @@ class _Mailbox:
     ordered pair of ranks: a send copies the bytes into a staging tensor on the sender's side stream and posts
     (tensor, event); the matching recv waits for the post, makes its stream wait for the event and copies."""
 
-    def __init__(self, n):
+    def __init__(self, n, delay_from=None, delay_cycles=0):
+        """delay_from = (receiver rank, sender rank): that link's receives are held back by `delay_cycles` GPU cycles"""
         import torch
+        self.delay_from, self.delay_cycles = delay_from, delay_cycles
         self.n = n
         self.links = {(a, b): queue.Queue() for a in range(n) for b in range(n)}
         self.hip = C.CDLL("libamdhip64.so")
@@ -129,6 +131,9 @@ class _Mailbox:
                 assert tmp.numel() == nbytes
                 s = torch.cuda.ExternalStream(stream)
                 s.wait_event(ev)
+                if self.delay_from == (rank, peer):
+                    with torch.cuda.stream(s):
+                        torch.cuda._sleep(int(self.delay_cycles))
                 assert self.hip.hipMemcpyAsync(buf, tmp.data_ptr(), nbytes, 3, stream) == 0
                 self.keep.append(tmp)
                 return 0
@@ -141,7 +146,8 @@ class _Mailbox:
         return t
 
 
-def _run_c_ring(n, S, H, causal, packed, padded, B=1, layout="contiguous", schedule="ring"):
+def _run_c_ring(n, S, H, causal, packed, padded, B=1, layout="contiguous", schedule="ring", fetch_groups=None, box=None,
+                timeline=None):
     import torch
     from lwm_amd.ring import SeqLayout
     from lwm_amd.ring_c import CRing
@@ -161,15 +167,19 @@ def _run_c_ring(n, S, H, causal, packed, padded, B=1, layout="contiguous", sched
         kv[:, 5:40] = 0
         kv = kv.cuda()
     lay = SeqLayout(layout, n, S)
-    box = _Mailbox(n)
+    box = box or _Mailbox(n)
     res, errs = [None] * n, []
 
     def worker(r):
         try:
             ring = CRing(rank=r, size=n, transport=box.transport(r) if n > 1 else None, layout=layout, schedule=schedule)
+            if fetch_groups:
+                ring.set_fetch_groups(fetch_groups)
             idx = lay.global_index(r).cuda()
             ql, kl, vl, dol = (t[:, idx].contiguous() for t in (q, k, v, do))
             out, lse = ring.forward(ql, kl, vl, causal=causal, segment_ids=seg, key_valid=kv)
+            if timeline is not None:
+                timeline[r] = ring.fetch_timeline()
             dq, dk, dv = ring.backward(ql, kl, vl, out, lse, dol, causal=causal, segment_ids=seg, key_valid=kv)
             torch.cuda.synchronize()
             res[r] = (idx, out, dq, dk, dv, ring.bytes_sent)
@@ -311,6 +321,71 @@ def test_c_ring8_at_config3_shard_shapes_vs_oracle(schedule, packed):
         check_dq(f"dq c-ring8 doc {i}", f(dq, win, h), rq[:, w0 - qa:], rqx[:, w0 - qa:])
         check(f"dk c-ring8 doc {i}", f(dk, win, h), rk[:, w0 - a:])
         check(f"dv c-ring8 doc {i}", f(dv, win, h), rv[:, w0 - a:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,packed", [(262144, False), (1 << 20, True)])
+def test_c_ring8_at_configs3_and_4_shard_shapes_vs_oracle(S, packed):
+    """The default N > 1 driver at the shard shapes of BASELINE configs[3] (S = 262144: c = 32768 per rank) and
+    configs[4] (S = 1,048,576: c = 131072, half-chunks at global offsets up to 983040; packed 4096-token documents so
+    that the fp64 oracle is a 4096 x 4096 problem wherever it is asked): 8 thread-played ranks, zigzag x direct, one
+    head, real kernels / events / workspace arithmetic -- what tests/test_gpu_ring_sim.py checks for the Python driver."""
+    import torch
+    from oracle import attention_ref as R
+    from tests._parity import check, check_dq
+    n, H, doc = 8, 1, 4096
+    seg_fn = (lambda S_: torch.arange(S_) // doc) if packed else False
+    got, (q, k, v, do, seg, kv), sent = _run_c_ring(n, S, H, True, seg_fn, False, layout="zigzag", schedule="direct")
+    out, dq, dk, dv = got
+    f = lambda t, rows: t[:, rows, 0:1].float().cpu().numpy()
+    if packed:
+        for d0 in (0, (S // 2) - doc, S // 2, 131072 * 5 + 8 * doc, S - doc):      # start, across the middle seam, rank 2's late chunk, end
+            rows = slice(d0, d0 + doc)
+            ro, _ = R.dense_attention(f(q, rows), f(k, rows), f(v, rows), causal=True)
+            rq, rk, rv, rqx = R.dense_attention_bwd(f(q, rows), f(k, rows), f(v, rows), f(do, rows), causal=True, out_saved=f(out, rows))
+            for name, a, b in zip(("out", "dk", "dv"), (out, dk, dv), (ro, rk, rv)):
+                check(f"{name} c-ring8@1M doc {d0 // doc}", f(a, rows), b)
+            check_dq(f"dq c-ring8@1M doc {d0 // doc}", f(dq, rows), rq, rqx)
+        return
+    c = S // n
+    for r0 in (c // 2 - 128, S - 256):          # across a half-chunk seam (ranks 0 / 1), the last rows
+        rows, keys = slice(r0, r0 + 256), slice(0, r0 + 256)
+        ro, _ = R.dense_attention(f(q, rows), f(k, keys), f(v, keys), causal=True, q_start=r0)
+        rq, _, _, rqx = R.dense_attention_bwd(f(q, rows), f(k, keys), f(v, keys), f(do, rows), causal=True, q_start=r0, out_saved=f(out, rows))
+        check(f"out c-ring8@256K row {r0}", f(out, rows), ro)
+        check_dq(f"dq c-ring8@256K row {r0}", f(dq, rows), rq, rqx)
+    K0 = S - 512
+    rows, allk = slice(K0, S), slice(0, S)
+    _, rk, rv = R.dense_attention_bwd(f(q, rows), f(k, allk), f(v, allk), f(do, rows), causal=True, q_start=K0)
+    check("dk c-ring8@256K last keys", f(dk, slice(K0, K0 + 256)), rk[:, K0:K0 + 256])
+    check("dv c-ring8@256K last keys", f(dv, slice(K0 + 256, S)), rv[:, K0 + 256:])
+
+
+@pytest.mark.gpu
+def test_c_ring_direct_hands_blocks_over_as_they_land(monkeypatch):
+    """The direct schedule's K/V fetch in one group per rank distance (lwm_ring_set_fetch_groups(n - 1)): step t waits for
+    the block of distance t only.  Rank 0's link from the FARTHEST rank is held back by ~100 ms of GPU time: the kernels
+    of its steps 1 and 2 must have finished long before that block lands (timestamps of the driver's own events,
+    lwm_ring_fetch_timeline), the result is unchanged, and with ONE group (the bulk-synchronous RCCL default) every step
+    waits for the late block."""
+    import torch
+    monkeypatch.setenv("LWM_RING_TIMING", "1")
+    n, S, H = 4, 2048, 2
+    cycles = int(0.1 * 1.5e9)
+    ref = _run_c_ring(n, S, H, False, False, False, layout="zigzag", schedule="direct")[0]
+    for groups, early in ((n - 1, True), (1, False)):
+        tl = {}
+        box = _Mailbox(n, delay_from=(0, 1), delay_cycles=cycles)       # rank 0 receives distance n-1 = 3 from rank 1
+        got = _run_c_ring(n, S, H, False, False, False, layout="zigzag", schedule="direct", fetch_groups=groups, box=box, timeline=tl)[0]
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+        kv_ms, kern_ms = tl[0]
+        assert kv_ms[n - 1] > 30.0, kv_ms                    # the held-back block
+        if early:
+            assert kern_ms[1] < 0.5 * kv_ms[n - 1] and kern_ms[2] < 0.5 * kv_ms[n - 1], (kv_ms, kern_ms)
+            assert kv_ms[1] < 0.5 * kv_ms[n - 1], kv_ms
+        else:
+            assert kern_ms[1] >= kv_ms[n - 1] - 1.0, (kv_ms, kern_ms)
 
 
 _RCCL_FIRST_CONTACT = r'''
