@@ -801,7 +801,7 @@ def main():
     class TimedOps(HipBlockOps):
         fwd = staticmethod(lambda *a, **kw: timer.run("attn_fwd64_kernel", ops.attn_fwd_block, *a, **kw))
         bwd_delta = staticmethod(lambda *a, **kw: timer.run("attn_bwd_delta_kernel", ops.attn_bwd_delta, *a, **kw))
-        bwd_dq = staticmethod(lambda *a, **kw: timer.run("attn_bwd_dq_kernel", ops.attn_bwd_dq_block, *a, **kw))
+        bwd_dq = staticmethod(lambda *a, **kw: timer.run("attn_bwd_dq4_kernel", ops.attn_bwd_dq_block, *a, **kw))
         bwd_dkdv = staticmethod(lambda *a, **kw: timer.run("attn_bwd_dkdv4_kernel", ops.attn_bwd_dkdv_block, *a, **kw))
 
     c_ring = None
@@ -1095,8 +1095,8 @@ def main():
             # dominant kernel by total time; algorithmic FLOPs per launch: fwd = 2 GEMM
             # units; the backward's 5 algorithmic units are apportioned to its two launches
             # by executed share (dkdv 4/7, dq 3/7) -- DESIGN.md "Work accounting".
-            algo_units = {"attn_fwd64_kernel": 2.0, "attn_bwd_dkdv4_kernel": 5.0 * 4 / 7, "attn_bwd_dq_kernel": 5.0 * 3 / 7}
-            exec_units = {"attn_fwd64_kernel": 2.0, "attn_bwd_dkdv4_kernel": 4.0, "attn_bwd_dq_kernel": 3.0}
+            algo_units = {"attn_fwd64_kernel": 2.0, "attn_bwd_dkdv4_kernel": 5.0 * 4 / 7, "attn_bwd_dq4_kernel": 5.0 * 3 / 7}
+            exec_units = {"attn_fwd64_kernel": 2.0, "attn_bwd_dkdv4_kernel": 4.0, "attn_bwd_dq4_kernel": 3.0}
             cand = {n: d for n, d in ks.items() if n in algo_units}
             dom = max(cand, key=lambda n: cand[n]["total_ms"])
             avg_s = cand[dom]["avg_ms"] * 1e-3

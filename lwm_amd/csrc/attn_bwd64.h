@@ -1,11 +1,11 @@
 // attn_bwd64.h -- blockwise attention backward, ONE WAVE PER SIMD (the structure of attn_fwd64.h): the dK/dV kernel
-// of the two-kernel backward for one (q block, kv block) ring step on gfx950.  Requires wave_ops.h, attn_common.h,
-// attn_fwd.h, attn_fwd64.h (f4_* instruction helpers) and attn_bwd.h (the delta kernel).
+// and (second half of the file) the dQ kernel of the two-kernel backward for one (q block, kv block) ring step on
+// gfx950.  Requires wave_ops.h, attn_common.h, attn_fwd.h, attn_fwd64.h (f4_* instruction helpers) and attn_bwd.h (the
+// delta kernel, the layout of the row statistics).
 //
-// Replaces the dk / dv part of the custom-VJP backward of `ringattention` (call site lwm/llama.py:539-569; SURVEY.md
-// Appendix A.1): p from the saved LSE, dv += p^T do, dp = do v^T, ds = p * (dp - rowsum(do * o)), dk += ds^T q * scale.
-// Same contract, operands, masks, carries and segment-block hints as attn_bwd_dkdv_kernel_w8 (attn_bwd.h), which
-// stays as the 8-wave reference build (-DLWM_DKDV_OLD).
+// dK/dV: replaces the dk / dv part of the custom-VJP backward of `ringattention` (call site lwm/llama.py:539-569;
+// SURVEY.md Appendix A.1): p from the saved LSE, dv += p^T do, dp = do v^T, ds = p * (dp - rowsum(do * o)),
+// dk += ds^T q * scale.
 //
 // Workgroup = 4 waves = 128 keys; a wave owns 32 keys and the SIMD's whole register file: its K and V fragments (B
 // operands, 32 + 32 registers) and the f32 dK^T / dV^T accumulators (64 + 64) live in the accumulator file -- the
@@ -91,6 +91,7 @@ LWM_DEVICE float d4_mul(float a, float b) { return a * b; }
 LWM_DEVICE void d4_dma_b32(uint32_t voff, const char* src, lds_t dst) { glds_load_b32(src + voff, dst); }
 LWM_DEVICE void d4_settle_t(f32x16&) {}
 LWM_DEVICE void d4_settle_acc(f32x16 (&)[4], f32x16 (&)[4]) {}
+LWM_DEVICE void d4_settle_acc4(f32x16 (&)[4]) {}
 #else
 // What hipcc does not know about an asm MFMA (cdna_hip_programming.md section 5.7 item 2): a register it has just
 // written itself -- a copy that moves a tuple into place, a zero it materialises late -- needs two wait states before
@@ -122,6 +123,7 @@ LWM_DEVICE void d4_settle_acc(f32x16 (&a)[4], f32x16 (&b)[4]) {
     asm volatile("s_nop 7\n\ts_nop 7"
                  : "+a"(a[0]), "+a"(a[1]), "+a"(a[2]), "+a"(a[3]), "+a"(b[0]), "+a"(b[1]), "+a"(b[2]), "+a"(b[3]));
 }
+LWM_DEVICE void d4_settle_acc4(f32x16 (&a)[4]) { asm volatile("s_nop 7\n\ts_nop 7" : "+a"(a[0]), "+a"(a[1]), "+a"(a[2]), "+a"(a[3])); }
 #endif
 
 // per-lane byte offsets of the wave's four pieces of a 64-row tile (piece = 4 rows = 1 KiB; wave w moves pieces
@@ -737,5 +739,475 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
 
 LWM_KERNEL(kD4Threads) void attn_bwd_dkdv4_kernel(AttnParams p) { attn_bwd_dkdv4_body<false>(p); }
 LWM_KERNEL(kD4Threads) void attn_bwd_dkdv4_meta_kernel(AttnParams p) { attn_bwd_dkdv4_body<true>(p); }
+
+
+// ====================================================================================================== dQ
+// The dQ kernel of the two-kernel backward in the same structure.  Replaces the dq part of the custom VJP (see the
+// file header): p from the saved LSE, dp = do v^T, ds = p * (dp - delta), dq += ds k * scale.  Same contract,
+// operands, masks, carries and segment-block hints as the dK/dV kernel above.
+//
+// Workgroup = 4 waves = 128 queries; a wave owns 32 query rows: their Q and dO fragments (B operands, 32 + 32
+// registers) and the f32 dQ^T accumulator (64) live in the accumulator file.  Everything is computed transposed, as
+// in the forward: a lane owns one query column, so the row statistics are two scalars per lane and -delta, the initial
+// value of the dP chain, is ONE constant tuple for the whole launch (no per-unit statistics traffic at all).  K / V
+// arrive by LDS-DMA in steps of 64 keys through the same ring of four 32-KiB slots [K tile | V tile]; a unit = 32 keys:
+//
+//   phase   matrix pipe                                                   vector pipe (same wave)
+//   X(u)    S^T(u) = K(u) Q^T  and  dP'^T(u) = V(u) dO^T - delta, 16      the vector work of unit u-1 continues
+//   Y(u)    dQ^T += K(u-1)^T dS^T(u-1), 8 MFMAs over 4 tuples             t = S c - lse2, p = exp2(t), dS = p dP' -> bf16
+//
+// S and dP' have two register tiles each (by unit parity): the 56 VALU of a unit spread over the 24 gaps of Y(u) and
+// X(u+1).  With key meta (segment ids, padded keys, a ragged last tile) the 64 meta words of a step are staged through
+// LDS by the threads themselves, as the forward does.
+//
+// LDS map: slot 0..3 = [K tile 64 rows | V tile 64 rows] (16 KiB each) | key meta 0..3 (64 words each)
+constexpr int kQ4BQ = 128;      // queries per workgroup
+constexpr int kQ4BK = 64;       // keys per step (two units of 32)
+constexpr int kQ4OffMeta = kD4Slots * kD4SlotBytes;
+constexpr int kQ4LdsBytes = kQ4OffMeta + kD4Slots * kQ4BK * 4;
+
+// G = 0..7 = the gaps of Y(u), G = 8..23 = the gaps of X(u+1).  F >= 1; E behind F, M behind E, D behind its two M; the
+// product of Y(u) still reads the OLD dS words: the first half (i < 4) may be rewritten from G = 4, the second from G = 8;
+// everything done by G = 21.
+struct Q4Sched {
+    int F[16], E[16], M[16], D[8];
+};
+constexpr bool q4_sched_ok(const Q4Sched& c) {
+    for (int e = 0; e < 16; ++e)
+        if (c.F[e] < 1 || c.E[e] <= c.F[e] || c.M[e] <= c.E[e] || c.M[e] > 21) return false;
+    for (int i = 0; i < 8; ++i)
+        if (c.D[i] < (i < 4 ? 4 : 8) || c.D[i] > 21 || c.D[i] <= c.M[2 * i] || c.D[i] <= c.M[2 * i + 1]) return false;
+    return true;
+}
+constexpr Q4Sched kQ4Sched = {      // two per gap beside the transposed reads of Y, three beside the row reads of X
+    /* F */ {1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8},
+    /* E */ {8, 9, 9, 9, 10, 10, 10, 11, 11, 11, 12, 12, 12, 13, 13, 13},
+    /* M */ {14, 14, 14, 15, 15, 15, 16, 16, 16, 17, 17, 17, 18, 18, 18, 19},
+    /* D */ {19, 19, 20, 20, 20, 21, 21, 21}};
+static_assert(q4_sched_ok(kQ4Sched), "filler schedule violates a dependency");
+
+struct Q4Ctx {
+    uint32_t ka[8];             // K row-fragment addresses (d step s), rows 0..31 of the CURRENT step's K tile
+    uint32_t tlo[4], tup[4];    // K transposed-fragment addresses (d block), rows 0..15 of the current step's K tile
+    uint32_t plo[4], pup[4];    // the same in the PREVIOUS step's slot
+    uint32_t meta;              // this step's key meta + 16 * hi
+    float c, nl;                // scale * log2(e); -lse * log2(e) of this lane's query (-inf: p = 0)
+};
+
+struct Q4Regs {
+    f32x16 s[2], dp[2];         // S^T / dP'^T tiles by unit parity (MFMA results, read-only for the vector pipe)
+    f32x16 ndl;                 // -delta of this lane's query in every element: the C operand that starts each dP chain
+    float t[16], ds[16];
+    bf16x8 dsb[2];
+    uint32_t dw[8];
+    bf16x8 fr[8];
+};
+
+#ifdef LWM_EMU
+LWM_DEVICE void q4_mfma_c_first(f32x16& d, bf16x8 a, bf16x8 b, const f32x16& c) { d = mfma_32x32x16(a, b, c); }
+LWM_DEVICE void q4_opaque(f32x16&) {}
+#else
+// first MFMA of a dP chain: C = the -delta tuple (two wait states in front, see d4_mfma_p_first)
+LWM_DEVICE void q4_mfma_c_first(f32x16& d, bf16x8 a, bf16x8 b, const f32x16& c) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));
+}
+// sixteen registers that hold the same value: hipcc must not know (it would keep one and copy it into a tuple in
+// front of every chain)
+LWM_DEVICE void q4_opaque(f32x16& x) { asm volatile("" : "+v"(x)); }
+#endif
+
+// fragment f of a unit (MFMA index 0..23; 24.. = the first fragments of the unit that follows):
+//   0..15   phase X: d step f>>1; even = K row fragment (S^T), odd = V row fragment (dP'^T)
+//   16..23  phase Y: K^T of the PREVIOUS unit, (key step (f>>2)&1, d block f&3)
+template <int HALF>
+LWM_DEVICE bf16x8 q4_frag(const Q4Ctx& cx, int f) {
+    if (f >= 24) {
+        const int g = f - 24;
+        return lds_read_b128(cx.ka[g >> 1] + (g & 1) * kD4TileBytes + (HALF == 0 ? 32 * kRowBytes : 0));
+    }
+    if (f < 16) return lds_read_b128(cx.ka[f >> 1] + (f & 1) * kD4TileBytes + HALF * 32 * kRowBytes);
+    const int j = f - 16, t = (j >> 2) & 1, db = j & 3;
+    const uint32_t alo = HALF == 0 ? cx.plo[db] : cx.tlo[db];
+    const uint32_t aup = HALF == 0 ? cx.pup[db] : cx.tup[db];
+    const uint32_t off = (HALF == 0 ? 32 * kRowBytes : 0) + 16 * t * kRowBytes;
+    bf16x4 lo = lds_read_tr16(alo + off);
+    bf16x4 up = lds_read_tr16(aup + off);
+    bf16x8 o;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+    o[4] = up[0]; o[5] = up[1]; o[6] = up[2]; o[7] = up[3];
+    return o;
+}
+
+// the vector work scheduled in gap G for the unit of parity PAR
+template <int G, int PAR>
+LWM_DEVICE void q4_fillers(const Q4Ctx& cx, Q4Regs& rg) {
+    if (!kD4xFill) return;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        if (kQ4Sched.F[e] == G) rg.t[e] = f4_fma(rg.s[PAR][e], cx.c, cx.nl);
+        if (kQ4Sched.E[e] == G) rg.t[e] = f4_exp2(rg.t[e]);
+        if (kQ4Sched.M[e] == G) rg.ds[e] = d4_mul(rg.t[e], rg.dp[PAR][e]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (kQ4Sched.D[i] == G) rg.dw[i] = f4_cvt_pk(rg.ds[2 * i], rg.ds[2 * i + 1]);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        int ld = 0;
+        for (int i = 4 * h; i < 4 * h + 4; ++i) ld = kQ4Sched.D[i] > ld ? kQ4Sched.D[i] : ld;
+        if (ld == G) rg.dsb[h] = __builtin_bit_cast(bf16x8, u32x4{rg.dw[4 * h], rg.dw[4 * h + 1], rg.dw[4 * h + 2], rg.dw[4 * h + 3]});
+    }
+}
+template <int G0, int N, int PAR>
+LWM_DEVICE void q4_fill_at(int g, const Q4Ctx& cx, Q4Regs& rg) {
+    if constexpr (N > 0) {
+        if (g == G0) q4_fillers<G0, PAR>(cx, rg);
+        else q4_fill_at<G0 + 1, N - 1, PAR>(g, cx, rg);
+    }
+}
+
+// Phase X of unit u (parity HALF): the two chains alternating, fragments requested and consumed in pairs (attn d4_x);
+// fillers: gaps 8..23 of unit u-1.
+template <int HALF, bool HAS_PREV, bool DMA>
+LWM_DEVICE void q4_x(const Q4Ctx& cx, Q4Regs& rg, const bf16x8 (&qf)[8], const bf16x8 (&dof)[8], const uint32_t (&vk)[4],
+                     const uint32_t (&vv)[4], const D4Dma& dm) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        if ((m & 1) == 0) {
+            rg.fr[(m + kD4Ahead) & 7] = q4_frag<HALF>(cx, m + kD4Ahead);
+            rg.fr[(m + kD4Ahead + 1) & 7] = q4_frag<HALF>(cx, m + kD4Ahead + 1);
+        }
+        sched_fence();
+        {
+            const int f = m ^ 1;      // even = K (S^T), odd = V (dP'^T)
+            if (f == 0) f4_mfma_s_first(rg.s[HALF], rg.fr[0], qf[0]);
+            else if ((f & 1) == 0) f4_mfma_s(rg.s[HALF], rg.fr[f & 7], qf[f >> 1]);
+            else if (f == 1) q4_mfma_c_first(rg.dp[HALF], rg.fr[1], dof[0], rg.ndl);
+            else f4_mfma_s(rg.dp[HALF], rg.fr[f & 7], dof[f >> 1]);
+        }
+#ifndef LWM_D4X_NODMA
+        if (DMA && (m & 1)) {
+            const int j = m >> 2;
+            if ((m & 2) == 0) f4_dma1(vk[j], dm.q_src, dm.dst + 4096 * j);
+            else f4_dma1(vv[j], dm.do_src, dm.dst + kD4TileBytes + 4096 * j);
+        }
+#endif
+        if (HAS_PREV) q4_fill_at<8, 16, HALF ^ 1>(8 + m, cx, rg);
+        sched_fence();
+    }
+}
+
+// masks of a unit on its transposed scores (lwm/llama.py:572-592): key row (r&3) + 8 (r>>2) + 4 hi of the unit is visible to
+// this lane's query iff it is not after it (rel = query position - position of the unit's key 0 - 4 hi, clamped) and, with
+// key meta, carries the query's segment (kSegInvalid: a padded / out-of-range key)
+template <int HALF, bool HAS_META>
+LWM_DEVICE void q4_mask(const Q4Ctx& cx, f32x16& s, int rel, int32_t seg_q) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (HAS_META) {
+            const u32x4 sg = lds_read_u32x4(cx.meta + HALF * 32 * 4 + 8 * g * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool vis = ((int32_t)sg[j] == seg_q) && (8 * g + j <= rel);
+                s[4 * g + j] = vis ? s[4 * g + j] : -INFINITY;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[4 * g + j] = (8 * g + j <= rel) ? s[4 * g + j] : -INFINITY;
+        }
+    }
+}
+
+// Phase Y of unit u: dQ^T += K(u-1)^T dS^T(u-1)  ||  gaps 0..7 of unit u.  INIT: the first products of the walk.
+template <int HALF, bool HAS_PREV, bool INIT>
+LWM_DEVICE void q4_y(const Q4Ctx& cx, Q4Regs& rg, f32x16 (&dq)[4]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int m = 16 + j;
+        if ((j & 1) == 0) {
+            rg.fr[(m + kD4Ahead) & 7] = q4_frag<HALF>(cx, m + kD4Ahead);
+            rg.fr[(m + kD4Ahead + 1) & 7] = q4_frag<HALF>(cx, m + kD4Ahead + 1);
+        }
+        sched_fence();
+        if (HAS_PREV) {
+            const int jf = j ^ 1;      // (pairs: the younger fragment first -- one wait per two MFMAs)
+            if (INIT && jf < 4) d4_mfma_o_first(dq[jf & 3], rg.fr[(16 + jf) & 7], rg.dsb[0]);
+            else f4_mfma_o(dq[jf & 3], rg.fr[(16 + jf) & 7], rg.dsb[jf >> 2]);
+        }
+        q4_fill_at<0, 8, HALF>(j, cx, rg);
+        sched_fence();
+    }
+}
+
+template <int PAR>
+LWM_DEVICE void q4_drain(const Q4Ctx& cx, Q4Regs& rg, f32x16 (&dq)[4]) {
+#pragma unroll
+    for (int g = 8; g < 24; ++g) q4_fill_at<8, 16, PAR>(g, cx, rg);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rg.fr[j] = q4_frag<0>(cx, 16 + j);
+    sched_fence();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f4_mfma_o(dq[j & 3], rg.fr[j], rg.dsb[j >> 2]);
+}
+
+// per-lane byte offsets of the wave's four pieces of a 64-row K / V tile, rows clamped to Sk-1 (rows past Sk are masked
+// through the key meta)
+LWM_DEVICE void q4_stage_offsets(const AttnParams& p, int wave, int lane, int st, uint32_t (&vk)[4], uint32_t (&vv)[4]) {
+    const int slot = lane & 15;
+    for (int j = 0; j < 4; ++j) {
+        const int row = 4 * (wave + 4 * j) + (lane >> 4);
+        int krow = st * kQ4BK + row;
+        krow = krow < p.Sk ? krow : p.Sk - 1;
+        const int rel = krow - st * kQ4BK;
+        const int col = (slot ^ swz(row)) << 3;
+        vk[j] = (uint32_t)(((int64_t)rel * p.k_ss + col) * 2);
+        vv[j] = (uint32_t)(((int64_t)rel * p.v_ss + col) * 2);
+    }
+}
+
+template <bool HAS_META>
+LWM_DEVICE void attn_bwd_dq4_body(const AttnParams& p) {
+    const lds_t lds = dyn_lds();
+    const int tid = thread_idx();
+    const int wave = wave_uniform(tid >> 6), lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+
+    // ---- block -> (q block, head, batch): all q blocks of one (b,h) on one XCD, longest walks (the last blocks) first
+    const int nqb = (p.Sq + kQ4BQ - 1) / kQ4BQ;
+    const int HB = p.H * p.B;
+    int lin = block_idx_x(), qbi, hb;
+    if ((HB & 7) == 0) {
+        int xcd = lin & 7, i = lin >> 3;
+        hb = xcd + 8 * (i / nqb);
+        qbi = nqb - 1 - (i % nqb);
+    } else {
+        hb = lin / nqb;
+        qbi = nqb - 1 - (lin % nqb);
+    }
+    const int b = hb / p.H, h = hb % p.H;
+    const bf16_t* qb = p.q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
+    const bf16_t* kb = p.k + (int64_t)b * p.k_sb + (int64_t)h * p.k_sh;
+    const bf16_t* vb = p.v + (int64_t)b * p.v_sb + (int64_t)h * p.v_sh;
+    const bf16_t* dob = p.dout + (int64_t)b * p.do_sb + (int64_t)h * p.do_sh;
+
+    // ---- this lane's query: fragments straight into the accumulator file (a row past Sq re-reads the last row: its
+    // results are never stored), its statistics
+    const int q_row = qbi * kQ4BQ + wave * 32 + l31;
+    const bool q_ok = q_row < p.Sq;
+    const int qr = q_ok ? q_row : p.Sq - 1;
+    bf16x8 qf[8], dof[8];
+    for (int s = 0; s < 8; ++s) qf[s] = f4_load_agpr(qb + (int64_t)qr * p.q_ss + 16 * s + 8 * hi);
+    for (int s = 0; s < 8; ++s) dof[s] = f4_load_agpr(dob + (int64_t)qr * p.do_ss + 16 * s + 8 * hi);
+    Q4Ctx cx;
+    Q4Regs rg;
+    {
+        const int64_t Sqp = bwd_stat_pad(p.Sq), srow = bwd_stat_row((int64_t)b * p.H + h, Sqp);
+        cx.nl = q_ok ? p.delta[srow + qr] : -INFINITY;
+        const float nd = p.delta[srow + Sqp + qr];
+        for (int r = 0; r < 16; ++r) rg.ndl[r] = nd;
+        q4_opaque(rg.ndl);
+    }
+    cx.c = p.scale * kLog2e;
+    const int32_t seg_q = (HAS_META && q_ok && p.seg_q) ? p.seg_q[(int64_t)b * p.Sq + q_row] : 0;
+
+    // ---- key step range of the walk (steps of 64 keys; causal: up to the diagonal of the workgroup's last query)
+    const int nst_all = (p.Sk + kQ4BK - 1) / kQ4BK;
+    int nst = nst_all, st0 = 0;
+    const int q_last = (qbi * kQ4BQ + kQ4BQ < p.Sq ? qbi * kQ4BQ + kQ4BQ : p.Sq) - 1;
+    if (p.causal) {
+        const int64_t d = p.q_start + q_last - p.k_start;      // last visible key index
+        if (d < 0) nst = 0;
+        else {
+            const int64_t t = d / kQ4BK + 1;
+            nst = t < nst_all ? (int)t : nst_all;
+        }
+    }
+    if (HAS_META && p.segb_q && p.segb_k && nst > 0) {     // packed sequences: skip other documents' key steps
+        const int nbq = (p.Sq + 31) >> 5, nbk = (p.Sk + 31) >> 5;
+        int smin, smax, lo, hi2;
+        seg_own_range(p.segb_q + (int64_t)b * nbq * 2, nbq, qbi * (kQ4BQ / 32), kQ4BQ / 32, smin, smax);
+        seg_narrow<kD4Threads>(p.segb_k + (int64_t)b * nbk * 2, nbk, kQ4BK / 32, 0, nst, smin, smax, lds + kQ4OffMeta, tid, lo, hi2);
+        st0 = lo;
+        nst = hi2;
+    }
+    const int n = nst > st0 ? nst - st0 : 0;       // walk index i -> key step st0 + i (ascending)
+
+    f32x16 dq[4];
+    if (n == 0)
+        for (int i = 0; i < 4; ++i) dq[i] = zero_f32x16();
+    f4_load_agpr_wait8(qf);
+    f4_load_agpr_wait8(dof);
+
+    if (n > 0) {
+        for (int s = 0; s < 8; ++s) cx.ka[s] = lds + tile_off(l31, 2 * s + hi);
+        {
+            const TrFragAddr t = frag_tr_addr(lds, lane);
+            for (int db = 0; db < 4; ++db) {
+                cx.tlo[db] = t.lo[db];
+                cx.tup[db] = t.up[db];
+                cx.plo[db] = t.lo[db];
+                cx.pup[db] = t.up[db];
+            }
+        }
+        cx.meta = lds + kQ4OffMeta + 16 * hi;
+        const int64_t k_step_bytes = (int64_t)kQ4BK * p.k_ss * 2, v_step_bytes = (int64_t)kQ4BK * p.v_ss * 2;
+        uint32_t vk[4], vv[4];
+        q4_stage_offsets(p, wave, lane, 0, vk, vv);       // full steps: nothing is clamped
+        // key meta of walk index i -> meta slot i & 3: segment id, or kSegInvalid for padded / out-of-range keys
+        auto meta_stage = [&](int i) {
+            if (HAS_META && tid < kQ4BK) {
+                const int krow = (st0 + i) * kQ4BK + tid;
+                const int kr = krow < p.Sk ? krow : p.Sk - 1;
+                const uint8_t kvalid = p.key_valid ? p.key_valid[(int64_t)b * p.Sk + kr] : (uint8_t)1;
+                const int32_t kseg = p.seg_k ? p.seg_k[(int64_t)b * p.Sk + kr] : 0;
+                lds_write_i32(lds + kQ4OffMeta + (i & 3) * kQ4BK * 4 + tid * 4, (krow < p.Sk && kvalid != 0) ? kseg : kSegInvalid);
+            }
+        };
+        auto stage_step = [&](int i) {
+            const int st = st0 + i;
+            const lds_t dst = lds + (i & 3) * kD4SlotBytes + (uint32_t)wave * 1024;
+            const char* ks = (const char*)kb + st * k_step_bytes;
+            const char* vs = (const char*)vb + st * v_step_bytes;
+            if (st * kQ4BK + kQ4BK > p.Sk) {
+                uint32_t v2[4], d2[4];
+                q4_stage_offsets(p, wave, lane, st, v2, d2);
+                f4_dma<4>(v2, ks, dst);
+                f4_dma<4>(d2, vs, dst + kD4TileBytes);
+            } else {
+                f4_dma<4>(vk, ks, dst);
+                f4_dma<4>(vv, vs, dst + kD4TileBytes);
+            }
+            meta_stage(i);
+        };
+        // the ragged last step of the K/V block may only be staged from this slow path: the pipelined steps stop before it
+        const bool ragged = (p.Sk % kQ4BK) != 0;
+        const int n_pipe_end = (ragged && nst == nst_all) ? n - 1 : n;      // walk indices >= this are never issued in-loop
+
+        // ---- prologue: steps 0 and 1 in flight
+        stage_step(0);
+        if (n > 1) stage_step(1);
+        glds_wait_all();
+        block_sync();
+
+        auto clamp32 = [](int64_t x) -> int { return x > (1 << 30) ? (1 << 30) : (x < -(1 << 30) ? -(1 << 30) : (int)x); };
+        const int wq_rel = clamp32(p.q_start + (int64_t)qbi * kQ4BQ + wave * 32 - p.k_start);      // the wave's first query
+        const int q_rel = clamp32(p.q_start + q_row - p.k_start) - 4 * hi;                         // this lane's query
+        // a unit (first key at row ub of the K/V block) needs the mask code when its last key lies after the wave's first query
+        auto needs_mask = [&](int ub) -> bool { return HAS_META || (p.causal && ub + 31 > wq_rel); };
+        auto rel_of = [&](int ub) -> int {
+            if (!p.causal) return 64;
+            const int d = q_rel - ub;
+            return d > 64 ? 64 : (d < -64 ? -64 : d);
+        };
+
+        for (int par = 0; par < 2; ++par) {
+            rg.s[par] = zero_f32x16();
+            rg.dp[par] = zero_f32x16();
+        }
+        for (int r = 0; r < 16; ++r) {
+            rg.t[r] = 0.0f;
+            rg.ds[r] = 0.0f;
+        }
+        for (int t = 0; t < 2; ++t) rg.dsb[t] = zero_bf16x8();
+        for (int j = 0; j < 8; ++j) rg.fr[j] = zero_bf16x8();
+        D4Dma dm = {};
+        for (int j = 0; j < kD4Ahead; ++j) rg.fr[j] = q4_frag<0>(cx, j);
+
+#define LWM_Q4_MASK(HALF_, HAS_PREV_, ub_)                                                                          \
+    do {                                                                                                            \
+        if (!(HAS_PREV_)) d4_settle_t(rg.s[HALF_]);     /* no MFMA stands between the S chain and its first reader */ \
+        if (needs_mask(ub_)) {                                                                                      \
+            if (HAS_PREV_) d4_settle_t(rg.s[HALF_]);                                                                \
+            q4_mask<HALF_, HAS_META>(cx, rg.s[HALF_], rel_of(ub_), seg_q);                                          \
+        }                                                                                                           \
+    } while (0)
+        int ub = st0 * kQ4BK;
+        const char* k_src2 = (const char*)kb + (int64_t)(st0 + 2) * k_step_bytes;
+        const char* v_src2 = (const char*)vb + (int64_t)(st0 + 2) * v_step_bytes;
+#define LWM_Q4_STEP(i, FIRST, PIPE)                                                                                 \
+    do {                                                                                                            \
+        if (PIPE) {                                                                                                 \
+            dm.q_src = k_src2;                                                                                      \
+            dm.do_src = v_src2;                                                                                     \
+            dm.dst = lds + (((i) + 2) & 3) * kD4SlotBytes + (uint32_t)wave * 1024;                                  \
+            k_src2 += k_step_bytes;                                                                                 \
+            v_src2 += v_step_bytes;                                                                                 \
+            meta_stage((i) + 2);                                                                                    \
+        }                                                                                                           \
+        const uint32_t d_ = (((i) & 3) == 3) ? (uint32_t)(-3 * kD4SlotBytes) : (uint32_t)kD4SlotBytes;             \
+        const uint32_t e_ = (((i) & 3) == 3) ? (uint32_t)(-3 * kQ4BK * 4) : (uint32_t)(kQ4BK * 4);                 \
+        q4_x<0, !(FIRST), PIPE>(cx, rg, qf, dof, vk, vv, dm);                                                       \
+        LWM_Q4_MASK(0, !(FIRST), ub);                                                                               \
+        q4_y<0, !(FIRST), false>(cx, rg, dq);                                                                       \
+        q4_x<1, true, false>(cx, rg, qf, dof, vk, vv, dm);                                                          \
+        for (int s_ = 0; s_ < 8; ++s_) cx.ka[s_] += d_;                                                             \
+        LWM_Q4_MASK(1, true, ub + 32);                                                                              \
+        q4_y<1, true, FIRST>(cx, rg, dq);                                                                           \
+        ub += kQ4BK;                                                                                                \
+        if ((FIRST) || !(PIPE)) d4_settle_acc4(dq);                                                                 \
+        glds_wait_all();                                                                                            \
+        block_sync_lds();                                                                                           \
+        for (int db_ = 0; db_ < 4; ++db_) {                                                                         \
+            cx.plo[db_] = cx.tlo[db_];                                                                              \
+            cx.pup[db_] = cx.tup[db_];                                                                              \
+            cx.tlo[db_] += d_;                                                                                      \
+            cx.tup[db_] += d_;                                                                                      \
+        }                                                                                                           \
+        cx.meta += e_;                                                                                              \
+    } while (0)
+
+        int i = 0;
+        if (n_pipe_end > 2) {
+            LWM_Q4_STEP(0, true, true);
+            for (i = 1; i + 2 < n_pipe_end; ++i) LWM_Q4_STEP(i, false, true);
+            // the ragged last step (if any) was not issued by the loop: stage it now, two steps ahead of its use
+            if (n_pipe_end < n) {
+                stage_step(n - 1);
+                glds_wait_all();
+                block_sync_lds();
+            }
+            for (; i < n; ++i) LWM_Q4_STEP(i, false, false);
+        } else {
+            if (n > 2) {                 // (n == 3 with a ragged last step: nothing was pipelined)
+                stage_step(2);
+                glds_wait_all();
+                block_sync_lds();
+            }
+            LWM_Q4_STEP(0, true, false);
+            for (i = 1; i < n; ++i) LWM_Q4_STEP(i, false, false);
+        }
+#undef LWM_Q4_STEP
+#undef LWM_Q4_MASK
+        // the last unit's product: its K tile is the second half of the PREVIOUS slot now (the registers moved on)
+        q4_drain<1>(cx, rg, dq);
+        d4_settle_acc4(dq);      // before the paths merge
+    }
+
+    // ---- epilogue: scale, merge with the ring carry, store (one query row per lane)
+    d4_settle_acc4(dq);
+    if (q_ok) {
+        const int64_t orow = (int64_t)b * p.dq_sb + (int64_t)q_row * p.dq_ss + (int64_t)h * p.dq_sh;
+        const int64_t arow = (int64_t)b * p.dqa_sb + (int64_t)q_row * p.dqa_ss + (int64_t)h * p.dqa_sh;
+        for (int db = 0; db < 4; ++db)
+            for (int rq = 0; rq < 4; ++rq) {
+                const int d0 = 32 * db + 8 * rq + 4 * hi;
+                float o0 = dq[db][4 * rq + 0] * p.scale, o1 = dq[db][4 * rq + 1] * p.scale;
+                float o2 = dq[db][4 * rq + 2] * p.scale, o3 = dq[db][4 * rq + 3] * p.scale;
+                if (p.carry_in) {
+                    const float* a = p.dq_acc + arow + d0;
+                    o0 += a[0]; o1 += a[1]; o2 += a[2]; o3 += a[3];
+                }
+                if (p.final_out) {
+                    global_store_b64(p.dq + orow + d0, u32x2{pack_bf16x2(o0, o1), pack_bf16x2(o2, o3)});
+                } else {
+                    global_store_b128(p.dq_acc + arow + d0,
+                                      u32x4{__builtin_bit_cast(uint32_t, o0), __builtin_bit_cast(uint32_t, o1),
+                                            __builtin_bit_cast(uint32_t, o2), __builtin_bit_cast(uint32_t, o3)});
+                }
+            }
+    }
+}
+
+LWM_KERNEL(kD4Threads) void attn_bwd_dq4_kernel(AttnParams p) { attn_bwd_dq4_body<false>(p); }
+LWM_KERNEL(kD4Threads) void attn_bwd_dq4_meta_kernel(AttnParams p) { attn_bwd_dq4_body<true>(p); }
 
 }  // namespace lwm
