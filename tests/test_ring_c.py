@@ -204,7 +204,7 @@ def _run_c_ring(n, S, H, causal, packed, padded, B=1, layout="contiguous", sched
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,causal,packed,padded,layout,schedule", [
-    (1, True, True, True, "contiguous", "ring"), (2, True, False, False, "contiguous", "ring"),
+    (1, True, True, True, "contiguous", "ring"), (3, True, False, False, "zigzag", "ring"),
     (4, True, True, True, "contiguous", "ring"), (4, False, False, True, "contiguous", "ring"),
     (8, True, True, False, "contiguous", "ring"),
     (4, True, True, True, "zigzag", "ring"), (2, True, False, False, "zigzag", "direct"),
@@ -215,7 +215,7 @@ def test_c_ring_schedule_vs_oracle_and_python_driver(n, causal, packed, padded, 
     from oracle import attention_ref as R
     from lwm_amd.ring import ring_attention
     from tests._parity import check
-    S, H = 512 * max(n // 2, 1) if n > 1 else 640, 2
+    S, H = (512 * max(n // 2, 1) if n != 3 else 768) if n > 1 else 640, 2
     got, (q, k, v, do, seg, kv), sent = _run_c_ring(n, S, H, causal, packed, padded, layout=layout, schedule=schedule)
     f = lambda t: t.float().cpu().numpy()
     sg = None if seg is None else seg.cpu().numpy()
@@ -354,11 +354,11 @@ def test_c_ring8_at_configs3_and_4_shard_shapes_vs_oracle(S, packed):
         rq, _, _, rqx = R.dense_attention_bwd(f(q, rows), f(k, keys), f(v, keys), f(do, rows), causal=True, q_start=r0, out_saved=f(out, rows))
         check(f"out c-ring8@256K row {r0}", f(out, rows), ro)
         check_dq(f"dq c-ring8@256K row {r0}", f(dq, rows), rq, rqx)
-    K0 = S - 512
+    K0 = S - 256
     rows, allk = slice(K0, S), slice(0, S)
     _, rk, rv = R.dense_attention_bwd(f(q, rows), f(k, allk), f(v, allk), f(do, rows), causal=True, q_start=K0)
-    check("dk c-ring8@256K last keys", f(dk, slice(K0, K0 + 256)), rk[:, K0:K0 + 256])
-    check("dv c-ring8@256K last keys", f(dv, slice(K0 + 256, S)), rv[:, K0 + 256:])
+    check("dk c-ring8@256K last keys", f(dk, slice(K0, K0 + 128)), rk[:, K0:K0 + 128])
+    check("dv c-ring8@256K last keys", f(dv, slice(K0 + 128, S)), rv[:, K0 + 128:])
 
 
 @pytest.mark.gpu
