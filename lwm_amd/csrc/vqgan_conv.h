@@ -74,10 +74,15 @@ LWM_DEVICE f32x4 zero_f32x4() {
 // conv): all staging loads are 16-byte and NOTHING in the staging path branches
 // at run time -- a load behind a runtime branch, even a uniform one, makes hipcc
 // wait vmcnt(0) before the next load (measured: 4.3k cycles per chunk).
-template <int WM, int WN, int MB, int NB, bool VEC>
+//
+// BDIRECT (Cin % 32 == 0, Cout % BN == 0): the B operand never passes through LDS -- a lane's B value of one MFMA is
+// ONE float of its column, fetched from L1/L2 into registers a chunk ahead (buffer loads with the row offset in an
+// SGPR, as the patch kernels below do); only the A tile is staged.  Half the staging loads and ds_writes, half the
+// fragment reads; same arithmetic.
+template <int WM, int WN, int MB, int NB, bool VEC, bool BDIRECT = false>
 LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
     using Cfg = ConvCfg<WM, WN, MB, NB>;
-    constexpr int BM = Cfg::BM, BN = Cfg::BN, AP = Cfg::AP, BP = Cfg::BP;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, AP = Cfg::AP, BP = BDIRECT ? 0 : Cfg::BP;
     const lds_t lds = dyn_lds();
     const int tid = thread_idx();
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -119,7 +124,7 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
     const int ntap = p.KH * p.KW;
     const int nit = ntap * nch;
 
-    f32x4 sa[AP], sb[BP];
+    f32x4 sa[AP], sb[BP > 0 ? BP : 1];
     uint32_t s_ok = 0;  // bit ps: sa[ps] valid; bit 8+ps: sb[ps] valid (else the tile gets zeros)
 
     // Loads are UNCONDITIONAL (out-of-image taps / channels read a clamped, valid
@@ -179,8 +184,7 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
 #pragma unroll
         for (int l = 0; l < AP + BP; ++l) stage_load_one(l);
     };
-    auto stage_write = [&](int buf) {
-        const uint32_t bo = (uint32_t)buf * Cfg::BUF_BYTES;
+    auto stage_write = [&](uint32_t bo) {       // bo = byte offset of the buffer
         for (int ps = 0; ps < AP; ++ps) {
             const int px = ps * Cfg::APX + (tid >> 3);
             lds_write_f32x4(a_w + bo + (uint32_t)ps * Cfg::APX * 128 + ((a_slot ^ ((px >> 1) & 7)) << 4),
@@ -208,10 +212,82 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
     }
     const lds_t b_r = lds + Cfg::A_BYTES + (uint32_t)(hi * BN + wn * NB * 32 + l31) * 4;
 
+    // BDIRECT: row (it*32 + 4u + 2t + hi) of the [taps*Cin][Cout] kernel matrix, column n0 + wn*NB*32 + j*32 + l31
+    const uint32_t b_voff = (uint32_t)(hi * p.Cout + n0 + wn * NB * 32 + l31) * 4u;
+    const uint32_t b_rowb = (uint32_t)p.Cout * 4u;
+    // two register sets of a quarter chunk each (k-quad pairs): pair q+1 is requested when pair q begins, 16 MFMAs
+    // (>= 1024 cycles) ahead of its first use
+    float bq[2][2][2][NB];
+    auto load_b = [&](int it, int pair) {          // pair 0..3 of chunk `it` -> set pair & 1 (all compile-time after unrolling)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    bq[pair & 1][u][t][j] = global_load_f32_at(p.w, b_voff + (uint32_t)j * 128u,
+                                                               (uint32_t)(it * 32 + 8 * pair + 4 * u + 2 * t) * b_rowb);
+    };
+    if constexpr (BDIRECT) load_b(0, 0);      // (load_b: unconditional -- past the end the last chunk is read again)
+
+    if constexpr (BDIRECT) {
+        // A ring of three buffers: chunk it+1 is written when iteration `it` BEGINS (it was loaded an iteration ago),
+        // the one barrier of the iteration sits in its middle -- behind it chunk it+1 is visible and chunk it-1 is no
+        // longer read by anyone -- and the last k-quad requests the first fragment of chunk it+1: no LDS latency is
+        // exposed at a chunk boundary, no ds_write waits for a load.
+        constexpr uint32_t AB = Cfg::A_BYTES;
+        f32x4 ar[2][MB];
+        auto load_a = [&](uint32_t bo, int u, int set) {
+            for (int i = 0; i < MB; ++i) ar[set][i] = lds_read_f32x4(a_r[i] + bo + ((u ^ a_sw[i]) << 4));
+        };
+        stage_load(0);
+        stage_write(0);
+        if (nit > 1) stage_load(1);
+        block_sync();
+        load_a(0, 0, 0);
+        uint32_t cur = 0, nxt = AB, nn = 2 * AB;
+        int in_tap = 0;
+        for (int it = 0; it < nit; ++it) {
+            const bool more = it + 1 < nit;
+            if (more) stage_write(nxt);
+            if (it + 2 < nit) stage_load(it + 2);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int set = u & 1;
+                if (u + 1 < 8) load_a(cur, u + 1, set ^ 1);
+                else load_a(more ? nxt : cur, 0, set ^ 1);
+                if ((u & 1) == 0) load_b(u == 6 ? (more ? it + 1 : it) : it, ((u >> 1) + 1) & 3);
+                sched_fence();  // keep the prefetch ABOVE this k-quad's MFMAs (hipcc sinks it otherwise)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float af[MB];
+                    for (int i = 0; i < MB; ++i) af[i] = hi ? ar[set][i][2 * t + 1] : ar[set][i][2 * t];
+                    for (int i = 0; i < MB; ++i)
+                        for (int j = 0; j < NB; ++j)
+                            acc_tap[i][j] = mfma_32x32x2_f32(af[i], bq[(u >> 1) & 1][u & 1][t][j], acc_tap[i][j]);
+                }
+                sched_fence();
+                if (u == 3) block_sync_lds();
+            }
+            if (++in_tap == nch) {  // tap finished: s = s + P_t
+                in_tap = 0;
+                for (int i = 0; i < MB; ++i)
+                    for (int j = 0; j < NB; ++j) {
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] + acc_tap[i][j][r];
+                        acc_tap[i][j] = zero_f32x16();
+                    }
+            }
+            const uint32_t t3 = cur;
+            cur = nxt;
+            nxt = nn;
+            nn = t3;
+        }
+    }
+    if constexpr (!BDIRECT) {
     stage_load(0);
     stage_write(0);
     block_sync();
-    for (int it = 0; it < nit; ++it) {
+    auto chunk = [&](int it) {
         const int buf = it & 1;
         const bool more = it + 1 < nit;
         if (more) stage_load(it + 1);
@@ -248,8 +324,10 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
                     acc_tap[i][j] = zero_f32x16();
                 }
         }
-        if (more) stage_write(buf ^ 1);
+        if (more) stage_write((uint32_t)(buf ^ 1) * Cfg::BUF_BYTES);
         block_sync();
+    };
+    for (int it = 0; it < nit; ++it) chunk(it);
     }
 
     // ---- epilogue: + bias [+ residual] [clip], one float per (pixel, channel).  32-bit offsets inside the
@@ -326,6 +404,31 @@ struct PatchCfg {
     static_assert(NCH % 2 == 0, "the chunk loop is unrolled by two");
 };
 
+// The halo patch of a TH x 16 output tile at (ty0, tx0) of one image (xb), all input channels, into LDS at `lds`
+// (every lane fetches SOME valid address; out-of-image slots are overwritten with zeros once the DMA has landed).
+// Ends with a workgroup barrier.
+template <class Cfg>
+LWM_DEVICE void conv_patch_fill(const ConvParams& p, const float* xb, int ty0, int tx0, int wave, int lane, lds_t lds) {
+    constexpr int NW = Cfg::NW, PW = Cfg::PW, CIN = Cfg::ROWB / 4;
+    const int Hv = p.Hin << p.up_shift, Wv = p.Win << p.up_shift;
+    uint32_t zmask = 0;
+    for (int k = 0; k * NW + wave < Cfg::NINS; ++k) {
+        const int g = (k * NW + wave) * 64 + lane;     // 16-byte slot of the patch image
+        const int pp = g / Cfg::SPP, q = g - pp * Cfg::SPP;
+        const int lslot = q ^ (pp & 15);
+        const int py = pp / PW, px = pp - py * PW;
+        const int vy = ty0 + py - 1, vx = tx0 + px - 1;
+        const bool ok = vy >= 0 && vy < Hv && vx >= 0 && vx < Wv;
+        const int sy = ok ? (vy >> p.up_shift) : 0, sx = ok ? (vx >> p.up_shift) : 0;
+        glds_load_b128(xb + ((int64_t)sy * p.Win + sx) * CIN + lslot * 4, lds + (uint32_t)(k * NW + wave) * 1024);
+        zmask |= ok ? 0u : (1u << k);
+    }
+    glds_wait_all();
+    for (int k = 0; k * NW + wave < Cfg::NINS; ++k)
+        if ((zmask >> k) & 1) lds_write_f32x4(lds + (uint32_t)((k * NW + wave) * 64 + lane) * 16, zero_f32x4());
+    block_sync_lds();
+}
+
 template <int CIN, int TH, int WM, int WN, int NB>
 LWM_DEVICE void conv_patch_body(const ConvParams& p) {
     using Cfg = PatchCfg<CIN, TH, WM, WN, NB>;
@@ -345,7 +448,6 @@ LWM_DEVICE void conv_patch_body(const ConvParams& p) {
     const int ty0 = (int)(bm % tiles_y) * TH;
     const int b = (int)(bm / tiles_y);
     const int n0 = bn * BN;
-    const int Hv = p.Hin << p.up_shift, Wv = p.Win << p.up_shift;
     const float* const xb = p.x + (int64_t)b * p.Hin * p.Win * CIN;
 
     // ---- B operands: row (it*32 + 4u + 2t + hi) of the [9*CIN][Cout] kernel matrix, column n0 + wn*NB*32 + j*32 + l31
@@ -363,24 +465,7 @@ LWM_DEVICE void conv_patch_body(const ConvParams& p) {
     };
     load_b(0, 0);
 
-    // ---- the halo patch (every lane fetches SOME valid address; out-of-image slots are overwritten with
-    // zeros once the DMA has landed)
-    uint32_t zmask = 0;
-    for (int k = 0; k * NW + wave < Cfg::NINS; ++k) {
-        const int g = (k * NW + wave) * 64 + lane;     // 16-byte slot of the patch image
-        const int pp = g / Cfg::SPP, q = g - pp * Cfg::SPP;
-        const int lslot = q ^ (pp & 15);
-        const int py = pp / PW, px = pp - py * PW;
-        const int vy = ty0 + py - 1, vx = tx0 + px - 1;
-        const bool ok = vy >= 0 && vy < Hv && vx >= 0 && vx < Wv;
-        const int sy = ok ? (vy >> p.up_shift) : 0, sx = ok ? (vx >> p.up_shift) : 0;
-        glds_load_b128(xb + ((int64_t)sy * p.Win + sx) * CIN + lslot * 4, lds + (uint32_t)(k * NW + wave) * 1024);
-        zmask |= ok ? 0u : (1u << k);
-    }
-    glds_wait_all();
-    for (int k = 0; k * NW + wave < Cfg::NINS; ++k)
-        if ((zmask >> k) & 1) lds_write_f32x4(lds + (uint32_t)((k * NW + wave) * 64 + lane) * 16, zero_f32x4());
-    block_sync_lds();
+    conv_patch_fill<Cfg>(p, xb, ty0, tx0, wave, lane, lds);
 
     // ---- A fragment addressing
     int pp0[MB];                                        // patch pixel of tap (0, 0) for this lane's pixel
@@ -471,6 +556,183 @@ LWM_DEVICE void conv_patch_body(const ConvParams& p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The two ends of the network, where the generic kernel pads one GEMM dimension tenfold:
+//
+// conv_in (3 -> 128 at 256 x 256, lwm/vqgan.py:155): K per tap is Cin = 3, not a 32-channel chunk.  One k-quad per
+// tap -- two MFMAs per (tap, 32 x 32 block) instead of sixteen, the fourth channel an exact zero -- with the A operand
+// read straight from global memory (12 bytes per pixel: the image stays in L1/L2) and the B operand, all 9 x 4 x NB
+// floats of a lane's columns, resident in registers.  No LDS, no barrier; bound by the output write.
+// Same arithmetic and order as the generic kernel: P_t = the fma chain over c_in from 0 (zeros add nothing),
+// s = s + P_t in tap order.
+constexpr int kCinPB = 4;        // 32-pixel blocks per wave
+template <int NB>
+LWM_DEVICE void conv_cin4_body(const ConvParams& p) {
+    const int tid = thread_idx();
+    const int wave = wave_uniform(tid >> 6), lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int ntn = p.Cout / (32 * NB);
+    const int bn = block_idx_x() % ntn;
+    const int64_t bm = block_idx_x() / ntn;
+    const int n0 = bn * 32 * NB;
+
+    float bq[9][2][NB];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int ci = 2 * t + hi;
+            const bool ok = ci < p.Cin;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const float v = p.w[(int64_t)(tap * p.Cin + (ok ? ci : 0)) * p.Cout + n0 + j * 32 + l31];
+                bq[tap][t][j] = ok ? v : 0.0f;
+            }
+        }
+    float bv[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) bv[j] = p.bias ? p.bias[n0 + j * 32 + l31] : 0.0f;
+    const int Hv = p.Hin << p.up_shift, Wv = p.Win << p.up_shift;
+
+#pragma unroll 1
+    for (int pb = 0; pb < kCinPB; ++pb) {
+        const int64_t mb = (bm * 4 + wave) * (kCinPB * 32) + pb * 32;      // first pixel of the block (uniform)
+        if (mb >= p.M) break;
+        const int64_t m = mb + l31 < p.M ? mb + l31 : p.M - 1;
+        const bool mok = mb + l31 < p.M;
+        const int ox = (int)(m % p.Wo);
+        const int64_t tq = m / p.Wo;
+        const int oy = (int)(tq % p.Ho);
+        const float* xb = p.x + (tq / p.Ho) * (int64_t)p.Hin * p.Win * p.Cin;
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+        float av[9][2];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            const int vy = iy0 + kh, vx = ix0 + kw;
+            const bool ok = mok && vy >= 0 && vy < Hv && vx >= 0 && vx < Wv;
+            const int off = ok ? ((vy >> p.up_shift) * p.Win + (vx >> p.up_shift)) * p.Cin : 0;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int ci = 2 * t + hi;
+                const float v = xb[off + (ci < p.Cin ? ci : 0)];       // unconditional load, select afterwards
+                av[tap][t] = (ok && ci < p.Cin) ? v : 0.0f;
+            }
+        }
+        f32x16 acc[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[j] = zero_f32x16();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            f32x16 pt[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) pt[j] = mfma_32x32x2_f32(av[tap][0], bq[tap][0][j], zero_f32x16());
+#pragma unroll
+            for (int j = 0; j < NB; ++j) pt[j] = mfma_32x32x2_f32(av[tap][1], bq[tap][1][j], pt[j]);
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                for (int r = 0; r < 16; ++r) acc[j][r] = acc[j][r] + pt[j][r];
+            sched_fence();      // (the taps are independent: left alone, hipcc issues all 72 MFMAs first -- 36 tuples live)
+        }
+        float* const yb = p.y + mb * p.Cout + n0;
+        const float* const rb = p.res ? p.res + mb * p.Cout + n0 : p.y;
+        const int64_t left = p.M - mb;
+        const int rows = left < 32 ? (int)left : 32;
+        auto store = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value != 0;
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const uint32_t off = (uint32_t)((FULL || ml < rows) ? ml : rows - 1) * (uint32_t)p.Cout + (uint32_t)(j * 32 + l31);
+                    float v = acc[j][r];
+                    if (p.bias) v = v + bv[j];
+                    if (p.res) v = v + rb[off];
+                    if (p.clip) v = v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);
+                    if (FULL || ml < rows) yb[off] = v;
+                }
+        };
+        if (rows == 32) store(IntTag<1>{});
+        else store(IntTag<0>{});
+    }
+}
+LWM_KERNEL(256) void conv_cin4_n128(ConvParams p) { conv_cin4_body<4>(p); }
+
+// conv_out (128 -> 3 at 256 x 256, lwm/vqgan.py:185 / the decoder's last layer): N is Cout = 3, not a 32-column MFMA
+// block.  On the vector pipe: a lane owns one pixel of a 4 x 16 tile whose halo patch sits in LDS exactly as for
+// conv_patch_c128; the weights of a (tap, c_in) are wave-uniform -- scalar loads, SGPR operands of v_fma_f32 -- and
+// the four waves take the taps round robin (P_t are independent chains), leave them in LDS, and wave 0 adds them in
+// tap order.  v_fma_f32 is the fma the MFMA performs per k step: same bits.
+template <int CIN, int COUT>
+struct PatchOutCfg {
+    using Patch = PatchCfg<CIN, 4, 2, 2, 1>;                 // 64 pixels, 4 waves (the tile shape is all that is used)
+    static constexpr int OFF_PART = Patch::LDS_BYTES;          // [9 taps][64 pixels] x 16 bytes
+    static constexpr int LDS_BYTES = OFF_PART + 9 * 64 * 16;
+    static_assert(COUT >= 1 && COUT <= 4, "one 16-byte partial per pixel and tap");
+};
+template <int CIN, int COUT>
+LWM_DEVICE void conv_patch_cout_body(const ConvParams& p) {
+    using Cfg = PatchOutCfg<CIN, COUT>;
+    using PC = typename Cfg::Patch;
+    const lds_t lds = dyn_lds();
+    const int tid = thread_idx();
+    const int wave = wave_uniform(tid >> 6), lane = tid & 63;
+    int64_t bm = block_idx_x();
+    const int tiles_x = p.Wo / PC::TW, tiles_y = p.Ho / 4;
+    const int tx0 = (int)(bm % tiles_x) * PC::TW;
+    bm /= tiles_x;
+    const int ty0 = (int)(bm % tiles_y) * 4;
+    const int b = (int)(bm / tiles_y);
+    conv_patch_fill<PC>(p, p.x + (int64_t)b * p.Hin * p.Win * CIN, ty0, tx0, wave, lane, lds);
+
+    const int pp0 = (lane / PC::TW) * PC::PW + (lane % PC::TW);
+    for (int tap = wave; tap < 9; tap += 4) {
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        const int pp = pp0 + kh * PC::PW + kw;
+        const float* wt = p.w + (int64_t)tap * CIN * COUT;          // wave-uniform
+        const lds_t row = lds + (uint32_t)pp * PC::ROWB;
+        const int sw = pp & 15;
+        float s[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) s[co] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < CIN / 4; ++q) {
+            const f32x4 a = lds_read_f32x4(row + (uint32_t)((q ^ sw) << 4));
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) s[co] = fmaf(a[c], uniform_load_f32(wt, (4 * q + c) * COUT + co), s[co]);
+        }
+        f32x4 o = zero_f32x4();
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) o[co] = s[co];
+        lds_write_f32x4(lds + Cfg::OFF_PART + (uint32_t)(tap * 64 + lane) * 16, o);
+    }
+    block_sync();
+    if (wave == 0) {
+        float acc[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = 0.0f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const f32x4 o = lds_read_f32x4(lds + Cfg::OFF_PART + (uint32_t)(tap * 64 + lane) * 16);
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) acc[co] = acc[co] + o[co];
+        }
+        const int64_t pix = ((int64_t)b * p.Ho + ty0 + lane / PC::TW) * p.Wo + tx0 + lane % PC::TW;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            float v = acc[co];
+            if (p.bias) v = v + p.bias[co];
+            if (p.res) v = v + p.res[pix * COUT + co];
+            if (p.clip) v = v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);
+            p.y[pix * COUT + co] = v;
+        }
+    }
+}
+using PatchOutC128 = PatchOutCfg<128, 3>;
+LWM_KERNEL_OCC(256, 2) void conv_patch_c128_out3(ConvParams p) { conv_patch_cout_body<128, 3>(p); }
+
 // (an 8 x 16-pixel tile with 8 waves for 128 input channels -- 90 KiB, one workgroup per CU -- measured 2-3 %
 // slower than two 4 x 16 workgroups; 64 x 128-channel tiles with 8 waves for 256 input channels 12 % slower than
 // 64 x 256; a 2 x 16-pixel x 256-channel tile for 512 input channels -- 144 KiB -- no faster than the generic
@@ -479,8 +741,11 @@ using PatchC128 = PatchCfg<128, 4, 2, 2, 2>;   // 64 pixels x 128 channels, 4 wa
 using PatchC256 = PatchCfg<256, 4, 2, 4, 2>;   // 64 pixels x 256 channels, 8 waves, 108 KiB
 LWM_KERNEL_OCC(256, 2) void conv_patch_c128(ConvParams p) { conv_patch_body<128, 4, 2, 2, 2>(p); }
 LWM_KERNEL(512) void conv_patch_c256(ConvParams p) { conv_patch_body<256, 4, 2, 4, 2>(p); }
+// (256 -> 128 channels with this patch and 4 waves x (32 pixels x 64 channels), one wave per SIMD: 92.9 TF/s against
+// 102.3 for the generic kernel and 108 for its B-direct form: dropped)
 
 LWM_KERNEL_OCC(256, 2) void conv_igemm_128x128(ConvParams p) { conv_igemm_body<2, 2, 2, 2, true>(p); }
+LWM_KERNEL_OCC(256, 2) void conv_igemm_128x128_bd(ConvParams p) { conv_igemm_body<2, 2, 2, 2, true, true>(p); }
 LWM_KERNEL(256) void conv_igemm_128x64(ConvParams p) { conv_igemm_body<4, 1, 1, 2, true>(p); }
 LWM_KERNEL(256) void conv_igemm_32x128(ConvParams p) { conv_igemm_body<1, 4, 1, 1, true>(p); }
 // generic (scalar staging) forms: Cin or Cout not a multiple of 4

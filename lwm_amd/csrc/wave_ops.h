@@ -203,6 +203,12 @@ LWM_DEVICE float global_load_f32_at(const float* base, uint32_t voff, uint32_t s
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
 
+// a float every lane of the wave reads from the same address of read-only memory: a scalar load (s_load_dword, the
+// value lands in an SGPR and can be an operand of a vector instruction directly)
+LWM_DEVICE float uniform_load_f32(const float* p, int idx) {
+    return ((const __attribute__((address_space(4))) float*)p)[idx];
+}
+
 LWM_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
     union { bf16_t h[2]; uint32_t u; } x;
     x.h[0] = (bf16_t)lo;

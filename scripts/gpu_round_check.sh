@@ -3,7 +3,8 @@
 #   1. pytest -m gpu (with the 30 slowest tests)        -> gpurun_out/$TAG/tests.txt
 #   2. __graft_entry__.smoke()                           -> gpurun_out/$TAG/smoke.txt
 #   3. the driver's bench command                        -> gpurun_out/$TAG/bench.json (+ bench.err)
-#   4. rocprofv3 --kernel-trace --stats, 4 layers        -> gpurun_out/$TAG/kernel_stats.csv
+#   4. rocprofv3 --kernel-trace --stats, 4 layers, main workload only (every launch of a kernel has the bench line's
+#      shape, so the average durations are comparable)   -> gpurun_out/$TAG/kernel_stats.csv
 # STEPS="tests smoke bench prof" selects (default all).  Copy what should be judged into profiles/.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; export TMPDIR=/tmp
 T=${TAG:-round}; O=$R/gpurun_out/$T; mkdir -p $O
@@ -31,7 +32,7 @@ fi
 if [[ " $STEPS " == *" prof "* ]]; then
   cd /tmp; rm -rf /tmp/prof_$T
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$T -o ks -- \
-      python $R/bench.py --steps 1 --warmup 0 --layers 4 --no-cpu-baseline > $O/prof.log 2>&1
+      python $R/bench.py --steps 3 --warmup 1 --layers 4 --no-cpu-baseline --no-vqgan > $O/prof.log 2>&1
   f=$(find /tmp/prof_$T -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp $f $O/kernel_stats.csv && head -8 $O/kernel_stats.csv
 fi

@@ -40,6 +40,8 @@ __global__ void bit_sum(const uint32_t* p, size_t n, unsigned long long* out) {
 struct Shape {
     const char* name;
     int H, W, Cin, Cout, up, res;
+    int stride = 1;      // 2 = Downsample: pad 0 (the zero pad bottom / right is the out-of-image rule), Ho = H / 2
+    int listed = 1;      // part of the "listed layers" total (the set of rounds 2-3)
 };
 
 int main(int argc, char** argv) {
@@ -69,6 +71,14 @@ int main(int argc, char** argv) {
         {"dec up 32^2->64^2 512->512", 32, 32, 512, 512, 1, 0},
         {"dec 64^2 512->256", 64, 64, 512, 256, 0, 0},
         {"16^2 768->768 (+res)", 16, 16, 768, 768, 0, 1},
+        // the rest of the network's shapes (not in the total above)
+        {"enc conv_in 256^2 3->128", 256, 256, 3, 128, 0, 0, 1, 0},
+        {"dec conv_out 256^2 128->3", 256, 256, 128, 3, 0, 0, 1, 0},
+        {"dec 256^2 256->128", 256, 256, 256, 128, 0, 0, 1, 0},
+        {"enc down 256^2->128^2 128->128", 256, 256, 128, 128, 0, 0, 2, 0},
+        {"enc down 128^2->64^2 256->256", 128, 128, 256, 256, 0, 0, 2, 0},
+        {"dec up 16^2->32^2 768->768", 16, 16, 768, 768, 1, 0, 1, 0},
+        {"dec 32^2 768->512", 32, 32, 768, 512, 0, 0, 1, 0},
     };
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
@@ -77,7 +87,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dsum, 8));
     double tot_flop = 0, tot_ms = 0;
     for (const Shape& s : shapes) {
-        const int Ho = s.H << s.up, Wo = s.W << s.up;
+        const int Ho = s.stride == 2 ? s.H / 2 : s.H << s.up, Wo = s.stride == 2 ? s.W / 2 : s.W << s.up;
         const size_t nx = (size_t)B * s.H * s.W * s.Cin, nw = (size_t)9 * s.Cin * s.Cout, ny = (size_t)B * Ho * Wo * s.Cout;
         float *x, *w, *bias, *res, *y;
         CK(hipMalloc(&x, nx * 4));
@@ -93,7 +103,7 @@ int main(int argc, char** argv) {
         memset(&a, 0, sizeof(a));
         a.x = x; a.w = w; a.bias = bias; a.residual = s.res ? res : nullptr; a.y = y;
         a.B = B; a.Hin = s.H; a.Win = s.W; a.Cin = s.Cin; a.Cout = s.Cout; a.KH = 3; a.KW = 3;
-        a.stride = 1; a.pad = 1; a.up_shift = s.up; a.Ho = Ho; a.Wo = Wo;
+        a.stride = s.stride; a.pad = s.stride == 2 ? 0 : 1; a.up_shift = s.up; a.Ho = Ho; a.Wo = Wo;
         if (conv(&a, nullptr) != 0) {
             fprintf(stderr, "conv: %s\n", last_error());
             return 2;
@@ -111,8 +121,10 @@ int main(int argc, char** argv) {
         unsigned long long h = 0;
         CK(hipMemcpy(&h, dsum, 8, hipMemcpyDeviceToHost));
         const double flop = 2.0 * B * Ho * Wo * 9.0 * s.Cin * s.Cout;
-        tot_flop += flop;
-        tot_ms += ms;
+        if (s.listed) {
+            tot_flop += flop;
+            tot_ms += ms;
+        }
         printf("  %-34s %8.3f ms  %6.1f TF/s  %.3f of roof  bits %016llx\n", s.name, ms, flop / ms * 1e-9, flop / ms * 1e-9 / 157.3, h);
         CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(bias)); CK(hipFree(res)); CK(hipFree(y));
     }

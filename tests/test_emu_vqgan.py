@@ -31,6 +31,12 @@ def _conv_case(seed, B, H, W, Cin, Cout, k, **kw):
     (1, 16, 16, 64, 64, 1, {}),                                    # 1x1 (quant_conv)
     (1, 16, 16, 32, 128, 3, dict(stride=2, pad=0, out_hw=(8, 8))), # Downsample
     (1, 6, 6, 32, 128, 3, dict(up_shift=1)),                       # Upsample
+    (1, 48, 32, 64, 256, 3, {}),                                   # 24 tiles of 128x128: the B-direct generic kernel
+    (1, 95, 65, 32, 128, 3, dict(stride=2, pad=0, out_hw=(47, 32))),  # ... with a stride and a ragged last tile (Downsample)
+    (2, 21, 13, 3, 256, 3, {}),                                    # conv_cin4: ragged M, two channel tiles
+    (1, 13, 9, 3, 128, 3, dict(stride=2, pad=0, out_hw=(6, 4))),   # conv_cin4 with a stride
+    (2, 8, 32, 128, 3, 3, dict(clip=True)),                        # conv_patch_c128_out3
+    (1, 4, 16, 128, 3, 3, dict(up_shift=1)),                       # ... over the upsampled image
 ])
 def test_conv_bit_exact(B, H, W, Cin, Cout, k, kw):
     x, w, b = _conv_case(1, B, H, W, Cin, Cout, k)

@@ -36,6 +36,10 @@ def _conv_inputs(seed, B, H, W, Cin, Cout, k):
     (1, 64, 64, 256, 256, 3, dict(stride=2, pad=0, out_hw=(32, 32))),  # Downsample
     (1, 32, 32, 256, 256, 3, dict(up_shift=1)),                     # Upsample
     (1, 21, 13, 40, 200, 3, {}),                                    # ragged everything
+    (2, 21, 13, 3, 256, 3, {}),                                     # conv_cin4: ragged M, two channel tiles
+    (1, 33, 17, 3, 128, 3, dict(stride=2, pad=0, out_hw=(16, 8))),  # conv_cin4 with a stride
+    (2, 8, 48, 128, 3, 3, dict(clip=True)),                         # conv_patch_c128_out3 (W % 16 == 0, H % 4 == 0)
+    (1, 8, 16, 128, 3, 3, dict(up_shift=1)),                        # ... over the upsampled image, no clip
 ])
 def test_conv_bit_exact(B, H, W, Cin, Cout, k, kw):
     import torch
