@@ -484,15 +484,17 @@ LWM_DEVICE void conv_patch_body(const ConvParams& p) {
         }
     };
 
-    f32x16 acc[MB][NB], acc_tap[MB][NB];
+    // P_t has two register tiles, by tap parity: the sum s = s + P_t of a finished tap is spread over the gaps of the
+    // NEXT tap's first (tap, chunk) -- the matrix pipe never waits for it -- and the first MFMA of a tap takes C = 0
+    // (no tile is ever zeroed).
+    f32x16 acc[MB][NB], pt[2][MB][NB];
     for (int i = 0; i < MB; ++i)
-        for (int j = 0; j < NB; ++j) {
-            acc[i][j] = zero_f32x16();
-            acc_tap[i][j] = zero_f32x16();
-        }
+        for (int j = 0; j < NB; ++j) acc[i][j] = zero_f32x16();
 
-    auto tile = [&](int it, auto set_tag) {
-        constexpr int SET = decltype(set_tag)::value;
+    // SET: B register set; PSET: P_t tile; FIRST: first (tap, chunk) of a tap; ADD: s = s + P_{t-1} rides along
+    auto tile = [&](int it, auto set_tag, auto pset_tag, auto first_tag, auto add_tag) {
+        constexpr int SET = decltype(set_tag)::value, PSET = decltype(pset_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value != 0, ADD = decltype(add_tag)::value != 0;
         if (it + 1 < nit) load_b(it + 1, SET ^ 1);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -504,23 +506,37 @@ LWM_DEVICE void conv_patch_body(const ConvParams& p) {
             for (int t = 0; t < 2; ++t)
                 for (int i = 0; i < MB; ++i) {
                     const float af = hi ? ar[as][i][2 * t + 1] : ar[as][i][2 * t];
-                    for (int j = 0; j < NB; ++j) acc_tap[i][j] = mfma_32x32x2_f32(af, bq[SET][u][t][j], acc_tap[i][j]);
+                    for (int j = 0; j < NB; ++j)
+                        pt[PSET][i][j] = mfma_32x32x2_f32(af, bq[SET][u][t][j], (FIRST && u == 0 && t == 0) ? zero_f32x16() : pt[PSET][i][j]);
                 }
+            if (ADD && u >= 2 && u < 6) {       // a quarter of the previous tap's sum per k-quad (its last MFMA retired long ago)
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+#pragma unroll
+                        for (int r = 4 * (u - 2); r < 4 * (u - 2) + 4; ++r) acc[i][j][r] = acc[i][j][r] + pt[PSET ^ 1][i][j][r];
+            }
             sched_fence();
         }
     };
-    load_a(0, 0, 0);
-    for (int tap = 0; tap < 9; ++tap) {
-        for (int ch = 0; ch < NCH; ch += 2) {          // (NCH is even: the register sets alternate 0, 1)
-            tile(tap * NCH + ch, IntTag<0>{});
-            tile(tap * NCH + ch + 1, IntTag<1>{});
+    auto tap_body = [&](int tap, auto pset_tag, auto add_tag) {
+        tile(tap * NCH, IntTag<0>{}, pset_tag, IntTag<1>{}, add_tag);
+        tile(tap * NCH + 1, IntTag<1>{}, pset_tag, IntTag<0>{}, IntTag<0>{});
+        for (int ch = 2; ch < NCH; ch += 2) {          // (NCH is even: the B register sets alternate 0, 1)
+            tile(tap * NCH + ch, IntTag<0>{}, pset_tag, IntTag<0>{}, IntTag<0>{});
+            tile(tap * NCH + ch + 1, IntTag<1>{}, pset_tag, IntTag<0>{}, IntTag<0>{});
         }
-        for (int i = 0; i < MB; ++i)                   // tap finished: s = s + P_t
-            for (int j = 0; j < NB; ++j) {
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] + acc_tap[i][j][r];
-                acc_tap[i][j] = zero_f32x16();
-            }
+    };
+    load_a(0, 0, 0);
+    tap_body(0, IntTag<0>{}, IntTag<0>{});
+    for (int tap = 1; tap < 9; tap += 2) {
+        tap_body(tap, IntTag<1>{}, IntTag<1>{});
+        tap_body(tap + 1, IntTag<0>{}, IntTag<1>{});
     }
+    for (int i = 0; i < MB; ++i)                        // the last tap (8: parity 0)
+        for (int j = 0; j < NB; ++j)
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] + pt[0][i][j][r];
 
     // ---- epilogue: + bias [+ residual] [clip].  Offsets are 32-bit inside the tile (uniform 64-bit base); the
     // 16 residual reads of an accumulator are issued together (a rolled loop would wait for each in turn).
@@ -559,7 +575,7 @@ LWM_DEVICE void conv_patch_body(const ConvParams& p) {
 // ---------------------------------------------------------------------------------------------------
 // The two ends of the network, where the generic kernel pads one GEMM dimension tenfold:
 //
-// conv_in (3 -> 128 at 256 x 256, lwm/vqgan.py:155): K per tap is Cin = 3, not a 32-channel chunk.  One k-quad per
+// conv_in (3 -> 128 at 256 x 256, lwm/vqgan.py:155; 64-column tiles, two waves per SIMD): K per tap is Cin = 3, not a 32-channel chunk.  One k-quad per
 // tap -- two MFMAs per (tap, 32 x 32 block) instead of sixteen, the fourth channel an exact zero -- with the A operand
 // read straight from global memory (12 bytes per pixel: the image stays in L1/L2) and the B operand, all 9 x 4 x NB
 // floats of a lane's columns, resident in registers.  No LDS, no barrier; bound by the output write.
@@ -656,7 +672,7 @@ LWM_DEVICE void conv_cin4_body(const ConvParams& p) {
         else store(IntTag<0>{});
     }
 }
-LWM_KERNEL(256) void conv_cin4_n128(ConvParams p) { conv_cin4_body<4>(p); }
+LWM_KERNEL_OCC(256, 2) void conv_cin4_n64(ConvParams p) { conv_cin4_body<2>(p); }
 
 // conv_out (128 -> 3 at 256 x 256, lwm/vqgan.py:185 / the decoder's last layer): N is Cout = 3, not a 32-column MFMA
 // block.  On the vector pipe: a lane owns one pixel of a 4 x 16 tile whose halo patch sits in LDS exactly as for
