@@ -50,6 +50,8 @@ int main(int argc, char** argv) {
         return 2;
     }
     const int B = argc > 2 ? atoi(argv[2]) : 32, reps = argc > 3 ? atoi(argv[3]) : 3;
+    // LWM_BENCH_AMP=0: all-zero operands (same instruction stream, no operand toggling: separates the clock from the kernel)
+    const float amp = getenv("LWM_BENCH_AMP") ? (float)atof(getenv("LWM_BENCH_AMP")) : 1.0f;
     void* lib = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
     if (!lib) {
         fprintf(stderr, "dlopen: %s\n", dlerror());
@@ -95,10 +97,10 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&bias, s.Cout * 4));
         CK(hipMalloc(&res, ny * 4));
         CK(hipMalloc(&y, ny * 4));
-        fill_f32<<<2048, 256>>>(x, nx, 1u, 1.0f);
-        fill_f32<<<256, 256>>>(w, nw, 2u, 0.03f);
+        fill_f32<<<2048, 256>>>(x, nx, 1u, 1.0f * amp);
+        fill_f32<<<256, 256>>>(w, nw, 2u, 0.03f * amp);
         fill_f32<<<1, 256>>>(bias, s.Cout, 3u, 0.1f);
-        fill_f32<<<2048, 256>>>(res, ny, 4u, 1.0f);
+        fill_f32<<<2048, 256>>>(res, ny, 4u, 1.0f * amp);
         LwmConvArgs a;
         memset(&a, 0, sizeof(a));
         a.x = x; a.w = w; a.bias = bias; a.residual = s.res ? res : nullptr; a.y = y;
