@@ -166,12 +166,12 @@ def test_ring8_at_config3_shard_shapes_vs_oracle(schedule, packed):
                                                   causal=True, q_start=r0, out_saved=f(out, rows, h))
             _check(f"out ring8 row {r0}", f(out, rows, h), ro)
             _check_dq(f"dq ring8 row {r0}", f(dq, rows, h), rq, rqx)
-        K0, h = S - 256, 1
+        K0, h = S - 512, 1
         rows, allk = slice(K0, S), slice(0, S)
         _, rk, rv = R.dense_attention_bwd(f(q, rows, h), f(k, allk, h), f(v, allk, h), f(do, rows, h),
                                           causal=True, q_start=K0)
-        _check("dk ring8 last keys", f(dk, slice(K0, K0 + 128), h), rk[:, K0:K0 + 128])
-        _check("dv ring8 last keys", f(dv, slice(K0 + 128, S), h), rv[:, K0 + 128:])
+        _check("dk ring8 last keys", f(dk, slice(K0, K0 + 256), h), rk[:, K0:K0 + 256])
+        _check("dv ring8 last keys", f(dv, slice(K0 + 256, S), h), rv[:, K0 + 256:])
         return
     for i, (a, b, w0) in enumerate(_doc_windows(bounds)):
         # a document longer than 30000 rows is too much for a dense fp64 oracle: its last rows only need

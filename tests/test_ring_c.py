@@ -354,11 +354,11 @@ def test_c_ring8_at_configs3_and_4_shard_shapes_vs_oracle(S, packed):
         rq, _, _, rqx = R.dense_attention_bwd(f(q, rows), f(k, keys), f(v, keys), f(do, rows), causal=True, q_start=r0, out_saved=f(out, rows))
         check(f"out c-ring8@256K row {r0}", f(out, rows), ro)
         check_dq(f"dq c-ring8@256K row {r0}", f(dq, rows), rq, rqx)
-    K0 = S - 256
+    K0 = S - 512
     rows, allk = slice(K0, S), slice(0, S)
     _, rk, rv = R.dense_attention_bwd(f(q, rows), f(k, allk), f(v, allk), f(do, rows), causal=True, q_start=K0)
-    check("dk c-ring8@256K last keys", f(dk, slice(K0, K0 + 128)), rk[:, K0:K0 + 128])
-    check("dv c-ring8@256K last keys", f(dv, slice(K0 + 128, S)), rv[:, K0 + 128:])
+    check("dk c-ring8@256K last keys", f(dk, slice(K0, K0 + 256)), rk[:, K0:K0 + 256])
+    check("dv c-ring8@256K last keys", f(dv, slice(K0 + 256, S)), rv[:, K0 + 256:])
 
 
 @pytest.mark.gpu
