@@ -701,6 +701,9 @@ def main():
     ap.add_argument("--packed-1m", action="store_true", help="(default since round 4; kept for old command lines)")
     ap.add_argument("--no-packed-1m", action="store_true",
                     help="N = 1: skip the 1M-token packed-documents leg (BASELINE configs[4]'s problem on one GPU, ~25 s)")
+    ap.add_argument("--force-configs34", action="store_true",
+                    help="(functional check) run the configs3 / configs4 legs even when the ranks share a GPU (--backend gloo "
+                         "--transport ipc): the IPC mailboxes are then sized for c = 1048576 / N")
     ap.add_argument("--no-configs34", action="store_true",
                     help="N > 1: skip the S = 262144 (BASELINE configs[3]) and packed S = 1048576 (configs[4]) legs of the line")
     args = ap.parse_args()
@@ -809,7 +812,9 @@ def main():
     S2 = 131072                     # BASELINE configs[2]'s sequence: a second leg of every N > 1 line
     if args.driver == "c" and world > 1:
         from lwm_amd.ring_c import CRing
-        c_max = max(c, S2 // world if not args.no_configs2 else 0)      # (configs3 / configs4 do not run over the IPC transport)
+        c_max = max(c, S2 // world if not args.no_configs2 else 0)      # (configs3 / configs4 do not run over the IPC transport ...
+        if args.force_configs34:                                       #  ... unless asked to)
+            c_max = max(c_max, (1 << 20) // world)
         c_ring = CRing(dist.group.WORLD, transport=args.transport, layout=args.layout, schedule=sched_c,
                        ipc_slot_bytes=c_max * N_HEADS * HEAD_DIM * 4, ipc_slots=4)      # (B = 1: at most 4 messages per pair and group)
 
@@ -1045,7 +1050,7 @@ def main():
             return {"error": repr(e)[:500]}
 
     configs3 = configs4 = None
-    if world > 1 and not args.no_configs34 and not args.packed and not shared:
+    if world > 1 and not args.no_configs34 and not args.packed and (not shared or args.force_configs34):
         torch.cuda.empty_cache()
         configs3 = other_config("configs[3] sequence (262144 tokens; its VQGAN tokenisation is the `vqgan` leg of the N = 1 line)", 262144, 2, False)
         torch.cuda.empty_cache()
