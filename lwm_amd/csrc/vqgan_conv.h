@@ -65,6 +65,23 @@ struct ConvCfg {
 template <int N>
 struct IntTag { static constexpr int value = N; };
 
+// A operand of one f32 MFMA: lane half hi supplies k = hi of the k pair, i.e. element 2t + hi of the lane's channel
+// quad.  Written as `hi ? q[2t+1] : q[2t]` hipcc turns it into a dynamic vector index and lowers that to a chain of
+// three v_cndmask (+ compares) per element; a bitfield insert under a lane mask the compiler cannot see through is one
+// v_bfi_b32.
+struct HiMask { uint32_t m; };
+LWM_DEVICE HiMask hi_mask(int hi) {
+    HiMask h = {hi ? 0xffffffffu : 0u};
+#ifndef LWM_EMU
+    asm volatile("" : "+v"(h.m));
+#endif
+    return h;
+}
+LWM_DEVICE float pick_hi(float even, float odd, HiMask h) {
+    return __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, odd) & h.m) | (__builtin_bit_cast(uint32_t, even) & ~h.m));
+}
+
+
 LWM_DEVICE f32x4 zero_f32x4() {
     f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
     return z;
@@ -87,6 +104,7 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
     const int tid = thread_idx();
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
+    const HiMask hm = hi_mask(hi);
 
     const int ntn = (p.Cout + BN - 1) / BN;
     const int64_t bm = block_idx_x() / ntn;
@@ -135,22 +153,38 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
     // Measured alternatives: issuing them one per k-quad inside the MFMA loop
     // instead of as a burst, or delaying co-resident workgroups against each other, do not
     // help; without any staging the loop runs 125 TF/s, with it 100 TF/s.
+    // The chunks are staged in order (0, 1, 2, ...): (tap, chunk) is a running counter, and what depends on the tap only
+    // -- where the tap's pixel of each staged row lies in its image, or that it lies outside -- is computed when the tap
+    // changes, not per chunk (a_tap: element offset inside the image, -1 = zero fill).
     int ld_kh = 0, ld_kw = 0, ld_ch = 0, ld_tap = 0;
-    auto stage_begin = [&](int it) {
-        ld_tap = it / nch;
-        ld_ch = it - ld_tap * nch;
-        ld_kh = ld_tap / p.KW;
-        ld_kw = ld_tap - ld_kh * p.KW;
-        s_ok = 0;
+    int a_tap[AP];
+    auto stage_tap = [&]() {
+#pragma unroll
+        for (int ps = 0; ps < AP; ++ps) {
+            const int vy = a_oy[ps] + ld_kh, vx = a_ox[ps] + ld_kw;
+            const bool ok = a_base[ps] >= 0 && vy >= 0 && vy < Hv && vx >= 0 && vx < Wv;
+            a_tap[ps] = ok ? ((vy >> p.up_shift) * p.Win + (vx >> p.up_shift)) * p.Cin : -1;
+        }
+    };
+    stage_tap();
+    auto stage_begin = [&](int) { s_ok = 0; };
+    auto stage_end = [&]() {           // advance to the next (tap, chunk)
+        if (++ld_ch == nch) {
+            ld_ch = 0;
+            ++ld_tap;
+            if (++ld_kw == p.KW) {
+                ld_kw = 0;
+                ++ld_kh;
+            }
+            stage_tap();
+        }
     };
     auto stage_load_one = [&](int l) {
         if (l < AP) {
             const int ps = l;
             const int c0 = ld_ch * kConvKC + a_slot * 4;
-            const int vy = a_oy[ps] + ld_kh, vx = a_ox[ps] + ld_kw;
-            const bool ok = a_base[ps] >= 0 && vy >= 0 && vy < Hv && vx >= 0 && vx < Wv && c0 < p.Cin;
-            const int64_t off = ok ? a_base[ps] + ((int64_t)(vy >> p.up_shift) * p.Win + (vx >> p.up_shift)) * p.Cin + c0
-                                   : (int64_t)0;
+            const bool ok = a_tap[ps] >= 0 && c0 < p.Cin;
+            const int64_t off = ok ? a_base[ps] + (int64_t)(a_tap[ps] + c0) : (int64_t)0;
             const float* src = p.x + off;
             if constexpr (cin_vec) {
                 sa[ps] = global_load_f32x4(src);
@@ -179,10 +213,11 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
             s_ok |= ok ? (1u << (8 + ps)) : 0u;
         }
     };
-    auto stage_load = [&](int it) {
+    auto stage_load = [&](int it) {      // (calls come in chunk order)
         stage_begin(it);
 #pragma unroll
         for (int l = 0; l < AP + BP; ++l) stage_load_one(l);
+        stage_end();
     };
     auto stage_write = [&](uint32_t bo) {       // bo = byte offset of the buffer
         for (int ps = 0; ps < AP; ++ps) {
@@ -261,7 +296,7 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     float af[MB];
-                    for (int i = 0; i < MB; ++i) af[i] = hi ? ar[set][i][2 * t + 1] : ar[set][i][2 * t];
+                    for (int i = 0; i < MB; ++i) af[i] = pick_hi(ar[set][i][2 * t], ar[set][i][2 * t + 1], hm);
                     for (int i = 0; i < MB; ++i)
                         for (int j = 0; j < NB; ++j)
                             acc_tap[i][j] = mfma_32x32x2_f32(af[i], bq[(u >> 1) & 1][u & 1][t][j], acc_tap[i][j]);
@@ -310,7 +345,7 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 float af[MB];
-                for (int i = 0; i < MB; ++i) af[i] = hi ? ar[set][i][2 * t + 1] : ar[set][i][2 * t];
+                for (int i = 0; i < MB; ++i) af[i] = pick_hi(ar[set][i][2 * t], ar[set][i][2 * t + 1], hm);
                 for (int i = 0; i < MB; ++i)
                     for (int j = 0; j < NB; ++j)
                         acc_tap[i][j] = mfma_32x32x2_f32(af[i], bf[set][t][j], acc_tap[i][j]);
@@ -438,6 +473,7 @@ LWM_DEVICE void conv_patch_body(const ConvParams& p) {
     const int tid = thread_idx();
     const int wave = wave_uniform(tid >> 6), lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
+    const HiMask hm = hi_mask(hi);
 
     const int ntn = p.Cout / BN;
     const int bn = block_idx_x() % ntn;
@@ -505,7 +541,7 @@ LWM_DEVICE void conv_patch_body(const ConvParams& p) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
                 for (int i = 0; i < MB; ++i) {
-                    const float af = hi ? ar[as][i][2 * t + 1] : ar[as][i][2 * t];
+                    const float af = pick_hi(ar[as][i][2 * t], ar[as][i][2 * t + 1], hm);
                     for (int j = 0; j < NB; ++j)
                         pt[PSET][i][j] = mfma_32x32x2_f32(af, bq[SET][u][t][j], (FIRST && u == 0 && t == 0) ? zero_f32x16() : pt[PSET][i][j]);
                 }
