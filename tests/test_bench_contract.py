@@ -1,5 +1,5 @@
 """The bench line the driver consumes: the newest committed profiles/*_bench.json (written by
-`python bench.py --steps 3 --warmup 1` on an MI355X, scripts/gpu_r1_final.sh) must carry every field of the
+the driver's command `python bench.py --gpus 1 --steps 20 --warmup 5` on an MI355X, scripts/gpu_round_check.sh) must carry every field of the
 contract, with the metric and workload BASELINE.json names, a roofline object for the dominant kernel and a
 CPU baseline from the same run -- and bench.py must keep the command-line contract."""
 import glob
@@ -12,9 +12,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _latest():
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench.json")))
+    """rNN_bench.json is the line of round NN's last evidence pass; rNNx_bench.json (x = a, b, ...) are earlier passes."""
+    import re
+    files = []
+    for f in glob.glob(os.path.join(ROOT, "profiles", "*_bench.json")):
+        m = re.fullmatch(r"r(\d+)([a-z]*)_bench\.json", os.path.basename(f))
+        if m:
+            files.append(((int(m.group(1)), m.group(2) == "", m.group(2)), f))
     assert files, "no committed bench line under profiles/"
-    return json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    return json.loads(open(max(files)[1]).read().strip().splitlines()[-1])
 
 
 def test_committed_bench_line_follows_the_contract():
@@ -44,6 +50,14 @@ def test_committed_bench_line_follows_the_contract():
     assert c["config1"]["tokens_per_s"] > 0 and "configs[0]" in c["config1"]["workload"] and c["config1"]["cores"] >= c["cores"]
     assert [p["S"] for p in c["op_points"]] == [4096, 8192, 16384]
     assert d["vqgan"]["cpu_baseline"]["cores"] == c["config1"]["cores"]
+    # round 4: the one-wave-per-SIMD backward kernels; the 1M-token leg in the default line; where `traffic` comes from;
+    # cpu_baseline.value = the port's fastest operating point, scaled
+    assert {"attn_fwd64_kernel", "attn_bwd_delta_kernel", "attn_bwd_dkdv4_kernel", "attn_bwd_dq4_kernel"} <= set(d["kernels"])
+    assert r["kernel"] == "attn_bwd_dkdv4_kernel" and "traffic_source" in r
+    assert r["traffic_profile"] is None or r["traffic_profile"].startswith("profiles/r04")
+    assert d["packed_1m"]["s_per_layer"] > 0 and "S=1048576" in d["packed_1m"]["workload"]
+    best = max(p["gflops"] for p in c["op_points"])
+    assert abs(c["gflops"] - best) < 1e-6 * best
 
 
 def test_bench_cli_contract_without_a_gpu():
@@ -71,5 +85,6 @@ def test_bench_cli_contract_without_a_gpu():
     else:
         assert r.returncode == 0 and lines[-1]["n_gpus"] == 2 and lines[-1]["rccl_ranks_seen"] == 2
     h = subprocess.run([sys.executable, bench, "--help"], capture_output=True, text=True, timeout=300)
-    for flag in ("--gpus", "--steps", "--warmup", "--driver", "--transport", "--schedule", "--layout", "--no-configs2"):
+    for flag in ("--gpus", "--steps", "--warmup", "--driver", "--transport", "--schedule", "--layout", "--no-configs2",
+                 "--no-configs34", "--no-packed-1m"):
         assert flag in h.stdout
