@@ -550,7 +550,10 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
         auto clamp32 = [](int64_t x) -> int { return x > (1 << 30) ? (1 << 30) : (x < -(1 << 30) ? -(1 << 30) : (int)x); };
         const int wk_rel = clamp32(p.k_start + (int64_t)kbi * kD4BK + wave * 32 + 31 - p.q_start);   // the wave's last key
         const int k_rel = clamp32(k_pos - p.q_start) - 4 * hi;                                      // this lane's key
-        auto needs_mask = [&](int ub) -> bool { return HAS_META || (p.causal && ub < wk_rel); };
+        auto needs_causal = [&](int ub) -> bool { return p.causal && ub < wk_rel; };
+        // the wave's 32 keys all valid and of one segment?  (then a step whose 64 queries carry it needs no segment test)
+        const int32_t own_seg = wave_uniform(kseg);
+        const bool own_uniform = HAS_META && !wave_any(kseg != own_seg || kseg == kSegInvalid);
         auto rel_of = [&](int ub) -> int {
             if (!p.causal) return -64;
             const int d = k_rel - ub;
@@ -592,9 +595,10 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
         /* (the wait states sit in ONE statement on every path that needs them: with two, hipcc merges the tuples */ \
         /* of the two paths by copies placed right behind the last MFMA)                                         */ \
         if (!(HAS_PREV_)) d4_settle_t(rg.s);     /* no MFMA stands between the S chain and its first reader */       \
-        if (needs_mask(ub_)) {                                                                                      \
+        if ((HAS_META && !uni_) || needs_causal(ub_)) {                                                             \
             if (HAS_PREV_) d4_settle_t(rg.s);                                                                       \
-            d4_mask<HALF_, HAS_META>(cx, rg, rel_of(ub_), kseg);                                                    \
+            if (HAS_META && !uni_) d4_mask<HALF_, HAS_META>(cx, rg, rel_of(ub_), kseg);                             \
+            else d4_mask<HALF_, false>(cx, rg, rel_of(ub_), kseg);                                                  \
         }                                                                                                           \
     } while (0)
         // (-DLWM_PROF builds, scripts/micro/attn_bench with LWM_PROF_DUMP=1: s_memtime laps of the pipelined steps of the
@@ -637,7 +641,9 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
         }                                                                                                           \
         const uint32_t d_ = (((i) & 3) == 3) ? (uint32_t)(-3 * kD4SlotBytes) : (uint32_t)kD4SlotBytes;             \
         const uint32_t e_ = (((i) & 3) == 3) ? (uint32_t)(-3 * kD4StatBytes) : (uint32_t)kD4StatBytes;             \
+        const int32_t segw_ = HAS_META ? seg_step_word(cx.stat - 16 * hi + 2 * kD4BQ * 4, lane) : 0;                \
         d4_x<0, !(FIRST), PIPE>(cx, rg, kf, vf, vq, vdo, dm);                                                       \
+        const bool uni_ = HAS_META && seg_step_uniform(segw_, own_uniform, own_seg);                                \
         D4_LAP2(0);                                                                                                 \
         LWM_D4_MASK(0, !(FIRST), ub);                                                                               \
         D4_LAP2(1);                                                                                                 \
@@ -1092,7 +1098,11 @@ LWM_DEVICE void attn_bwd_dq4_body(const AttnParams& p) {
         const int wq_rel = clamp32(p.q_start + (int64_t)qbi * kQ4BQ + wave * 32 - p.k_start);      // the wave's first query
         const int q_rel = clamp32(p.q_start + q_row - p.k_start) - 4 * hi;                         // this lane's query
         // a unit (first key at row ub of the K/V block) needs the mask code when its last key lies after the wave's first query
-        auto needs_mask = [&](int ub) -> bool { return HAS_META || (p.causal && ub + 31 > wq_rel); };
+        auto needs_causal = [&](int ub) -> bool { return p.causal && ub + 31 > wq_rel; };
+        // the wave's 32 queries of one segment?  (then a step whose 64 keys carry it needs no segment test; rows past Sq
+        // are never stored and do not count)
+        const int32_t own_seg = wave_uniform(seg_q);
+        const bool own_uniform = HAS_META && !wave_any(q_ok && seg_q != own_seg);
         auto rel_of = [&](int ub) -> int {
             if (!p.causal) return 64;
             const int d = q_rel - ub;
@@ -1115,9 +1125,10 @@ LWM_DEVICE void attn_bwd_dq4_body(const AttnParams& p) {
 #define LWM_Q4_MASK(HALF_, HAS_PREV_, ub_)                                                                          \
     do {                                                                                                            \
         if (!(HAS_PREV_)) d4_settle_t(rg.s[HALF_]);     /* no MFMA stands between the S chain and its first reader */ \
-        if (needs_mask(ub_)) {                                                                                      \
+        if ((HAS_META && !uni_) || needs_causal(ub_)) {                                                             \
             if (HAS_PREV_) d4_settle_t(rg.s[HALF_]);                                                                \
-            q4_mask<HALF_, HAS_META>(cx, rg.s[HALF_], rel_of(ub_), seg_q);                                          \
+            if (HAS_META && !uni_) q4_mask<HALF_, HAS_META>(cx, rg.s[HALF_], rel_of(ub_), seg_q);                   \
+            else q4_mask<HALF_, false>(cx, rg.s[HALF_], rel_of(ub_), seg_q);                                        \
         }                                                                                                           \
     } while (0)
         int ub = st0 * kQ4BK;
@@ -1135,7 +1146,9 @@ LWM_DEVICE void attn_bwd_dq4_body(const AttnParams& p) {
         }                                                                                                           \
         const uint32_t d_ = (((i) & 3) == 3) ? (uint32_t)(-3 * kD4SlotBytes) : (uint32_t)kD4SlotBytes;             \
         const uint32_t e_ = (((i) & 3) == 3) ? (uint32_t)(-3 * kQ4BK * 4) : (uint32_t)(kQ4BK * 4);                 \
+        const int32_t segw_ = HAS_META ? seg_step_word(cx.meta - 16 * hi, lane) : 0;                               \
         q4_x<0, !(FIRST), PIPE>(cx, rg, qf, dof, vk, vv, dm);                                                       \
+        const bool uni_ = HAS_META && seg_step_uniform(segw_, own_uniform, own_seg);                                \
         LWM_Q4_MASK(0, !(FIRST), ub);                                                                               \
         q4_y<0, !(FIRST), false>(cx, rg, dq);                                                                       \
         q4_x<1, true, false>(cx, rg, qf, dof, vk, vv, dm);                                                          \

@@ -205,6 +205,15 @@ LWM_DEVICE void seg_narrow(const int32_t* blk, int nblk, int per, int t0, int t1
     if (lo >= hi) { lo = t0; hi = t0; }
 }
 
+// Packed sequences, per step of 64 staged rows of the OTHER operand: do all of them carry the wave's own segment?  Then
+// the per-element segment test of the step (4 LDS reads + 32 compare / select per 32 x 32 unit) is skipped and only the
+// causal test remains where the unit touches the diagonal -- deep inside a document a packed batch then costs what a
+// dense one costs.  `words` = the step's 64 staged segment words (kSegInvalid marks padded / out-of-range rows and
+// never matches); own_uniform = all rows the wave owns carry `own_seg`.  Wave-uniform answer.
+// (two parts, so that a phase of MFMAs can stand between the LDS read and the vote)
+LWM_DEVICE int32_t seg_step_word(lds_t words, int lane) { return lds_read_i32(words + (uint32_t)lane * 4); }
+LWM_DEVICE bool seg_step_uniform(int32_t word, bool own_uniform, int32_t own_seg) { return own_uniform && !wave_any(word != own_seg); }
+
 // (min, max) over blocks [b0, b0+n) of a (min,max) block table
 LWM_DEVICE void seg_own_range(const int32_t* blk, int nblk, int b0, int n, int& smin, int& smax) {
     smin = 0x7fffffff;

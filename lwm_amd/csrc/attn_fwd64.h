@@ -627,7 +627,23 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
             const int64_t ft = (t >= 0 ? t / kF4BK : -((-t + kF4BK - 1) / kF4BK)) + 1 - kt0;
             first_mask = ft < 0 ? 0 : (ft > 0x7fffffff ? 0x7fffffff : (int)ft);
         }
-        auto needs_mask = [&](int rel) -> bool { return HAS_META || rel >= first_mask; };
+        auto needs_causal = [&](int rel) -> bool { return rel >= first_mask; };
+        // Packed sequences: the wave's 64 queries of one segment?  Then a key tile whose 64 staged segment words all carry
+        // it needs no segment test (attn_common.h, seg_step_uniform); rows past Sq are never stored and do not count.
+        const int32_t own_seg = wave_uniform(seg_q[0]);
+        const bool own_uniform = HAS_META && !wave_any((q_ok[0] && seg_q[0] != own_seg) || (q_ok[1] && seg_q[1] != own_seg));
+        auto meta_words = [&](int mbuf) -> lds_t { return cx.lds + kF4OffMeta + mbuf * kF4BK * 4; };
+        bool uni_c = false;      // the tile whose masks come next
+#define LWM_F4_MASK(KHALF_, s_, rel_, mbuf_, uni_, SETTLE_)                                                          \
+    do {                                                                                                            \
+        if ((HAS_META && !(uni_)) || needs_causal(rel_)) {                                                          \
+            int r_[2];                                                                                              \
+            rel_of(rel_, r_);                                                                                       \
+            if (SETTLE_) f4_settle_s(s_);                                                                           \
+            if (HAS_META && !(uni_)) f4_mask<HAS_META, KHALF_>(cx, s_, r_, seg_q, mbuf_);                           \
+            else f4_mask<false, KHALF_>(cx, s_, r_, seg_q, mbuf_);                                                  \
+        }                                                                                                           \
+    } while (0)
 
         // ---- prologue: K(0), V(0) and the first half of K(1) in flight -> S of half tile 0, its masks, its reference
         stage_k(0, 0);
@@ -662,11 +678,8 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
             for (int j = 0; j < kF4Ahead; ++j) kfr[j] = f4_kread<0>(cx, j);
             f4_phase1<0, true, false, -1, -1>(cx, qf, sA, tt, ps, pb, kfr, vfr, st, dm);
             f4_settle_s(sA);       // (no P.V MFMA follows here: the max / exponent fillers read the scores at once)
-            if (needs_mask(0)) {
-                int r[2];
-                rel_of(0, r);
-                f4_mask<HAS_META, 0>(cx, sA, r, seg_q, 0);
-            }
+            uni_c = HAS_META && seg_step_uniform(seg_step_word(meta_words(0), lane), own_uniform, own_seg);
+            LWM_F4_MASK(0, sA, 0, 0, uni_c, false);
             f4_phase2<0, false, true, -1, -1>(cx, pb, acc, ps, sA, tt, mx, kfr, vfr, st, dm);
             if (wave_any(mx[0] > cx.thr[0] || mx[1] > cx.thr[1])) f4_rescale(cx, mx, acc, tt);
         }
@@ -708,14 +721,11 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
 #endif
 #define LWM_F4_TILE(i, D0, D1, D2, D3)                                                                             \
     do {                                                                                                            \
+        const int32_t segw_ = HAS_META ? seg_step_word(meta_words(((i) + 1) % 3), lane) : 0;     /* the next tile's */  \
         f4_phase1<1, true, true, 0, D0>(cx, qf, sB, tt, ps, pb, kfr, vfr, st, dm);   /* S(2i+1) || finish(2i) */   \
         F4_LAP(0);                                                                                                  \
-        if (needs_mask(i)) {                                                                                        \
-            int r_[2];                                                                                              \
-            rel_of(i, r_);                                                                                          \
-            f4_settle_s(sB);                                                                                        \
-            f4_mask<HAS_META, 1>(cx, sB, r_, seg_q, (i) % 3);                                                       \
-        }                                                                                                           \
+        LWM_F4_MASK(1, sB, i, (i) % 3, uni_c, true);                                                                \
+        uni_c = HAS_META && seg_step_uniform(segw_, own_uniform, own_seg);                                          \
         toggle_k();                                                                                                 \
         F4_LAP(1);                                                                                                  \
         f4_phase2<0, true, true, 0, D1>(cx, pb, acc, ps, sB, tt, mx, kfr, vfr, st, dm);   /* P.V(2i) */            \
@@ -723,12 +733,7 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
         F4_LAP(2);                                                                                                  \
         f4_phase1<0, true, true, 1, D2>(cx, qf, sA, tt, ps, pb, kfr, vfr, st, dm);   /* S(2i+2) || finish(2i+1) */ \
         F4_LAP(3);                                                                                                  \
-        if (needs_mask((i) + 1)) {                                                                                  \
-            int r_[2];                                                                                              \
-            rel_of((i) + 1, r_);                                                                                    \
-            f4_settle_s(sA);                                                                                        \
-            f4_mask<HAS_META, 0>(cx, sA, r_, seg_q, ((i) + 1) % 3);                                                 \
-        }                                                                                                           \
+        LWM_F4_MASK(0, sA, (i) + 1, ((i) + 1) % 3, uni_c, true);                                                    \
         F4_LAP(4);                                                                                                  \
         f4_phase2<1, true, true, -1, D3>(cx, pb, acc, ps, sA, tt, mx, kfr, vfr, st, dm);   /* P.V(2i+1) */         \
         if (wave_any(mx[0] > cx.thr[0] || mx[1] > cx.thr[1])) f4_rescale(cx, mx, acc, tt);                          \
@@ -781,12 +786,8 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
             for (int j = 0; j < kF4Ahead; ++j) kfr[j] = f4_kread<1>(cx, j);
             stage_iter(i);
             f4_phase1<1, true, true, 0, -1>(cx, qf, sB, tt, ps, pb, kfr, vfr, st, dm);
-            if (needs_mask(i)) {
-                int r[2];
-                rel_of(i, r);
-                f4_settle_s(sB);
-                f4_mask<HAS_META, 1>(cx, sB, r, seg_q, i % 3);
-            }
+            LWM_F4_MASK(1, sB, i, i % 3, uni_c, true);
+#undef LWM_F4_MASK
             f4_phase2<0, true, true, -1, -1>(cx, pb, acc, ps, sB, tt, mx, kfr, vfr, st, dm);
             if (wave_any(mx[0] > cx.thr[0] || mx[1] > cx.thr[1])) f4_rescale(cx, mx, acc, tt);
             f4_phase1<0, false, true, 1, -1>(cx, qf, sA, tt, ps, pb, kfr, vfr, st, dm);
