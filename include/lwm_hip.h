@@ -101,7 +101,7 @@ typedef struct LwmAttnArgs {
 
 int lwm_attn_fwd(const LwmAttnArgs* args, void* stream);
 /* The backward of one ring step = three launches (no atomics, bit-reproducible): the row statistics once per query
- * block, then dq (a workgroup owns 256 queries and streams K/V: 3 GEMM units) and dk, dv (a workgroup owns 128 keys
+ * block, then dq (a workgroup owns 128 queries and streams K/V: 3 GEMM units) and dk, dv (a workgroup owns 128 keys
  * and streams Q/dO: 4 units) per (query block, K/V block) pair, chained through the f32 carries.  [A form that
  * computed S and dP once and summed bf16 dq partials -- 5 units -- was measured in rounds 2-3 and retired in round 4:
  * profiles/r04_backward.md.] */
