@@ -240,7 +240,13 @@ struct D4Dma {
 };
 
 // Live state of a wave across units.
+// -DLWM_D4X_STOREDS (experiment, profiles/r04_backward.md section 4): every unit also writes its bf16 dS operand (2 x 16 bytes
+// per lane, lane-linear: the best case for the store path) to a scratch buffer handed over in AttnParams::dq_acc -- what
+// a backward that spills dS for a one-unit dQ kernel would add to this kernel's loop.
 struct D4Regs {
+#ifdef LWM_D4X_STOREDS
+    char* ds_out;
+#endif
     f32x16 s;               // S tile (MFMA result, read-only for the vector pipe)
     f32x16 dp[2];           // dP' tiles by unit parity: preloaded with -delta (in C/D register order), then the dP chain
     float nl[16];           // -lse * log2(e) of the unit's rows, C/D register order
@@ -275,7 +281,15 @@ LWM_DEVICE void d4_fillers(const D4Ctx& cx, D4Regs& rg, const f32x16& dpu) {
             ld = kD4Sched.D[i] > ld ? kD4Sched.D[i] : ld;
         }
         if (lp == G) rg.pb[h] = __builtin_bit_cast(bf16x8, u32x4{rg.pw[4 * h], rg.pw[4 * h + 1], rg.pw[4 * h + 2], rg.pw[4 * h + 3]});
-        if (ld == G) rg.dsb[h] = __builtin_bit_cast(bf16x8, u32x4{rg.dw[4 * h], rg.dw[4 * h + 1], rg.dw[4 * h + 2], rg.dw[4 * h + 3]});
+        if (ld == G) {
+            rg.dsb[h] = __builtin_bit_cast(bf16x8, u32x4{rg.dw[4 * h], rg.dw[4 * h + 1], rg.dw[4 * h + 2], rg.dw[4 * h + 3]});
+#ifdef LWM_D4X_STOREDS
+            if (rg.ds_out) {
+                global_store_b128(rg.ds_out + h * 1024, u32x4{rg.dw[4 * h], rg.dw[4 * h + 1], rg.dw[4 * h + 2], rg.dw[4 * h + 3]});
+                if (h == 1) rg.ds_out += 4 * 2048;
+            }
+#endif
+        }
     }
 }
 // dispatch a loop index to the compile-time gap (the loops are fully unrolled: the chain folds to one call)
@@ -561,6 +575,11 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
         };
 
         D4Regs rg;
+#ifdef LWM_D4X_STOREDS
+        rg.ds_out = p.dq_acc ? (char*)p.dq_acc + ((int64_t)(hb * ((p.Sk + kD4BK - 1) / kD4BK) + kbi) * ((p.Sq + kD4BQ - 1) / kD4BQ)) * 16384 +
+                                   wave * 2048 + lane * 16
+                             : nullptr;
+#endif
         rg.s = zero_f32x16();
         rg.dp[0] = zero_f32x16();
         rg.dp[1] = zero_f32x16();

@@ -163,7 +163,17 @@ int main(int argc, char** argv) {
     const float ms_delta = time_ms([&] { must(bdelta(&a, nullptr), "delta"); });
     if (dump > 0)
         laps(bdkdv, "dK/dV, key block 0 of head 0: cycles per step (X0, mask, Y0, X1, mask, Y1, wait, barrier, addresses | steps, total)", 12, 9, 9);
+    // LWM_BENCH_DS=1 with a -DLWM_D4X_STOREDS build: a scratch buffer for the dS spill experiment rides in dq_acc
+    float* ds_scratch = nullptr;
+    if (getenv("LWM_BENCH_DS") && atoi(getenv("LWM_BENCH_DS"))) {
+        const size_t bytes = (size_t)H * ((S + 127) / 128) * ((S + 63) / 64) * 16384;
+        CK(hipMalloc(&ds_scratch, bytes));
+        fprintf(stderr, "dS scratch: %.1f GB\n", bytes * 1e-9);
+    }
+    float* const dq_acc_saved = a.dq_acc;
+    a.dq_acc = ds_scratch ? ds_scratch : a.dq_acc;
     const float ms_dkdv = time_ms([&] { must(bdkdv(&a, nullptr), "dkdv"); });
+    a.dq_acc = dq_acc_saved;
     const float ms_dq = time_ms([&] { must(bdq(&a, nullptr), "dq"); });
     printf("%-34s S=%d H=%d  fwd %.3f  delta %.3f  dkdv %.3f  dq %.3f ms   |dq| %.6f |dk| %.6f |dv| %.6f\n", argv[1], S, H, ms_fwd,
            ms_delta, ms_dkdv, ms_dq, checksum(dq), checksum(dk), checksum(dv));
