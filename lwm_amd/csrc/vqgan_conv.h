@@ -80,6 +80,28 @@ LWM_DEVICE HiMask hi_mask(int hi) {
 LWM_DEVICE float pick_hi(float even, float odd, HiMask h) {
     return __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, odd) & h.m) | (__builtin_bit_cast(uint32_t, even) & ~h.m));
 }
+// All picks of one k-quad (MFMA t = 0, 1 x the wave's MB pixel blocks) as v_bfi_b32 -- hipcc splits the C form above
+// into v_and + v_and_or once the inverted mask is hoisted.  The statement ends with two wait states: hipcc does not
+// know that an asm statement is a VALU write, so it would not keep the matrix pipe's read of these registers apart
+// from it (measured: wrong sums without the s_nop).
+template <int MB>
+LWM_DEVICE void pick_quad(float (&af)[2][MB], const f32x4 (&q)[MB], HiMask h) {
+#ifdef LWM_EMU
+    for (int t = 0; t < 2; ++t)
+        for (int i = 0; i < MB; ++i) af[t][i] = pick_hi(q[i][2 * t], q[i][2 * t + 1], h);
+#else
+    static_assert(MB == 1 || MB == 2, "pick_quad");
+    if constexpr (MB == 1) {
+        asm("v_bfi_b32 %0, %2, %4, %3\n\tv_bfi_b32 %1, %2, %6, %5\n\ts_nop 1"
+            : "=&v"(af[0][0]), "=&v"(af[1][0])
+            : "v"(h.m), "v"(q[0][0]), "v"(q[0][1]), "v"(q[0][2]), "v"(q[0][3]));
+    } else {
+        asm("v_bfi_b32 %0, %4, %6, %5\n\tv_bfi_b32 %1, %4, %10, %9\n\tv_bfi_b32 %2, %4, %8, %7\n\tv_bfi_b32 %3, %4, %12, %11\n\ts_nop 1"
+            : "=&v"(af[0][0]), "=&v"(af[0][1]), "=&v"(af[1][0]), "=&v"(af[1][1])
+            : "v"(h.m), "v"(q[0][0]), "v"(q[0][1]), "v"(q[0][2]), "v"(q[0][3]), "v"(q[1][0]), "v"(q[1][1]), "v"(q[1][2]), "v"(q[1][3]));
+    }
+#endif
+}
 
 
 LWM_DEVICE f32x4 zero_f32x4() {
@@ -293,14 +315,13 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
                 else load_a(more ? nxt : cur, 0, set ^ 1);
                 if ((u & 1) == 0) load_b(u == 6 ? (more ? it + 1 : it) : it, ((u >> 1) + 1) & 3);
                 sched_fence();  // keep the prefetch ABOVE this k-quad's MFMAs (hipcc sinks it otherwise)
+                float af[2][MB];
+                pick_quad<MB>(af, ar[set], hm);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    float af[MB];
-                    for (int i = 0; i < MB; ++i) af[i] = pick_hi(ar[set][i][2 * t], ar[set][i][2 * t + 1], hm);
+                for (int t = 0; t < 2; ++t)
                     for (int i = 0; i < MB; ++i)
                         for (int j = 0; j < NB; ++j)
-                            acc_tap[i][j] = mfma_32x32x2_f32(af[i], bq[(u >> 1) & 1][u & 1][t][j], acc_tap[i][j]);
-                }
+                            acc_tap[i][j] = mfma_32x32x2_f32(af[t][i], bq[(u >> 1) & 1][u & 1][t][j], acc_tap[i][j]);
                 sched_fence();
                 if (u == 3) block_sync_lds();
             }
@@ -342,14 +363,13 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
             const int set = u & 1;
             if (u + 1 < 8) load_frag(u + 1, set ^ 1);
             sched_fence();  // keep the prefetch ABOVE this k-quad's MFMAs (hipcc sinks it otherwise)
+            float af[2][MB];
+            pick_quad<MB>(af, ar[set], hm);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                float af[MB];
-                for (int i = 0; i < MB; ++i) af[i] = pick_hi(ar[set][i][2 * t], ar[set][i][2 * t + 1], hm);
+            for (int t = 0; t < 2; ++t)
                 for (int i = 0; i < MB; ++i)
                     for (int j = 0; j < NB; ++j)
-                        acc_tap[i][j] = mfma_32x32x2_f32(af[i], bf[set][t][j], acc_tap[i][j]);
-            }
+                        acc_tap[i][j] = mfma_32x32x2_f32(af[t][i], bf[set][t][j], acc_tap[i][j]);
             sched_fence();
         }
         if ((it + 1) % nch == 0) {  // tap finished: s = s + P_t
@@ -538,13 +558,13 @@ LWM_DEVICE void conv_patch_body(const ConvParams& p) {
             if (u + 1 < 8) load_a(it, u + 1, as ^ 1);
             else if (it + 1 < nit) load_a(it + 1, 0, as ^ 1);
             sched_fence();
+            float af[2][MB];
+            pick_quad<MB>(af, ar[as], hm);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
-                for (int i = 0; i < MB; ++i) {
-                    const float af = pick_hi(ar[as][i][2 * t], ar[as][i][2 * t + 1], hm);
+                for (int i = 0; i < MB; ++i)
                     for (int j = 0; j < NB; ++j)
-                        pt[PSET][i][j] = mfma_32x32x2_f32(af, bq[SET][u][t][j], (FIRST && u == 0 && t == 0) ? zero_f32x16() : pt[PSET][i][j]);
-                }
+                        pt[PSET][i][j] = mfma_32x32x2_f32(af[t][i], bq[SET][u][t][j], (FIRST && u == 0 && t == 0) ? zero_f32x16() : pt[PSET][i][j]);
             if (ADD && u >= 2 && u < 6) {       // a quarter of the previous tap's sum per k-quad (its last MFMA retired long ago)
 #pragma unroll
                 for (int i = 0; i < MB; ++i)
