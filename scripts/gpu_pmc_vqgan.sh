@@ -1,7 +1,7 @@
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/pmcv
 cd /tmp && export TMPDIR=/tmp
-(timeout 300 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmcv -o p1 -- python $R/scripts/bench_vqgan.py 8 2>&1 | tail -3) > $R/gpurun_out/pmcv.log
+(timeout 300 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmcv -o p1 -- python $R/scripts/bench_vqgan.py ${PMCV_FRAMES:-32} 2>&1 | tail -3) > $R/gpurun_out/pmcv.log
 cd $R
 python - <<'PY'
 import csv, collections
