@@ -246,6 +246,7 @@ struct D4Dma {
 struct D4Regs {
 #ifdef LWM_D4X_STOREDS
     char* ds_out;
+    uint32_t hold[16];      // (LWM_D4X_STOREDS = 2: the words of two finished units, stored in the NEXT step's first phase)
 #endif
     f32x16 s;               // S tile (MFMA result, read-only for the vector pipe)
     f32x16 dp[2];           // dP' tiles by unit parity: preloaded with -delta (in C/D register order), then the dP chain
@@ -283,7 +284,7 @@ LWM_DEVICE void d4_fillers(const D4Ctx& cx, D4Regs& rg, const f32x16& dpu) {
         if (lp == G) rg.pb[h] = __builtin_bit_cast(bf16x8, u32x4{rg.pw[4 * h], rg.pw[4 * h + 1], rg.pw[4 * h + 2], rg.pw[4 * h + 3]});
         if (ld == G) {
             rg.dsb[h] = __builtin_bit_cast(bf16x8, u32x4{rg.dw[4 * h], rg.dw[4 * h + 1], rg.dw[4 * h + 2], rg.dw[4 * h + 3]});
-#ifdef LWM_D4X_STOREDS
+#if defined(LWM_D4X_STOREDS) && LWM_D4X_STOREDS == 1
             if (rg.ds_out) {
                 global_store_b128(rg.ds_out + h * 1024, u32x4{rg.dw[4 * h], rg.dw[4 * h + 1], rg.dw[4 * h + 2], rg.dw[4 * h + 3]});
                 if (h == 1) rg.ds_out += 4 * 2048;
@@ -346,9 +347,25 @@ LWM_DEVICE void d4_x(const D4Ctx& cx, D4Regs& rg, const bf16x8 (&kf)[8], const b
             else f4_dma1(vdo[j], dm.do_src, dm.dst + kD4TileBytes + 4096 * j);
         }
 #endif
+#if defined(LWM_D4X_STOREDS) && LWM_D4X_STOREDS == 2
+        if (HALF == 0 && m == 0 && rg.ds_out) {     // the units finished during the two phases X of the step before
+            for (int h = 0; h < 4; ++h) {
+#ifdef LWM_D4X_STOREDS_NT
+                const u32x4 w_ = {rg.hold[4 * h], rg.hold[4 * h + 1], rg.hold[4 * h + 2], rg.hold[4 * h + 3]};
+                __builtin_nontemporal_store(w_, (u32x4*)(rg.ds_out + h * 1024));
+#else
+                global_store_b128(rg.ds_out + h * 1024, u32x4{rg.hold[4 * h], rg.hold[4 * h + 1], rg.hold[4 * h + 2], rg.hold[4 * h + 3]});
+#endif
+            }
+            rg.ds_out += 2 * 4 * 2048;
+        }
+#endif
         if (HAS_PREV) d4_fill_at<16, 16>(16 + m, cx, rg, dpo);
         sched_fence();
     }
+#if defined(LWM_D4X_STOREDS) && LWM_D4X_STOREDS == 2
+    for (int i = 0; i < 8; ++i) rg.hold[8 * (HALF ^ 1) + i] = rg.dw[i];
+#endif
 }
 
 // masks of a unit on its scores (lwm/llama.py:572-592): query row (r&3) + 8 (r>>2) + 4 hi of the unit sees this lane's
@@ -576,6 +593,7 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
 
         D4Regs rg;
 #ifdef LWM_D4X_STOREDS
+        for (int i = 0; i < 16; ++i) rg.hold[i] = 0;
         rg.ds_out = p.dq_acc ? (char*)p.dq_acc + ((int64_t)(hb * ((p.Sk + kD4BK - 1) / kD4BK) + kbi) * ((p.Sq + kD4BQ - 1) / kD4BQ)) * 16384 +
                                    wave * 2048 + lane * 16
                              : nullptr;
