@@ -228,21 +228,38 @@ def vqgan_leg(torch, frames=64, reps=3, config4_frames=1020):
     return res
 
 
-PROFILE_ROUND = "r04"      # only PMC summaries of THIS round's kernels may label this round's bench line
+ATTN_KERNEL_SOURCES = ("attn_common.h", "attn_fwd64.h", "attn_bwd.h", "attn_bwd64.h", "wave_ops.h")
+
+
+def attn_kernel_stamp():
+    """sha256 over the sources of the attention kernels of the main workload (lwm_amd/csrc/): scripts/summarise_pmc.py
+    writes it into every PMC summary, and pmc_traffic() only accepts a summary whose stamp equals the tree's -- a
+    counter pass of an older kernel cannot label a newer one (the round prefix of the file name is not consulted)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ATTN_KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "lwm_amd", "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(kernel, S):
-    """(HBM bytes per launch of `kernel`, profile file) from the committed PMC passes of this same command
-    and ROUND (profiles/r02*pmc_attention*.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
-    rocprofv3 --pmc passes).  bench.py cannot collect counters itself; (None, None) when no profile of this
-    workload and round is committed -- a stale file must not label a newer kernel."""
+    """(HBM bytes per launch of `kernel`, profile file) from a committed PMC pass of this same command
+    (profiles/*pmc_attention*.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate rocprofv3 --pmc
+    passes) WHOSE KERNEL SOURCES ARE THE TREE'S (`kernel_source_stamp`, see attn_kernel_stamp).  bench.py cannot
+    collect counters itself; (None, None) when no such profile is committed -- a stale file must not label a
+    newer kernel."""
     if S != 32768:
         return None, None
     import glob
+    stamp = attn_kernel_stamp()
     best = (None, None)
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", PROFILE_ROUND + "*pmc_attention*.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_attention*.json"))):
         try:
-            ks = json.load(open(f))["kernels"]
+            doc = json.load(open(f))
+            if doc.get("kernel_source_stamp") != stamp:
+                continue
+            ks = doc["kernels"]
         except Exception:
             continue
         for name, d in ks.items():
@@ -740,7 +757,7 @@ def main():
     dev_index = local_rank % n_dev if shared else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    rccl_ranks_seen = None
+    rccl_ranks_seen = ranks_seen = None
     if world > 1:
         import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -762,7 +779,10 @@ def main():
             # (RCCL over xGMI, or gloo in the dry run) and one neighbour send/recv goes round the ring
             one = torch.ones(1, dtype=torch.float32, device="cpu" if shared else dev)
             dist.all_reduce(one)
-            rccl_ranks_seen = int(one.item())
+            ranks_seen = int(one.item())
+            # RCCL saw these ranks only when the backend IS RCCL; a gloo bootstrap reports under its own name, so that a
+            # dry run cannot be mistaken for the first real multi-GPU line
+            rccl_ranks_seen = ranks_seen if dist.get_backend() == "nccl" else None
             if not shared:
                 tok = torch.full((1,), float(rank), device=dev)
                 got = torch.empty(1, device=dev)
@@ -1090,6 +1110,8 @@ def main():
             "configs4": configs4,
             "driver_fallback": driver_fallback,
             "rccl_ranks_seen": rccl_ranks_seen,
+            "bootstrap_ranks_seen": ranks_seen if world > 1 else None,
+            "bootstrap_backend": dist.get_backend() if world > 1 else None,
             "dry_run": ("ranks share devices, messages staged through host memory; timings are not xGMI" if dry else
                         "ranks share devices (IPC transport inside one GPU); timings are not xGMI" if shared and world > 1 else None),
             "path_algorithmic_tflops_per_gpu": algo_flops_step / (ms_per_step * 1e-3) / 1e12 / world,

@@ -32,8 +32,17 @@ def setup_mesh(mesh_dim: str):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         local = int(os.environ.get("LOCAL_RANK", "0"))
+        # LWM_DIST_BACKEND=gloo: a dry run of N processes on fewer GPUs than ranks (ranks share devices; with
+        # LWM_RING_TRANSPORT=ipc the K/V exchange then goes through the library's IPC transport, everything else
+        # through host memory) -- the whole multi-process code path on a 1-GPU box
+        backend = os.environ.get("LWM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
-            torch.cuda.set_device(local)
+            n_dev = torch.cuda.device_count()
+            if backend == "nccl" and local >= n_dev:
+                raise SystemExit(f"local rank {local} has no GPU of its own ({n_dev} visible): one process per GPU "
+                                 f"(LWM_DIST_BACKEND=gloo is the dry run on shared devices)")
+            torch.cuda.set_device(local % n_dev)
+        if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group("gloo")
@@ -75,8 +84,11 @@ def torch_dtype(name: str):
         raise SystemExit(f"unknown --dtype {name!r}")
     if name not in ("bf16", "bfloat16"):
         raise SystemExit(f"--dtype={name}: not supported -- the MI355X attention kernels take bf16 operands (f32 logits, "
-                         f"softmax and accumulation).  Pass --dtype=bf16 explicitly; the run is then the reference's "
-                         f"bf16 configuration, not its fp32 default.")
+                         f"softmax and accumulation).  The reference's launch scripts pass --dtype='fp32' "
+                         f"(scripts/run_train_text.sh:21, run_eval_needle.sh:17, lwm/train.py:36): replace that ONE flag by\n"
+                         f"    --dtype='bf16'\n"
+                         f"and keep the rest of the command line; the run is then the reference's bf16 configuration "
+                         f"(BASELINE configs 2-5: bf16 operands, float32_logits=True), not its fp32 default.")
     return torch.bfloat16
 
 

@@ -4,7 +4,14 @@ scripts/run_train_vision_text.sh).  Runs --total_steps optimisation steps of the
 the loss of lwm/train.py:171-209, AdamW with the reference's warm-up + cosine schedule
 (--optimizer.adamw_optimizer.*).  Data: synthetic token batches of the configured shape (the reference's
 dataset / tokenizer pipeline, wandb logging and GCS checkpoint streaming are not part of the hot path;
-their flags are accepted and listed as unused)."""
+their flags are accepted and listed as unused).
+
+Sequence parallelism (--mesh_dim ...,sp): the ranks of one "sp" group share a batch; each holds the rows its ownership
+rule gives it -- ZIGZAG half-chunks by default (lwm_amd.ringattention.set_sp_group; LWM_SP_LAYOUT=contiguous selects the
+reference's contiguous blocks, lwm/llama.py:560-562) -- cut with `sp_shard`, positions from `sp_positions`; the K/V
+exchange is driven by the C-ABI ring driver (RCCL on a side stream) when the job's backend is RCCL.  Two flags beyond the
+reference's set, for tests and diagnosis: --lwm_dump_grads=<file> (rank 0 saves the loss and every gradient of the
+last step) and --lwm_balance_report (the attention launches of every sp rank timed in turn on this rank's GPU)."""
 from __future__ import annotations
 
 import math
@@ -20,7 +27,7 @@ DEFAULTS = dict(
     modality="text", use_data_sharded_loader=True, seed=42, mesh_dim="1,-1,1,1", dtype="bf16", total_steps=10000,
     load_llama_config="", update_llama_config="", load_checkpoint="", load_dataset_state="", log_freq=50,
     save_model_freq=0, save_milestone_freq=0, eval_steps=0, tokenizer="LargeWorldModel/LWM-Text-1M",
-    log_all_worker=False, autoresume=False)
+    log_all_worker=False, autoresume=False, lwm_dump_grads="", lwm_balance_report=False)
 GROUPS = ("train_dataset", "eval_dataset", "optimizer", "checkpointer", "llama", "logger", "jax_distributed")
 
 
@@ -72,43 +79,52 @@ def main(argv=None):
                             float(opt_cfg.get("b2", 0.95))), weight_decay=float(opt_cfg.get("weight_decay", 1e-4)))
     clip = float(opt_cfg.get("clip_gradient", 1.0))
     import torch.distributed as dist
-    sp_rank, world_rank = 0, 0
-    if dist.is_available() and dist.is_initialized():
-        world_rank = dist.get_rank()
-        if sp > 1:
-            from ..ringattention import sp_size_rank
-            sp_rank = sp_size_rank("sp")[1]
+    from ..ringattention import sp_all_reduce_sum, sp_layout, sp_shard
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    world_rank = dist.get_rank() if multi else 0
+    gloo = multi and dist.get_backend() != "nccl"
+    if sp > 1:
+        C.note(f"sp axis: {sp} ranks, layout {sp_layout('sp', seq // sp)}")
     # the ranks of one sp group share a batch (each holds a slice of its sequences); data-parallel replicas draw
     # DIFFERENT batches: seed by the replica's coordinate (sp is the fastest axis of the mesh, lwm_amd/mesh.py)
     gen = torch.Generator(device=dev).manual_seed(F.seed + 17 * (world_rank // max(sp, 1)))
-    c = seq // sp
     history = []
     for step in range(int(F.total_steps)):
         for pg in opt.param_groups:
             pg["lr"] = lr_at(step, opt_cfg)
         t0 = time.perf_counter()
         for _ in range(accum):
-            # a global batch of seq+1 tokens; this process holds the rows [sp_rank*c, (sp_rank+1)*c) of it
+            # a global batch of seq+1 tokens; this process holds ITS rows of every sequence (sp_shard: the ownership
+            # rule bound to the "sp" axis).  Each rank's loss is its share of the per-sequence mean (the count of targets
+            # is summed over the ring inside the loss operator), so the shares add up to the 1-process loss.
             full = torch.randint(0, cfg.vocab_size, (local_b, seq + 1), device=dev, generator=gen)
-            sl = slice(sp_rank * c, (sp_rank + 1) * c)
-            inp, tgt = full[:, :-1][:, sl], full[:, 1:][:, sl]
             if vision:
                 vm_full = torch.zeros(local_b, seq + 1, dtype=torch.bool, device=dev)
                 vm_full[:, seq // 4: seq // 4 + (seq // 2)] = True       # a block of vision tokens mid-sequence
                 full = torch.where(vm_full, full % cfg.vision_vocab_size, full)
-                inp, tgt = full[:, :-1][:, sl], full[:, 1:][:, sl]
-                loss, metrics = model.loss(inp, vm_full[:, :-1][:, sl], tgt, vm_full[:, 1:][:, sl])
+                loss, metrics = model.loss(sp_shard(full[:, :-1]), sp_shard(vm_full[:, :-1]), sp_shard(full[:, 1:]),
+                                           sp_shard(vm_full[:, 1:]))
             else:
-                loss, acc = model.loss(inp, tgt)
+                loss, acc = model.loss(sp_shard(full[:, :-1]), sp_shard(full[:, 1:]))
                 metrics = dict(accuracy=acc)
             (loss / accum).backward()
-        if sp > 1 or dp > 1:        # parameters are replicated: average the gradients over the job, in buckets
+        if sp > 1:          # the whole sequence's figures, for the log
+            loss = sp_all_reduce_sum(loss.detach().clone())
+            metrics = {k: sp_all_reduce_sum(v.detach().clone()) for k, v in metrics.items()}
+        if multi:           # parameters are replicated: SUM of the sp shares, MEAN over the data-parallel replicas, in buckets
             grads = [p.grad for p in model.parameters() if p.grad is not None]
             bucket, size = [], 0
             for g in grads + [None]:
                 if g is None or (bucket and (size + g.numel() > (1 << 26) or g.dtype != bucket[0].dtype)):
                     flat = torch.cat([x.reshape(-1) for x in bucket])
-                    dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+                    if gloo:        # gloo moves host memory and has no bf16: staged as f32 (a dry run on shared devices)
+                        host = flat.float().cpu()
+                        dist.all_reduce(host)
+                        flat.copy_(host.div_(max(dp, 1)))
+                    else:
+                        red = flat.float() if flat.dtype != torch.float32 else flat
+                        dist.all_reduce(red)
+                        flat.copy_(red.div_(max(dp, 1)))
                     off = 0
                     for x in bucket:
                         x.copy_(flat[off:off + x.numel()].view_as(x))
@@ -117,6 +133,10 @@ def main(argv=None):
                 if g is not None:
                     bucket.append(g)
                     size += g.numel()
+        if F.lwm_dump_grads and step == int(F.total_steps) - 1 and world_rank == 0:
+            torch.save({"loss": float(loss), "metrics": {k: float(v) for k, v in metrics.items()},
+                        "grads": {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.grad is not None}},
+                       F.lwm_dump_grads)
         torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
         opt.step()
         opt.zero_grad(set_to_none=True)
@@ -125,9 +145,61 @@ def main(argv=None):
         rec = dict(step=step, loss=float(loss), learning_rate=lr_at(step, opt_cfg), tokens_per_s=batch * seq * accum / dt,
                    **{k: float(v) for k, v in metrics.items()})
         history.append(rec)
-        if F.log_freq and step % int(F.log_freq) == 0:
+        if F.log_freq and step % int(F.log_freq) == 0 and (world_rank == 0 or F.log_all_worker):
             print(rec, flush=True)
+    if sp > 1:
+        from ..ring import ring_driver_info
+        from ..ringattention import _resolve_axis
+        info = ring_driver_info(_resolve_axis("sp"))
+        C.note(f"ring driver: {info}")
+        history.append(dict(ring=info, layout=sp_layout("sp", seq // sp)))
+        if F.lwm_balance_report:
+            history.append(dict(balance=balance_report(cfg, local_b, seq // sp, sp, dev)))
+            if world_rank == 0:
+                print("LWM_BALANCE " + __import__("json").dumps(history[-1]["balance"]), flush=True)
     return history
+
+
+def balance_report(cfg, B, c, n, dev, reps=3):
+    """Per-rank attention time of ONE layer of this job's shard shape, measured without the other ranks in the way: every
+    rank of the sp ring is played in turn on THIS process's GPU by the C ring driver over a transport that moves nothing
+    (CRing.null) -- the launch list of rank r under the ownership rule in force, forward + backward.  Ranks take turns
+    (a barrier each), so processes that share a GPU do not time each other.  -> {"ms_per_rank": [...], "max_over_mean"}"""
+    import torch.distributed as dist
+    from ..ring_c import CRing
+    from ..ringattention import sp_layout, sp_size_rank
+    H, D = cfg.num_attention_heads, cfg.hidden_size // cfg.num_attention_heads
+    kind = sp_layout("sp", c)
+    me = sp_size_rank("sp")[1]
+    g = torch.Generator(device=dev).manual_seed(5)
+    q, k, v, do = (torch.randn(B, c, H, D, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16) for _ in range(4))
+    ms = []
+    for turn in range(n):
+        if dist.is_initialized():
+            torch.cuda.synchronize()
+            dist.barrier()
+        if turn != me:
+            continue
+        for r in range(n):
+            ring = CRing.null(r, n, layout=kind, schedule="direct", device=dev)
+            def layer():
+                o, l = ring.forward(q, k, v, causal=True)
+                ring.backward(q, k, v, o, l, do, causal=True)
+            layer()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                layer()
+            e1.record()
+            torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1) / reps)
+            ring.close()
+    if dist.is_initialized():
+        torch.cuda.synchronize()
+        dist.barrier()
+    return {"layout": kind, "shape": [B, c, H, D], "ms_per_rank": [round(x, 4) for x in ms],
+            "max_over_mean": max(ms) / (sum(ms) / len(ms))}
 
 
 if __name__ == "__main__":

@@ -52,28 +52,8 @@ constexpr int kD4Ahead = LWM_D4_AHEAD;
 static_assert(kD4Ahead >= 1 && kD4Ahead <= 7, "prefetch distance in fragments");
 // Fragments are requested and consumed in PAIRS (the two chains of X, the two products of Y): both requests go out in
 // the even gap, and the pair's YOUNGER fragment is consumed first -- the s_waitcnt hipcc puts in front of that MFMA
-// covers the older one too, so there is one wait per two MFMAs.  (0: one fragment per gap, consumed in request order.)
-#ifndef LWM_D4_PAIR
-#define LWM_D4_PAIR 1
-#endif
-constexpr bool kD4Pair = LWM_D4_PAIR != 0;
-static_assert(!kD4Pair || (kD4Ahead % 2) == 0, "paired requests need an even distance");
-// timing experiments only (wrong results): -DLWM_D4X_NODMA / _NOFILL / _NOBAR / _NOSTAT / _NOSLOAD drop one ingredient of the loop
-#ifdef LWM_D4X_NOFILL
-constexpr bool kD4xFill = false;
-#else
-constexpr bool kD4xFill = true;
-#endif
-#ifdef LWM_D4X_NOSLOAD
-constexpr bool kD4xSload = false;
-#else
-constexpr bool kD4xSload = true;
-#endif
-#ifdef LWM_D4X_NOSTAT
-constexpr bool kD4xStat = false;
-#else
-constexpr bool kD4xStat = true;
-#endif
+// covers the older one too, so there is one wait per two MFMAs.
+static_assert((kD4Ahead % 2) == 0, "paired requests need an even distance");
 
 struct D4Ctx {
     uint32_t qa[8];             // Q row-fragment addresses (d step s), rows 0..31 of the CURRENT step's Q tile
@@ -177,7 +157,7 @@ LWM_DEVICE bf16x8 d4_frag(const D4Ctx& cx, int f) {
 //   P(i)  P words -> bf16         >= 1 gap behind E(2i), E(2i+1); the products of Y(u) still read the OLD P: word i of
 //   D(i)  dS words -> bf16           the first half (i < 4) from G = 8, of the second from G = 16; D(i) likewise, >= 1 gap
 //                                    behind M(2i), M(2i+1); everything done by G = 29 (Y(u+1) reads them at G = 32)
-// d4_sched_ok() checks a table at compile time.  LWM_D4_SCHED selects (A/B in profiles/r04_backward.md).
+// d4_sched_ok() checks the table at compile time.
 struct D4Sched {
     int F[16], E[16], M[16], P[8], D[8];
 };
@@ -193,43 +173,14 @@ constexpr bool d4_sched_ok(const D4Sched& c) {
     }
     return true;
 }
-#ifndef LWM_D4_SCHED
-#define LWM_D4_SCHED 0
-#endif
-#if LWM_D4_SCHED == 0
-// exponentials in Y (beside the transposed reads), multiplies and packs in X
+// exponentials in Y (beside the transposed reads), multiplies and packs in X (three other placements measured within
+// the run-to-run noise: profiles/r04_backward.md)
 constexpr D4Sched kD4Sched = {
     /* F */ {1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8},
     /* E */ {2, 3, 4, 4, 5, 6, 7, 7, 8, 9, 9, 10, 10, 11, 11, 12},
     /* M */ {16, 16, 17, 17, 18, 18, 19, 19, 20, 20, 21, 21, 22, 22, 23, 23},
     /* P */ {16, 17, 18, 19, 20, 21, 22, 23},
     /* D */ {24, 25, 26, 27, 28, 29, 29, 29}};
-#elif LWM_D4_SCHED == 1
-// one exponential per gap from G = 9 on (7 beside the transposed reads of Y, 9 beside the row reads of X), each
-// followed by its multiply and the packs as they become possible
-constexpr D4Sched kD4Sched = {
-    /* F */ {1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8},
-    /* E */ {9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24},
-    /* M */ {10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25},
-    /* P */ {11, 13, 15, 17, 19, 21, 23, 25},
-    /* D */ {12, 14, 16, 18, 20, 22, 24, 26}};
-#elif LWM_D4_SCHED == 2
-// every exponential in X: Y keeps the 16 fmas only
-constexpr D4Sched kD4Sched = {
-    /* F */ {1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8},
-    /* E */ {16, 16, 17, 17, 18, 18, 19, 19, 20, 20, 21, 21, 22, 22, 23, 23},
-    /* M */ {17, 17, 18, 18, 19, 19, 20, 20, 21, 21, 22, 22, 23, 23, 24, 24},
-    /* P */ {17, 18, 19, 20, 21, 22, 23, 24},
-    /* D */ {18, 19, 20, 21, 22, 23, 24, 25}};
-#elif LWM_D4_SCHED == 3
-// fmas and exponentials spread over all of Y (1 + 1 per gap), the rest in X
-constexpr D4Sched kD4Sched = {
-    /* F */ {1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 14},
-    /* E */ {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 15, 16},
-    /* M */ {16, 16, 17, 17, 18, 18, 19, 19, 20, 20, 21, 21, 22, 22, 23, 23},
-    /* P */ {16, 17, 18, 19, 20, 21, 22, 23},
-    /* D */ {24, 25, 26, 27, 28, 29, 29, 29}};
-#endif
 static_assert(d4_sched_ok(kD4Sched), "filler schedule violates a dependency");
 
 // the LDS-DMA pieces one step issues (all wave-uniform but the offsets): Q and dO of the step two ahead
@@ -240,14 +191,7 @@ struct D4Dma {
 };
 
 // Live state of a wave across units.
-// -DLWM_D4X_STOREDS (experiment, profiles/r04_backward.md section 4): every unit also writes its bf16 dS operand (2 x 16 bytes
-// per lane, lane-linear: the best case for the store path) to a scratch buffer handed over in AttnParams::dq_acc -- what
-// a backward that spills dS for a one-unit dQ kernel would add to this kernel's loop.
 struct D4Regs {
-#ifdef LWM_D4X_STOREDS
-    char* ds_out;
-    uint32_t hold[16];      // (LWM_D4X_STOREDS = 2: the words of two finished units, stored in the NEXT step's first phase)
-#endif
     f32x16 s;               // S tile (MFMA result, read-only for the vector pipe)
     f32x16 dp[2];           // dP' tiles by unit parity: preloaded with -delta (in C/D register order), then the dP chain
     float nl[16];           // -lse * log2(e) of the unit's rows, C/D register order
@@ -261,7 +205,6 @@ struct D4Regs {
 // the vector work scheduled in gap G; dpu = the dP' tile of the unit being finished
 template <int G>
 LWM_DEVICE void d4_fillers(const D4Ctx& cx, D4Regs& rg, const f32x16& dpu) {
-    if (!kD4xFill) return;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         if (kD4Sched.F[e] == G) rg.t[e] = f4_fma(rg.s[e], cx.c, rg.nl[e]);
@@ -282,15 +225,7 @@ LWM_DEVICE void d4_fillers(const D4Ctx& cx, D4Regs& rg, const f32x16& dpu) {
             ld = kD4Sched.D[i] > ld ? kD4Sched.D[i] : ld;
         }
         if (lp == G) rg.pb[h] = __builtin_bit_cast(bf16x8, u32x4{rg.pw[4 * h], rg.pw[4 * h + 1], rg.pw[4 * h + 2], rg.pw[4 * h + 3]});
-        if (ld == G) {
-            rg.dsb[h] = __builtin_bit_cast(bf16x8, u32x4{rg.dw[4 * h], rg.dw[4 * h + 1], rg.dw[4 * h + 2], rg.dw[4 * h + 3]});
-#if defined(LWM_D4X_STOREDS) && LWM_D4X_STOREDS == 1
-            if (rg.ds_out) {
-                global_store_b128(rg.ds_out + h * 1024, u32x4{rg.dw[4 * h], rg.dw[4 * h + 1], rg.dw[4 * h + 2], rg.dw[4 * h + 3]});
-                if (h == 1) rg.ds_out += 4 * 2048;
-            }
-#endif
-        }
+        if (ld == G) rg.dsb[h] = __builtin_bit_cast(bf16x8, u32x4{rg.dw[4 * h], rg.dw[4 * h + 1], rg.dw[4 * h + 2], rg.dw[4 * h + 3]});
     }
 }
 // dispatch a loop index to the compile-time gap (the loops are fully unrolled: the chain folds to one call)
@@ -321,51 +256,31 @@ LWM_DEVICE void d4_x(const D4Ctx& cx, D4Regs& rg, const bf16x8 (&kf)[8], const b
     const f32x16& dpo = rg.dp[HALF ^ 1];  // the previous unit's
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
-        if (!kD4Pair) {
-            rg.fr[(m + kD4Ahead) & 7] = d4_frag<HALF>(cx, m + kD4Ahead);
-        } else if ((m & 1) == 0) {
+        if ((m & 1) == 0) {
             rg.fr[(m + kD4Ahead) & 7] = d4_frag<HALF>(cx, m + kD4Ahead);
             rg.fr[(m + kD4Ahead + 1) & 7] = d4_frag<HALF>(cx, m + kD4Ahead + 1);
         }
-        if (kD4xStat && (m & 3) == 2) {      // the unit's -lse * log2 e (needed from gap 1 of phase Y)
+        if ((m & 3) == 2) {      // the unit's -lse * log2 e (needed from gap 1 of phase Y)
             const int g = m >> 2;
             const f32x4 v = lds_read_f32x4(cx.stat + HALF * 32 * 4 + 8 * g * 4);
             rg.nl[4 * g + 0] = v[0]; rg.nl[4 * g + 1] = v[1]; rg.nl[4 * g + 2] = v[2]; rg.nl[4 * g + 3] = v[3];
         }
         sched_fence();
         {
-            const int f = kD4Pair ? (m ^ 1) : m;      // the fragment this gap's MFMA consumes: even = Q (S), odd = dO (dP')
+            const int f = m ^ 1;      // the fragment this gap's MFMA consumes: even = Q (S), odd = dO (dP')
             if (f == 0) f4_mfma_s_first(rg.s, rg.fr[0], kf[0]);
             else if ((f & 1) == 0) f4_mfma_s(rg.s, rg.fr[f & 7], kf[f >> 1]);
             else if (f == 1) d4_mfma_p_first(dpn, rg.fr[1], vf[0]);
             else f4_mfma_s(dpn, rg.fr[f & 7], vf[f >> 1]);
         }
-#ifndef LWM_D4X_NODMA
         if (DMA && (m & 1)) {         // the wave's 4 Q and 4 dO pieces of the step two ahead, all in the step's first phase
             const int j = m >> 2;
             if ((m & 2) == 0) f4_dma1(vq[j], dm.q_src, dm.dst + 4096 * j);
             else f4_dma1(vdo[j], dm.do_src, dm.dst + kD4TileBytes + 4096 * j);
         }
-#endif
-#if defined(LWM_D4X_STOREDS) && LWM_D4X_STOREDS == 2
-        if (HALF == 0 && m == 0 && rg.ds_out) {     // the units finished during the two phases X of the step before
-            for (int h = 0; h < 4; ++h) {
-#ifdef LWM_D4X_STOREDS_NT
-                const u32x4 w_ = {rg.hold[4 * h], rg.hold[4 * h + 1], rg.hold[4 * h + 2], rg.hold[4 * h + 3]};
-                __builtin_nontemporal_store(w_, (u32x4*)(rg.ds_out + h * 1024));
-#else
-                global_store_b128(rg.ds_out + h * 1024, u32x4{rg.hold[4 * h], rg.hold[4 * h + 1], rg.hold[4 * h + 2], rg.hold[4 * h + 3]});
-#endif
-            }
-            rg.ds_out += 2 * 4 * 2048;
-        }
-#endif
         if (HAS_PREV) d4_fill_at<16, 16>(16 + m, cx, rg, dpo);
         sched_fence();
     }
-#if defined(LWM_D4X_STOREDS) && LWM_D4X_STOREDS == 2
-    for (int i = 0; i < 8; ++i) rg.hold[8 * (HALF ^ 1) + i] = rg.dw[i];
-#endif
 }
 
 // masks of a unit on its scores (lwm/llama.py:572-592): query row (r&3) + 8 (r>>2) + 4 hi of the unit sees this lane's
@@ -399,16 +314,14 @@ LWM_DEVICE void d4_y(const D4Ctx& cx, D4Regs& rg, f32x16 (&dk)[4], f32x16 (&dv)[
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int m = 16 + j;
-        if (!kD4Pair) {
-            if (m + kD4Ahead < 32 || NEXT) rg.fr[(m + kD4Ahead) & 7] = d4_frag<HALF>(cx, m + kD4Ahead);
-        } else if ((j & 1) == 0 && (m + kD4Ahead < 32 || NEXT)) {
+        if ((j & 1) == 0 && (m + kD4Ahead < 32 || NEXT)) {
             rg.fr[(m + kD4Ahead) & 7] = d4_frag<HALF>(cx, m + kD4Ahead);
             rg.fr[(m + kD4Ahead + 1) & 7] = d4_frag<HALF>(cx, m + kD4Ahead + 1);
         }
-        if (kD4xStat && NEXT && j >= 12) d4_load_ndelta<HALF ^ 1>(statn, rg.dp[HALF ^ 1], j - 12);
+        if (NEXT && j >= 12) d4_load_ndelta<HALF ^ 1>(statn, rg.dp[HALF ^ 1], j - 12);
         sched_fence();
         if (HAS_PREV) {
-            const int jf = kD4Pair ? (j ^ 1) : j;      // the fragment consumed: even = dO^T (dV), odd = Q^T (dK)
+            const int jf = j ^ 1;      // the fragment consumed: even = dO^T (dV), odd = Q^T (dK)
             if (INIT && jf < 8) {
                 if ((jf & 1) == 0) d4_mfma_o_first(dv[(jf >> 1) & 3], rg.fr[(16 + jf) & 7], rg.pb[0]);
                 else d4_mfma_o_first(dk[(jf >> 1) & 3], rg.fr[(16 + jf) & 7], rg.dsb[0]);
@@ -592,12 +505,6 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
         };
 
         D4Regs rg;
-#ifdef LWM_D4X_STOREDS
-        for (int i = 0; i < 16; ++i) rg.hold[i] = 0;
-        rg.ds_out = p.dq_acc ? (char*)p.dq_acc + ((int64_t)(hb * ((p.Sk + kD4BK - 1) / kD4BK) + kbi) * ((p.Sq + kD4BQ - 1) / kD4BQ)) * 16384 +
-                                   wave * 2048 + lane * 16
-                             : nullptr;
-#endif
         rg.s = zero_f32x16();
         rg.dp[0] = zero_f32x16();
         rg.dp[1] = zero_f32x16();
@@ -622,11 +529,6 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
         // this one), the others behind the barrier.  Top: the statistics piece and, inside the first X phase, the
         // LDS-DMA pieces of step i+2 -> slot (i+2) & 3 (last read by the lagging products at the head of step i-1).
         // Bottom: this wave's pieces have landed (they were issued >= 2000 cycles ago), one barrier.
-#ifdef LWM_D4X_NOBAR
-#define LWM_D4_BAR()
-#else
-#define LWM_D4_BAR() block_sync_lds()
-#endif
 #define LWM_D4_MASK(HALF_, HAS_PREV_, ub_)                                                                          \
     do {                                                                                                            \
         /* (the wait states sit in ONE statement on every path that needs them: with two, hipcc merges the tuples */ \
@@ -668,7 +570,7 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
 #define LWM_D4_STEP(i, FIRST, PIPE)                                                                                 \
     do {                                                                                                            \
         if (PIPE) {                                                                                                 \
-            if (kD4xSload && stat_on) d4_dma_b32(vstat, st_src2, stat_dst + (((i) + 2) & 3) * kD4StatBytes);        \
+            if (stat_on) d4_dma_b32(vstat, st_src2, stat_dst + (((i) + 2) & 3) * kD4StatBytes);        \
             dm.q_src = q_src2;                                                                                      \
             dm.do_src = do_src2;                                                                                    \
             dm.dst = lds + (((i) + 2) & 3) * kD4SlotBytes + (uint32_t)wave * 1024;                                  \
@@ -699,7 +601,7 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
         if ((FIRST) || !(PIPE)) d4_settle_acc(dk, dv);                                                              \
         glds_wait_all();                                                                                            \
         D4_LAP(6);                                                                                                  \
-        LWM_D4_BAR();                                                                                               \
+        block_sync_lds();                                                                                           \
         D4_LAP(7);                                                                                                  \
         for (int db_ = 0; db_ < 4; ++db_) {                                                                         \
             cx.plo[db_] = cx.tlo[db_];                                                                              \
@@ -739,7 +641,6 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
 #undef D4_LAP
 #undef D4_LAP2
 #undef LWM_D4_MASK
-#undef LWM_D4_BAR
         // the last unit's products: its tiles are the second half of the PREVIOUS slot now (the registers moved on)
         d4_drain<1>(cx, rg, dk, dv);
         d4_settle_acc(dk, dv);      // before the paths merge (hipcc reconciles the tuples by copies at the merge)
@@ -884,7 +785,6 @@ LWM_DEVICE bf16x8 q4_frag(const Q4Ctx& cx, int f) {
 // the vector work scheduled in gap G for the unit of parity PAR
 template <int G, int PAR>
 LWM_DEVICE void q4_fillers(const Q4Ctx& cx, Q4Regs& rg) {
-    if (!kD4xFill) return;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         if (kQ4Sched.F[e] == G) rg.t[e] = f4_fma(rg.s[PAR][e], cx.c, cx.nl);
@@ -928,13 +828,11 @@ LWM_DEVICE void q4_x(const Q4Ctx& cx, Q4Regs& rg, const bf16x8 (&qf)[8], const b
             else if (f == 1) q4_mfma_c_first(rg.dp[HALF], rg.fr[1], dof[0], rg.ndl);
             else f4_mfma_s(rg.dp[HALF], rg.fr[f & 7], dof[f >> 1]);
         }
-#ifndef LWM_D4X_NODMA
         if (DMA && (m & 1)) {
             const int j = m >> 2;
             if ((m & 2) == 0) f4_dma1(vk[j], dm.q_src, dm.dst + 4096 * j);
             else f4_dma1(vv[j], dm.do_src, dm.dst + kD4TileBytes + 4096 * j);
         }
-#endif
         if (HAS_PREV) q4_fill_at<8, 16, HALF ^ 1>(8 + m, cx, rg);
         sched_fence();
     }

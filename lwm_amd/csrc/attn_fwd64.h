@@ -18,10 +18,10 @@
 //
 // Scores are computed transposed (S^T = K Q^T: a lane owns one query column, as in attn_fwd.h).  What is
 // new in the arithmetic:
-//   * Q is pre-multiplied by scale*log2(e) and rounded to bf16 once per workgroup ("Q~"), so a score leaves
-//     the MFMA in log2 units;
-//   * p = exp2(s*c - m*c) is ONE fma + one exp per score (m = the query's running reference, its maximum at the
-//     last rescale; scores stay raw in their registers);
+//   * p = exp2(s*c - m*c), c = scale*log2(e), is ONE fma + one exp per score (m = the query's running reference, its
+//     maximum at the last rescale; scores stay raw q.k in their registers.  Pre-multiplying Q by c and rounding it to
+//     bf16 once per workgroup saves the multiply but moves the LSE by up to ~2e-3: measured in round 3 and dropped,
+//     profiles/r03_fwd64_dma.txt);
 //   * the reference moves only when some row would exceed 2^kDeferLog2 (deferred rescale, as before) and the
 //     decision needs no cross-lane traffic; the rescale itself is a rare, non-interleaved block that runs
 //     after the P.V of the tile in flight is complete.
@@ -40,13 +40,6 @@ constexpr int kF4TileBytes = kF4BK * kRowBytes;                 // 16 KiB
 constexpr int kF4OffMeta = 4 * kF4TileBytes;
 constexpr int kF4OffScan = kF4OffMeta + 3 * kF4BK * 4;   // three key-meta buffers: tile t in buffer t % 3
 constexpr int kF4LdsBytes = kF4OffScan + 64;
-// 1: Q~ = bf16(q * scale * log2 e) -- p = exp2(S), one VALU per score, but the rounding of Q~ (2^-9 relative per
-//    element) moves a score by ~1.6e-3 and the LSE by up to ~2e-3 (measured, tests/emu); 0: Q as given, S in raw
-//    q.k units, p = exp2(S * c) -- one more multiply per score, LSE exact to f32.  (A/B: profiles/r03_fwd64.md)
-#ifndef LWM_F4_PRESCALE
-#define LWM_F4_PRESCALE 0
-#endif
-constexpr bool kF4Prescale = LWM_F4_PRESCALE != 0;
 // LDS fragments (K row fragments for S, V transposed fragments for P.V: eight of each per half tile) are requested
 // kF4Ahead MFMA pairs before the MFMA that consumes them, through register rings of eight (index = fragment): with ONE
 // wave on the SIMD nothing else covers the LDS latency, and 512 registers leave room for the deeper ring.  The first
@@ -70,9 +63,9 @@ struct F4Ctx {
     float thr[2];               // raw-score threshold of the deferred rescale: -inf until the row's reference is set,
                                 // then mref + kDeferLog2 / c
     float mref[2];              // the reference, a raw score q.k (-inf: none yet)
-    float nbase[2];             // -mref * c (0 while mref = -inf; +mref when prescaled: f4_sub) -- the fma's addend
+    float nbase[2];             // -mref * c (0 while mref = -inf) -- the fma's addend
     float lsum[2];              // this half-wave's partial row sum
-    float c;                    // scale * log2(e): scores -> log2 units (1 when Q is prescaled)
+    float c;                    // scale * log2(e): scores -> log2 units
     float thr_on;               // kDeferLog2 in raw score units
 };
 
@@ -194,13 +187,11 @@ LWM_DEVICE void f4_mfma_settle() {}
 LWM_DEVICE void f4_settle_s(f32x16 (&)[2]) {}
 LWM_DEVICE void f4_settle_acc(f32x16 (&)[2][4]) {}
 LWM_DEVICE float f4_fma(float x, float c, float d) { return fmaf(x, c, d); }
-LWM_DEVICE float f4_sub(float x, float d) { return x - d; }
 LWM_DEVICE float f4_exp2(float x) { return exp2f(x); }
 LWM_DEVICE uint32_t f4_cvt_pk(float lo, float hi) { return pack_bf16x2(lo, hi); }
 LWM_DEVICE void f4_add(float& acc, float x) { acc += x; }
 LWM_DEVICE float f4_add2(float a, float b) { return a + b; }
 LWM_DEVICE void f4_max3(float& m, float a, float b) { m = fmaxf(fmaxf(m, a), b); }
-LWM_DEVICE bf16x8 f4_to_agpr(bf16x8 x) { return x; }
 LWM_DEVICE bf16x8 f4_load_agpr(const bf16_t* g) { return __builtin_bit_cast(bf16x8, global_load_b128(g)); }
 LWM_DEVICE void f4_load_agpr_wait(bf16x8 (&)[2][8]) {}
 LWM_DEVICE void f4_load_agpr_wait8(bf16x8 (&)[8]) {}
@@ -229,11 +220,6 @@ LWM_DEVICE float f4_fma(float x, float c, float d) {
     asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(y) : "v"(x), "v"(c), "v"(d));
     return y;
 }
-LWM_DEVICE float f4_sub(float x, float d) {
-    float y;
-    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(y) : "v"(x), "v"(d));
-    return y;
-}
 LWM_DEVICE float f4_exp2(float x) {
     float y;
     asm volatile("v_exp_f32 %0, %1" : "=v"(y) : "v"(x));
@@ -249,17 +235,6 @@ LWM_DEVICE float f4_add2(float a, float b) {
     float y;
     asm volatile("v_add_f32 %0, %1, %2" : "=v"(y) : "v"(a), "v"(b));
     return y;
-}
-// a fragment whose HOME is the accumulator file: each dword is defined by an asm with an AGPR output, so that the
-// "a" operands of the MFMAs coalesce with it instead of being re-copied from a VGPR before every use
-LWM_DEVICE bf16x8 f4_to_agpr(bf16x8 x) {
-    const u32x4 v = __builtin_bit_cast(u32x4, x);
-    uint32_t w0, w1, w2, w3;
-    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(w0) : "v"(v[0]));
-    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(w1) : "v"(v[1]));
-    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(w2) : "v"(v[2]));
-    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(w3) : "v"(v[3]));
-    return __builtin_bit_cast(bf16x8, u32x4{w0, w1, w2, w3});
 }
 // 16 bytes from global memory straight into the accumulator file (gfx90a+: a load may target AGPRs).  hipcc does not
 // count the load: f4_load_agpr_wait names every destination, so that nothing is read or moved before the data is in
@@ -366,7 +341,7 @@ LWM_DEVICE void f4_phase1(const F4Ctx& cx, const bf16x8 (&qf)[2][8], f32x16 (&sN
 }
 
 // Phase 2 (16 MFMAs): O^T += V^T P^T  ||  row sums (the pair sums ps), running max of the next half tile's scores (sN)
-// and its exponents tN = s*c - m*c (one fma per score; a subtract when Q is prescaled: c = 1).
+// and its exponents tN = s*c - m*c (one fma per score).
 // VHALF = key half of the half tile being finished inside the V buffer; its fragments 0..kF4Ahead-1 are already in vfr.
 // KNEXT >= 0: request the first three K fragments of the phase 1 that follows (key half KNEXT of the buffer cx.ka
 // points at NOW) during the last gaps.
@@ -392,8 +367,8 @@ LWM_DEVICE void f4_phase2(F4Ctx& cx, const bf16x8 (&pb)[2][2], f32x16 (&acc)[2][
         if (DO_PV) f4_add(ls[fq], ps[fq][r >> 1]);
         if (DO_MAX) {
             f4_max3(mp[fq], sN[fq][r], sN[fq][r + 1]);
-            tN[fq][r] = kF4Prescale ? f4_sub(sN[fq][r], cx.nbase[fq]) : f4_fma(sN[fq][r], cx.c, cx.nbase[fq]);
-            tN[fq][r + 1] = kF4Prescale ? f4_sub(sN[fq][r + 1], cx.nbase[fq]) : f4_fma(sN[fq][r + 1], cx.c, cx.nbase[fq]);
+            tN[fq][r] = f4_fma(sN[fq][r], cx.c, cx.nbase[fq]);
+            tN[fq][r + 1] = f4_fma(sN[fq][r + 1], cx.c, cx.nbase[fq]);
         }
         sched_fence();
     }
@@ -441,8 +416,8 @@ LWM_DEVICE void f4_rescale(F4Ctx& cx, const float (&mx)[2], f32x16 (&acc)[2][4],
         const float alpha = fast_exp2((cx.mref[qb] - ms) * cx.c); // 0 while the old reference is -inf
         cx.lsum[qb] *= alpha;
         for (int db = 0; db < 4; ++db) f4_scale_acc(acc[qb][db], alpha);
-        const float nb_new = kF4Prescale ? ms : -ms * cx.c;
-        const float dt = kF4Prescale ? -(nb_new - cx.nbase[qb]) : nb_new - cx.nbase[qb];    // change of the exponents
+        const float nb_new = -ms * cx.c;
+        const float dt = nb_new - cx.nbase[qb];    // change of the exponents
         for (int r = 0; r < 16; ++r) tN[qb][r] += dt;              // (-inf stays -inf)
         cx.mref[qb] = m_new;
         cx.nbase[qb] = nb_new;
@@ -485,11 +460,10 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
             cx.vup[db] = t.up[db];
         }
     }
-    const float c = p.scale * kLog2e;
-    cx.c = kF4Prescale ? 1.0f : c;
-    cx.thr_on = kF4Prescale ? kDeferLog2 : kDeferLog2 / c;
+    cx.c = p.scale * kLog2e;
+    cx.thr_on = kDeferLog2 / cx.c;
 
-    // ---- this lane's two query rows (Q~ = bf16(q * scale * log2 e) when prescaled)
+    // ---- this lane's two query rows
     bf16x8 qf[2][8];
     int q_row[2];
     bool q_ok[2];
@@ -501,28 +475,15 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
         q_ok[qb] = q_row[qb] < p.Sq;
         q_pos[qb] = p.q_start + q_row[qb];
         seg_q[qb] = (HAS_META && q_ok[qb] && p.seg_q) ? p.seg_q[(int64_t)b * p.Sq + q_row[qb]] : 0;
-        if (kF4Prescale) {
-            for (int s = 0; s < 8; ++s) {
-                if (q_ok[qb]) {
-                    const bf16x8 raw = __builtin_bit_cast(bf16x8, global_load_b128(qb_ + (int64_t)q_row[qb] * p.q_ss + 16 * s + 8 * hi));
-                    bf16x8 o;
-                    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)raw[j] * c);
-                    qf[qb][s] = f4_to_agpr(o);
-                } else {
-                    qf[qb][s] = f4_to_agpr(zero_bf16x8());
-                }
-            }
-        } else {
-            // straight into the accumulator file (a row past Sq re-reads the last row: its results are never stored)
-            const int qr = q_ok[qb] ? q_row[qb] : p.Sq - 1;
-            for (int s = 0; s < 8; ++s) qf[qb][s] = f4_load_agpr(qb_ + (int64_t)qr * p.q_ss + 16 * s + 8 * hi);
-        }
+        // straight into the accumulator file (a row past Sq re-reads the last row: its results are never stored)
+        const int qr = q_ok[qb] ? q_row[qb] : p.Sq - 1;
+        for (int s = 0; s < 8; ++s) qf[qb][s] = f4_load_agpr(qb_ + (int64_t)qr * p.q_ss + 16 * s + 8 * hi);
         cx.thr[qb] = -INFINITY;
         cx.mref[qb] = -INFINITY;
         cx.nbase[qb] = 0.0f;
         cx.lsum[qb] = 0.0f;
     }
-    if (!kF4Prescale) f4_load_agpr_wait(qf);
+    f4_load_agpr_wait(qf);
     const int64_t wq_min = p.q_start + (int64_t)qt * kF4BQ + wave * 64;   // first / last query position of this wave
     const int64_t wq_max = wq_min + 63;
 
@@ -750,9 +711,6 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
         int n_fast = n_hot < n_wg - 2 ? n_hot : n_wg - 2;
         if (ragged && n_fast > nkt_all - 1 - kt0 - 2) n_fast = nkt_all - 1 - kt0 - 2;
         if (n_fast < 0) n_fast = 0;
-#ifdef LWM_F4_DMA_TOP      // (A/B builds only: every iteration stages at its top)
-        n_fast = 0;
-#endif
         int i = 0;
         for (; i < n_fast; ++i) {
             for (int j = 0; j < kF4Ahead; ++j) kfr[j] = f4_kread<1>(cx, j);
@@ -812,8 +770,7 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
         float inv = 0.0f, lse_b = -INFINITY;
         if (l_tot > 0.0f) {
             inv = 1.0f / l_tot;
-            // the reference is a score of Q~ (log2 units) when prescaled, a raw q.k otherwise
-            lse_b = cx.mref[qb] * (kF4Prescale ? kLn2 : p.scale) + logf(l_tot);
+            lse_b = cx.mref[qb] * p.scale + logf(l_tot);      // (the reference is a raw q.k)
         }
         float w_a = 0.0f, w_b = 1.0f, lse_new = lse_b;
         const int64_t lse_idx = ((int64_t)b * p.H + h) * p.Sq + q_row[qb];

@@ -20,7 +20,7 @@ from . import ops as _ops
 from .llama_ops import (LLaMAMLP, RMSNorm, apply_rotary_emb, chunked_lm_head_loss, dense, dense_multi,
                         precompute_freqs_cis, swiglu)
 from .ringattention import (blockwise_feedforward, concatenate_to_cache, ringattention,
-                            ringattention_inference, sp_size_rank)
+                            ringattention_inference, sp_positions, sp_size_rank)
 
 # The model sizes of lwm/llama.py:33-130:
 # name: (hidden, intermediate, layers, heads, max_sequence_length, rms_norm_eps)
@@ -243,15 +243,22 @@ class LLaMAForCausalLM(torch.nn.Module):
             self._freqs = precompute_freqs_cis(head_dim, self.cfg.max_sequence_length, self.cfg.theta, device=device)
         return self._freqs
 
-    def hidden_states(self, input_ids, attention_mask=None, segment_ids=None, position_ids=None, cache=None):
-        n_sp, r_sp = sp_size_rank("sp")
+    @staticmethod
+    def _ring_position_ids(input_ids, position_ids, cache):
+        """position_ids of a sequence-sharded training batch: the GLOBAL positions of this rank's rows under the
+        ownership rule bound to the "sp" axis (lwm_amd.ringattention.set_sp_group: zigzag by default, or the
+        reference's contiguous blocks, lwm/llama.py:560-562) -- the rows were cut with `sp_shard`, so RoPE and the
+        causal mask both see where each token really sits."""
+        n_sp = sp_size_rank("sp")[0]
         if n_sp > 1 and position_ids is None and cache is None:
-            # contiguous ownership (lwm/llama.py:560-562): this rank's rows are global positions r*S..(r+1)*S-1
-            S = input_ids.shape[1]
-            position_ids = (torch.arange(S, device=input_ids.device, dtype=torch.int32) + r_sp * S)[None] \
-                .expand(input_ids.shape[0], S).contiguous()
+            B, S = input_ids.shape
+            position_ids = sp_positions(S, "sp", input_ids.device).to(torch.int32)[None].expand(B, S).contiguous()
         if n_sp > 1 and position_ids is None:
             raise ValueError("cached inference over a sequence ring needs explicit global position_ids")
+        return n_sp, position_ids
+
+    def hidden_states(self, input_ids, attention_mask=None, segment_ids=None, position_ids=None, cache=None):
+        n_sp, position_ids = self._ring_position_ids(input_ids, position_ids, cache)
         x = torch.nn.functional.embedding(input_ids.long(), self.wte)
         fc = self._table(x.device)
         if cache is not None and self._fused_decode_ok(x, n_sp):

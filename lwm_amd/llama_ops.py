@@ -135,9 +135,15 @@ def _softmax_ce(logits2d, target, weight, want_grad):
 
 
 def _row_weights(valid, B, S, device):
-    """valid (B,S) or None -> (valid f32, per-row gradient weight valid / (max(sum_s valid, 1e-10) * B))."""
+    """valid (B,S) or None -> (valid f32, per-row gradient weight valid / (max(sum_s valid, 1e-10) * B)).
+    Over a sequence ring S is this rank's SHARD of each sequence: the count of valid targets is summed over the "sp"
+    axis, so that each rank's loss is its share of the reference's per-sequence mean (tux.cross_entropy_loss_and_accuracy,
+    lwm/train.py:177-181) and the shares ADD UP to it -- whatever the masks do to the counts per rank."""
     v = torch.ones(B, S, dtype=torch.float32, device=device) if valid is None else valid.to(torch.float32)
-    denom = v.sum(dim=-1, keepdim=True).clamp_min(1e-10) * B
+    count = v.sum(dim=-1, keepdim=True)
+    from .ringattention import sp_all_reduce_sum
+    sp_all_reduce_sum(count, "sp")
+    denom = count.clamp_min(1e-10) * B
     return v, (v / denom).contiguous()
 
 

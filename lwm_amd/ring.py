@@ -584,49 +584,105 @@ class _RingAttention(torch.autograd.Function):
         return dq, dk, dv, None, None, None
 
 
+_TORCH_COMMS = {}
+
+
+def _torch_comm(group):
+    """one communicator per process group: its exchange-buffer pool (TorchRingComm.pooled) is what makes the buffers
+    allocate-once across layers and steps"""
+    cm = _TORCH_COMMS.get(id(group))
+    if cm is None or cm[0] is not group:
+        cm = _TORCH_COMMS[id(group)] = (group, TorchRingComm(group))
+    return cm[1]
+
+
 _C_RINGS = {}
 _C_RING_REFUSED = set()     # groups whose first contact with the C driver failed on some rank: they stay on this module's driver
 
 
-def _c_driver_wanted(group, block_ops):
-    """The C-ABI ring driver (lwm_ring_attn_fwd / _bwd) is OPT-IN for the library entry point: LWM_RING_DRIVER=c.  It has
-    run between real processes (IPC transport, one GPU) and against RCCL at n = 1, never across GPUs, so the default stays
-    this module's driver over torch.distributed; bench.py asks for it explicitly (--driver c) under the same vote."""
-    if block_ops is not None or os.environ.get("LWM_RING_DRIVER", "python") != "c" or group in _C_RING_REFUSED:
-        return False
+def _c_driver_transport(group, block_ops, q):
+    """Which transport the C-ABI ring driver (lwm_ring_attn_fwd / _bwd) would use for this call, or None = this module's
+    driver over torch.distributed.  The C driver is the DEFAULT on GPUs when the group's backend is RCCL ("nccl");
+    on a gloo group (the CPU tests; a dry run of N processes on one GPU) it runs only when LWM_RING_TRANSPORT=ipc
+    selects the library's own IPC transport -- gloo itself cannot carry device memory.  LWM_RING_DRIVER=python opts out,
+    =c insists (a refusal is then an error instead of a fallback)."""
+    want = os.environ.get("LWM_RING_DRIVER") or "auto"
+    if block_ops is not None or want == "python" or group in _C_RING_REFUSED or not q.is_cuda:
+        return None
     try:
-        return dist.get_backend(group) == "nccl" and dist.get_world_size(group) > 1
+        backend, size = dist.get_backend(group), dist.get_world_size(group)
     except Exception:
-        return False
+        return None
+    if size < 2:
+        return None
+    transport = os.environ.get("LWM_RING_TRANSPORT") or ("rccl" if backend == "nccl" else None)
+    if transport == "rccl" and backend != "nccl":
+        return None          # (an RCCL communicator of our own beside a gloo job: not what anybody asked for)
+    return transport if transport in ("rccl", "ipc") else None
 
 
-def _c_ring_for(group, layout_kind, schedule):
-    """One C ring object (communicator, side stream, workspace) per (group, layout, schedule), reused by every layer; None
-    when the first contact fails on ANY rank (collective vote: every rank then takes this module's driver).  The direct
-    schedule's owner-side reduction takes at most 16 sources (lwm_sum_f32_to_bf16): larger groups get the neighbour ring."""
+def _vote(group, ok):
+    """min over the group of a 0/1 flag (on the device for RCCL, on the host for gloo)"""
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    v = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(v, op=dist.ReduceOp.MIN, group=group)
+    return int(v.item()) == 1
+
+
+def _c_ring_for(group, layout_kind, schedule, transport, slot_bytes, slots=8):
+    """One C ring object (communicator / mailboxes, side stream, workspace) per (group, layout, schedule, transport),
+    reused by every layer; None when the set-up fails on ANY rank: every rank then takes this module's driver.
+    Every collective of the set-up is entered by every rank whatever happened on it before (a rank that
+    failed ahead of the bootstrap broadcast used to meet the others in a different collective): (1) a capability
+    vote -- the library loads, and for RCCL its run-time symbol table resolves -- (2) the bootstrap inside CRing, whose
+    own exchanges carry an ok flag, (3) a vote on the finished object.
+    The direct schedule's owner-side reduction takes at most 16 sources (lwm_sum_f32_to_bf16): larger groups get the
+    neighbour ring."""
     from .ring_c import CRing
     if schedule in ("mesh", "direct") and dist.get_world_size(group) > 16:
         schedule = "ring"
-    key = (group, layout_kind, schedule, torch.cuda.current_device())      # (the group object itself: an id() can be recycled)
+    key = (group, layout_kind, schedule, transport, torch.cuda.current_device())      # (the group object itself: an id() can be recycled)
     ring = _C_RINGS.get(key)
+    if ring is not None and transport == "ipc" and (ring.ipc_slot_bytes < slot_bytes or ring._ipc_slots < slots):
+        ring.close()          # a larger shard than the mailboxes were cut for: every rank sees the same shapes, so
+        ring = None           # every rank comes through here together
     if ring is None:
-        ok, err = 1, None
+        err = None
         try:
-            ring = CRing(group, layout=layout_kind, schedule=schedule)
+            CRing.probe(transport)
         except Exception as e:       # noqa: BLE001 -- whatever it is, the vote decides
-            ok, err = 0, e
-        vote = torch.tensor([ok], dtype=torch.int32, device="cuda")
-        dist.all_reduce(vote, op=dist.ReduceOp.MIN, group=group)
-        if int(vote.item()) == 0:
+            err = e
+        if _vote(group, err is None):
+            try:
+                ring = CRing(group, layout=layout_kind, schedule=schedule, transport=transport,
+                             ipc_slot_bytes=slot_bytes if transport == "ipc" else None, ipc_slots=slots)
+            except Exception as e:       # noqa: BLE001
+                err = e
+            if not _vote(group, err is None):
+                err = err or RuntimeError("another rank failed")
+        else:
+            err = err or RuntimeError("another rank failed")
+        if err is not None:
+            if ring is not None:
+                ring.close()
+            _C_RING_REFUSED.add(group)
+            _C_RINGS.pop(key, None)
+            if os.environ.get("LWM_RING_DRIVER") == "c":
+                raise RuntimeError(f"LWM_RING_DRIVER=c, but the C ring driver could not be set up on every rank: {err!r}")
             import warnings
             warnings.warn(f"lwm_amd.ring: the C ring driver could not be set up on every rank of this group ({err!r} here); "
                           "falling back to the torch.distributed driver")
-            _C_RING_REFUSED.add(group)
-            if ring is not None:
-                ring.close()
             return None
         _C_RINGS[key] = ring
     return ring
+
+
+def ring_driver_info(group):
+    """What carried the last ring_attention calls of this group: {"driver": "c" | "python", ...} (logging / tests)."""
+    for (g, lay, sched, transport, _dev), ring in _C_RINGS.items():
+        if g is group:
+            return {"driver": "c", "layout": lay, "schedule": sched, "transport": transport, "bytes_sent": ring.bytes_sent}
+    return {"driver": "python", "refused_c_driver": group in _C_RING_REFUSED}
 
 
 def ring_attention(q, k, v, *, group=None, causal=True, segment_ids=None, key_valid=None,
@@ -636,6 +692,11 @@ def ring_attention(q, k, v, *, group=None, causal=True, segment_ids=None, key_va
     segment_ids / key_valid are the FULL-length (B, S_global) tensors, replicated
     on every rank, exactly as the reference passes attn_bias / segment_ids
     un-sharded (lwm/llama.py:563-564).
+
+    `layout` names which positions the local rows ARE (the caller sharded the sequence that way): "contiguous" =
+    the reference's, "zigzag" = balanced causal work.  This low-level entry keeps the reference's rule as its
+    default; the operator surface above it (lwm_amd.ringattention: set_sp_group / sp_shard / ringattention) defaults to
+    zigzag for more than one rank.
     """
     if comm is None:
         if group is None and not (dist.is_available() and dist.is_initialized()):
@@ -646,19 +707,20 @@ def ring_attention(q, k, v, *, group=None, causal=True, segment_ids=None, key_va
             # never default to WORLD: a data-parallel job would silently ring its replicas
             raise RuntimeError("ring_attention in a multi-process job needs the sequence-parallel group "
                                "(group=... or comm=...; torch.distributed.group.WORLD for a pure ring)")
-        elif _c_driver_wanted(group, block_ops):
-            # LWM_RING_DRIVER=c, N > 1 on GPUs: the exchange is driven by the C-ABI ring driver (lwm_ring_attn_fwd / _bwd:
-            # RCCL on a side HIP stream, the same layouts, the direct schedule = this module's "mesh").
-            from .ring_c import ring_attention_c
-            kind = layout.kind if isinstance(layout, SeqLayout) else layout
-            sched = os.environ.get("LWM_RING_SCHEDULE") or "mesh"
-            c_ring = _c_ring_for(group, kind, sched)
-            if c_ring is not None:
-                return ring_attention_c(q, k, v, c_ring, causal=causal, segment_ids=segment_ids,
-                                        key_valid=key_valid, scale=scale)
-            comm = TorchRingComm(group)
         else:
-            comm = TorchRingComm(group)
+            transport = _c_driver_transport(group, block_ops, q)
+            if transport is not None:
+                # N > 1 on GPUs: the exchange is driven by the C-ABI ring driver (lwm_ring_attn_fwd / _bwd: RCCL -- or the
+                # library's IPC transport -- on a side HIP stream, the same layouts, the direct schedule = this module's
+                # "mesh").
+                from .ring_c import ring_attention_c
+                kind = layout.kind if isinstance(layout, SeqLayout) else layout
+                sched = os.environ.get("LWM_RING_SCHEDULE") or "mesh"
+                c_ring = _c_ring_for(group, kind, sched, transport, q.numel() * 4, max(8, 4 * q.shape[0]))
+                if c_ring is not None:
+                    return ring_attention_c(q, k, v, c_ring, causal=causal, segment_ids=segment_ids,
+                                            key_valid=key_valid, scale=scale)
+            comm = _torch_comm(group)
     block = block_ops if block_ops is not None else HipBlockOps
     lay = layout if isinstance(layout, SeqLayout) else SeqLayout(layout, comm.size,
                                                                  q.shape[1] * comm.size)

@@ -29,6 +29,30 @@ class CRing:
     B * c * H * D * 4 bytes, the f32 dK/dV piece of a whole shard, covers everything); or a _capi.LwmRingTransport
     (tests).  `group` may be a gloo group: only the bootstrap (id / handle exchange) goes through it."""
 
+    @staticmethod
+    def probe(transport=None):
+        """Can this process create a ring over `transport` at all?  Raises if not: the library does not load, or -- for
+        RCCL -- its run-time symbol table does not resolve.  Touches no other rank (callers vote on the outcome before
+        they enter the collective bootstrap of __init__)."""
+        L = lib()
+        if transport in (None, "rccl"):
+            _capi.check(L, L.lwm_ring_unique_id((C.c_char * 128)()), "lwm_ring_unique_id")
+        elif transport == "ipc":
+            if int(L.lwm_ring_ipc_info_bytes()) <= 0:
+                raise RuntimeError("lwm_ring_ipc_info_bytes() <= 0")
+
+    @classmethod
+    def null(cls, rank, size, *, layout="zigzag", schedule="direct", device=None):
+        """Rank `rank` of a `size`-rank ring over a transport that moves NOTHING (receive buffers stay as allocated): the
+        launches that rank would make, on this GPU, with every transfer free -- what bench.py prices the exchange with
+        and what balance reports time rank by rank.  Results are meaningless."""
+        ok = lambda *a: 0
+        fns = (_capi.RING_GROUP_FN(ok), _capi.RING_SEND_FN(ok), _capi.RING_SEND_FN(ok), _capi.RING_GROUP_FN(ok))
+        ring = cls(rank=rank, size=size, transport=_capi.LwmRingTransport(None, *fns), layout=layout, schedule=schedule,
+                   device=device)
+        ring._keep = fns
+        return ring
+
     def __init__(self, group=None, *, rank=None, size=None, transport=None, device=None, layout="contiguous",
                  schedule="ring", ipc_slot_bytes=None, ipc_slots=8):
         import torch.distributed as dist
@@ -46,6 +70,10 @@ class CRing:
         self._transport = transport           # keep the callbacks alive
         self._ipc = None
         self._ipc_slots = int(ipc_slots) if transport == "ipc" else None
+        self.ipc_slot_bytes = int(ipc_slot_bytes or 0) if transport == "ipc" else 0
+        # Every collective below is entered by EVERY rank, whatever failed on it before: a local failure travels as
+        # an ok flag inside the exchange and is raised on all ranks after it (a rank that raised ahead of the exchange
+        # would leave the others waiting in it).
         if self.size == 1:
             rc = L.lwm_ring_create(None, 0, 1, None, C.byref(h))
         elif transport == "ipc":
@@ -54,13 +82,21 @@ class CRing:
             nb = int(L.lwm_ring_ipc_info_bytes())
             info = (C.c_char * nb)()
             ipc = C.c_void_p()
-            with torch.cuda.device(self.device):
-                _capi.check(L, L.lwm_ring_ipc_export(self.rank, self.size, int(ipc_slot_bytes), int(ipc_slots), info, C.byref(ipc)),
-                            "lwm_ring_ipc_export")
-            self._ipc = ipc
+            err = None
+            try:
+                with torch.cuda.device(self.device):
+                    _capi.check(L, L.lwm_ring_ipc_export(self.rank, self.size, int(ipc_slot_bytes), int(ipc_slots), info, C.byref(ipc)),
+                                "lwm_ring_ipc_export")
+                self._ipc = ipc
+            except Exception as e:      # noqa: BLE001 -- reported to every rank below
+                err = repr(e)
             blobs = [None] * self.size
-            dist.all_gather_object(blobs, bytes(info), group=group)
-            allinfo = (C.c_char * (nb * self.size)).from_buffer_copy(b"".join(blobs))
+            dist.all_gather_object(blobs, (err, bytes(info)), group=group)
+            bad = [(r, e) for r, (e, _) in enumerate(blobs) if e is not None]
+            if bad:
+                self.close()
+                raise RuntimeError(f"lwm_ring_ipc_export failed on rank(s) {bad}")
+            allinfo = (C.c_char * (nb * self.size)).from_buffer_copy(b"".join(b for _, b in blobs))
             with torch.cuda.device(self.device):
                 _capi.check(L, L.lwm_ring_ipc_connect(ipc, allinfo), "lwm_ring_ipc_connect")
             rc = L.lwm_ring_create_ipc(ipc, side_ptr, C.byref(h))
@@ -68,12 +104,18 @@ class CRing:
             rc = L.lwm_ring_create_transport(C.byref(transport), self.rank, self.size, side_ptr, C.byref(h))
         else:
             ident = (C.c_char * 128)()
+            err = None
             if self.rank == 0:
-                _capi.check(L, L.lwm_ring_unique_id(ident), "lwm_ring_unique_id")
-            box = [bytes(ident)]
+                try:
+                    _capi.check(L, L.lwm_ring_unique_id(ident), "lwm_ring_unique_id")
+                except Exception as e:      # noqa: BLE001 -- broadcast with the id, raised on every rank
+                    err = repr(e)
+            box = [(err, bytes(ident))]
             src = dist.get_global_rank(group, 0) if group is not None else 0
             dist.broadcast_object_list(box, src=src, group=group)
-            ident = (C.c_char * 128).from_buffer_copy(box[0])
+            if box[0][0] is not None:
+                raise RuntimeError(f"lwm_ring_unique_id failed on rank 0 of the group: {box[0][0]}")
+            ident = (C.c_char * 128).from_buffer_copy(box[0][1])
             rc = L.lwm_ring_create_from_id(ident, self.rank, self.size, side_ptr, C.byref(h))
         _capi.check(L, rc, "lwm_ring_create")
         self._h = h
@@ -124,10 +166,14 @@ class CRing:
         return self._ws.data_ptr() + off
 
     def _args(self, q, k, v, out, lse, segment_ids, key_valid, scale, causal, backward):
-        if self._ipc_slots is not None and 4 * q.shape[0] > self._ipc_slots:
-            # the direct schedule posts (2 segments x {K, V} x B) messages per pair in one group: more than `slots` of
-            # them would make a send wait for an acknowledgement of its own group (the transport refuses that)
-            raise ValueError(f"CRing(transport='ipc', ipc_slots={self._ipc_slots}): batch {q.shape[0]} needs ipc_slots >= {4 * q.shape[0]}")
+        if (self._ipc_slots is not None and self.schedule == _capi.RING_SCHEDULE["direct"] and
+                (1 + (self.layout == _capi.RING_LAYOUT["zigzag"])) * 2 * q.shape[0] > self._ipc_slots):
+            # the direct schedule posts (segments x {K, V} x B) messages per pair in one group: more than `slots` of
+            # them would make a send wait for an acknowledgement of its own group.  The transport refuses that itself
+            # (ring_ipc.inc, ipc_send); this is the same rule with the number to pass instead.
+            need = (1 + (self.layout == _capi.RING_LAYOUT["zigzag"])) * 2 * q.shape[0]
+            raise ValueError(f"CRing(transport='ipc', ipc_slots={self._ipc_slots}): the direct schedule at batch {q.shape[0]} "
+                             f"needs ipc_slots >= {need}")
         B, c, H, D = q.shape
         a = _capi.LwmRingArgs()
         a.q, a.k, a.v, a.out = _t4(q, "q"), _t4(k, "k"), _t4(v, "v"), _t4(out, "out")

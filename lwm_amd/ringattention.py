@@ -7,19 +7,38 @@ Reference call sites:  lwm/llama.py:30 (import), :539-569 (training op),
 behaviour; tile sizes are the kernels' own (the reference's
 query/key_chunk_size only trade memory for speed and do not change results).
 """
+import os
+
 import torch
 
-from .ring import (HipBlockOps, SingleComm, TorchRingComm, cache_update, ring_attention,
+from .ring import (HipBlockOps, SeqLayout, SingleComm, TorchRingComm, cache_update, ring_attention,
                    ring_inference)
 
-_SP_GROUP = {"group": None, "bound": False}
+_SP_GROUP = {"group": None, "bound": False, "layout": None}
 
 
-def set_sp_group(group):
+def set_sp_group(group, layout=None):
     """Bind mesh axis name "sp" (lwm/llama.py:201-203) to a process group (`dist.group.WORLD` for a
-    job that is one sequence ring; None unbinds)."""
+    job that is one sequence ring; None unbinds) and choose WHICH positions a rank of it owns:
+
+      layout="zigzag"      rank r holds the half-chunks r and 2n-1-r of the sequence (local rows [0, c/2) and
+                           [c/2, c)): causal work is the same on every rank.  The DEFAULT for a group of more than one
+                           rank (LWM_SP_LAYOUT overrides): the harness, the CLI entry points and `ringattention` all
+                           follow it -- shard token / target / mask tensors with `sp_shard`, take positions from
+                           `sp_positions`.
+      layout="contiguous"  the reference's ownership, rank r holds [r*c, (r+1)*c) (lwm/llama.py:560-562,
+                           lwm/data.py:494-500): under a causal mask rank n-1 then computes ~1.9x the mean at n = 8
+                           and every step of the job waits for it.
+
+    Results do not depend on the layout (attention sees global positions, tests/test_ring_gloo.py); only which rank
+    computes what does."""
     _SP_GROUP["group"] = group
     _SP_GROUP["bound"] = group is not None
+    if layout is None:
+        layout = os.environ.get("LWM_SP_LAYOUT") or None
+    if layout not in (None, "zigzag", "contiguous"):
+        raise ValueError(f"unknown sp layout {layout!r} (zigzag | contiguous)")
+    _SP_GROUP["layout"] = layout if group is not None else None
 
 
 def _resolve_axis(axis_name):
@@ -49,12 +68,65 @@ def sp_size_rank(axis_name="sp"):
     return dist.get_world_size(g), dist.get_rank(g)
 
 
+def sp_layout(axis_name="sp", local_len=None):
+    """The ownership rule in force along the "sp" axis: "contiguous" for one rank; else what set_sp_group was given,
+    else "zigzag" (when `local_len` is given and odd -- zigzag needs two half-chunks -- "contiguous")."""
+    n, _ = sp_size_rank(axis_name)
+    if n == 1:
+        return "contiguous"
+    kind = _SP_GROUP["layout"] if (axis_name is None or isinstance(axis_name, str)) else None
+    if kind is None:
+        kind = "zigzag" if (local_len is None or local_len % 2 == 0) else "contiguous"
+    return kind
+
+
+def sp_positions(local_len, axis_name="sp", device=None):
+    """Global token positions of this rank's `local_len` rows, int64 (c,): what the loader slices with, what RoPE
+    rotates by (the reference's contiguous ownership makes this arange(c) + r*c, lwm/llama.py:1081-1082 + :560-562)."""
+    n, r = sp_size_rank(axis_name)
+    idx = SeqLayout(sp_layout(axis_name, local_len), n, local_len * n).global_index(r)
+    return idx if device is None else idx.to(device)
+
+
+def sp_shard(t, dim=1, axis_name="sp"):
+    """This rank's rows of a FULL-length tensor along `dim` (tokens, targets, loss masks, vision masks): the
+    boundary permutation of the ownership rule in force.  The attention masks (attention_mask / segment_ids) are NOT
+    sharded: every rank keeps them full length (lwm/llama.py:563-564)."""
+    n, _ = sp_size_rank(axis_name)
+    if n == 1:
+        return t
+    S = t.shape[dim]
+    if S % n:
+        raise ValueError(f"length {S} is not divisible by the sp axis ({n})")
+    return t.index_select(dim, sp_positions(S // n, axis_name, t.device))
+
+
+def sp_all_reduce_sum(t, axis_name="sp"):
+    """Sum of `t` over the ranks of the "sp" axis, in place (no-op for one rank): what makes a per-sequence statistic
+    of a sequence-sharded batch -- the count of valid targets of a row, a loss term -- the whole sequence's.  f32 / f64
+    / integer tensors; a gloo group moves host memory, so a device tensor is staged through the host there."""
+    import torch.distributed as dist
+    n, _ = sp_size_rank(axis_name)
+    if n == 1:
+        return t
+    g = _resolve_axis(axis_name)
+    if t.is_cuda and dist.get_backend(g) != "nccl":
+        h = t.detach().cpu()
+        dist.all_reduce(h, group=g)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, group=g)
+    return t
+
+
 def ringattention(q, k, v, attn_bias, segment_ids, axis_name="sp", float32_logits=True,
-                  cache_idx=None, blockwise_kwargs=None, layout="contiguous"):
+                  cache_idx=None, blockwise_kwargs=None, layout=None):
     """q,k,v: local (B, S/sp, H, D) bf16 shards.  attn_bias: (B,1,1,S_global)
     additive key-padding bias {0, finfo.min} or None (lwm/llama.py:533-537);
     segment_ids: (B, S_global) int or None -- both replicated on every rank
-    (lwm/llama.py:563-564).  Returns out with q's shape/dtype."""
+    (lwm/llama.py:563-564).  Returns out with q's shape/dtype.
+    `layout` (extension): which positions the local rows are -- None = the rule bound by set_sp_group
+    (sp_layout(): zigzag for more than one rank)."""
     kw = dict(blockwise_kwargs or {})
     if cache_idx is not None:
         raise NotImplementedError("cache_idx is None at every reference call site (lwm/llama.py:544)")
@@ -72,6 +144,8 @@ def ringattention(q, k, v, attn_bias, segment_ids, axis_name="sp", float32_logit
         if attn_bias.dim() != 4 or attn_bias.shape[1] != 1 or attn_bias.shape[2] != 1:
             raise ValueError("attn_bias must be (B,1,1,S_global) as built at lwm/llama.py:527-537")
         key_valid = (attn_bias[:, 0, 0, :].float() > -1e30).to(torch.uint8).contiguous()
+    if layout is None:
+        layout = sp_layout(axis_name, q.shape[1])
     return ring_attention(q, k, v, group=_resolve_axis(axis_name), causal=cbs == 1,
                           segment_ids=segment_ids, key_valid=key_valid, layout=layout)
 
@@ -84,15 +158,8 @@ def _comm(group):
         return SingleComm()
     if group is None:   # unbound "sp" axis: _resolve_axis has raised already for axis names
         raise RuntimeError("no sequence-parallel group: call set_sp_group first")
-    # one communicator per process group: its exchange-buffer pool (lwm_amd/ring.py TorchRingComm.pooled) is what
-    # makes the buffers allocate-once across layers and steps
-    cm = _COMMS.get(id(group))
-    if cm is None or cm[0] is not group:
-        cm = _COMMS[id(group)] = (group, TorchRingComm(group))
-    return cm[1]
-
-
-_COMMS = {}
+    from .ring import _torch_comm
+    return _torch_comm(group)       # one communicator (and exchange-buffer pool) per process group
 
 
 def ringattention_inference(q, k, v, attn_mask, axis_name="sp", q_sharded=None, block_ops=None, comm=None, *,

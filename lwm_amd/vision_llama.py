@@ -46,6 +46,7 @@ class VideoLLaMAForCausalLM(LLaMAForCausalLM):
 
     def hidden_states(self, input_ids, vision_masks, attention_mask=None, segment_ids=None, position_ids=None,
                       cache=None):
+        _, position_ids = self._ring_position_ids(input_ids, position_ids, cache)
         x = self._embed(input_ids, vision_masks)
         fc = self._table(x.device)
         for i, blk in enumerate(self.h):

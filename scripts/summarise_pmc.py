@@ -46,7 +46,11 @@ for k in kern.values():
     if k.get("GRBM_GUI_ACTIVE"):
         k["mfma_util"] = k.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (k["GRBM_GUI_ACTIVE"] / 8 * 1024)
         k["lds_idx_active_frac"] = k.get("SQ_LDS_IDX_ACTIVE", 0.0) / (k["GRBM_GUI_ACTIVE"] / 8 * 256)
+sys.path.insert(0, ROOT)
+from bench import attn_kernel_stamp      # noqa: E402  (the stamp bench.py checks before it quotes this file)
+
 out = {
+    "kernel_source_stamp": attn_kernel_stamp(),
     "command": "rocprofv3 --kernel-trace --pmc <set> -- python bench.py --steps 1 --warmup 0 --layers 1 --no-cpu-baseline "
                "--no-vqgan  (one pass per counter set; S=32768, 32 heads, 1 layer, one launch per kernel)",
     "notes": "FETCH_SIZE/WRITE_SIZE are KiB as reported; fetch_bytes applies the gfx950 x2 correction for wide (16 B/lane) "

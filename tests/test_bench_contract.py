@@ -83,7 +83,9 @@ def test_bench_cli_contract_without_a_gpu():
         assert lines and all(l["value"] is None and l["error"]["stage"] == "devices" for l in lines)
         assert {l["error"]["world_size"] for l in lines} == {2} and {l["error"]["rank"] for l in lines} == {0, 1}
     else:
-        assert r.returncode == 0 and lines[-1]["n_gpus"] == 2 and lines[-1]["rccl_ranks_seen"] == 2
+        # (a gloo bootstrap is not RCCL: the field that names RCCL stays null in a dry run)
+        assert r.returncode == 0 and lines[-1]["n_gpus"] == 2 and lines[-1]["bootstrap_ranks_seen"] == 2
+        assert lines[-1]["rccl_ranks_seen"] is None and lines[-1]["bootstrap_backend"] == "gloo"
     h = subprocess.run([sys.executable, bench, "--help"], capture_output=True, text=True, timeout=300)
     for flag in ("--gpus", "--steps", "--warmup", "--driver", "--transport", "--schedule", "--layout", "--no-configs2",
                  "--no-configs34", "--no-packed-1m"):

@@ -370,11 +370,10 @@ def test_addressing_beyond_4g_elements_at_1m_tokens():
     out1 = ring_attention(q1, k1, v1, causal=True, segment_ids=seg)
     out1.backward(do[:, :, h:h + 1].contiguous())
     assert torch.equal(out.detach()[:, :, h:h + 1], out1.detach())
-    for a, b in ((k.grad, k1.grad), (v.grad, v1.grad)):
+    # the backward has no atomics and fixed summation orders: every gradient of a head is the same bits whether the
+    # head is launched alone or among 32
+    for a, b in ((q.grad, q1.grad), (k.grad, k1.grad), (v.grad, v1.grad)):
         assert torch.equal(a[:, :, h:h + 1], b)
-    # dq: f32 atomic adds in arrival order (bit-equal under LWM_DETERMINISTIC=1) -- one bf16 rounding apart at most
-    a, b = q.grad[:, :, h:h + 1].float(), q1.grad.float()
-    assert ((a - b).abs().max() / b.abs().max()).item() <= 2.0 ** -8
     # and the last rows of the last head are really attention over their own document
     f = lambda t: t.detach()[0, S - doc:, h].float().cpu().numpy()[None, :, None]
     ro, _ = R.dense_attention(f(q), f(k), f(v), causal=True)
