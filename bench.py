@@ -479,39 +479,73 @@ def generate_leg(torch, layers=4, prompt=2048, new=136, max_length=32768, short=
     return out
 
 
-def ring_model_leg(torch, n=8, S=131072, schedule="mesh"):
-    """What the compute side of BASELINE configs[2] (S=131072, ring 8) costs, measured on ONE GPU: every
-    rank's launches of the n-rank zigzag ring (same shapes, offsets and masks; the exchange replaced by a
-    communicator that moves nothing) are run in turn for one layer.  The slowest rank bounds the job:
-    tokens/s <= S / (max_r ms_per_layer * 32 layers).  What the 8-GPU run adds on top is exchange time that
-    is not hidden (bench `exchange.exposed_ms_per_step` at N > 1)."""
+def packed_documents(S, seed=0, lo_frac=256, hi_frac=4):
+    """the synthetic packing of BASELINE configs[4]: document lengths log-uniform in
+    [S / lo_frac, S / hi_frac] until S tokens; -> (segment ids (1, S) int32 numpy, lengths)"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    seg = np.zeros((1, S), np.int32)
+    pos, d, lens = 0, 0, []
+    while pos < S:
+        ln = min(int(np.exp(rng.uniform(np.log(S / lo_frac), np.log(S / hi_frac)))), S - pos)
+        seg[:, pos:pos + ln] = d
+        lens.append(ln)
+        pos, d = pos + ln, d + 1
+    return seg, lens
+
+
+def ring_model_leg(torch, n=8, S=131072, schedule="mesh", driver="c", packed=False, layout="zigzag", reps=2):
+    """What the compute side of an n-rank ring costs, measured on ONE GPU: every rank's launches (same shapes, offsets
+    and masks; the exchange replaced by a transport that moves nothing) are run in turn for one layer.  The slowest
+    rank bounds the job: tokens/s <= S / (max_r ms_per_layer * 32 layers).  What the 8-GPU run adds on top is exchange
+    time that is not hidden (bench `exchange.exposed_ms_per_step` at N > 1).
+    driver "c" = the product path on RCCL groups (lwm_ring_attn_fwd / _bwd; the direct schedule's gathered form where
+    it applies: `form`); "python" = lwm_amd/ring.py's launch list (one launch per segment pair).
+    packed: BASELINE configs[4]'s 15-document packing -- FLOPs are then counted over visible pairs only."""
     from lwm_amd.ring import HipBlockOps, SeqLayout, ring_backward, ring_forward
-    lay = SeqLayout("zigzag", n, S)
+    from lwm_amd.ring_c import CRing
+    lay = SeqLayout(layout, n, S)
     c = lay.local_len
     g = torch.Generator(device="cuda").manual_seed(4321)
     mk = lambda: torch.randn(1, c, N_HEADS, HEAD_DIM, generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
     q, k, v, do = mk(), mk(), mk(), mk()
-    per_rank = []
+    seg, lens = None, None
+    if packed:
+        seg_np, lens = packed_documents(S)
+        seg = torch.from_numpy(seg_np).cuda()
+    per_rank, forms = [], []
     for r in range(n):
-        comm = NullComm(rank=r, size=n, schedule=schedule)
+        if driver == "c":
+            ring = CRing.null(r, n, layout=layout, schedule="direct" if schedule in ("mesh", "direct") else "ring")
 
-        def layer():
-            out, lses = ring_forward(HipBlockOps, comm, q, k, v, layout=lay, causal=True)
-            ring_backward(HipBlockOps, comm, q, k, v, out, lses, do, layout=lay, causal=True)
+            def layer():
+                o, l = ring.forward(q, k, v, causal=True, segment_ids=seg)
+                ring.backward(q, k, v, o, l, do, causal=True, segment_ids=seg)
+        else:
+            comm = NullComm(rank=r, size=n, schedule=schedule)
+
+            def layer():
+                out, lses = ring_forward(HipBlockOps, comm, q, k, v, layout=lay, causal=True, segment_ids=seg)
+                ring_backward(HipBlockOps, comm, q, k, v, out, lses, do, layout=lay, causal=True, segment_ids=seg)
 
         layer()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        layer()
-        layer()
+        for _ in range(reps):
+            layer()
         e1.record()
         torch.cuda.synchronize()
-        per_rank.append(e0.elapsed_time(e1) / 2)
+        per_rank.append(e0.elapsed_time(e1) / reps)
+        if driver == "c":
+            forms.append(ring.last_form)
+            ring.close()
     worst = max(per_rank)
-    flops_layer = 7.0 * gemm_unit_flops(S)
-    return {"workload": f"compute side of an {n}-rank zigzag ring at S={S} ({schedule} schedule), each rank's launches "
-                        f"run on this GPU, 1 layer, no exchange",
+    flops_layer = 7.0 * (gemm_unit_flops(S) if not packed else sum(gemm_unit_flops(l) for l in lens))
+    return {"workload": f"compute side of an {n}-rank {layout} ring at S={S} ({schedule} schedule, {driver} driver"
+                        + (f", {len(lens)} packed documents" if packed else "") + "), each rank's launches run on this GPU, "
+                        "1 layer, no exchange",
+            "driver": driver, "form": (None if driver != "c" else "gathered" if all(forms) else "per pair" if not any(forms) else "mixed"),
             "per_rank_ms_per_layer": [round(x, 3) for x in per_rank],
             "imbalance_max_over_mean": worst / (sum(per_rank) / n),
             "compute_bound_tokens_per_s": S / (worst * 1e-3 * N_LAYERS),
@@ -1159,7 +1193,12 @@ def main():
                 res["decode"] = leg(decode_leg, torch)
                 res["generate"] = leg(generate_leg, torch)
                 res["ring8_compute_model"] = leg(ring_model_leg, torch)
-                res["ring8_compute_model_32k"] = leg(ring_model_leg, torch, S=32768)     # what `--gpus 8` runs by default
+                res["ring8_compute_model_32k"] = leg(ring_model_leg, torch, S=32768, reps=5)     # what `--gpus 8` runs by default
+                res["ring8_compute_model_32k_per_pair"] = leg(ring_model_leg, torch, S=32768, driver="python", reps=5)   # (the launch list of rounds 1-4)
+                if not args.no_packed_1m:
+                    # BASELINE configs[4] under ring 8: 1,048,576 tokens in 15 packed documents, zigzag -- does the
+                    # ownership that balances a full causal triangle balance documents too?
+                    res["ring8_compute_model_packed_1m"] = leg(ring_model_leg, torch, S=1 << 20, packed=True, reps=1)
                 res["elementwise"] = leg(elementwise_leg, torch)
         print(json.dumps(res), flush=True)
     if world > 1:

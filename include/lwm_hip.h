@@ -97,6 +97,23 @@ typedef struct LwmAttnArgs {
     const int32_t* seg_blocks_k;
     /* lwm_attn_bwd_dq: 0 = dq_acc is [B,Sq,H,D], 1 = head-major [B,H,Sq,D]. */
     int32_t dq_acc_head_major;
+    /* Two-piece position maps (lwm_version() >= 500; 0 = one piece, the fields above say everything).  A shard under
+     * zigzag ownership is TWO runs of consecutive positions (half-chunks r and 2n-1-r), and so is the K/V a rank has
+     * gathered from its peers (what lies below its own low half-chunk | what lies between its two half-chunks):
+     *   query rows [0, q_split) sit at q_start + row, rows [q_split, Sq) at q_start2 + (row - q_split);
+     *   key   rows [0, k_split) sit at k_start + row, rows [k_split, Sk) at k_start2 + (row - k_split).
+     * One launch then covers what took one launch per (q segment, k segment) pair, with no carry in between -- at small
+     * shards (S = 32768 over 8 ranks: 2048-row half-chunks) the pair launches cannot fill 256 CUs.  Requirements:
+     * splits are multiples of 256 rows and lie strictly inside (0, S); *_start2 >= *_start + *_split (positions ascend
+     * with the row).  Training kernels only (lwm_attn_fwd without dense_mask / k_splits, lwm_attn_bwd_dq / _dkdv);
+     * results are bitwise those of the single-piece launch on the same rows when the two pieces happen to be adjacent
+     * (q_start2 = q_start + q_split). */
+    int32_t q_split, k_split;
+    int64_t q_start2, k_start2;
+    /* Size in bytes of the buffer behind `delta`, or 0 = not given.  When given, lwm_attn_bwd_delta / _dq / _dkdv
+     * refuse a buffer smaller than lwm_attn_bwd_delta_bytes(B,H,Sq) instead of overrunning it (the layout of the
+     * statistics changed at lwm_version() 400: a [B,H,Sq] buffer of earlier versions is too small). */
+    int64_t delta_bytes;
 } LwmAttnArgs;
 
 int lwm_attn_fwd(const LwmAttnArgs* args, void* stream);
@@ -162,8 +179,9 @@ typedef struct LwmRingArgs {
 /* Ownership.  CONTIGUOUS = the reference's: rank r holds positions [r*c, (r+1)*c) (lwm/llama.py:560-562).
  * ZIGZAG: rank r holds the half-chunks r and 2n-1-r (c/2 positions each, local rows [0,c/2) and [c/2,c)) -- the
  * permutation applied at the boundary that balances causal work: under contiguous ownership rank n-1 computes n
- * blocks and rank 0 one.  With two segments lse is two dense [B,H,c/2] pieces, one per segment (an opaque residual
- * between lwm_ring_attn_fwd and _bwd); everything else keeps its [B,c,H,D] shape in local row order. */
+ * blocks and rank 0 one.  lse is an OPAQUE residual between lwm_ring_attn_fwd and _bwd of the same ring and geometry
+ * (two dense [B,H,c/2] pieces, one per segment, or one [B,H,c] piece in local row order, as the form of the call has it);
+ * everything else keeps its [B,c,H,D] shape in local row order. */
 enum { LWM_RING_LAYOUT_CONTIGUOUS = 0, LWM_RING_LAYOUT_ZIGZAG = 1 };
 /* Exchange.  RING = the reference's (lax.ppermute i -> i+1): the K/V block, and in the backward its f32 dK/dV
  * carry, hop to the next rank once per step -- every byte crosses ONE link per step, n-1 (n) times.
@@ -191,10 +209,18 @@ int64_t lwm_ring_planned_bytes(int32_t layout, int32_t schedule, int32_t n, int3
                                int32_t D, int32_t causal, int32_t backward);
 /* bytes this ring object has sent since creation (diagnostic) */
 int64_t lwm_ring_bytes_sent(const LwmRing* ring);
+/* Which form the last lwm_ring_attn_fwd / _bwd call took (diagnostic): 0 = one launch per (q segment, k segment) pair,
+ * chained through f32 carries; 1 = the GATHERED form of the direct schedule -- the fetched K/V segments laid down in
+ * position order in one buffer and read through two-piece position maps (LwmAttnArgs::q_split / k_split): per kernel
+ * two launches per call, the local block under the fetch and everything that arrived after it.  Taken when the call is
+ * causal, B = 1, the K/V fetch is one group (lwm_ring_set_fetch_groups: the default) and every segment of a shard is a
+ * multiple of 256 rows; same results up to f32 association (fewer carries: closer to the exact sum). */
+int lwm_ring_last_form(const LwmRing* ring);
 /* Direct schedule: the K/V fetch of a call goes out as `groups` grouped exchanges over contiguous ranges of rank distance,
  * nearest first, each with its own arrival event; step t of the schedule waits only for the group that holds distance t.
- * 1 (default with RCCL: one bulk-synchronous group keeps all xGMI links busy) ... n - 1 (default of the IPC transport,
- * whose copies are serial anyway: every block is handed over as it lands).  Values above n - 1 mean n - 1. */
+ * 1 (the default: one bulk-synchronous group keeps all xGMI links busy, and the kernels of the remote blocks run as ONE
+ * launch per kernel over everything that arrived -- lwm_ring_last_form) ... n - 1 (every block is handed over as it lands, a
+ * launch per block: for transports whose transfers are serial anyway, such as the IPC one).  Values above n - 1 mean n - 1. */
 int lwm_ring_set_fetch_groups(LwmRing* ring, int32_t groups);
 /* Diagnostic (rings created with LWM_RING_TIMING=1 in the environment: their events then carry timestamps): after the
  * last lwm_ring_attn_fwd / _bwd call has completed, the milliseconds from the call's entry to (kv_ms[t]) the arrival of

@@ -34,6 +34,8 @@ class LwmAttnArgs(C.Structure):
         ("k_splits", C.c_int32),
         ("seg_blocks_q", C.c_void_p), ("seg_blocks_k", C.c_void_p),
         ("dq_acc_head_major", C.c_int32),
+        ("q_split", C.c_int32), ("k_split", C.c_int32), ("q_start2", C.c_int64), ("k_start2", C.c_int64),
+        ("delta_bytes", C.c_int64),
     ]
 
 
@@ -99,6 +101,7 @@ PROTOTYPES = {
     "lwm_ring_planned_bytes": (C.c_int64, [C.c_int32] * 10),
     "lwm_ring_selftest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "lwm_ring_set_fetch_groups": (C.c_int, [C.c_void_p, C.c_int32]),
+    "lwm_ring_last_form": (C.c_int, [C.c_void_p]),
     "lwm_ring_fetch_timeline": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32]),
     "lwm_ring_ipc_info_bytes": (C.c_int64, []),
     "lwm_ring_ipc_export": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -10,8 +10,9 @@ Sequence parallelism (--mesh_dim ...,sp): the ranks of one "sp" group share a ba
 rule gives it -- ZIGZAG half-chunks by default (lwm_amd.ringattention.set_sp_group; LWM_SP_LAYOUT=contiguous selects the
 reference's contiguous blocks, lwm/llama.py:560-562) -- cut with `sp_shard`, positions from `sp_positions`; the K/V
 exchange is driven by the C-ABI ring driver (RCCL on a side stream) when the job's backend is RCCL.  Two flags beyond the
-reference's set, for tests and diagnosis: --lwm_dump_grads=<file> (rank 0 saves the loss and every gradient of the
-last step) and --lwm_balance_report (the attention launches of every sp rank timed in turn on this rank's GPU)."""
+reference's set, for tests and diagnosis: --lwm_dump_grads=<file> (rank 0 saves the batch, the parameters, the loss
+and every gradient of the last step) and --lwm_balance_report (the attention launches of every sp rank timed in turn on
+this rank's GPU; --lwm_balance_seq=<S> times another sequence length than the job's)."""
 from __future__ import annotations
 
 import math
@@ -27,7 +28,7 @@ DEFAULTS = dict(
     modality="text", use_data_sharded_loader=True, seed=42, mesh_dim="1,-1,1,1", dtype="bf16", total_steps=10000,
     load_llama_config="", update_llama_config="", load_checkpoint="", load_dataset_state="", log_freq=50,
     save_model_freq=0, save_milestone_freq=0, eval_steps=0, tokenizer="LargeWorldModel/LWM-Text-1M",
-    log_all_worker=False, autoresume=False, lwm_dump_grads="", lwm_balance_report=False)
+    log_all_worker=False, autoresume=False, lwm_dump_grads="", lwm_balance_report=False, lwm_balance_seq=0)
 GROUPS = ("train_dataset", "eval_dataset", "optimizer", "checkpointer", "llama", "logger", "jax_distributed")
 
 
@@ -134,7 +135,8 @@ def main(argv=None):
                     bucket.append(g)
                     size += g.numel()
         if F.lwm_dump_grads and step == int(F.total_steps) - 1 and world_rank == 0:
-            torch.save({"loss": float(loss), "metrics": {k: float(v) for k, v in metrics.items()},
+            torch.save({"loss": float(loss.detach()), "metrics": {k: float(v) for k, v in metrics.items()}, "tokens": full.cpu(),
+                        "params": {n: p.detach().float().cpu() for n, p in model.named_parameters()},
                         "grads": {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.grad is not None}},
                        F.lwm_dump_grads)
         torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
@@ -142,7 +144,7 @@ def main(argv=None):
         opt.zero_grad(set_to_none=True)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        rec = dict(step=step, loss=float(loss), learning_rate=lr_at(step, opt_cfg), tokens_per_s=batch * seq * accum / dt,
+        rec = dict(step=step, loss=float(loss.detach()), learning_rate=lr_at(step, opt_cfg), tokens_per_s=batch * seq * accum / dt,
                    **{k: float(v) for k, v in metrics.items()})
         history.append(rec)
         if F.log_freq and step % int(F.log_freq) == 0 and (world_rank == 0 or F.log_all_worker):
@@ -154,13 +156,13 @@ def main(argv=None):
         C.note(f"ring driver: {info}")
         history.append(dict(ring=info, layout=sp_layout("sp", seq // sp)))
         if F.lwm_balance_report:
-            history.append(dict(balance=balance_report(cfg, local_b, seq // sp, sp, dev)))
+            history.append(dict(balance=balance_report(cfg, local_b, (int(F.lwm_balance_seq) or seq) // sp, sp, dev)))
             if world_rank == 0:
                 print("LWM_BALANCE " + __import__("json").dumps(history[-1]["balance"]), flush=True)
     return history
 
 
-def balance_report(cfg, B, c, n, dev, reps=3):
+def balance_report(cfg, B, c, n, dev, reps=5):
     """Per-rank attention time of ONE layer of this job's shard shape, measured without the other ranks in the way: every
     rank of the sp ring is played in turn on THIS process's GPU by the C ring driver over a transport that moves nothing
     (CRing.null) -- the launch list of rank r under the ownership rule in force, forward + backward.  Ranks take turns

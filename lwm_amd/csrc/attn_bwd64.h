@@ -388,7 +388,9 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
     bf16x8 kf[8], vf[8];
     for (int s = 0; s < 8; ++s) kf[s] = f4_load_agpr(kb + (int64_t)kr * p.k_ss + 16 * s + 8 * hi);
     for (int s = 0; s < 8; ++s) vf[s] = f4_load_agpr(vb + (int64_t)kr * p.v_ss + 16 * s + 8 * hi);
-    const int64_t k_pos = p.k_start + k_row;
+    const PosMap qm = q_map(p);
+    const int64_t k_base = pos_base(k_map(p), kbi * kD4BK);       // position of key row r of this workgroup = k_base + r
+    const int64_t k_pos = k_base + k_row;
     int32_t kseg = 0;
     if (HAS_META) {
         kseg = kSegInvalid;
@@ -401,10 +403,7 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
     // ---- step range of the walk (steps of 64 queries; causal: skip steps wholly before this key block)
     int nst = (p.Sq + kD4BQ - 1) / kD4BQ;
     int st0 = 0;
-    if (p.causal) {
-        const int64_t d = p.k_start + (int64_t)kbi * kD4BK - p.q_start;   // first q row that can see key 0
-        if (d > 0) st0 = (int)(d / kD4BQ < nst ? d / kD4BQ : nst);
-    }
+    if (p.causal) st0 = tiles_below(qm, kD4BQ, nst, k_base + (int64_t)kbi * kD4BK - 1);   // steps wholly before the block's key 0
     if (HAS_META && p.segb_q && p.segb_k && st0 < nst) {     // packed sequences: skip other documents' query steps
         const int nbq = (p.Sq + 31) >> 5, nbk = (p.Sk + 31) >> 5;
         int smin, smax, lo, hi2;
@@ -492,16 +491,19 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
         // another reason than causality).  Units are named by the row of their first query inside the q block,
         // ub = 64 * step + 32 * half (steps descend, the halves of a step ascend); everything is clamped to 32 bits once.
         auto clamp32 = [](int64_t x) -> int { return x > (1 << 30) ? (1 << 30) : (x < -(1 << 30) ? -(1 << 30) : (int)x); };
-        const int wk_rel = clamp32(p.k_start + (int64_t)kbi * kD4BK + wave * 32 + 31 - p.q_start);   // the wave's last key
-        const int k_rel = clamp32(k_pos - p.q_start) - 4 * hi;                                      // this lane's key
-        auto needs_causal = [&](int ub) -> bool { return p.causal && ub < wk_rel; };
+        // positions relative to q_start; a unit's first query (row ub of the q block) sits at ub + q_gap(ub)
+        const int wk_rel = clamp32(k_base + (int64_t)kbi * kD4BK + wave * 32 + 31 - p.q_start);   // the wave's last key
+        const int k_rel = clamp32(k_pos - p.q_start) - 4 * hi;                                     // this lane's key
+        const int q_gap2 = clamp32(p.q_start2 - p.q_split - p.q_start);      // (0 for one piece; >= 0)
+        auto q_rel_of = [&](int ub) -> int { return ub < p.q_split ? ub : (ub > (1 << 30) - q_gap2 ? (1 << 30) : ub + q_gap2); };
+        auto needs_causal = [&](int ub) -> bool { return p.causal && q_rel_of(ub) < wk_rel; };
         // the wave's 32 keys all valid and of one segment?  (then a step whose 64 queries carry it needs no segment test)
         const int32_t own_seg = wave_uniform(kseg);
         const bool own_uniform = HAS_META && !wave_any(kseg != own_seg || kseg == kSegInvalid);
         auto rel_of = [&](int ub) -> int {
             if (!p.causal) return -64;
-            const int d = k_rel - ub;
-            return d > 64 ? 64 : (d < -64 ? -64 : d);
+            const int64_t d = (int64_t)k_rel - q_rel_of(ub);
+            return d > 64 ? 64 : (d < -64 ? -64 : (int)d);
         };
 
         D4Regs rg;
@@ -949,19 +951,14 @@ LWM_DEVICE void attn_bwd_dq4_body(const AttnParams& p) {
     }
     cx.c = p.scale * kLog2e;
     const int32_t seg_q = (HAS_META && q_ok && p.seg_q) ? p.seg_q[(int64_t)b * p.Sq + q_row] : 0;
+    const PosMap km = k_map(p);
+    const int64_t q_base = pos_base(q_map(p), qbi * kQ4BQ);       // position of query row r of this workgroup = q_base + r
 
     // ---- key step range of the walk (steps of 64 keys; causal: up to the diagonal of the workgroup's last query)
     const int nst_all = (p.Sk + kQ4BK - 1) / kQ4BK;
     int nst = nst_all, st0 = 0;
     const int q_last = (qbi * kQ4BQ + kQ4BQ < p.Sq ? qbi * kQ4BQ + kQ4BQ : p.Sq) - 1;
-    if (p.causal) {
-        const int64_t d = p.q_start + q_last - p.k_start;      // last visible key index
-        if (d < 0) nst = 0;
-        else {
-            const int64_t t = d / kQ4BK + 1;
-            nst = t < nst_all ? (int)t : nst_all;
-        }
-    }
+    if (p.causal) nst = tiles_reaching(km, kQ4BK, nst_all, q_base + q_last);      // up to the step of the last visible key
     if (HAS_META && p.segb_q && p.segb_k && nst > 0) {     // packed sequences: skip other documents' key steps
         const int nbq = (p.Sq + 31) >> 5, nbk = (p.Sk + 31) >> 5;
         int smin, smax, lo, hi2;
@@ -1030,18 +1027,21 @@ LWM_DEVICE void attn_bwd_dq4_body(const AttnParams& p) {
         block_sync();
 
         auto clamp32 = [](int64_t x) -> int { return x > (1 << 30) ? (1 << 30) : (x < -(1 << 30) ? -(1 << 30) : (int)x); };
-        const int wq_rel = clamp32(p.q_start + (int64_t)qbi * kQ4BQ + wave * 32 - p.k_start);      // the wave's first query
-        const int q_rel = clamp32(p.q_start + q_row - p.k_start) - 4 * hi;                         // this lane's query
-        // a unit (first key at row ub of the K/V block) needs the mask code when its last key lies after the wave's first query
-        auto needs_causal = [&](int ub) -> bool { return p.causal && ub + 31 > wq_rel; };
+        // positions relative to k_start; a unit's first key (row ub of the K/V block) sits at ub + k_gap(ub)
+        const int wq_rel = clamp32(q_base + (int64_t)qbi * kQ4BQ + wave * 32 - p.k_start);      // the wave's first query
+        const int q_rel = clamp32(q_base + q_row - p.k_start) - 4 * hi;                         // this lane's query
+        const int k_gap2 = clamp32(p.k_start2 - p.k_split - p.k_start);      // (0 for one piece; >= 0)
+        auto k_rel_of = [&](int ub) -> int { return ub < p.k_split ? ub : (ub > (1 << 30) - k_gap2 ? (1 << 30) : ub + k_gap2); };
+        // a unit needs the mask code when its last key lies after the wave's first query
+        auto needs_causal = [&](int ub) -> bool { return p.causal && k_rel_of(ub) + 31 > wq_rel; };
         // the wave's 32 queries of one segment?  (then a step whose 64 keys carry it needs no segment test; rows past Sq
         // are never stored and do not count)
         const int32_t own_seg = wave_uniform(seg_q);
         const bool own_uniform = HAS_META && !wave_any(q_ok && seg_q != own_seg);
         auto rel_of = [&](int ub) -> int {
             if (!p.causal) return 64;
-            const int d = q_rel - ub;
-            return d > 64 ? 64 : (d < -64 ? -64 : d);
+            const int64_t d = (int64_t)q_rel - k_rel_of(ub);
+            return d > 64 ? 64 : (d < -64 ? -64 : (int)d);
         };
 
         for (int par = 0; par < 2; ++par) {

@@ -58,6 +58,11 @@ struct AttnParams {
     int64_t dv_sb, dv_ss, dv_sh;
     int32_t B, H, Sq, Sk;
     int64_t q_start, k_start;  // global token position of row 0 (ring offset)
+    // Two-piece position maps (a zigzag shard is two runs of consecutive positions; so is the K/V a rank gathers from its
+    // peers): rows [0, split) sit at start + row, rows [split, S) at start2 + (row - split), start2 >= start + split.
+    // One piece: split = S (api.inc).  Splits are multiples of 256 rows, so no workgroup tile straddles one.
+    int32_t q_split, k_split;
+    int64_t q_start2, k_start2;
     float scale;               // softmax scale, 1/sqrt(D)
     int32_t causal;
     int32_t carry_in;          // merge with *_acc before writing
@@ -71,6 +76,29 @@ struct AttnParams {
     const int32_t* segb_q;
     const int32_t* segb_k;
 };
+
+// ---- position maps (see AttnParams): everything below is wave-uniform scalar arithmetic.
+struct PosMap {
+    int64_t start, start2;
+    int32_t split, S;
+};
+LWM_DEVICE PosMap q_map(const AttnParams& p) { return PosMap{p.q_start, p.q_start2, p.q_split, p.Sq}; }
+LWM_DEVICE PosMap k_map(const AttnParams& p) { return PosMap{p.k_start, p.k_start2, p.k_split, p.Sk}; }
+// position of row r = pos_base(m, row0) + r for every row r of a tile that begins at row0
+LWM_DEVICE int64_t pos_base(const PosMap& m, int row0) { return row0 < m.split ? m.start : m.start2 - m.split; }
+// How many LEADING tiles (of `per` rows; n_tiles = ceil(S / per)) begin at a position <= P -- positions ascend with the
+// row, so those are the tiles a query at P can see a key of (or, mirrored, the query steps that lie wholly before a key
+// at P + 1 when asked with P = key - per).
+LWM_DEVICE int tiles_reaching(const PosMap& m, int per, int n_tiles, int64_t P) {
+    const int st = m.split >= m.S ? n_tiles : m.split / per;
+    int64_t c1 = P < m.start ? 0 : (P - m.start) / per + 1;
+    if (c1 < st) return (int)c1;
+    const int rest = n_tiles - st;
+    int64_t c2 = P < m.start2 ? 0 : (P - m.start2) / per + 1;
+    return st + (int)(c2 < rest ? c2 : rest);
+}
+// ... whose EVERY row lies at a position <= P
+LWM_DEVICE int tiles_below(const PosMap& m, int per, int n_tiles, int64_t P) { return tiles_reaching(m, per, n_tiles, P - (per - 1)); }
 
 LWM_DEVICE int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 LWM_DEVICE uint32_t tile_off(int row, int slot) {

@@ -469,11 +469,13 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
     bool q_ok[2];
     int32_t seg_q[2];
     int64_t q_pos[2];
+    const PosMap km = k_map(p);
+    const int64_t q_base = pos_base(q_map(p), qt * kF4BQ);       // position of row r of this workgroup = q_base + r
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         q_row[qb] = qt * kF4BQ + wave * 64 + 32 * qb + l31;
         q_ok[qb] = q_row[qb] < p.Sq;
-        q_pos[qb] = p.q_start + q_row[qb];
+        q_pos[qb] = q_base + q_row[qb];
         seg_q[qb] = (HAS_META && q_ok[qb] && p.seg_q) ? p.seg_q[(int64_t)b * p.Sq + q_row[qb]] : 0;
         // straight into the accumulator file (a row past Sq re-reads the last row: its results are never stored)
         const int qr = q_ok[qb] ? q_row[qb] : p.Sq - 1;
@@ -484,21 +486,14 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
         cx.lsum[qb] = 0.0f;
     }
     f4_load_agpr_wait(qf);
-    const int64_t wq_min = p.q_start + (int64_t)qt * kF4BQ + wave * 64;   // first / last query position of this wave
+    const int64_t wq_min = q_base + (int64_t)qt * kF4BQ + wave * 64;   // first / last query position of this wave
     const int64_t wq_max = wq_min + 63;
 
     // ---- kv tile range of the WORKGROUP (causal: skip tiles wholly in the future of its last row)
     const int nkt_all = (p.Sk + kF4BK - 1) / kF4BK;
     int nkt = nkt_all, kt0 = 0;
     const int q_last = (qt * kF4BQ + kF4BQ < p.Sq ? qt * kF4BQ + kF4BQ : p.Sq) - 1;
-    if (p.causal) {
-        const int64_t d = p.q_start + q_last - p.k_start;  // last visible key index
-        if (d < 0) nkt = 0;
-        else {
-            const int64_t t = d / kF4BK + 1;
-            nkt = t < nkt_all ? (int)t : nkt_all;
-        }
-    }
+    if (p.causal) nkt = tiles_reaching(km, kF4BK, nkt_all, q_base + q_last);      // up to the tile of the last visible key
     if (HAS_META && p.segb_q && p.segb_k && nkt > 0) {      // packed sequences: skip other documents' key tiles
         const int nbq = (p.Sq + 31) >> 5, nbk = (p.Sk + 31) >> 5;
         int smin, smax, lo, hi2;
@@ -517,10 +512,8 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
     // tiles this WAVE computes: [kt0, kt0 + n_w) -- its rows see nothing beyond its own diagonal tile
     int n_w = n_wg;
     if (p.causal) {
-        const int64_t d = wq_max - p.k_start;
-        const int64_t lim = d < 0 ? 0 : d / kF4BK + 1;
-        const int64_t nw = lim - kt0;
-        n_w = nw < 0 ? 0 : (nw < n_wg ? (int)nw : n_wg);
+        const int nw = tiles_reaching(km, kF4BK, nkt_all, wq_max) - kt0;
+        n_w = nw < 0 ? 0 : (nw < n_wg ? nw : n_wg);
     }
     if (wave_uniform(qt * kF4BQ + wave * 64 >= p.Sq ? 1 : 0)) n_w = 0;    // a wave past the ragged end of Sq
 
@@ -574,7 +567,7 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
             if (HAS_META && i + 2 < n_wg) f4_meta_stage(p, cx, b, kt0 + i + 2, (i + 2) % 3);
         };
         auto rel_of = [&](int rel, int (&r)[2]) {       // mask offsets of tile `rel` for the two query blocks
-            const int64_t k_pos0 = p.k_start + (int64_t)(kt0 + rel) * kF4BK;
+            const int64_t k_pos0 = pos_base(km, (kt0 + rel) * kF4BK) + (int64_t)(kt0 + rel) * kF4BK;
             for (int qb = 0; qb < 2; ++qb) {
                 const int64_t d = p.causal ? (q_pos[qb] - k_pos0) : (int64_t)kF4BK;
                 r[qb] = d > kF4BK ? kF4BK : (d < -1 ? -1 : (int)d);
@@ -584,9 +577,8 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
         // another reason than causality): from tile first_mask on -- one integer compare per half step in the loop
         int first_mask = 0x7fffffff;
         if (p.causal) {
-            const int64_t t = wq_min - p.k_start - (kF4BK - 1);        // k_pos0 > t  <=>  mask
-            const int64_t ft = (t >= 0 ? t / kF4BK : -((-t + kF4BK - 1) / kF4BK)) + 1 - kt0;
-            first_mask = ft < 0 ? 0 : (ft > 0x7fffffff ? 0x7fffffff : (int)ft);
+            const int ft = tiles_below(km, kF4BK, nkt_all, wq_min) - kt0;     // the tiles before it lie wholly at or below wq_min
+            first_mask = ft < 0 ? 0 : ft;
         }
         auto needs_causal = [&](int rel) -> bool { return rel >= first_mask; };
         // Packed sequences: the wave's 64 queries of one segment?  Then a key tile whose 64 staged segment words all carry

@@ -48,13 +48,19 @@ def _f32(t, name, shape=None):
     return t.data_ptr()
 
 
-def _base(q, k, v, *, q_start, k_start, causal, seg_q, seg_k, key_valid, scale):
+def _base(q, k, v, *, q_start, k_start, causal, seg_q, seg_k, key_valid, scale, q_piece2=None, k_piece2=None):
+    """q_piece2 / k_piece2 = (split row, position of that row): the two-piece position maps of LwmAttnArgs (rows before
+    the split sit at *_start + row, rows from it on at position + (row - split); splits are multiples of 256 rows)"""
     B, Sq, H, D = q.shape
     Sk = k.shape[1]
     a = _capi.LwmAttnArgs()
     a.q, a.k, a.v = _t4(q, "q"), _t4(k, "k"), _t4(v, "v")
     a.B, a.H, a.Sq, a.Sk, a.D = B, H, Sq, Sk, D
     a.q_start, a.k_start = int(q_start), int(k_start)
+    if q_piece2 is not None:
+        a.q_split, a.q_start2 = int(q_piece2[0]), int(q_piece2[1])
+    if k_piece2 is not None:
+        a.k_split, a.k_start2 = int(k_piece2[0]), int(k_piece2[1])
     a.scale = float(scale) if scale is not None else 1.0 / math.sqrt(D)
     a.causal = int(bool(causal))
     if (seg_q is None) != (seg_k is None):
@@ -105,13 +111,13 @@ def segment_blocks(seg, valid=None):
 
 def attn_fwd_block(q, k, v, *, q_start=0, k_start=0, causal=True, seg_q=None, seg_k=None,
                    key_valid=None, scale=None, out=None, lse=None, out_acc=None, lse_acc=None,
-                   carry_in=False, final=True, dense_mask=None):
+                   carry_in=False, final=True, dense_mask=None, q_piece2=None, k_piece2=None):
     """One ring step of the forward (lwm_attn_fwd).  Returns (out, lse) when
     `final`, else the updated (out_acc, lse_acc).  dense_mask: optional u8
     (B,Sq,Sk) view (last dim contiguous) ANDed with the other masks."""
     B, Sq, H, D = q.shape
     a = _base(q, k, v, q_start=q_start, k_start=k_start, causal=causal, seg_q=seg_q, seg_k=seg_k,
-              key_valid=key_valid, scale=scale)
+              key_valid=key_valid, scale=scale, q_piece2=q_piece2, k_piece2=k_piece2)
     _set_dense_mask(a, dense_mask, B, Sq, k.shape[1])
     if final:
         if out is None:
@@ -234,6 +240,7 @@ def attn_bwd_delta(out, dout, lse, delta=None):
     a.B, a.H, a.Sq, a.Sk, a.D = B, H, Sq, 0, D
     a.lse = _f32(lse, "lse", (B, H, Sq))
     a.delta = _f32(delta, "delta", bwd_stats_shape(B, H, Sq))
+    a.delta_bytes = delta.numel() * 4
     L = lib()
     _capi.check(L, L.lwm_attn_bwd_delta(C.byref(a), _stream_ptr()), "lwm_attn_bwd_delta")
     return delta
@@ -245,6 +252,7 @@ def _bwd_base(q, k, v, dout, lse, delta, kw):
     a.dout = _t4(dout, "dout")
     a.lse = _f32(lse, "lse", (B, H, Sq))
     a.delta = _f32(delta, "delta", bwd_stats_shape(B, H, Sq))
+    a.delta_bytes = delta.numel() * 4
     return a
 
 
@@ -255,11 +263,11 @@ def _acc_shape(B, Sq, H, D, head_major):
 
 def attn_bwd_dq_block(q, k, v, dout, lse, delta, *, q_start=0, k_start=0, causal=True,
                       seg_q=None, seg_k=None, key_valid=None, scale=None, dq=None, dq_acc=None,
-                      carry_in=False, final=True, acc_head_major=False):
+                      carry_in=False, final=True, acc_head_major=False, q_piece2=None, k_piece2=None):
     B, Sq, H, D = q.shape
     a = _bwd_base(q, k, v, dout, lse, delta,
                   dict(q_start=q_start, k_start=k_start, causal=causal, seg_q=seg_q, seg_k=seg_k,
-                       key_valid=key_valid, scale=scale))
+                       key_valid=key_valid, scale=scale, q_piece2=q_piece2, k_piece2=k_piece2))
     if final:
         if dq is None:
             dq = torch.empty((B, Sq, H, D), dtype=torch.bfloat16, device=q.device)
@@ -277,11 +285,11 @@ def attn_bwd_dq_block(q, k, v, dout, lse, delta, *, q_start=0, k_start=0, causal
 
 def attn_bwd_dkdv_block(q, k, v, dout, lse, delta, *, q_start=0, k_start=0, causal=True,
                         seg_q=None, seg_k=None, key_valid=None, scale=None, dk=None, dv=None,
-                        dk_acc=None, dv_acc=None, carry_in=False, final=True):
+                        dk_acc=None, dv_acc=None, carry_in=False, final=True, q_piece2=None, k_piece2=None):
     B, Sk, H, D = k.shape
     a = _bwd_base(q, k, v, dout, lse, delta,
                   dict(q_start=q_start, k_start=k_start, causal=causal, seg_q=seg_q, seg_k=seg_k,
-                       key_valid=key_valid, scale=scale))
+                       key_valid=key_valid, scale=scale, q_piece2=q_piece2, k_piece2=k_piece2))
     if final:
         if dk is None:
             dk = torch.empty((B, Sk, H, D), dtype=torch.bfloat16, device=q.device)

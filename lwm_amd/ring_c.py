@@ -141,6 +141,11 @@ class CRing:
     def bytes_sent(self):
         return int(lib().lwm_ring_bytes_sent(self._h))
 
+    @property
+    def last_form(self):
+        """0 = the last call launched per (q segment, k segment) pair, 1 = gathered form (lwm_ring_last_form)"""
+        return int(lib().lwm_ring_last_form(self._h))
+
     def set_fetch_groups(self, groups):
         """direct schedule: grouped exchanges of the K/V fetch (lwm_ring_set_fetch_groups)"""
         _capi.check(lib(), lib().lwm_ring_set_fetch_groups(self._h, int(groups)), "lwm_ring_set_fetch_groups")

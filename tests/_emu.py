@@ -69,13 +69,18 @@ def bf16_array(x):
     return a
 
 
-def base_args(q, k, v, *, causal, q_start, k_start, seg_q, seg_k, key_valid, scale):
+def base_args(q, k, v, *, causal, q_start, k_start, seg_q, seg_k, key_valid, scale, q_piece2=None, k_piece2=None):
+    """q_piece2 / k_piece2 = (split row, position of that row): the two-piece position maps of LwmAttnArgs"""
     B, Sq, H, D = q.shape
     Sk = k.shape[1]
     a = _capi.LwmAttnArgs()
     a.q, a.k, a.v = _t4(q), _t4(k), _t4(v)
     a.B, a.H, a.Sq, a.Sk, a.D = B, H, Sq, Sk, D
     a.q_start, a.k_start = q_start, k_start
+    if q_piece2 is not None:
+        a.q_split, a.q_start2 = q_piece2
+    if k_piece2 is not None:
+        a.k_split, a.k_start2 = k_piece2
     a.scale = scale if scale is not None else 1.0 / np.sqrt(D)
     a.causal = int(causal)
     keep = []
@@ -104,14 +109,14 @@ SEGMENT_SKIP = True
 
 
 def attn_fwd(q, k, v, *, causal=True, q_start=0, k_start=0, seg_q=None, seg_k=None,
-             key_valid=None, scale=None, carry=None, final=True):
+             key_valid=None, scale=None, carry=None, final=True, q_piece2=None, k_piece2=None):
     """q,k,v: float arrays (rounded to bf16 here).  Returns (out f32, lse f32) or the
     updated carry (out_acc, lse_acc) when final=False."""
     L = lib()
     qb, kb, vb = bf16_array(q), bf16_array(k), bf16_array(v)
     B, Sq, H, D = q.shape
     a, keep = base_args(qb, kb, vb, causal=causal, q_start=q_start, k_start=k_start, seg_q=seg_q,
-                        seg_k=seg_k, key_valid=key_valid, scale=scale)
+                        seg_k=seg_k, key_valid=key_valid, scale=scale, q_piece2=q_piece2, k_piece2=k_piece2)
     out = aligned((B, Sq, H, D), np.uint16)
     lse = aligned((B, H, Sq), np.float32)
     if carry is not None:
@@ -130,7 +135,7 @@ def attn_fwd(q, k, v, *, causal=True, q_start=0, k_start=0, seg_q=None, seg_k=No
 
 
 def attn_bwd(q, k, v, out, lse, dout, *, causal=True, q_start=0, k_start=0, seg_q=None,
-             seg_k=None, key_valid=None, scale=None, carry=None, final=True):
+             seg_k=None, key_valid=None, scale=None, carry=None, final=True, q_piece2=None, k_piece2=None):
     """Returns (dq, dk, dv) as f32 (bf16-rounded when final): lwm_attn_bwd_delta + lwm_attn_bwd_dkdv + lwm_attn_bwd_dq."""
     L = lib()
     qb, kb, vb = bf16_array(q), bf16_array(k), bf16_array(v)
@@ -138,7 +143,7 @@ def attn_bwd(q, k, v, out, lse, dout, *, causal=True, q_start=0, k_start=0, seg_
     B, Sq, H, D = q.shape
     Sk = k.shape[1]
     a, keep = base_args(qb, kb, vb, causal=causal, q_start=q_start, k_start=k_start, seg_q=seg_q,
-                        seg_k=seg_k, key_valid=key_valid, scale=scale)
+                        seg_k=seg_k, key_valid=key_valid, scale=scale, q_piece2=q_piece2, k_piece2=k_piece2)
     lse_a = aligned((B, H, Sq), np.float32)
     lse_a[...] = lse
     delta = aligned((L.lwm_attn_bwd_delta_bytes(B, H, Sq) // 4,), np.float32)
@@ -155,6 +160,7 @@ def attn_bwd(q, k, v, out, lse, dout, *, causal=True, q_start=0, k_start=0, seg_
     a.out, a.dout = _t4(ob), _t4(dob)
     a.dq, a.dk, a.dv = _t4(dq), _t4(dk), _t4(dv)
     a.lse, a.delta = lse_a.ctypes.data, delta.ctypes.data
+    a.delta_bytes = delta.nbytes
     a.dq_acc, a.dk_acc, a.dv_acc = dq_acc.ctypes.data, dk_acc.ctypes.data, dv_acc.ctypes.data
     a.final_out = int(final)
     _capi.check(L, L.lwm_attn_bwd_delta(C.byref(a), None), "lwm_attn_bwd_delta")

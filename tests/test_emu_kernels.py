@@ -205,3 +205,94 @@ def test_segment_block_table():
     assert out[0, 0].tolist() == [0, 1] and out[0, 1].tolist() == [1, 2]
     assert out[0, 2].tolist() == [2 ** 31 - 1, -2 ** 31] and out[0, 3].tolist() == out[0, 2].tolist()
     assert out[0, 4].tolist() == [4, 4]
+
+
+# ---------------------------------------------------------------- two-piece position maps (lwm_version() >= 500)
+def _embed(x, pos, n):
+    """rows of x placed at their positions in a length-n sequence (zeros elsewhere)"""
+    out = np.zeros((x.shape[0], n) + x.shape[2:], x.dtype)
+    out[:, pos] = x
+    return out
+
+
+def _two_piece_case(Sq, q1, qg, Sk, k1, kg):
+    """q rows [0,q1) at qg[0]+r, [q1,Sq) at qg[1]+(r-q1); likewise keys.  -> (positions, _emu keyword arguments)"""
+    qpos = np.concatenate([qg[0] + np.arange(q1), qg[1] + np.arange(Sq - q1)])
+    kpos = np.concatenate([kg[0] + np.arange(k1), kg[1] + np.arange(Sk - k1)])
+    kw = dict(q_start=qg[0], k_start=kg[0])
+    if q1 < Sq:
+        kw["q_piece2"] = (q1, qg[1])
+    if k1 < Sk:
+        kw["k_piece2"] = (k1, kg[1])
+    return qpos, kpos, kw
+
+
+@pytest.mark.parametrize("name,Sq,q1,qg,Sk,k1,kg", [
+    # a zigzag shard against itself (rank 1 of 4, half-chunks of 256): lo x lo diagonal, hi x lo full, hi x hi diagonal
+    ("local", 512, 256, (256, 1536), 512, 256, (256, 1536)),
+    # ... against what it gathered from its peers: [below its low half | between its halves]; the low queries see piece 1 only
+    ("remote", 512, 256, (256, 1536), 1280, 256, (0, 512)),
+    # one-piece queries (contiguous ownership) against two-piece keys, ragged ends on both sides
+    ("ragged", 300, 300, (900, 0), 570, 256, (0, 700)),
+    # two-piece queries, one-piece keys that end inside the first query piece's range
+    ("qsplit", 512, 256, (0, 2048), 384, 384, (100, 0)),
+])
+def test_emulated_two_piece_position_maps(name, Sq, q1, qg, Sk, k1, kg):
+    """One launch over a (two-piece q) x (two-piece k) block == dense attention on the positions the maps name: the
+    operands embedded at their positions in the global sequence, absent keys masked out (fp64 oracle)."""
+    H = 1
+    q, k, v, do = _rnd((1, Sq, H, 128), 11), _rnd((1, Sk, H, 128), 12), _rnd((1, Sk, H, 128), 13), _rnd((1, Sq, H, 128), 14)
+    qpos, kpos, kw = _two_piece_case(Sq, q1, qg, Sk, k1, kg)
+    out, lse = _emu.attn_fwd(q, k, v, causal=True, **kw)
+    n = int(max(qpos.max(), kpos.max())) + 1
+    present = np.zeros((1, n), np.uint8)
+    present[:, kpos] = 1
+    ro, rl = R.dense_attention(_embed(q, qpos, n), _embed(k, kpos, n), _embed(v, kpos, n), causal=True, key_valid=present)
+    ro, rl = ro[:, qpos], rl[:, :, qpos]
+    assert _rel(out, ro) < 1e-2
+    fin = np.isfinite(rl)
+    assert np.array_equal(np.isfinite(lse), fin) and np.abs(lse[fin] - rl[fin]).max() < 1e-4
+    assert not out[~np.isfinite(lse).transpose(0, 2, 1)].any()          # rows that see no key: out = 0
+    dq, dk, dv = _emu.attn_bwd(q, k, v, out, lse, do, causal=True, **kw)
+    rq, rk, rv = R.dense_attention_bwd(_embed(q, qpos, n), _embed(k, kpos, n), _embed(v, kpos, n), _embed(do, qpos, n),
+                                       causal=True, key_valid=present)
+    assert _rel(dq, rq[:, qpos]) < 1e-2 and _rel(dk, rk[:, kpos]) < 1e-2 and _rel(dv, rv[:, kpos]) < 1e-2
+
+
+def test_emulated_adjacent_pieces_are_the_single_piece_launch_bit_for_bit():
+    """two pieces that happen to be adjacent (start2 = start + split) name the same positions as one piece: same tiles,
+    same instruction stream, same bits -- forward, dq, dk, dv, with a packed batch on top"""
+    Sq = Sk = 768
+    q, k, v, do = _rnd((1, Sq, 1, 128), 21), _rnd((1, Sk, 1, 128), 22), _rnd((1, Sk, 1, 128), 23), _rnd((1, Sq, 1, 128), 24)
+    seg = np.zeros((1, Sq), np.int32)
+    seg[:, 300:] = 1
+    m = dict(seg_q=seg, seg_k=seg)
+    one = _emu.attn_fwd(q, k, v, causal=True, q_start=4096, k_start=4096, **m)
+    two = _emu.attn_fwd(q, k, v, causal=True, q_start=4096, k_start=4096, q_piece2=(256, 4096 + 256), k_piece2=(512, 4096 + 512), **m)
+    assert np.array_equal(one[0], two[0]) and np.array_equal(one[1], two[1])
+    g1 = _emu.attn_bwd(q, k, v, one[0], one[1], do, causal=True, q_start=4096, k_start=4096, **m)
+    g2 = _emu.attn_bwd(q, k, v, one[0], one[1], do, causal=True, q_start=4096, k_start=4096, q_piece2=(512, 4096 + 512),
+                       k_piece2=(256, 4096 + 256), **m)
+    for a, b in zip(g1, g2):
+        assert np.array_equal(a, b)
+
+
+def test_two_piece_maps_are_validated():
+    import ctypes as C
+    from lwm_amd import _capi
+    L = _emu.lib()
+    q = _emu.bf16_array(np.zeros((1, 512, 1, 128), np.float32))
+    out = _emu.aligned((1, 512, 1, 128), np.uint16)
+    lse = _emu.aligned((1, 1, 512), np.float32)
+    for bad in (dict(q_piece2=(100, 4096)), dict(q_piece2=(512, 4096)), dict(k_piece2=(256, 100)), dict(q_piece2=(256, 255))):
+        a, _ = _emu.base_args(q, q, q, causal=True, q_start=0, k_start=0, seg_q=None, seg_k=None, key_valid=None, scale=None, **bad)
+        a.out, a.lse, a.final_out = _emu._t4(out), lse.ctypes.data, 1
+        assert L.lwm_attn_fwd(C.byref(a), None) == _capi.LWM_EINVAL, bad
+        assert b"split" in L.lwm_last_error()
+    # the backward refuses a statistics buffer of the pre-400 size when told how large it is
+    a, _ = _emu.base_args(q, q, q, causal=True, q_start=0, k_start=0, seg_q=None, seg_k=None, key_valid=None, scale=None)
+    small = _emu.aligned((512,), np.float32)
+    a.out = a.dout = a.dq = _emu._t4(out)
+    a.lse, a.delta, a.delta_bytes, a.final_out = lse.ctypes.data, small.ctypes.data, small.nbytes, 1
+    assert L.lwm_attn_bwd_delta(C.byref(a), None) == _capi.LWM_EINVAL and b"lwm_attn_bwd_delta_bytes" in L.lwm_last_error()
+    assert L.lwm_attn_bwd_dq(C.byref(a), None) == _capi.LWM_EINVAL

@@ -378,3 +378,72 @@ def test_addressing_beyond_4g_elements_at_1m_tokens():
     f = lambda t: t.detach()[0, S - doc:, h].float().cpu().numpy()[None, :, None]
     ro, _ = R.dense_attention(f(q), f(k), f(v), causal=True)
     _check("out tail", f(out), ro)
+
+
+@pytest.mark.parametrize("name,Sq,q1,qg,Sk,k1,kg,packed", [
+    # rank 2 of an 8-rank zigzag ring with half-chunks of 512 rows: its own shard against itself ...
+    ("local", 1024, 512, (1024, 6656), 1024, 512, (1024, 6656), False),
+    # ... and against what it gathered: [0, 1024) | [1536, 6656)
+    ("remote", 1024, 512, (1024, 6656), 6144, 1024, (0, 1536), True),
+    ("ragged", 700, 700, (3000, 0), 1300, 768, (0, 2000), False),
+])
+def test_two_piece_position_maps_vs_oracle(name, Sq, q1, qg, Sk, k1, kg, packed):
+    """LwmAttnArgs::q_split / k_split on the device: one launch over a (two-piece q) x (two-piece k) block equals dense
+    attention on the positions the maps name (operands embedded at their positions, absent keys masked out), forward
+    and both backward kernels; with packed documents on top (segment ids follow the rows)."""
+    import torch
+    from lwm_amd import ops
+    H = 2
+    q, k, v, do = _rand((1, Sq, H, 128), 31), _rand((1, Sk, H, 128), 32), _rand((1, Sk, H, 128), 33), _rand((1, Sq, H, 128), 34)
+    qpos = np.concatenate([qg[0] + np.arange(q1), qg[1] + np.arange(Sq - q1)])
+    kpos = np.concatenate([kg[0] + np.arange(k1), kg[1] + np.arange(Sk - k1)])
+    n = int(max(qpos.max(), kpos.max())) + 1
+    kw = dict(q_start=qg[0], k_start=kg[0], causal=True, q_piece2=(q1, qg[1]) if q1 < Sq else None, k_piece2=(k1, kg[1]) if k1 < Sk else None)
+    seg_full = None
+    if packed:
+        seg_full = (np.arange(n) >= 900).astype(np.int32) + (np.arange(n) >= 4000).astype(np.int32)
+        kw["seg_q"] = torch.from_numpy(seg_full[qpos][None]).cuda().contiguous()
+        kw["seg_k"] = torch.from_numpy(seg_full[kpos][None]).cuda().contiguous()
+    qd, kd, vd, dod = (t.cuda() for t in (q, k, v, do))
+    out, lse = ops.attn_fwd_block(qd, kd, vd, **kw)
+    delta = ops.attn_bwd_delta(out, dod, lse)
+    dq = ops.attn_bwd_dq_block(qd, kd, vd, dod, lse, delta, **kw)
+    dk, dv = ops.attn_bwd_dkdv_block(qd, kd, vd, dod, lse, delta, **kw)
+
+    def emb(x, pos):
+        e = np.zeros((1, n) + x.shape[2:], np.float32)
+        e[:, pos] = _np(x)
+        return e
+    present = np.zeros((1, n), np.uint8)
+    present[:, kpos] = 1
+    okw = dict(causal=True, key_valid=present)
+    if packed:
+        okw.update(seg_q=seg_full[None], seg_k=seg_full[None])
+    ro, rl = R.dense_attention(emb(q, qpos), emb(k, kpos), emb(v, kpos), **okw)
+    out_e = emb(out, qpos)
+    rq, rk, rv, rqx = R.dense_attention_bwd(emb(q, qpos), emb(k, kpos), emb(v, kpos), emb(do, qpos), out_saved=out_e, **okw)
+    _check(f"out two-piece {name}", _np(out), ro[:, qpos])
+    fin = np.isfinite(rl[:, :, qpos])
+    assert np.array_equal(np.isfinite(_np(lse)), fin) and np.abs(_np(lse)[fin] - rl[:, :, qpos][fin]).max() <= 2e-3
+    _check_dq(f"dq two-piece {name}", _np(dq), rq[:, qpos], rqx[:, qpos])
+    _check(f"dk two-piece {name}", _np(dk), rk[:, kpos])
+    _check(f"dv two-piece {name}", _np(dv), rv[:, kpos])
+
+
+def test_adjacent_pieces_are_the_single_piece_launch_bit_for_bit():
+    """two pieces that happen to be adjacent name the positions of one piece: the same tiles through the same
+    instruction streams -- out, lse, dq, dk, dv identical to the launch without a split, at S = 8192 x 4 heads"""
+    import torch
+    from lwm_amd import ops
+    S, H = 8192, 4
+    q, k, v, do = (_rand((1, S, H, 128), 40 + i).cuda() for i in range(4))
+    one = ops.attn_fwd_block(q, k, v, q_start=5000, k_start=5000, causal=True)
+    two = ops.attn_fwd_block(q, k, v, q_start=5000, k_start=5000, causal=True, q_piece2=(2048, 5000 + 2048), k_piece2=(6144, 5000 + 6144))
+    assert torch.equal(one[0], two[0]) and torch.equal(one[1], two[1])
+    delta = ops.attn_bwd_delta(one[0], do, one[1])
+    kw2 = dict(q_start=5000, k_start=5000, causal=True, q_piece2=(4096, 5000 + 4096), k_piece2=(256, 5000 + 256))
+    assert torch.equal(ops.attn_bwd_dq_block(q, k, v, do, one[1], delta, q_start=5000, k_start=5000, causal=True),
+                       ops.attn_bwd_dq_block(q, k, v, do, one[1], delta, **kw2))
+    a = ops.attn_bwd_dkdv_block(q, k, v, do, one[1], delta, q_start=5000, k_start=5000, causal=True)
+    b = ops.attn_bwd_dkdv_block(q, k, v, do, one[1], delta, **kw2)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])

@@ -147,7 +147,7 @@ class _Mailbox:
 
 
 def _run_c_ring(n, S, H, causal, packed, padded, B=1, layout="contiguous", schedule="ring", fetch_groups=None, box=None,
-                timeline=None):
+                timeline=None, forms=None):
     import torch
     from lwm_amd.ring import SeqLayout
     from lwm_amd.ring_c import CRing
@@ -180,7 +180,10 @@ def _run_c_ring(n, S, H, causal, packed, padded, B=1, layout="contiguous", sched
             out, lse = ring.forward(ql, kl, vl, causal=causal, segment_ids=seg, key_valid=kv)
             if timeline is not None:
                 timeline[r] = ring.fetch_timeline()
+            f_fwd = ring.last_form
             dq, dk, dv = ring.backward(ql, kl, vl, out, lse, dol, causal=causal, segment_ids=seg, key_valid=kv)
+            if forms is not None:
+                forms[r] = (f_fwd, ring.last_form)
             torch.cuda.synchronize()
             res[r] = (idx, out, dq, dk, dv, ring.bytes_sent)
             ring.close()
@@ -252,6 +255,38 @@ def test_c_ring_schedule_vs_oracle_and_python_driver(n, causal, packed, padded, 
         c = S // n
         blk = c * H * 128
         assert all(s == (n - 1) * (2 * 2 * blk * 2 + 2 * blk * 4) for s in sent), sent
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,layout,packed,padded,S", [
+    (2, "zigzag", False, False, 1024), (3, "zigzag", False, True, 1536), (4, "zigzag", True, True, 2048),
+    (8, "zigzag", True, False, 4096), (4, "contiguous", True, True, 1024), (8, "zigzag", True, True, 8192)])
+def test_c_ring_gathered_form_vs_oracle(n, layout, packed, padded, S):
+    """The direct schedule's GATHERED form (lwm_ring_last_form = 1: half-chunks of a multiple of 256 rows, B = 1, causal,
+    one fetch group): the fetched segments in position order in one buffer, two-piece position maps, two launches per
+    kernel and call.  Against the fp64 oracle, against the per-pair form of the same driver (n - 1 fetch groups), and
+    byte for byte the same traffic."""
+    import torch
+    from oracle import attention_ref as R
+    from tests._parity import check, check_dq
+    H = 2
+    forms, forms_pair = {}, {}
+    got, (q, k, v, do, seg, kv), sent = _run_c_ring(n, S, H, True, packed, padded, layout=layout, schedule="direct", forms=forms)
+    assert all(forms[r] == (1, 1) for r in range(n)), forms
+    f = lambda t: t.float().cpu().numpy()
+    sg = None if seg is None else seg.cpu().numpy()
+    kvn = None if kv is None else kv.cpu().numpy()
+    ro, _ = R.dense_attention(f(q), f(k), f(v), causal=True, seg_q=sg, seg_k=sg, key_valid=kvn)
+    rq, rk, rv, rqx = R.dense_attention_bwd(f(q), f(k), f(v), f(do), causal=True, seg_q=sg, seg_k=sg, key_valid=kvn, out_saved=f(got[0]))
+    for name, a, b in zip(("out", "dk", "dv"), (got[0], got[2], got[3]), (ro, rk, rv)):
+        check(f"{name} c-ring gathered n={n} {layout}", f(a), b)
+    check_dq(f"dq c-ring gathered n={n} {layout}", f(got[1]), rq, rqx)
+    if n > 2:       # (n = 2 has one peer: one fetch group whatever is asked for)
+        pair, _, sent_pair = _run_c_ring(n, S, H, True, packed, padded, layout=layout, schedule="direct", fetch_groups=n - 1, forms=forms_pair)
+        assert all(forms_pair[r] == (0, 0) for r in range(n)), forms_pair
+        assert sent == sent_pair
+        for name, a, b in zip(("out", "dq", "dk", "dv"), got, pair):
+            assert ((a.float() - b.float()).abs().max() / b.float().abs().max()).item() <= 8e-3, name
 
 
 @pytest.mark.gpu
