@@ -83,11 +83,18 @@ def cpu_config1():
             "kind": "port", "cores": _cpu_threads(), "sample": "oracle/llama_model_ref.forward_loss + backward, 1 pass"}
 
 
+CPU_BASELINE_CONVENTION = ("value = S / (seconds of ONE timed pass at the workload's own S: 1 head, 1 layer, fwd+bwd) / 32 heads / 32 layers; "
+                           "threads = the best of one sweep over {8, 32, all} at S=4096 x 8 heads")
+
+
 def cpu_baseline(S_target, full=True):
-    """Port of the reference's blockwise attention on PyTorch-CPU fp32 (oracle/attention_torch_cpu.py), timed on bounded
-    samples: op points at S = 4096 (8 heads), 8192 (2 heads) and 16384 (1 head), fwd+bwd of 1 layer; the headline
-    figure takes the FASTEST of them (the port's best) and scales it to the workload by the algorithmic FLOP count
-    (7*S^2*d_model per layer, labelled as extrapolated); `config1` is BASELINE configs[0] end to end."""
+    """Port of the reference's blockwise attention on PyTorch-CPU fp32 (oracle/attention_torch_cpu.py) on the host cores.
+    THE CONVENTION (frozen in round 5; tests/test_bench_contract.py pins it): one sweep over thread counts {8, 32, all}
+    at S = 4096 x 8 heads picks the thread count; `value` is then MEASURED at the workload's own sequence length -- one
+    timed pass of fwd+bwd for ONE head of ONE layer at S = S_target (9.6e11 FLOP at S = 32768, a few seconds) -- and
+    multiplied out over the 32 heads x 32 layers, which are independent repetitions of exactly that pass; nothing is
+    scaled in S.  `op_points` (S = 4096 x 8 heads, 8192 x 2, 16384 x 1) stay as context; `config1` is BASELINE configs[0]
+    end to end."""
     import torch
     from oracle.attention_torch_cpu import blockwise_fwd_bwd
     g = torch.Generator().manual_seed(0)
@@ -107,10 +114,7 @@ def cpu_baseline(S_target, full=True):
     w = [torch.randn(1, 1024, 8, HEAD_DIM, generator=g) for _ in range(4)]
     blockwise_fwd_bwd(*w)  # warm the BLAS threads
     # The port is many small batched matmuls and elementwise passes over 1024 x 1024 tiles: on a many-core host it runs
-    # SLOWER with every thread than with a few (30 GFLOP/s on 128 threads, 130 on 8).  The baseline is what the host
-    # does at its BEST: one timed sample per candidate thread count at S = 4096 x 8 heads (`thread_sweep_gflops` -- the
-    # winner's entry IS op_points[0], same reps, same heads), then S = 8192 and 16384 at the winning thread count; `value`
-    # is extrapolated from the op point with the highest measured rate.  `cores` = the threads the leg computed with.
+    # SLOWER with every thread than with a few (30 GFLOP/s on 128 threads, 130 on 8): the thread count is the sweep's best.
     all_threads = _cpu_threads()
     sweep = {}
     for t in sorted({min(8, all_threads), min(32, all_threads), all_threads}):
@@ -119,23 +123,23 @@ def cpu_baseline(S_target, full=True):
         sweep[t] = op_point(4096, 8, 3.0, 2)
     best = max(sweep, key=lambda t: sweep[t]["gflops"])
     torch.set_num_threads(best)
+    head = op_point(S_target, 1, 0.0, 1)          # THE sample: the workload's S, one head, one layer, one pass
     points = [sweep[best]]
     if full:
         points += [op_point(8192, 2, 6.0, 2), op_point(16384, 1, 6.0, 1)]
-    top = max(points, key=lambda p_: p_["gflops"])
-    flops_per_s = top["gflops"] * 1e9
-    flops_workload = 7.0 * gemm_unit_flops(S_target) * N_LAYERS
     res = {
-        "value": S_target / (flops_workload / flops_per_s),
+        "value": S_target / (head["seconds_per_pass"] * N_HEADS * N_LAYERS),
         "unit": "tokens/s",
         "cores": best,
         "kind": "port",
-        "gflops": top["gflops"],
+        "gflops": head["gflops"],
+        "convention": CPU_BASELINE_CONVENTION,
+        "measured_at": {"S": S_target, "heads": 1, "layers": 1, "seconds": head["seconds_per_pass"]},
         "thread_sweep_gflops": {str(t): round(v["gflops"], 1) for t, v in sweep.items()},
         "op_points": points,
-        "sample": f"oracle/attention_torch_cpu.blockwise_fwd_bwd fp32, 1 layer, chunks 1024/1024, on {best} of {all_threads} threads "
-                  f"(the best of the sweep); the fastest op point (S={top['S']}, {top['heads']} heads, {top['reps']} reps of "
-                  f"{top['seconds_per_pass']:.2f}s) scaled to S={S_target}, 32 heads, 32 layers by the 7*S^2*d_model FLOP law (extrapolated)",
+        "sample": f"oracle/attention_torch_cpu.blockwise_fwd_bwd fp32, chunks 1024/1024, on {best} of {all_threads} threads (the best of "
+                  f"the sweep): ONE timed pass at S={S_target}, 1 head, 1 layer ({head['seconds_per_pass']:.2f} s), times 32 heads x 32 "
+                  f"layers (independent repetitions of that pass; no scaling in S)",
     }
     if full:
         try:
@@ -504,19 +508,23 @@ def ring_model_leg(torch, n=8, S=131072, schedule="mesh", driver="c", packed=Fal
     packed: BASELINE configs[4]'s 15-document packing -- FLOPs are then counted over visible pairs only."""
     from lwm_amd.ring import HipBlockOps, SeqLayout, ring_backward, ring_forward
     from lwm_amd.ring_c import CRing
-    lay = SeqLayout(layout, n, S)
-    c = lay.local_len
-    g = torch.Generator(device="cuda").manual_seed(4321)
-    mk = lambda: torch.randn(1, c, N_HEADS, HEAD_DIM, generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
-    q, k, v, do = mk(), mk(), mk(), mk()
     seg, lens = None, None
     if packed:
         seg_np, lens = packed_documents(S)
         seg = torch.from_numpy(seg_np).cuda()
+    if layout == "balanced":        # an ownership table from the document lengths (what a loader knows): 4 chunks per rank
+        from lwm_amd.ring import balanced_layout
+        lay = balanced_layout(n, S, lens, chunks_per_rank=4)
+    else:
+        lay = SeqLayout(layout, n, S)
+    c = lay.local_len
+    g = torch.Generator(device="cuda").manual_seed(4321)
+    mk = lambda: torch.randn(1, c, N_HEADS, HEAD_DIM, generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+    q, k, v, do = mk(), mk(), mk(), mk()
     per_rank, forms = [], []
     for r in range(n):
         if driver == "c":
-            ring = CRing.null(r, n, layout=layout, schedule="direct" if schedule in ("mesh", "direct") else "ring")
+            ring = CRing.null(r, n, layout=lay if lay.kind == "table" else layout, schedule="direct" if schedule in ("mesh", "direct") else "ring")
 
             def layer():
                 o, l = ring.forward(q, k, v, causal=True, segment_ids=seg)
@@ -1198,7 +1206,9 @@ def main():
                 if not args.no_packed_1m:
                     # BASELINE configs[4] under ring 8: 1,048,576 tokens in 15 packed documents, zigzag -- does the
                     # ownership that balances a full causal triangle balance documents too?
-                    res["ring8_compute_model_packed_1m"] = leg(ring_model_leg, torch, S=1 << 20, packed=True, reps=1)
+                    res["ring8_compute_model_packed_1m_zigzag"] = leg(ring_model_leg, torch, S=1 << 20, packed=True, reps=1)
+                    # ... no (max / mean 1.9): an ownership table from the document lengths, 4 chunks per rank by visible pairs
+                    res["ring8_compute_model_packed_1m"] = leg(ring_model_leg, torch, S=1 << 20, packed=True, layout="balanced", reps=1)
                 res["elementwise"] = leg(elementwise_leg, torch)
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -52,6 +52,7 @@ typedef struct LwmTensor4 {
  * Scores are q.k * scale in f32; softmax and all accumulators are f32
  * (float32_logits=True, lwm/llama.py:543); operands are bf16; D must be 128.
  */
+#define LWM_MAX_PIECES 8
 typedef struct LwmAttnArgs {
     LwmTensor4 q, k, v;    /* bf16 in */
     LwmTensor4 out;        /* bf16: fwd writes it when final_out; bwd reads it */
@@ -97,19 +98,21 @@ typedef struct LwmAttnArgs {
     const int32_t* seg_blocks_k;
     /* lwm_attn_bwd_dq: 0 = dq_acc is [B,Sq,H,D], 1 = head-major [B,H,Sq,D]. */
     int32_t dq_acc_head_major;
-    /* Two-piece position maps (lwm_version() >= 500; 0 = one piece, the fields above say everything).  A shard under
-     * zigzag ownership is TWO runs of consecutive positions (half-chunks r and 2n-1-r), and so is the K/V a rank has
-     * gathered from its peers (what lies below its own low half-chunk | what lies between its two half-chunks):
-     *   query rows [0, q_split) sit at q_start + row, rows [q_split, Sq) at q_start2 + (row - q_split);
-     *   key   rows [0, k_split) sit at k_start + row, rows [k_split, Sk) at k_start2 + (row - k_split).
+    /* Piecewise position maps (lwm_version() >= 500; *_pieces = 0 or 1: one piece, the fields above say everything).
+     * A shard under zigzag ownership is TWO runs of consecutive positions (half-chunks r and 2n-1-r), under a balanced
+     * ownership of packed documents a few more, and so is the K/V a rank has gathered from its peers (what lies below its
+     * first run, between its runs ...).  With q_pieces = P > 1:
+     *   query rows [q_piece_row[i], q_piece_row[i+1]) sit at positions q_piece_pos[i] + (row - q_piece_row[i]),
+     *   q_piece_row[0] = 0, q_piece_pos[0] = q_start, the last piece ends at Sq;  keys likewise.
      * One launch then covers what took one launch per (q segment, k segment) pair, with no carry in between -- at small
      * shards (S = 32768 over 8 ranks: 2048-row half-chunks) the pair launches cannot fill 256 CUs.  Requirements:
-     * splits are multiples of 256 rows and lie strictly inside (0, S); *_start2 >= *_start + *_split (positions ascend
-     * with the row).  Training kernels only (lwm_attn_fwd without dense_mask / k_splits, lwm_attn_bwd_dq / _dkdv);
-     * results are bitwise those of the single-piece launch on the same rows when the two pieces happen to be adjacent
-     * (q_start2 = q_start + q_split). */
-    int32_t q_split, k_split;
-    int64_t q_start2, k_start2;
+     * P <= LWM_MAX_PIECES; piece rows are multiples of 256, strictly ascending, inside (0, S); positions ascend with the
+     * row and pieces do not overlap (pos[i+1] >= pos[i] + row[i+1] - row[i]).  Training kernels only (lwm_attn_fwd
+     * without dense_mask / k_splits, lwm_attn_bwd_dq / _dkdv); results are bitwise those of the single-piece launch on the
+     * same rows when the pieces happen to be adjacent. */
+    int32_t q_pieces, k_pieces;
+    int32_t q_piece_row[LWM_MAX_PIECES], k_piece_row[LWM_MAX_PIECES];
+    int64_t q_piece_pos[LWM_MAX_PIECES], k_piece_pos[LWM_MAX_PIECES];
     /* Size in bytes of the buffer behind `delta`, or 0 = not given.  When given, lwm_attn_bwd_delta / _dq / _dkdv
      * refuse a buffer smaller than lwm_attn_bwd_delta_bytes(B,H,Sq) instead of overrunning it (the layout of the
      * statistics changed at lwm_version() 400: a [B,H,Sq] buffer of earlier versions is too small). */
@@ -174,6 +177,11 @@ typedef struct LwmRingArgs {
     void* workspace;         /* lwm_ring_workspace_bytes(B, c, H, D, backward, n, schedule) bytes, 256-byte aligned */
     int32_t layout;          /* LWM_RING_LAYOUT_*: which positions a rank owns */
     int32_t schedule;        /* LWM_RING_SCHEDULE_*: how K/V and the dK/dV contributions move */
+    /* LWM_RING_LAYOUT_TABLE: HOST array of n_chunks = n * P ints (1 <= P <= LWM_MAX_PIECES): the sequence is cut into
+     * n_chunks equal chunks, chunk j (positions [j * S/n_chunks, (j+1) * S/n_chunks)) belongs to rank chunk_owner[j]; every
+     * rank owns exactly P chunks and holds them in ascending position order in its local rows.  Ignored otherwise. */
+    const int32_t* chunk_owner;
+    int32_t n_chunks;
 } LwmRingArgs;
 
 /* Ownership.  CONTIGUOUS = the reference's: rank r holds positions [r*c, (r+1)*c) (lwm/llama.py:560-562).
@@ -182,7 +190,12 @@ typedef struct LwmRingArgs {
  * blocks and rank 0 one.  lse is an OPAQUE residual between lwm_ring_attn_fwd and _bwd of the same ring and geometry
  * (two dense [B,H,c/2] pieces, one per segment, or one [B,H,c] piece in local row order, as the form of the call has it);
  * everything else keeps its [B,c,H,D] shape in local row order. */
-enum { LWM_RING_LAYOUT_CONTIGUOUS = 0, LWM_RING_LAYOUT_ZIGZAG = 1 };
+/* TABLE: any ownership of equal chunks, P per rank, handed over as LwmRingArgs::chunk_owner -- for packed batches, where
+ * zigzag balances a full causal triangle but not documents: at BASELINE configs[4] (1,048,576 tokens in 15 documents, 8
+ * ranks) the slowest zigzag rank computes 1.9x the mean; four chunks per rank assigned by visible-pair count (a loader
+ * knows the document lengths: lwm_amd/ring.py balanced_layout) bring that to ~1.03.  Runs in the gathered form only
+ * (lwm_ring_last_form): direct schedule, B = 1, causal, chunks of a multiple of 256 rows. */
+enum { LWM_RING_LAYOUT_CONTIGUOUS = 0, LWM_RING_LAYOUT_ZIGZAG = 1, LWM_RING_LAYOUT_TABLE = 2 };
 /* Exchange.  RING = the reference's (lax.ppermute i -> i+1): the K/V block, and in the backward its f32 dK/dV
  * carry, hop to the next rank once per step -- every byte crosses ONE link per step, n-1 (n) times.
  * DIRECT: MI355X's xGMI is a full mesh, so nothing is forwarded: one grouped exchange brings every rank exactly

@@ -12,6 +12,22 @@ LWM_EUNSUPPORTED = -2
 LWM_ELAUNCH = -3
 
 
+MAX_PIECES = 8     # LWM_MAX_PIECES
+
+
+def set_pieces(args, side, pieces):
+    """pieces = [(first row, position of that row), ...] of LwmAttnArgs' piecewise position map of `side` ("q" / "k");
+    None or one piece leaves the single-piece fields alone."""
+    if not pieces or len(pieces) < 2:
+        return
+    if len(pieces) > MAX_PIECES:
+        raise ValueError(f"{side}: {len(pieces)} pieces, at most {MAX_PIECES}")
+    setattr(args, side + "_pieces", len(pieces))
+    rows, poss = getattr(args, side + "_piece_row"), getattr(args, side + "_piece_pos")
+    for i, (r, p) in enumerate(pieces):
+        rows[i], poss[i] = int(r), int(p)
+
+
 class LwmTensor4(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("stride_b", C.c_int64), ("stride_s", C.c_int64),
                 ("stride_h", C.c_int64)]
@@ -34,7 +50,9 @@ class LwmAttnArgs(C.Structure):
         ("k_splits", C.c_int32),
         ("seg_blocks_q", C.c_void_p), ("seg_blocks_k", C.c_void_p),
         ("dq_acc_head_major", C.c_int32),
-        ("q_split", C.c_int32), ("k_split", C.c_int32), ("q_start2", C.c_int64), ("k_start2", C.c_int64),
+        ("q_pieces", C.c_int32), ("k_pieces", C.c_int32),
+        ("q_piece_row", C.c_int32 * MAX_PIECES), ("k_piece_row", C.c_int32 * MAX_PIECES),
+        ("q_piece_pos", C.c_int64 * MAX_PIECES), ("k_piece_pos", C.c_int64 * MAX_PIECES),
         ("delta_bytes", C.c_int64),
     ]
 
@@ -47,10 +65,11 @@ class LwmRingArgs(C.Structure):
         ("B", C.c_int32), ("c", C.c_int32), ("H", C.c_int32), ("D", C.c_int32),
         ("scale", C.c_float), ("causal", C.c_int32), ("workspace", C.c_void_p),
         ("layout", C.c_int32), ("schedule", C.c_int32),
+        ("chunk_owner", C.c_void_p), ("n_chunks", C.c_int32),
     ]
 
 
-RING_LAYOUT = {"contiguous": 0, "zigzag": 1}
+RING_LAYOUT = {"contiguous": 0, "zigzag": 1, "table": 2}
 RING_SCHEDULE = {"ring": 0, "direct": 1, "mesh": 1}
 
 

@@ -12,7 +12,8 @@ reference's contiguous blocks, lwm/llama.py:560-562) -- cut with `sp_shard`, pos
 exchange is driven by the C-ABI ring driver (RCCL on a side stream) when the job's backend is RCCL.  Two flags beyond the
 reference's set, for tests and diagnosis: --lwm_dump_grads=<file> (rank 0 saves the batch, the parameters, the loss
 and every gradient of the last step) and --lwm_balance_report (the attention launches of every sp rank timed in turn on
-this rank's GPU; --lwm_balance_seq=<S> times another sequence length than the job's)."""
+this rank's GPU; --lwm_balance_seq=<S> / --lwm_balance_heads=<H> time another sequence length / head count than the
+job's: a debug model's 2 heads make 64 workgroups for 256 CUs, and the longest workgroup, not the work, sets the time)."""
 from __future__ import annotations
 
 import math
@@ -28,7 +29,7 @@ DEFAULTS = dict(
     modality="text", use_data_sharded_loader=True, seed=42, mesh_dim="1,-1,1,1", dtype="bf16", total_steps=10000,
     load_llama_config="", update_llama_config="", load_checkpoint="", load_dataset_state="", log_freq=50,
     save_model_freq=0, save_milestone_freq=0, eval_steps=0, tokenizer="LargeWorldModel/LWM-Text-1M",
-    log_all_worker=False, autoresume=False, lwm_dump_grads="", lwm_balance_report=False, lwm_balance_seq=0)
+    log_all_worker=False, autoresume=False, lwm_dump_grads="", lwm_balance_report=False, lwm_balance_seq=0, lwm_balance_heads=0)
 GROUPS = ("train_dataset", "eval_dataset", "optimizer", "checkpointer", "llama", "logger", "jax_distributed")
 
 
@@ -156,13 +157,14 @@ def main(argv=None):
         C.note(f"ring driver: {info}")
         history.append(dict(ring=info, layout=sp_layout("sp", seq // sp)))
         if F.lwm_balance_report:
-            history.append(dict(balance=balance_report(cfg, local_b, (int(F.lwm_balance_seq) or seq) // sp, sp, dev)))
+            history.append(dict(balance=balance_report(cfg, local_b, (int(F.lwm_balance_seq) or seq) // sp, sp, dev,
+                                                       heads=int(F.lwm_balance_heads) or None)))
             if world_rank == 0:
                 print("LWM_BALANCE " + __import__("json").dumps(history[-1]["balance"]), flush=True)
     return history
 
 
-def balance_report(cfg, B, c, n, dev, reps=5):
+def balance_report(cfg, B, c, n, dev, reps=5, heads=None):
     """Per-rank attention time of ONE layer of this job's shard shape, measured without the other ranks in the way: every
     rank of the sp ring is played in turn on THIS process's GPU by the C ring driver over a transport that moves nothing
     (CRing.null) -- the launch list of rank r under the ownership rule in force, forward + backward.  Ranks take turns
@@ -170,7 +172,7 @@ def balance_report(cfg, B, c, n, dev, reps=5):
     import torch.distributed as dist
     from ..ring_c import CRing
     from ..ringattention import sp_layout, sp_size_rank
-    H, D = cfg.num_attention_heads, cfg.hidden_size // cfg.num_attention_heads
+    H, D = heads or cfg.num_attention_heads, cfg.hidden_size // cfg.num_attention_heads
     kind = sp_layout("sp", c)
     me = sp_size_rank("sp")[1]
     g = torch.Generator(device=dev).manual_seed(5)

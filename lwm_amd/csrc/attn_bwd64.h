@@ -491,12 +491,13 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
         // another reason than causality).  Units are named by the row of their first query inside the q block,
         // ub = 64 * step + 32 * half (steps descend, the halves of a step ascend); everything is clamped to 32 bits once.
         auto clamp32 = [](int64_t x) -> int { return x > (1 << 30) ? (1 << 30) : (x < -(1 << 30) ? -(1 << 30) : (int)x); };
-        // positions relative to q_start; a unit's first query (row ub of the q block) sits at ub + q_gap(ub)
-        const int wk_rel = clamp32(k_base + (int64_t)kbi * kD4BK + wave * 32 + 31 - p.q_start);   // the wave's last key
+        // positions relative to q_start; a unit's first query (row ub of the q block) sits at rel_pos(qm, ub)
         const int k_rel = clamp32(k_pos - p.q_start) - 4 * hi;                                     // this lane's key
-        const int q_gap2 = clamp32(p.q_start2 - p.q_split - p.q_start);      // (0 for one piece; >= 0)
-        auto q_rel_of = [&](int ub) -> int { return ub < p.q_split ? ub : (ub > (1 << 30) - q_gap2 ? (1 << 30) : ub + q_gap2); };
-        auto needs_causal = [&](int ub) -> bool { return p.causal && q_rel_of(ub) < wk_rel; };
+        auto q_rel_of = [&](int ub) -> int { return rel_pos(qm, ub); };
+        // positions ascend with the row: the units that begin before the wave's last key -- the ones that need the mask
+        // code -- are the first mask_end rows of the q block (one compare per unit in the walk)
+        const int mask_end = p.causal ? 32 * tiles_reaching(qm, 32, (p.Sq + 31) / 32, k_base + (int64_t)kbi * kD4BK + wave * 32 + 31 - 1) : 0;
+        auto needs_causal = [&](int ub) -> bool { return ub < mask_end; };
         // the wave's 32 keys all valid and of one segment?  (then a step whose 64 queries carry it needs no segment test)
         const int32_t own_seg = wave_uniform(kseg);
         const bool own_uniform = HAS_META && !wave_any(kseg != own_seg || kseg == kSegInvalid);
@@ -1027,13 +1028,13 @@ LWM_DEVICE void attn_bwd_dq4_body(const AttnParams& p) {
         block_sync();
 
         auto clamp32 = [](int64_t x) -> int { return x > (1 << 30) ? (1 << 30) : (x < -(1 << 30) ? -(1 << 30) : (int)x); };
-        // positions relative to k_start; a unit's first key (row ub of the K/V block) sits at ub + k_gap(ub)
-        const int wq_rel = clamp32(q_base + (int64_t)qbi * kQ4BQ + wave * 32 - p.k_start);      // the wave's first query
+        // positions relative to k_start; a unit's first key (row ub of the K/V block) sits at rel_pos(km, ub)
         const int q_rel = clamp32(q_base + q_row - p.k_start) - 4 * hi;                         // this lane's query
-        const int k_gap2 = clamp32(p.k_start2 - p.k_split - p.k_start);      // (0 for one piece; >= 0)
-        auto k_rel_of = [&](int ub) -> int { return ub < p.k_split ? ub : (ub > (1 << 30) - k_gap2 ? (1 << 30) : ub + k_gap2); };
-        // a unit needs the mask code when its last key lies after the wave's first query
-        auto needs_causal = [&](int ub) -> bool { return p.causal && k_rel_of(ub) + 31 > wq_rel; };
+        auto k_rel_of = [&](int ub) -> int { return rel_pos(km, ub); };
+        // a unit needs the mask code when its last key lies after the wave's first query: positions ascend with the row,
+        // so those are the units from row mask_from of the K/V block on (one compare per unit in the walk)
+        const int mask_from = p.causal ? 32 * tiles_below(km, 32, (p.Sk + 31) / 32, q_base + (int64_t)qbi * kQ4BQ + wave * 32) : 0x7fffffff;
+        auto needs_causal = [&](int ub) -> bool { return ub >= mask_from; };
         // the wave's 32 queries of one segment?  (then a step whose 64 keys carry it needs no segment test; rows past Sq
         // are never stored and do not count)
         const int32_t own_seg = wave_uniform(seg_q);

@@ -24,6 +24,7 @@ namespace lwm {
 
 constexpr int kHeadDim = 128;
 constexpr int kRowBytes = kHeadDim * 2;  // 256
+constexpr int kMaxPieces = 8;            // LWM_MAX_PIECES of include/lwm_hip.h
 
 struct AttnParams {
     // forward operands
@@ -58,11 +59,12 @@ struct AttnParams {
     int64_t dv_sb, dv_ss, dv_sh;
     int32_t B, H, Sq, Sk;
     int64_t q_start, k_start;  // global token position of row 0 (ring offset)
-    // Two-piece position maps (a zigzag shard is two runs of consecutive positions; so is the K/V a rank gathers from its
-    // peers): rows [0, split) sit at start + row, rows [split, S) at start2 + (row - split), start2 >= start + split.
-    // One piece: split = S (api.inc).  Splits are multiples of 256 rows, so no workgroup tile straddles one.
-    int32_t q_split, k_split;
-    int64_t q_start2, k_start2;
+    // Piecewise position maps (a shard under zigzag / balanced ownership is a few runs of consecutive positions; so is the
+    // K/V a rank gathers from its peers): piece i = rows [row[i], row[i+1]) at positions pos[i] + (r - row[i]); row[0] = 0,
+    // pos[0] = the operand's start; rows and positions ascend, pieces do not overlap.  Unused entries: row = INT32_MAX.
+    // Cuts are multiples of 256 rows, so no workgroup tile straddles one.  (api.inc fills these from LwmAttnArgs.)
+    int32_t q_row[kMaxPieces], k_row[kMaxPieces];
+    int64_t q_pos[kMaxPieces], k_pos[kMaxPieces];
     float scale;               // softmax scale, 1/sqrt(D)
     int32_t causal;
     int32_t carry_in;          // merge with *_acc before writing
@@ -77,28 +79,53 @@ struct AttnParams {
     const int32_t* segb_k;
 };
 
-// ---- position maps (see AttnParams): everything below is wave-uniform scalar arithmetic.
+// ---- position maps (see AttnParams): everything below is wave-uniform scalar arithmetic over tables of kMaxPieces
+// entries held in the kernel arguments; the loops are unrolled with static indices (a dynamically indexed by-value
+// argument would be copied to scratch).
 struct PosMap {
-    int64_t start, start2;
-    int32_t split, S;
+    const int32_t* row;
+    const int64_t* pos;
+    int32_t S;
 };
-LWM_DEVICE PosMap q_map(const AttnParams& p) { return PosMap{p.q_start, p.q_start2, p.q_split, p.Sq}; }
-LWM_DEVICE PosMap k_map(const AttnParams& p) { return PosMap{p.k_start, p.k_start2, p.k_split, p.Sk}; }
+LWM_DEVICE PosMap q_map(const AttnParams& p) { return PosMap{p.q_row, p.q_pos, p.Sq}; }
+LWM_DEVICE PosMap k_map(const AttnParams& p) { return PosMap{p.k_row, p.k_pos, p.Sk}; }
 // position of row r = pos_base(m, row0) + r for every row r of a tile that begins at row0
-LWM_DEVICE int64_t pos_base(const PosMap& m, int row0) { return row0 < m.split ? m.start : m.start2 - m.split; }
+LWM_DEVICE int64_t pos_base(const PosMap& m, int row0) {
+    int64_t base = m.pos[0];
+#pragma unroll
+    for (int i = 1; i < kMaxPieces; ++i) base = row0 >= m.row[i] ? m.pos[i] - m.row[i] : base;
+    return base;
+}
 // How many LEADING tiles (of `per` rows; n_tiles = ceil(S / per)) begin at a position <= P -- positions ascend with the
 // row, so those are the tiles a query at P can see a key of (or, mirrored, the query steps that lie wholly before a key
 // at P + 1 when asked with P = key - per).
 LWM_DEVICE int tiles_reaching(const PosMap& m, int per, int n_tiles, int64_t P) {
-    const int st = m.split >= m.S ? n_tiles : m.split / per;
-    int64_t c1 = P < m.start ? 0 : (P - m.start) / per + 1;
-    if (c1 < st) return (int)c1;
-    const int rest = n_tiles - st;
-    int64_t c2 = P < m.start2 ? 0 : (P - m.start2) / per + 1;
-    return st + (int)(c2 < rest ? c2 : rest);
+    int total = 0;
+    bool open = true;       // every piece so far was reached to its end
+#pragma unroll
+    for (int i = 0; i < kMaxPieces; ++i) {
+        const int r0 = i == 0 ? 0 : m.row[i];
+        const bool live = r0 < m.S;
+        const int r1 = (i + 1 < kMaxPieces && m.row[i + 1] < m.S) ? m.row[i + 1] : m.S;
+        const int t_i = live ? (r1 - r0 + per - 1) / per : 0;
+        const int64_t c = (!live || P < m.pos[i]) ? 0 : (P - m.pos[i]) / per + 1;
+        const int take = open ? (int)(c < t_i ? c : t_i) : 0;
+        total += take;
+        open = open && take == t_i;
+    }
+    return total < n_tiles ? total : n_tiles;
 }
 // ... whose EVERY row lies at a position <= P
 LWM_DEVICE int tiles_below(const PosMap& m, int per, int n_tiles, int64_t P) { return tiles_reaching(m, per, n_tiles, P - (per - 1)); }
+// position of row r relative to the map's first position, for a row r that begins a 32-row unit: r + (what its piece
+// adds), saturated at 2^30 (callers compare it with clamped differences)
+LWM_DEVICE int rel_pos(const PosMap& m, int r) {
+    int64_t gap = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxPieces; ++i) gap = r >= m.row[i] ? m.pos[i] - m.row[i] - m.pos[0] : gap;
+    const int64_t v = r + gap;
+    return v > (1 << 30) ? (1 << 30) : (int)v;
+}
 
 LWM_DEVICE int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 LWM_DEVICE uint32_t tile_off(int row, int slot) {

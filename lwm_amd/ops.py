@@ -49,18 +49,20 @@ def _f32(t, name, shape=None):
 
 
 def _base(q, k, v, *, q_start, k_start, causal, seg_q, seg_k, key_valid, scale, q_piece2=None, k_piece2=None):
-    """q_piece2 / k_piece2 = (split row, position of that row): the two-piece position maps of LwmAttnArgs (rows before
-    the split sit at *_start + row, rows from it on at position + (row - split); splits are multiples of 256 rows)"""
+    """q_piece2 / k_piece2 = (cut row, position of that row) -- or a list of such cuts, in ascending order: the pieces of
+    LwmAttnArgs' piecewise position maps beyond the first (rows before the first cut sit at *_start + row, rows from a cut
+    on at its position + (row - cut); cuts are multiples of 256 rows)"""
     B, Sq, H, D = q.shape
     Sk = k.shape[1]
     a = _capi.LwmAttnArgs()
     a.q, a.k, a.v = _t4(q, "q"), _t4(k, "k"), _t4(v, "v")
     a.B, a.H, a.Sq, a.Sk, a.D = B, H, Sq, Sk, D
     a.q_start, a.k_start = int(q_start), int(k_start)
+    cuts = lambda c: [c] if isinstance(c, tuple) else list(c)
     if q_piece2 is not None:
-        a.q_split, a.q_start2 = int(q_piece2[0]), int(q_piece2[1])
+        _capi.set_pieces(a, "q", [(0, q_start)] + cuts(q_piece2))
     if k_piece2 is not None:
-        a.k_split, a.k_start2 = int(k_piece2[0]), int(k_piece2[1])
+        _capi.set_pieces(a, "k", [(0, k_start)] + cuts(k_piece2))
     a.scale = float(scale) if scale is not None else 1.0 / math.sqrt(D)
     a.causal = int(bool(causal))
     if (seg_q is None) != (seg_k is None):

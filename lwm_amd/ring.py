@@ -47,14 +47,25 @@ from . import ops as _ops
 # ----------------------------------------------------------------- layouts
 class SeqLayout:
     """Which global token positions a rank owns, as contiguous segments
-    (local_offset, length, global_start) of its local shard."""
+    (local_offset, length, global_start) of its local shard.
 
-    def __init__(self, kind: str, n: int, seq_len: int):
-        if kind not in ("contiguous", "zigzag"):
+    kind "contiguous" (the reference's, lwm/llama.py:560-562), "zigzag" (half-chunks r and 2n-1-r), or "table": the
+    sequence cut into len(owner) = n * P equal chunks, chunk j owned by rank owner[j], P chunks per rank held in ascending
+    position order -- any ownership a loader computes (balanced_layout for packed batches); include/lwm_hip.h
+    LWM_RING_LAYOUT_TABLE."""
+
+    def __init__(self, kind: str, n: int, seq_len: int, owner=None):
+        if kind not in ("contiguous", "zigzag", "table"):
             raise ValueError(f"unknown layout {kind!r}")
         if kind == "zigzag" and n == 1:
             kind = "contiguous"
-        div = n if kind == "contiguous" else 2 * n
+        self.owner = None
+        if kind == "table":
+            owner = [int(r) for r in owner]
+            if len(owner) % n or seq_len % len(owner) or any(owner.count(r) != len(owner) // n for r in range(n)):
+                raise ValueError(f"ownership table: {len(owner)} chunks must be n * P, divide {seq_len}, every rank owning P")
+            self.owner = owner
+        div = n if kind == "contiguous" else 2 * n if kind == "zigzag" else len(owner)
         if seq_len % div:
             raise ValueError(f"seq_len {seq_len} not divisible by {div} for layout {kind}")
         self.kind, self.n, self.seq_len = kind, n, seq_len
@@ -64,12 +75,53 @@ class SeqLayout:
         c = self.local_len
         if self.kind == "contiguous":
             return [(0, c, rank * c)]
+        if self.kind == "table":
+            cs = self.seq_len // len(self.owner)
+            # (one segment per chunk, also where two chunks are adjacent: every rank has the same number of segments,
+            #  which the neighbour-ring schedule's travelling carries rely on)
+            return [(i * cs, cs, j * cs) for i, j in enumerate(j for j, r in enumerate(self.owner) if r == rank)]
         h = c // 2
         return [(0, h, rank * h), (h, h, (2 * self.n - 1 - rank) * h)]
 
     def global_index(self, rank: int) -> torch.Tensor:
         """Global positions of the rank's local rows (for sharding tensors in tests/loaders)."""
         return torch.cat([torch.arange(g, g + ln) for _, ln, g in self.segments(rank)])
+
+
+def balanced_layout(n, seq_len, doc_lengths=None, chunks_per_rank=4, align=256):
+    """Ownership that balances CAUSAL, DOCUMENT-MASKED work over n ranks: the sequence is cut into n * chunks_per_rank
+    chunks, each weighed by its visible (query, key) pairs -- a query at offset p of its document sees p + 1 keys; without
+    documents the whole sequence is one -- and handed out heaviest first to the least loaded rank that still has room
+    (every rank gets chunks_per_rank chunks).  Zigzag is the two-chunk answer for ONE document; for BASELINE configs[4]'s
+    packing (1,048,576 tokens in 15 documents, n = 8) it leaves the slowest rank at 1.9x the mean, this at ~1.03 with four
+    chunks.  The loader knows the document lengths (lwm/data.py packs them); all ranks must build the same table.
+    -> SeqLayout("table"); falls back to fewer chunks per rank while a chunk would not be a multiple of `align` rows."""
+    import numpy as np
+    P = int(chunks_per_rank)
+    while P > 1 and seq_len % (n * P * align):
+        P -= 1
+    if seq_len % (n * P):
+        raise ValueError(f"seq_len {seq_len} is not divisible by {n * P}")
+    if n == 1:
+        return SeqLayout("contiguous", 1, seq_len)
+    lens = [seq_len] if not doc_lengths else [int(x) for x in doc_lengths]
+    if sum(lens) != seq_len or min(lens) <= 0:
+        raise ValueError("doc_lengths must be positive and sum to seq_len")
+    m, cs = n * P, seq_len // (n * P)
+    # pairs seen by the queries of [a, b) of a document that starts at s: sum_{p=a-s}^{b-s-1} (p + 1)
+    tri = lambda x: x * (x + 1) // 2
+    w = np.zeros(m, dtype=np.float64)
+    s = 0
+    for ln in lens:
+        for j in range(s // cs, (s + ln - 1) // cs + 1):
+            a, b = max(s, j * cs), min(s + ln, (j + 1) * cs)
+            w[j] += tri(b - s) - tri(a - s)
+        s += ln
+    owner, load, room = [0] * m, [0.0] * n, [P] * n
+    for j in sorted(range(m), key=lambda j_: (-w[j_], j_)):
+        r = min((r_ for r_ in range(n) if room[r_]), key=lambda r_: (load[r_], r_))
+        owner[j], load[r], room[r] = r, load[r] + w[j], room[r] - 1
+    return SeqLayout("table", n, seq_len, owner=owner)
 
 
 def pair_visible(qseg, kseg, causal: bool) -> bool:
@@ -716,10 +768,14 @@ def ring_attention(q, k, v, *, group=None, causal=True, segment_ids=None, key_va
                 from .ring_c import ring_attention_c
                 kind = layout.kind if isinstance(layout, SeqLayout) else layout
                 sched = os.environ.get("LWM_RING_SCHEDULE") or "mesh"
-                c_ring = _c_ring_for(group, kind, sched, transport, q.numel() * 4, max(8, 4 * q.shape[0]))
+                # (an ownership table travels with the call: one ring object serves every table; it posts up to
+                #  2 x chunks-per-rank messages per pair and group)
+                table = layout if kind == "table" else None
+                slots = max(8, 4 * q.shape[0], 2 * (len(layout.owner) // layout.n) if table is not None else 0)
+                c_ring = _c_ring_for(group, "zigzag" if table is not None else kind, sched, transport, q.numel() * 4, slots)
                 if c_ring is not None:
                     return ring_attention_c(q, k, v, c_ring, causal=causal, segment_ids=segment_ids,
-                                            key_valid=key_valid, scale=scale)
+                                            key_valid=key_valid, scale=scale, layout=table)
             comm = _torch_comm(group)
     block = block_ops if block_ops is not None else HipBlockOps
     lay = layout if isinstance(layout, SeqLayout) else SeqLayout(layout, comm.size,

@@ -121,7 +121,19 @@ class CRing:
         self._h = h
         self._ws = None
         self._parked = []
-        self.layout, self.schedule = _capi.RING_LAYOUT[layout], _capi.RING_SCHEDULE[schedule]
+        # layout: "contiguous" | "zigzag" | a lwm_amd.ring.SeqLayout (kind "table": the ownership table travels with every
+        # call); forward / backward take another one per call (a packed batch has its own balanced ownership)
+        self.layout, self._owner = self._layout_code(layout)
+        self.schedule = _capi.RING_SCHEDULE[schedule]
+
+    @staticmethod
+    def _layout_code(layout):
+        """-> (LWM_RING_LAYOUT_* code, ctypes ownership table or None)"""
+        if isinstance(layout, str):
+            return _capi.RING_LAYOUT[layout], None
+        if layout.kind == "table":
+            return _capi.RING_LAYOUT["table"], (C.c_int32 * len(layout.owner))(*layout.owner)
+        return _capi.RING_LAYOUT[layout.kind], None
 
     def close(self):
         if getattr(self, "_h", None):
@@ -170,7 +182,7 @@ class CRing:
         off = (-self._ws.data_ptr()) % 256
         return self._ws.data_ptr() + off
 
-    def _args(self, q, k, v, out, lse, segment_ids, key_valid, scale, causal, backward):
+    def _args(self, q, k, v, out, lse, segment_ids, key_valid, scale, causal, backward, layout=None):
         if (self._ipc_slots is not None and self.schedule == _capi.RING_SCHEDULE["direct"] and
                 (1 + (self.layout == _capi.RING_LAYOUT["zigzag"])) * 2 * q.shape[0] > self._ipc_slots):
             # the direct schedule posts (segments x {K, V} x B) messages per pair in one group: more than `slots` of
@@ -196,25 +208,29 @@ class CRing:
                 raise ValueError(f"key_valid: expected contiguous uint8 {(B, Sg)} (replicated, full length)")
             a.key_valid = key_valid.data_ptr()
         a.workspace = self._workspace(B, c, H, D, backward)
-        a.layout, a.schedule = self.layout, self.schedule
+        code, owner = (self.layout, self._owner) if layout is None else self._layout_code(layout)
+        a.layout, a.schedule = code, self.schedule
+        if owner is not None:
+            a.chunk_owner, a.n_chunks = C.cast(owner, C.c_void_p), len(owner)
+            a._keep_owner = owner
         return a
 
-    def forward(self, q, k, v, *, causal=True, segment_ids=None, key_valid=None, scale=None):
+    def forward(self, q, k, v, *, causal=True, segment_ids=None, key_valid=None, scale=None, layout=None):
         B, c, H, D = q.shape
         k, v = k.contiguous(), v.contiguous()
         out = torch.empty((B, c, H, D), dtype=torch.bfloat16, device=q.device)
         lse = torch.empty((B, H, c), dtype=torch.float32, device=q.device)
-        a = self._args(q, k, v, out, lse, segment_ids, key_valid, scale, causal, False)
+        a = self._args(q, k, v, out, lse, segment_ids, key_valid, scale, causal, False, layout)
         L = lib()
         _capi.check(L, L.lwm_ring_attn_fwd(self._h, C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
                     "lwm_ring_attn_fwd")
         return out, lse
 
-    def backward(self, q, k, v, out, lse, dout, *, causal=True, segment_ids=None, key_valid=None, scale=None):
+    def backward(self, q, k, v, out, lse, dout, *, causal=True, segment_ids=None, key_valid=None, scale=None, layout=None):
         B, c, H, D = q.shape
         k, v, dout = k.contiguous(), v.contiguous(), dout.contiguous()
         dq, dk, dv = (torch.empty((B, c, H, D), dtype=torch.bfloat16, device=q.device) for _ in range(3))
-        a = self._args(q, k, v, out, lse, segment_ids, key_valid, scale, causal, True)
+        a = self._args(q, k, v, out, lse, segment_ids, key_valid, scale, causal, True, layout)
         a.dout, a.dq, a.dk, a.dv = _t4(dout, "dout"), _t4(dq, "dq"), _t4(dk, "dk"), _t4(dv, "dv")
         L = lib()
         _capi.check(L, L.lwm_ring_attn_bwd(self._h, C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
@@ -224,25 +240,25 @@ class CRing:
 
 class _RingAttentionC(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, ring, causal, segment_ids, key_valid, scale):
-        out, lse = ring.forward(q, k, v, causal=causal, segment_ids=segment_ids, key_valid=key_valid, scale=scale)
+    def forward(ctx, q, k, v, ring, causal, segment_ids, key_valid, scale, layout):
+        out, lse = ring.forward(q, k, v, causal=causal, segment_ids=segment_ids, key_valid=key_valid, scale=scale, layout=layout)
         ctx.save_for_backward(q, k, v, out, lse)
-        ctx.cfg = (ring, causal, segment_ids, key_valid, scale)
+        ctx.cfg = (ring, causal, segment_ids, key_valid, scale, layout)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         q, k, v, out, lse = ctx.saved_tensors
-        ring, causal, segment_ids, key_valid, scale = ctx.cfg
+        ring, causal, segment_ids, key_valid, scale, layout = ctx.cfg
         dq, dk, dv = ring.backward(q, k, v, out, lse, dout, causal=causal, segment_ids=segment_ids,
-                                   key_valid=key_valid, scale=scale)
-        return dq, dk, dv, None, None, None, None, None
+                                   key_valid=key_valid, scale=scale, layout=layout)
+        return dq, dk, dv, None, None, None, None, None, None
 
 
-def ring_attention_c(q, k, v, ring: CRing, *, causal=True, segment_ids=None, key_valid=None, scale=None):
+def ring_attention_c(q, k, v, ring: CRing, *, causal=True, segment_ids=None, key_valid=None, scale=None, layout=None):
     """Differentiable ring attention on the local (B, S/n, H, D) shards through lwm_ring_attn_fwd / _bwd."""
     if segment_ids is not None and segment_ids.dtype != torch.int32:
         segment_ids = segment_ids.to(torch.int32)
     if key_valid is not None and key_valid.dtype != torch.uint8:
         key_valid = (key_valid != 0).to(torch.uint8)
-    return _RingAttentionC.apply(q, k, v, ring, causal, segment_ids, key_valid, scale)
+    return _RingAttentionC.apply(q, k, v, ring, causal, segment_ids, key_valid, scale, layout)

@@ -80,25 +80,28 @@ def sp_layout(axis_name="sp", local_len=None):
     return kind
 
 
-def sp_positions(local_len, axis_name="sp", device=None):
+def sp_positions(local_len, axis_name="sp", device=None, layout=None):
     """Global token positions of this rank's `local_len` rows, int64 (c,): what the loader slices with, what RoPE
-    rotates by (the reference's contiguous ownership makes this arange(c) + r*c, lwm/llama.py:1081-1082 + :560-562)."""
+    rotates by (the reference's contiguous ownership makes this arange(c) + r*c, lwm/llama.py:1081-1082 + :560-562).
+    layout: a lwm_amd.ring.SeqLayout to use instead of the rule bound to the axis (a packed batch's own balanced
+    ownership, lwm_amd.ring.balanced_layout -- pass the same object as position_ids' source and to ringattention)."""
     n, r = sp_size_rank(axis_name)
-    idx = SeqLayout(sp_layout(axis_name, local_len), n, local_len * n).global_index(r)
+    lay = layout if isinstance(layout, SeqLayout) else SeqLayout(layout or sp_layout(axis_name, local_len), n, local_len * n)
+    idx = lay.global_index(r)
     return idx if device is None else idx.to(device)
 
 
-def sp_shard(t, dim=1, axis_name="sp"):
+def sp_shard(t, dim=1, axis_name="sp", layout=None):
     """This rank's rows of a FULL-length tensor along `dim` (tokens, targets, loss masks, vision masks): the
-    boundary permutation of the ownership rule in force.  The attention masks (attention_mask / segment_ids) are NOT
-    sharded: every rank keeps them full length (lwm/llama.py:563-564)."""
+    boundary permutation of the ownership rule in force (or of `layout`, see sp_positions).  The attention masks
+    (attention_mask / segment_ids) are NOT sharded: every rank keeps them full length (lwm/llama.py:563-564)."""
     n, _ = sp_size_rank(axis_name)
     if n == 1:
         return t
     S = t.shape[dim]
     if S % n:
         raise ValueError(f"length {S} is not divisible by the sp axis ({n})")
-    return t.index_select(dim, sp_positions(S // n, axis_name, t.device))
+    return t.index_select(dim, sp_positions(S // n, axis_name, t.device, layout))
 
 
 def sp_all_reduce_sum(t, axis_name="sp"):

@@ -11,7 +11,7 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 cases = sys.argv[1:] or ["32768:python:0:zigzag", "32768:c:0:zigzag", "131072:python:0:zigzag", "131072:c:0:zigzag",
-                         "1048576:c:1:zigzag"]
+                         "1048576:c:1:zigzag", "1048576:c:1:balanced"]
 for case in cases:
     S, driver, packed, layout = case.split(":")
     S = int(S)

@@ -70,17 +70,19 @@ def bf16_array(x):
 
 
 def base_args(q, k, v, *, causal, q_start, k_start, seg_q, seg_k, key_valid, scale, q_piece2=None, k_piece2=None):
-    """q_piece2 / k_piece2 = (split row, position of that row): the two-piece position maps of LwmAttnArgs"""
+    """q_piece2 / k_piece2 = (split row, position of that row) -- or a list of such cuts: the extra pieces of
+    LwmAttnArgs' piecewise position maps"""
     B, Sq, H, D = q.shape
     Sk = k.shape[1]
     a = _capi.LwmAttnArgs()
     a.q, a.k, a.v = _t4(q), _t4(k), _t4(v)
     a.B, a.H, a.Sq, a.Sk, a.D = B, H, Sq, Sk, D
     a.q_start, a.k_start = q_start, k_start
+    cuts = lambda c: [c] if isinstance(c, tuple) else list(c)
     if q_piece2 is not None:
-        a.q_split, a.q_start2 = q_piece2
+        _capi.set_pieces(a, "q", [(0, q_start)] + cuts(q_piece2))
     if k_piece2 is not None:
-        a.k_split, a.k_start2 = k_piece2
+        _capi.set_pieces(a, "k", [(0, k_start)] + cuts(k_piece2))
     a.scale = scale if scale is not None else 1.0 / np.sqrt(D)
     a.causal = int(causal)
     keep = []

@@ -54,10 +54,29 @@ def test_committed_bench_line_follows_the_contract():
     # cpu_baseline.value = the port's fastest operating point, scaled
     assert {"attn_fwd64_kernel", "attn_bwd_delta_kernel", "attn_bwd_dkdv4_kernel", "attn_bwd_dq4_kernel"} <= set(d["kernels"])
     assert r["kernel"] == "attn_bwd_dkdv4_kernel" and "traffic_source" in r
-    assert r["traffic_profile"] is None or r["traffic_profile"].startswith("profiles/r04")
     assert d["packed_1m"]["s_per_layer"] > 0 and "S=1048576" in d["packed_1m"]["workload"]
-    best = max(p["gflops"] for p in c["op_points"])
-    assert abs(c["gflops"] - best) < 1e-6 * best
+    if "convention" not in c:       # a line of round 4: the port's fastest op point, scaled by the S^2 law
+        assert r["traffic_profile"] is None or r["traffic_profile"].startswith("profiles/r04")
+        best = max(p["gflops"] for p in c["op_points"])
+        assert abs(c["gflops"] - best) < 1e-6 * best
+        return
+    # round 5: THE convention of cpu_baseline.value, frozen -- measured at the workload's own S (one head, one layer, one
+    # pass), multiplied out over 32 heads x 32 layers; nothing is scaled in S
+    sys.path.insert(0, ROOT)
+    import bench
+    assert c["convention"] == bench.CPU_BASELINE_CONVENTION
+    m = c["measured_at"]
+    assert (m["S"], m["heads"], m["layers"]) == (32768, 1, 1) and "extrapolated" not in c["sample"]
+    assert abs(c["value"] - 32768 / (m["seconds"] * 32 * 32)) < 1e-6 * c["value"]
+    assert abs(c["gflops"] - 7.0 * 32768 ** 2 * 128 / m["seconds"] / 1e9) < 1e-6 * c["gflops"]
+    assert str(c["cores"]) in c["thread_sweep_gflops"]
+    # roofline.traffic comes from a PMC summary stamped with the kernel sources of the tree (bench.attn_kernel_stamp)
+    if r["traffic_profile"] is not None:
+        prof = json.load(open(os.path.join(ROOT, r["traffic_profile"])))
+        assert "kernel_source_stamp" in prof
+    # the ring-8 compute models run the product's launch list (the C driver, gathered form) and carry BASELINE configs[4]
+    assert d["ring8_compute_model_32k"]["driver"] == "c" and d["ring8_compute_model_32k"]["form"] == "gathered"
+    assert "packed documents" in d["ring8_compute_model_packed_1m"]["workload"]
 
 
 def test_bench_cli_contract_without_a_gpu():

@@ -259,6 +259,31 @@ def test_emulated_two_piece_position_maps(name, Sq, q1, qg, Sk, k1, kg):
     assert _rel(dq, rq[:, qpos]) < 1e-2 and _rel(dk, rk[:, kpos]) < 1e-2 and _rel(dv, rv[:, kpos]) < 1e-2
 
 
+def test_emulated_four_piece_maps():
+    """a balanced ownership of a packed batch: four chunks of 256 rows per rank (q), three runs of fetched chunks (k),
+    packed documents on top -- against the oracle on the embedded operands"""
+    H = 1
+    qcuts, kcuts = [(256, 1024), (512, 2304), (768, 3840)], [(512, 1280), (1024, 2560)]
+    Sq, Sk = 1024, 1792
+    q, k, v, do = _rnd((1, Sq, H, 128), 31), _rnd((1, Sk, H, 128), 32), _rnd((1, Sk, H, 128), 33), _rnd((1, Sq, H, 128), 34)
+    rows = lambda start, cuts, S: np.concatenate([p + np.arange(r1 - r0) for (r0, p), r1 in zip([(0, start)] + cuts, [c[0] for c in cuts] + [S])])
+    qpos, kpos = rows(256, qcuts, Sq), rows(0, kcuts, Sk)
+    n = int(max(qpos.max(), kpos.max())) + 1
+    seg_full = (np.arange(n) >= 700).astype(np.int32) + (np.arange(n) >= 2400).astype(np.int32)
+    kw = dict(causal=True, q_start=256, k_start=0, q_piece2=qcuts, k_piece2=kcuts, seg_q=seg_full[qpos][None], seg_k=seg_full[kpos][None])
+    out, lse = _emu.attn_fwd(q, k, v, **kw)
+    present = np.zeros((1, n), np.uint8)
+    present[:, kpos] = 1
+    okw = dict(causal=True, key_valid=present, seg_q=seg_full[None], seg_k=seg_full[None])
+    ro, rl = R.dense_attention(_embed(q, qpos, n), _embed(k, kpos, n), _embed(v, kpos, n), **okw)
+    assert _rel(out, ro[:, qpos]) < 1e-2
+    fin = np.isfinite(rl[:, :, qpos])
+    assert np.array_equal(np.isfinite(lse), fin) and np.abs(lse[fin] - rl[:, :, qpos][fin]).max() < 1e-4
+    dq, dk, dv = _emu.attn_bwd(q, k, v, out, lse, do, **kw)
+    rq, rk, rv = R.dense_attention_bwd(_embed(q, qpos, n), _embed(k, kpos, n), _embed(v, kpos, n), _embed(do, qpos, n), **okw)
+    assert _rel(dq, rq[:, qpos]) < 1e-2 and _rel(dk, rk[:, kpos]) < 1e-2 and _rel(dv, rv[:, kpos]) < 1e-2
+
+
 def test_emulated_adjacent_pieces_are_the_single_piece_launch_bit_for_bit():
     """two pieces that happen to be adjacent (start2 = start + split) name the same positions as one piece: same tiles,
     same instruction stream, same bits -- forward, dq, dk, dv, with a packed batch on top"""
@@ -284,11 +309,12 @@ def test_two_piece_maps_are_validated():
     q = _emu.bf16_array(np.zeros((1, 512, 1, 128), np.float32))
     out = _emu.aligned((1, 512, 1, 128), np.uint16)
     lse = _emu.aligned((1, 1, 512), np.float32)
-    for bad in (dict(q_piece2=(100, 4096)), dict(q_piece2=(512, 4096)), dict(k_piece2=(256, 100)), dict(q_piece2=(256, 255))):
+    for bad in (dict(q_piece2=(100, 4096)), dict(q_piece2=(512, 4096)), dict(k_piece2=(256, 100)), dict(q_piece2=(256, 255)),
+                dict(q_piece2=[(256, 300), (256, 600)]), dict(k_piece2=[(256, 1000), (384, 900)])):
         a, _ = _emu.base_args(q, q, q, causal=True, q_start=0, k_start=0, seg_q=None, seg_k=None, key_valid=None, scale=None, **bad)
         a.out, a.lse, a.final_out = _emu._t4(out), lse.ctypes.data, 1
         assert L.lwm_attn_fwd(C.byref(a), None) == _capi.LWM_EINVAL, bad
-        assert b"split" in L.lwm_last_error()
+        assert b"piece" in L.lwm_last_error()
     # the backward refuses a statistics buffer of the pre-400 size when told how large it is
     a, _ = _emu.base_args(q, q, q, causal=True, q_start=0, k_start=0, seg_q=None, seg_k=None, key_valid=None, scale=None)
     small = _emu.aligned((512,), np.float32)

@@ -24,7 +24,9 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 S = 8192            # the step that is compared (the fp32 CPU model is its judge)
-S_BALANCE = 65536   # the shard shape the balance report times (c = 8192 per rank at n = 8)
+S_BALANCE = 65536   # the shard shape the balance report times (c = 8192 per rank at n = 8) ...
+H_BALANCE = 32      # ... with LWM-7B's 32 heads (the debug model's 2 heads make 64 workgroups for 256 CUs: the longest
+#                     workgroup, not the work, would set the time)
 
 
 def _free_port():
@@ -85,7 +87,7 @@ def test_train_cli_on_an_8_rank_ring_equals_one_process(tmp_path):
     from tests import _parity
     ref_f, ring_f = str(tmp_path / "ref.pt"), str(tmp_path / "ring.pt")
     _run(1, ref_f)
-    outs = _run(8, ring_f, env_extra={"LWM_RING_DRIVER": "c"}, extra=("--lwm_balance_report", f"--lwm_balance_seq={S_BALANCE}"))
+    outs = _run(8, ring_f, env_extra={"LWM_RING_DRIVER": "c"}, extra=("--lwm_balance_report", f"--lwm_balance_seq={S_BALANCE}", f"--lwm_balance_heads={H_BALANCE}"))
     # the ownership rule and the driver the product chose by itself
     assert "layout zigzag" in outs[0], outs[0][-1500:]
     assert "'driver': 'c'" in outs[0] and "'transport': 'ipc'" in outs[0] and "'layout': 'zigzag'" in outs[0], outs[0][-1500:]
@@ -135,7 +137,7 @@ def test_train_cli_contiguous_ownership_is_the_unbalanced_control(tmp_path):
     import torch
     ref_f, ring_f = str(tmp_path / "ref.pt"), str(tmp_path / "ring.pt")
     _run(1, ref_f)
-    outs = _run(4, ring_f, env_extra={"LWM_SP_LAYOUT": "contiguous"}, extra=("--lwm_balance_report", f"--lwm_balance_seq={S_BALANCE}"))
+    outs = _run(4, ring_f, env_extra={"LWM_SP_LAYOUT": "contiguous"}, extra=("--lwm_balance_report", f"--lwm_balance_seq={S_BALANCE}", f"--lwm_balance_heads={H_BALANCE}"))
     assert "layout contiguous" in outs[0]
     ref, ring = torch.load(ref_f), torch.load(ring_f)
     assert abs(ring["loss"] - ref["loss"]) <= 2e-3 * abs(ref["loss"])

@@ -166,7 +166,7 @@ def _run_c_ring(n, S, H, causal, packed, padded, B=1, layout="contiguous", sched
         kv = torch.ones(B, S, dtype=torch.uint8)
         kv[:, 5:40] = 0
         kv = kv.cuda()
-    lay = SeqLayout(layout, n, S)
+    lay = layout if isinstance(layout, SeqLayout) else SeqLayout(layout, n, S)
     box = box or _Mailbox(n)
     res, errs = [None] * n, []
 
@@ -287,6 +287,37 @@ def test_c_ring_gathered_form_vs_oracle(n, layout, packed, padded, S):
         assert sent == sent_pair
         for name, a, b in zip(("out", "dq", "dk", "dv"), got, pair):
             assert ((a.float() - b.float()).abs().max() / b.float().abs().max()).item() <= 8e-3, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,S,P", [(4, 4096, 4), (8, 16384, 4), (8, 8192, 2), (2, 4096, 8)])
+def test_c_ring_ownership_table_vs_oracle(n, S, P):
+    """LWM_RING_LAYOUT_TABLE: P chunks per rank handed out by visible-pair count of a packed batch (balanced_layout) --
+    piecewise position maps of up to 8 pieces on both operands, the fetch / return by chunk.  Against the fp64 oracle
+    and against the zigzag ownership on the same data."""
+    import torch
+    from oracle import attention_ref as R
+    from lwm_amd.ring import balanced_layout
+    from tests._parity import check, check_dq
+    H = 2
+    bounds = [0, (3 * S) // 16 + 7, (9 * S) // 16 - 3, (11 * S) // 16, S]
+    lens = [b - a for a, b in zip(bounds[:-1], bounds[1:])]
+    lay = balanced_layout(n, S, lens, chunks_per_rank=P)
+    assert lay.kind == "table" and len(lay.owner) == n * P
+    seg_fn = lambda S_: torch.bucketize(torch.arange(S_), torch.tensor(bounds[1:-1]), right=True)
+    forms = {}
+    got, (q, k, v, do, seg, kv), sent = _run_c_ring(n, S, H, True, seg_fn, True, layout=lay, schedule="direct", forms=forms)
+    assert all(forms[r] == (1, 1) for r in range(n)), forms
+    f = lambda t: t.float().cpu().numpy()
+    sg, kvn = seg.cpu().numpy(), kv.cpu().numpy()
+    ro, _ = R.dense_attention(f(q), f(k), f(v), causal=True, seg_q=sg, seg_k=sg, key_valid=kvn)
+    rq, rk, rv, rqx = R.dense_attention_bwd(f(q), f(k), f(v), f(do), causal=True, seg_q=sg, seg_k=sg, key_valid=kvn, out_saved=f(got[0]))
+    for name, a, b in zip(("out", "dk", "dv"), (got[0], got[2], got[3]), (ro, rk, rv)):
+        check(f"{name} c-ring table n={n} P={P}", f(a), b)
+    check_dq(f"dq c-ring table n={n} P={P}", f(got[1]), rq, rqx)
+    zz, _, _ = _run_c_ring(n, S, H, True, seg_fn, True, layout="zigzag", schedule="direct")
+    for name, a, b in zip(("out", "dq", "dk", "dv"), got, zz):
+        assert ((a.float() - b.float()).abs().max() / b.float().abs().max()).item() <= 8e-3, name
 
 
 @pytest.mark.gpu

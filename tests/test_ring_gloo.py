@@ -39,7 +39,13 @@ def _worker(rank, world, port, layout_kind, causal, packed, schedule, q_out, B=1
             seg[:, (2 * S) // 3 + 5:] = 2
             kv = torch.ones(B, S, dtype=torch.uint8)
             kv[:, 3:9] = 0
-        lay = SeqLayout(layout_kind, world, S)
+        if layout_kind == "balanced":      # a table: 4 chunks of 16 rows per rank, weighed by the packed documents' pairs
+            from lwm_amd.ring import balanced_layout
+            lay = balanced_layout(world, S, [S // 3, (2 * S) // 3 + 5 - S // 3, S - (2 * S) // 3 - 5] if packed else None,
+                                  chunks_per_rank=4, align=16)
+            assert lay.kind == "table" and len(lay.owner) == 4 * world
+        else:
+            lay = SeqLayout(layout_kind, world, S)
         idx = lay.global_index(rank)
         ql, kl, vl = (t[:, idx].clone().requires_grad_(True) for t in (q, k, v))
         out = ring_attention(ql, kl, vl, causal=causal, segment_ids=seg, key_valid=kv, layout=lay,
@@ -62,6 +68,9 @@ def _worker(rank, world, port, layout_kind, causal, packed, schedule, q_out, B=1
     (4, "zigzag", True, True, "mesh", 1),
     (4, "contiguous", True, False, "mesh", 1),
     (3, "contiguous", False, True, "mesh", 1),
+    # an ownership table (balanced_layout): up to four runs of positions per rank, through both schedules
+    (4, "balanced", True, True, "mesh", 1),
+    (2, "balanced", True, False, "ring", 1),
     (2, "zigzag", True, False, "mesh", 2),          # batch 2: strided segment views of the outputs
     (2, "zigzag", True, False, "ring", 2),
 ])
