@@ -421,8 +421,10 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
             dk[i] = zero_f32x16();
             dv[i] = zero_f32x16();
         }
-    f4_load_agpr_wait8(kf);
-    f4_load_agpr_wait8(vf);
+    if (n == 0) {       // (no walk: the fragments are unused, their loads are not left in flight)
+        f4_load_agpr_wait8(kf);
+        f4_load_agpr_wait8(vf);
+    }
 
     if (n > 0) {
         D4Ctx cx;
@@ -481,10 +483,12 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
             }
         };
 
-        // ---- prologue: steps 0 and 1 in flight
+        // ---- prologue: steps 0 and 1 in flight; the K / V fragments are waited for together with them (one memory
+        // latency per workgroup, not two in a row: 2-3 us of the ~50 us a 32-step walk of a ring shard takes)
         stage_step(0);
         if (n > 1) stage_step(1);
-        glds_wait_all();
+        f4_load_agpr_wait8(kf);      // vmcnt(0): everything requested so far
+        f4_load_agpr_wait8(vf);
         block_sync();
 
         // A unit needs the mask code when its first query lies before the wave's last key (or keys can be masked for
@@ -493,7 +497,11 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
         auto clamp32 = [](int64_t x) -> int { return x > (1 << 30) ? (1 << 30) : (x < -(1 << 30) ? -(1 << 30) : (int)x); };
         // positions relative to q_start; a unit's first query (row ub of the q block) sits at rel_pos(qm, ub)
         const int k_rel = clamp32(k_pos - p.q_start) - 4 * hi;                                     // this lane's key
-        auto q_rel_of = [&](int ub) -> int { return rel_pos(qm, ub); };
+        PosCursor qc = cursor_begin(qm);
+        auto q_rel_of = [&](int ub) -> int {             // (the walk descends: a compare while the unit is inside the piece)
+            cursor_seek(qm, qc, ub);
+            return clamp32(qc.base + ub - p.q_start);
+        };
         // positions ascend with the row: the units that begin before the wave's last key -- the ones that need the mask
         // code -- are the first mask_end rows of the q block (one compare per unit in the walk)
         const int mask_end = p.causal ? 32 * tiles_reaching(qm, 32, (p.Sq + 31) / 32, k_base + (int64_t)kbi * kD4BK + wave * 32 + 31 - 1) : 0;
@@ -973,8 +981,10 @@ LWM_DEVICE void attn_bwd_dq4_body(const AttnParams& p) {
     f32x16 dq[4];
     if (n == 0)
         for (int i = 0; i < 4; ++i) dq[i] = zero_f32x16();
-    f4_load_agpr_wait8(qf);
-    f4_load_agpr_wait8(dof);
+    if (n == 0) {
+        f4_load_agpr_wait8(qf);
+        f4_load_agpr_wait8(dof);
+    }
 
     if (n > 0) {
         for (int s = 0; s < 8; ++s) cx.ka[s] = lds + tile_off(l31, 2 * s + hi);
@@ -1021,16 +1031,21 @@ LWM_DEVICE void attn_bwd_dq4_body(const AttnParams& p) {
         const bool ragged = (p.Sk % kQ4BK) != 0;
         const int n_pipe_end = (ragged && nst == nst_all) ? n - 1 : n;      // walk indices >= this are never issued in-loop
 
-        // ---- prologue: steps 0 and 1 in flight
+        // ---- prologue: steps 0 and 1 in flight, waited for together with the Q / dO fragments
         stage_step(0);
         if (n > 1) stage_step(1);
-        glds_wait_all();
+        f4_load_agpr_wait8(qf);      // vmcnt(0): everything requested so far
+        f4_load_agpr_wait8(dof);
         block_sync();
 
         auto clamp32 = [](int64_t x) -> int { return x > (1 << 30) ? (1 << 30) : (x < -(1 << 30) ? -(1 << 30) : (int)x); };
         // positions relative to k_start; a unit's first key (row ub of the K/V block) sits at rel_pos(km, ub)
         const int q_rel = clamp32(q_base + q_row - p.k_start) - 4 * hi;                         // this lane's query
-        auto k_rel_of = [&](int ub) -> int { return rel_pos(km, ub); };
+        PosCursor kc = cursor_begin(km);
+        auto k_rel_of = [&](int ub) -> int {             // (the walk ascends)
+            cursor_seek(km, kc, ub);
+            return clamp32(kc.base + ub - p.k_start);
+        };
         // a unit needs the mask code when its last key lies after the wave's first query: positions ascend with the row,
         // so those are the units from row mask_from of the K/V block on (one compare per unit in the walk)
         const int mask_from = p.causal ? 32 * tiles_below(km, 32, (p.Sk + 31) / 32, q_base + (int64_t)qbi * kQ4BQ + wave * 32) : 0x7fffffff;

@@ -61,8 +61,9 @@ struct AttnParams {
     int64_t q_start, k_start;  // global token position of row 0 (ring offset)
     // Piecewise position maps (a shard under zigzag / balanced ownership is a few runs of consecutive positions; so is the
     // K/V a rank gathers from its peers): piece i = rows [row[i], row[i+1]) at positions pos[i] + (r - row[i]); row[0] = 0,
-    // pos[0] = the operand's start; rows and positions ascend, pieces do not overlap.  Unused entries: row = INT32_MAX.
+    // pos[0] = the operand's start; rows and positions ascend, pieces do not overlap; q_np / k_np >= 1 pieces are in use.
     // Cuts are multiples of 256 rows, so no workgroup tile straddles one.  (api.inc fills these from LwmAttnArgs.)
+    int32_t q_np, k_np;
     int32_t q_row[kMaxPieces], k_row[kMaxPieces];
     int64_t q_pos[kMaxPieces], k_pos[kMaxPieces];
     float scale;               // softmax scale, 1/sqrt(D)
@@ -79,21 +80,21 @@ struct AttnParams {
     const int32_t* segb_k;
 };
 
-// ---- position maps (see AttnParams): everything below is wave-uniform scalar arithmetic over tables of kMaxPieces
-// entries held in the kernel arguments; the loops are unrolled with static indices (a dynamically indexed by-value
-// argument would be copied to scratch).
+// ---- position maps (see AttnParams): everything below is wave-uniform scalar arithmetic over the piece tables in the
+// kernel arguments, read with scalar loads where they are needed (prologue; the rare masked tile) -- nothing of them
+// stays in registers across the tile loops.
 struct PosMap {
     const int32_t* row;
     const int64_t* pos;
-    int32_t S;
+    int32_t n, S;
 };
-LWM_DEVICE PosMap q_map(const AttnParams& p) { return PosMap{p.q_row, p.q_pos, p.Sq}; }
-LWM_DEVICE PosMap k_map(const AttnParams& p) { return PosMap{p.k_row, p.k_pos, p.Sk}; }
+LWM_DEVICE PosMap q_map(const AttnParams& p) { return PosMap{p.q_row, p.q_pos, p.q_np, p.Sq}; }
+LWM_DEVICE PosMap k_map(const AttnParams& p) { return PosMap{p.k_row, p.k_pos, p.k_np, p.Sk}; }
 // position of row r = pos_base(m, row0) + r for every row r of a tile that begins at row0
 LWM_DEVICE int64_t pos_base(const PosMap& m, int row0) {
     int64_t base = m.pos[0];
-#pragma unroll
-    for (int i = 1; i < kMaxPieces; ++i) base = row0 >= m.row[i] ? m.pos[i] - m.row[i] : base;
+    for (int i = 1; i < m.n; ++i)
+        if (row0 >= m.row[i]) base = m.pos[i] - m.row[i];
     return base;
 }
 // How many LEADING tiles (of `per` rows; n_tiles = ceil(S / per)) begin at a position <= P -- positions ascend with the
@@ -101,30 +102,38 @@ LWM_DEVICE int64_t pos_base(const PosMap& m, int row0) {
 // at P + 1 when asked with P = key - per).
 LWM_DEVICE int tiles_reaching(const PosMap& m, int per, int n_tiles, int64_t P) {
     int total = 0;
-    bool open = true;       // every piece so far was reached to its end
-#pragma unroll
-    for (int i = 0; i < kMaxPieces; ++i) {
-        const int r0 = i == 0 ? 0 : m.row[i];
-        const bool live = r0 < m.S;
-        const int r1 = (i + 1 < kMaxPieces && m.row[i + 1] < m.S) ? m.row[i + 1] : m.S;
-        const int t_i = live ? (r1 - r0 + per - 1) / per : 0;
-        const int64_t c = (!live || P < m.pos[i]) ? 0 : (P - m.pos[i]) / per + 1;
-        const int take = open ? (int)(c < t_i ? c : t_i) : 0;
-        total += take;
-        open = open && take == t_i;
+    for (int i = 0; i < m.n; ++i) {
+        const int r0 = m.row[i], r1 = i + 1 < m.n ? m.row[i + 1] : m.S;
+        const int t_i = (r1 - r0 + per - 1) / per;
+        const int64_t p0 = m.pos[i];
+        const int64_t c = P < p0 ? 0 : (P - p0) / per + 1;
+        if (c < t_i) return total + (int)c;       // the piece is not reached to its end: the later ones lie above P
+        total += t_i;
     }
     return total < n_tiles ? total : n_tiles;
 }
 // ... whose EVERY row lies at a position <= P
 LWM_DEVICE int tiles_below(const PosMap& m, int per, int n_tiles, int64_t P) { return tiles_reaching(m, per, n_tiles, P - (per - 1)); }
-// position of row r relative to the map's first position, for a row r that begins a 32-row unit: r + (what its piece
-// adds), saturated at 2^30 (callers compare it with clamped differences)
-LWM_DEVICE int rel_pos(const PosMap& m, int r) {
-    int64_t gap = 0;
-#pragma unroll
-    for (int i = 1; i < kMaxPieces; ++i) gap = r >= m.row[i] ? m.pos[i] - m.row[i] - m.pos[0] : gap;
-    const int64_t v = r + gap;
-    return v > (1 << 30) ? (1 << 30) : (int)v;
+// A cursor over the pieces for a walk that moves monotonically through the rows: rows [lo, hi) sit at base + row.
+// seek() is called where a position is needed (a masked tile); it costs a compare when the row is still inside the piece.
+struct PosCursor {
+    int64_t base;
+    int32_t lo, hi, i;
+};
+LWM_DEVICE PosCursor cursor_begin(const PosMap& m) { return PosCursor{m.pos[0], 0, m.n > 1 ? m.row[1] : m.S, 0}; }
+LWM_DEVICE void cursor_seek(const PosMap& m, PosCursor& c, int row) {
+    while (row >= c.hi && c.i + 1 < m.n) {
+        ++c.i;
+        c.lo = m.row[c.i];
+        c.hi = c.i + 1 < m.n ? m.row[c.i + 1] : m.S;
+        c.base = m.pos[c.i] - c.lo;
+    }
+    while (row < c.lo && c.i > 0) {
+        --c.i;
+        c.hi = c.lo;
+        c.lo = m.row[c.i];
+        c.base = m.pos[c.i] - c.lo;
+    }
 }
 
 LWM_DEVICE int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }

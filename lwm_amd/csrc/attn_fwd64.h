@@ -485,7 +485,8 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
         cx.nbase[qb] = 0.0f;
         cx.lsum[qb] = 0.0f;
     }
-    f4_load_agpr_wait(qf);
+    // (the Q fragments are waited for together with the first staged tiles below: one memory latency per workgroup, not
+    //  two in a row -- at the short walks of a ring shard that is 2-3 us of a 50 us workgroup)
     const int64_t wq_min = q_base + (int64_t)qt * kF4BQ + wave * 64;   // first / last query position of this wave
     const int64_t wq_max = wq_min + 63;
 
@@ -566,8 +567,11 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
             }
             if (HAS_META && i + 2 < n_wg) f4_meta_stage(p, cx, b, kt0 + i + 2, (i + 2) % 3);
         };
+        PosCursor kc = cursor_begin(km);
         auto rel_of = [&](int rel, int (&r)[2]) {       // mask offsets of tile `rel` for the two query blocks
-            const int64_t k_pos0 = pos_base(km, (kt0 + rel) * kF4BK) + (int64_t)(kt0 + rel) * kF4BK;
+            const int krow0 = (kt0 + rel) * kF4BK;
+            cursor_seek(km, kc, krow0);                 // (the walk ascends: a compare while the tile is inside the piece)
+            const int64_t k_pos0 = kc.base + krow0;
             for (int qb = 0; qb < 2; ++qb) {
                 const int64_t d = p.causal ? (q_pos[qb] - k_pos0) : (int64_t)kF4BK;
                 r[qb] = d > kF4BK ? kF4BK : (d < -1 ? -1 : (int)d);
@@ -591,8 +595,8 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
     do {                                                                                                            \
         if ((HAS_META && !(uni_)) || needs_causal(rel_)) {                                                          \
             int r_[2];                                                                                              \
+            if (SETTLE_) f4_settle_s(s_);      /* first: rel_of may branch, and hipcc copies tuples at merges */       \
             rel_of(rel_, r_);                                                                                       \
-            if (SETTLE_) f4_settle_s(s_);                                                                           \
             if (HAS_META && !(uni_)) f4_mask<HAS_META, KHALF_>(cx, s_, r_, seg_q, mbuf_);                           \
             else f4_mask<false, KHALF_>(cx, s_, r_, seg_q, mbuf_);                                                  \
         }                                                                                                           \
@@ -607,7 +611,7 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
             f4_meta_stage(p, cx, b, kt0, 0);
             if (n_wg > 1) f4_meta_stage(p, cx, b, kt0 + 1, 1);
         }
-        glds_wait_all();
+        f4_load_agpr_wait(qf);      // vmcnt(0): Q fragments AND the tiles just requested
         block_sync();
 
         f32x16 sA[2], sB[2];
@@ -754,6 +758,7 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
         }
     }
 
+    if (n_wg <= 0) f4_load_agpr_wait(qf);      // (no walk: the fragments are unused, their loads are not left in flight)
     // ---- epilogue: normalise, merge with the ring carry, store (per query block)
     f4_settle_acc(acc);
 #pragma unroll
