@@ -878,7 +878,7 @@ def main():
         if args.force_configs34:                                       #  ... unless asked to)
             c_max = max(c_max, (1 << 20) // world)
         c_ring = CRing(dist.group.WORLD, transport=args.transport, layout=args.layout, schedule=sched_c,
-                       ipc_slot_bytes=c_max * N_HEADS * HEAD_DIM * 4, ipc_slots=4)      # (B = 1: at most 4 messages per pair and group)
+                       ipc_slot_bytes=c_max * N_HEADS * HEAD_DIM * 4, ipc_slots=8)      # (B = 1: 4 messages per pair and group; 8 with the 4-chunk ownership table of the packed leg)
 
     driver_fallback = None
     if c_ring is not None:
@@ -908,8 +908,9 @@ def main():
         seg = segment_ids if ten is None else seg
         for _ in range(args.layers if layers is None else layers):
             if ring is not None:
-                o_, l_ = ring.forward(q_, k_, v_, causal=True, segment_ids=seg)
-                ring.backward(q_, k_, v_, o_, l_, do_, causal=True, segment_ids=seg)
+                tab = lay if lay.kind == "table" else None      # (an ownership table travels with the call)
+                o_, l_ = ring.forward(q_, k_, v_, causal=True, segment_ids=seg, layout=tab)
+                ring.backward(q_, k_, v_, o_, l_, do_, causal=True, segment_ids=seg, layout=tab)
                 continue
             out, lses = ring_forward(TimedOps, comm, q_, k_, v_, layout=lay, causal=True, segment_ids=seg)
             ring_backward(TimedOps, comm, q_, k_, v_, out, lses, do_, layout=lay, causal=True, segment_ids=seg)
@@ -1068,25 +1069,35 @@ def main():
     def other_config(tag, Sx, layers_x, packed_docs):
         """One more configuration of BASELINE.json in the same N > 1 line: the sequence ring at S = Sx over these N GPUs,
         `layers_x` layers (scaled to 32 and labelled), one warm-up step + one timed step."""
+        # The set-up (a 1M-token shard is 1 GiB per tensor) may fail on ONE rank: the ranks vote before the first step, so
+        # that a failure skips the leg everywhere instead of leaving the others inside the ring's exchange (ADVICE r04).
+        err, tenx, segx, lens = None, None, None, None
         try:
-            layx = SeqLayout(args.layout, world, Sx)
+            pair_units = 0.5 * float(Sx) * Sx       # causal: half the square
+            if packed_docs:
+                sg, lens = packed_documents(Sx, lo_frac=Sx // 4096, hi_frac=Sx // 262144)      # 4096 .. 262144 tokens
+                pair_units = 0.5 * sum(float(l) * l for l in lens)
+            if packed_docs and args.layout == "zigzag" and c_ring is not None:
+                # a packed batch brings its own ownership (what a loader knows): chunks handed out by visible pairs
+                from lwm_amd.ring import balanced_layout
+                layx = balanced_layout(world, Sx, lens, chunks_per_rank=4)
+            else:
+                layx = SeqLayout(args.layout, world, Sx)
             cx = layx.local_len
             gx = torch.Generator(device=dev).manual_seed(8765 + rank)
             tenx = [torch.randn(1, cx, N_HEADS, HEAD_DIM, generator=gx, device=dev, dtype=torch.float32).to(torch.bfloat16)
                     for _ in range(4)]
-            segx, pair_units = None, 0.5 * float(Sx) * Sx       # causal: half the square
             if packed_docs:
-                import numpy as np
-                rng = np.random.default_rng(0)
-                sg = np.zeros((1, Sx), np.int32)
-                pos, d, lens = 0, 0, []
-                while pos < Sx:
-                    ln = min(int(np.exp(rng.uniform(np.log(4096), np.log(262144)))), Sx - pos)
-                    sg[:, pos:pos + ln] = d
-                    lens.append(ln)
-                    pos, d = pos + ln, d + 1
                 segx = torch.from_numpy(sg).to(dev)
-                pair_units = 0.5 * sum(float(l) * l for l in lens)
+        except Exception as e:      # noqa: BLE001
+            err = repr(e)[:500]
+        vote = torch.tensor([0 if err else 1], dtype=torch.int32, device="cpu" if shared else dev)
+        dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+        if int(vote.item()) == 0:
+            del tenx
+            torch.cuda.empty_cache()
+            return {"error": err or "the set-up failed on another rank", "skipped_on_every_rank": True}
+        try:
             sent0 = c_ring.bytes_sent if c_ring is not None else None
             step(ten=tenx, lay=layx, seg=segx, layers=layers_x)
             barrier()
