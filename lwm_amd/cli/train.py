@@ -146,7 +146,7 @@ def main(argv=None):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         rec = dict(step=step, loss=float(loss.detach()), learning_rate=lr_at(step, opt_cfg), tokens_per_s=batch * seq * accum / dt,
-                   **{k: float(v) for k, v in metrics.items()})
+                   **{k: float(v.detach()) if hasattr(v, "detach") else float(v) for k, v in metrics.items()})
         history.append(rec)
         if F.log_freq and step % int(F.log_freq) == 0 and (world_rank == 0 or F.log_all_worker):
             print(rec, flush=True)
