@@ -877,15 +877,30 @@ def main():
         c_max = max(c, S2 // world if not args.no_configs2 else 0)      # (configs3 / configs4 do not run over the IPC transport ...
         if args.force_configs34:                                       #  ... unless asked to)
             c_max = max(c_max, (1 << 20) // world)
-        c_ring = CRing(dist.group.WORLD, transport=args.transport, layout=args.layout, schedule=sched_c,
-                       ipc_slot_bytes=c_max * N_HEADS * HEAD_DIM * 4, ipc_slots=8)      # (B = 1: 4 messages per pair and group; 8 with the 4-chunk ownership table of the packed leg)
-
-    driver_fallback = None
-    if c_ring is not None:
-        # The C driver has met RCCL on one GPU and real processes over IPC, never several GPUs: its first layer runs under a
+        # The C driver has met RCCL on one GPU and real processes over IPC, never several GPUs: its set-up (every collective
+        # of CRing's bootstrap is entered by every rank whatever failed on it before) and its first layer run under a
         # collective vote, and a rank that fails takes everybody to the torch.distributed driver instead of killing the line.
         ok, why = 1, ""
         try:
+            CRing.probe(args.transport)
+        except Exception as e:      # noqa: BLE001
+            ok, why = 0, repr(e)[:500]
+        vote = torch.tensor([ok], dtype=torch.int32, device="cpu" if shared else dev)
+        dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+        if int(vote.item()) == 1:
+            try:
+                c_ring = CRing(dist.group.WORLD, transport=args.transport, layout=args.layout, schedule=sched_c,
+                               ipc_slot_bytes=c_max * N_HEADS * HEAD_DIM * 4, ipc_slots=8)      # (B = 1: 4 messages per pair and group; 8 with the 4-chunk ownership table of the packed leg)
+            except Exception as e:      # noqa: BLE001
+                ok, why = 0, repr(e)[:500]
+        ring_setup_failed = why if not ok else None
+
+    driver_fallback = None
+    if args.driver == "c" and world > 1:
+        ok, why = (1, "") if c_ring is not None else (0, ring_setup_failed or "the ring could not be set up on another rank")
+        try:
+            if c_ring is None:
+                raise RuntimeError(why)
             o_, l_ = c_ring.forward(q, k, v, causal=True, segment_ids=segment_ids)
             c_ring.backward(q, k, v, o_, l_, do, causal=True, segment_ids=segment_ids)
             torch.cuda.synchronize()
@@ -899,6 +914,8 @@ def main():
                 os._exit(5)
             driver_fallback = {"from": f"C driver ({args.transport}, {sched_c})", "to": "lwm_amd/ring.py over torch.distributed",
                                "first_error_on_this_rank": why or None}
+            if c_ring is not None:
+                c_ring.close()
             c_ring = None
 
     def step(ring=None, ten=None, lay=None, seg=None, layers=None):
