@@ -504,7 +504,8 @@ def ring_model_leg(torch, n=8, S=131072, schedule="mesh", driver="c", packed=Fal
     rank bounds the job: tokens/s <= S / (max_r ms_per_layer * 32 layers).  What the 8-GPU run adds on top is exchange
     time that is not hidden (bench `exchange.exposed_ms_per_step` at N > 1).
     driver "c" = the product path on RCCL groups (lwm_ring_attn_fwd / _bwd; the direct schedule's gathered form where
-    it applies: `form`); "python" = lwm_amd/ring.py's launch list (one launch per segment pair).
+    it applies: `form`); "python" = lwm_amd/ring.py's PER-PAIR launch list (one launch per segment pair: what rounds 1-4
+    ran; LWM_RING_FORM=pairs keeps that driver from taking its own gathered form).
     packed: BASELINE configs[4]'s 15-document packing -- FLOPs are then counted over visible pairs only."""
     from lwm_amd.ring import HipBlockOps, SeqLayout, ring_backward, ring_forward
     from lwm_amd.ring_c import CRing
@@ -533,8 +534,13 @@ def ring_model_leg(torch, n=8, S=131072, schedule="mesh", driver="c", packed=Fal
             comm = NullComm(rank=r, size=n, schedule=schedule)
 
             def layer():
-                out, lses = ring_forward(HipBlockOps, comm, q, k, v, layout=lay, causal=True, segment_ids=seg)
-                ring_backward(HipBlockOps, comm, q, k, v, out, lses, do, layout=lay, causal=True, segment_ids=seg)
+                keep = os.environ.get("LWM_RING_FORM")
+                os.environ["LWM_RING_FORM"] = "pairs"
+                try:
+                    out, lses = ring_forward(HipBlockOps, comm, q, k, v, layout=lay, causal=True, segment_ids=seg)
+                    ring_backward(HipBlockOps, comm, q, k, v, out, lses, do, layout=lay, causal=True, segment_ids=seg)
+                finally:
+                    os.environ.pop("LWM_RING_FORM") if keep is None else os.environ.__setitem__("LWM_RING_FORM", keep)
 
         layer()
         torch.cuda.synchronize()
@@ -553,7 +559,7 @@ def ring_model_leg(torch, n=8, S=131072, schedule="mesh", driver="c", packed=Fal
     return {"workload": f"compute side of an {n}-rank {layout} ring at S={S} ({schedule} schedule, {driver} driver"
                         + (f", {len(lens)} packed documents" if packed else "") + "), each rank's launches run on this GPU, "
                         "1 layer, no exchange",
-            "driver": driver, "form": (None if driver != "c" else "gathered" if all(forms) else "per pair" if not any(forms) else "mixed"),
+            "driver": driver, "form": ("per pair" if driver != "c" else "gathered" if all(forms) else "per pair" if not any(forms) else "mixed"),
             "per_rank_ms_per_layer": [round(x, 3) for x in per_rank],
             "imbalance_max_over_mean": worst / (sum(per_rank) / n),
             "compute_bound_tokens_per_s": S / (worst * 1e-3 * N_LAYERS),

@@ -220,6 +220,11 @@ int lwm_ring_attn_bwd(LwmRing* ring, const LwmRingArgs* args, void* compute_stre
  * forward's K/V, and in the backward the K/V again plus the f32 dK/dV carries (ring) or partials (direct). */
 int64_t lwm_ring_planned_bytes(int32_t layout, int32_t schedule, int32_t n, int32_t rank, int32_t B, int32_t c, int32_t H,
                                int32_t D, int32_t causal, int32_t backward);
+/* The same for LWM_RING_LAYOUT_TABLE (direct schedule, causal, B = 1 -- the form a table runs in): a rank sends each of its
+ * chunks to every peer whose last chunk lies above it and, in the backward, returns an f32 dK and dV partial for every
+ * chunk it fetched.  -1 for an unusable table. */
+int64_t lwm_ring_planned_bytes_table(const int32_t* chunk_owner, int32_t n_chunks, int32_t n, int32_t rank, int32_t c, int32_t H,
+                                     int32_t D, int32_t backward);
 /* bytes this ring object has sent since creation (diagnostic) */
 int64_t lwm_ring_bytes_sent(const LwmRing* ring);
 /* Which form the last lwm_ring_attn_fwd / _bwd call took (diagnostic): 0 = one launch per (q segment, k segment) pair,

@@ -118,6 +118,7 @@ PROTOTYPES = {
     "lwm_ring_attn_bwd": (C.c_int, [C.c_void_p, C.POINTER(LwmRingArgs), C.c_void_p]),
     "lwm_ring_bytes_sent": (C.c_int64, [C.c_void_p]),
     "lwm_ring_planned_bytes": (C.c_int64, [C.c_int32] * 10),
+    "lwm_ring_planned_bytes_table": (C.c_int64, [C.c_void_p] + [C.c_int32] * 7),
     "lwm_ring_selftest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "lwm_ring_set_fetch_groups": (C.c_int, [C.c_void_p, C.c_int32]),
     "lwm_ring_last_form": (C.c_int, [C.c_void_p]),

@@ -235,6 +235,8 @@ class SingleComm:
 class HipBlockOps:
     """The product backend: hand-written HIP kernels through the C ABI."""
 
+    piece_align = 256        # piecewise position maps: cuts on multiples of 256 rows (include/lwm_hip.h)
+
     fwd = staticmethod(_ops.attn_fwd_block)
     bwd_delta = staticmethod(_ops.attn_bwd_delta)
     bwd_dq = staticmethod(_ops.attn_bwd_dq_block)
@@ -365,10 +367,161 @@ class _MeshBlocks:
             h.wait()
 
 
+# ----------------------------------------------------------------- the mesh schedule's gathered form
+# What the C driver does since round 5 (lwm_amd/csrc/ring_driver.inc, "gathered form"), restated over
+# torch.distributed: the K/V segments a rank can see of its peers -- every segment that begins below the end of its own
+# last one -- are received in POSITION order into one buffer and read by the kernels through piecewise position maps
+# (ops: q_piece2 / k_piece2), the local shard likewise; per kernel TWO launches per call (the local block while the
+# fetch is in flight, then everything that arrived) instead of one per (q segment, k segment) pair.
+MAX_PIECES = 8
+
+
+class _Gathered:
+    """The plan of one rank: local pieces, the fetched segments in position order, who sends what to whom."""
+
+    def __init__(self, layout, rank, n):
+        self.own = layout.segments(rank)                    # [(off, len, g)], ascending g, local rows in that order
+        self.end = {r_: max(g + ln for _, ln, g in layout.segments(r_)) for r_ in range(n)}   # end of a rank's last segment
+        self.q_cuts = [(off, g) for off, ln, g in self.own[1:]]
+        self.q_start = self.own[0][2]
+        # fetched segments: (g, len, src rank, ki), ascending position
+        need = sorted((g, ln, s_, ki) for s_ in range(n) if s_ != rank for ki, (_, ln, g) in enumerate(layout.segments(s_))
+                      if g < self.end[rank])
+        self.rows, self.k_cuts, at, prev_end = {}, [], 0, None
+        for g, ln, s_, ki in need:
+            if prev_end is not None and g != prev_end:
+                self.k_cuts.append((at, g))
+            self.rows[(s_, ki)] = (at, ln)
+            at, prev_end = at + ln, g + ln
+        self.Lg = at
+        self.k_start = need[0][0] if need else 0
+        self.pos_runs = []                                  # (row, len, g) runs of the gathered buffer, for mask slices
+        for g, ln, s_, ki in need:
+            if self.pos_runs and self.pos_runs[-1][2] + self.pos_runs[-1][1] == g:
+                self.pos_runs[-1] = (self.pos_runs[-1][0], self.pos_runs[-1][1] + ln, self.pos_runs[-1][2])
+            else:
+                self.pos_runs.append((self.rows[(s_, ki)][0], ln, g))
+
+    @staticmethod
+    def applies(block, comm, layout, q, causal):
+        if not (_is_mesh(comm) and causal and q.shape[0] == 1 and getattr(block, "piece_align", 0)):
+            return False
+        if os.environ.get("LWM_RING_FORM") == "pairs":
+            return False
+        n = comm.size
+        segs = [layout.segments(r_) for r_ in range(n)]
+        if any(ln % block.piece_align or off % block.piece_align for ss in segs for off, ln, _ in ss):
+            return False
+        if any(len(ss) > MAX_PIECES or any(a[2] >= b[2] for a, b in zip(ss, ss[1:])) for ss in segs):
+            return False
+        return all(len(_Gathered(layout, r_, n).k_cuts) < MAX_PIECES for r_ in range(n))
+
+
+def _gathered_masks(g, segment_ids, key_valid):
+    """(seg local, key_valid local, seg gathered, key_valid gathered) in row order"""
+    cut = lambda src, runs: None if src is None else torch.cat([src[:, p:p + ln] for _, ln, p in runs], dim=1).contiguous()
+    loc = [(off, ln, gpos) for off, ln, gpos in g.own]
+    return cut(segment_ids, loc), cut(key_valid, loc), cut(segment_ids, g.pos_runs), cut(key_valid, g.pos_runs)
+
+
+def _gathered_fetch(comm, block, layout, g, tensors, tag):
+    """posts the exchange of the K / V segments in one grouped launch -> (handle, [gathered buffer per tensor])"""
+    n, r = comm.size, comm.rank
+    bufs = [_xbuf(comm, block, ("gath", tag, j), (1, max(g.Lg, 1)) + tuple(x.shape[2:]), x.dtype, x) for j, x in enumerate(tensors)]
+    sends, recvs = [], []
+    for t in range(1, n):
+        dst, src = (r + t) % n, (r - t) % n
+        for off, ln, gpos in g.own:                               # ours that dst can see, ascending
+            if gpos < g.end[dst]:
+                sends += [(dst, x[:, off:off + ln]) for x in tensors]
+        for ki in range(len(layout.segments(src))):               # src's that we can see, ascending
+            if (src, ki) in g.rows:
+                at, ln = g.rows[(src, ki)]
+                recvs += [(src, b[:, at:at + ln]) for b in bufs]
+    return comm.exchange_async(sends, recvs), [b[:, :g.Lg] for b in bufs]
+
+
+def _gathered_forward(block, comm, q, k, v, *, layout, segment_ids, key_valid, scale):
+    n, r = comm.size, comm.rank
+    B, c, H, D = q.shape
+    g = _Gathered(layout, r, n)
+    k = k if k.is_contiguous() else k.contiguous()
+    v = v if v.is_contiguous() else v.contiguous()
+    handle, (kg, vg) = _gathered_fetch(comm, block, layout, g, [k, v], "fwd")
+    sq, kvl, sg, kvg = _gathered_masks(g, segment_ids, key_valid)
+    out = block.empty((B, c, H, D), q.dtype, q)
+    lse = block.empty((B, H, c), torch.float32, q)
+    remote = g.Lg > 0
+    acc_o = block.empty((B, c, H, D), torch.float32, q) if remote else None
+    acc_l = block.empty((B, H, c), torch.float32, q) if remote else None
+    qkw = dict(q_start=g.q_start, q_piece2=g.q_cuts or None, causal=True, scale=scale)
+    # the local block, while the fetch is in flight
+    block.fwd(q, k, v, k_start=g.q_start, k_piece2=g.q_cuts or None, seg_q=sq, seg_k=sq, key_valid=kvl,
+              out=None if remote else out, lse=None if remote else lse, out_acc=acc_o, lse_acc=acc_l, carry_in=False,
+              final=not remote, **qkw)
+    handle.wait()
+    if remote:      # everything that arrived, in one launch
+        block.fwd(q, kg, vg, k_start=g.k_start, k_piece2=g.k_cuts or None, seg_q=sq, seg_k=sg, key_valid=kvg,
+                  out=out, lse=lse, out_acc=acc_o, lse_acc=acc_l, carry_in=True, final=True, **qkw)
+    return out, [lse]
+
+
+def _gathered_backward(block, comm, q, k, v, out, lses, dout, *, layout, segment_ids, key_valid, scale):
+    n, r = comm.size, comm.rank
+    B, c, H, D = q.shape
+    g = _Gathered(layout, r, n)
+    k = k if k.is_contiguous() else k.contiguous()
+    v = v if v.is_contiguous() else v.contiguous()
+    dout = dout if dout.is_contiguous() else dout.contiguous()
+    lse = lses[0]
+    delta = block.bwd_delta(out, dout, lse)
+    handle, (kg, vg) = _gathered_fetch(comm, block, layout, g, [k, v], "bwd")
+    sq, kvl, sg, kvg = _gathered_masks(g, segment_ids, key_valid)
+    remote = g.Lg > 0
+    qkw = dict(q_start=g.q_start, q_piece2=g.q_cuts or None, causal=True, scale=scale)
+    loc = dict(k_start=g.q_start, k_piece2=g.q_cuts or None, seg_q=sq, seg_k=sq, key_valid=kvl, **qkw)
+    rem = dict(k_start=g.k_start, k_piece2=g.k_cuts or None, seg_q=sq, seg_k=sg, key_valid=kvg, **qkw)
+    dq = block.empty((B, c, H, D), q.dtype, q)
+    dq_acc = block.empty((B, c, H, D), torch.float32, q) if remote else None
+    block.bwd_dq(q, k, v, dout, lse, delta, dq=None if remote else dq, dq_acc=dq_acc, carry_in=False, final=not remote, **loc)
+    handle.wait()
+    part = None
+    if remote:
+        block.bwd_dq(q, kg, vg, dout, lse, delta, dq=dq, dq_acc=dq_acc, carry_in=True, final=True, **rem)
+        part = [_xbuf(comm, block, ("gpart", w), (1, g.Lg, H, D), torch.float32, q) for w in (0, 1)]
+        block.bwd_dkdv(q, kg, vg, dout, lse, delta, dk_acc=part[0], dv_acc=part[1], carry_in=False, final=False, **rem)
+    # every owner gets its pieces straight back; what the peers computed for OUR rows arrives in the same exchange
+    sends, recvs, got = [], [], {}
+    for t in range(1, n):
+        owner, giver = (r - t) % n, (r + t) % n
+        for ki in range(len(layout.segments(owner))):
+            if (owner, ki) in g.rows:
+                at, ln = g.rows[(owner, ki)]
+                sends += [(owner, part[0][:, at:at + ln]), (owner, part[1][:, at:at + ln])]
+        for ki, (off, ln, gpos) in enumerate(g.own):
+            if gpos < g.end[giver]:
+                got[(t, ki)] = tuple(_xbuf(comm, block, ("gret", t, ki, w), (1, ln, H, D), torch.float32, q) for w in (0, 1))
+                recvs += [(giver, got[(t, ki)][0]), (giver, got[(t, ki)][1])]
+    ret = comm.exchange_async(sends, recvs)
+    dk_loc, dv_loc = (block.empty((B, c, H, D), torch.float32, q) for _ in range(2))
+    block.bwd_dkdv(q, k, v, dout, lse, delta, dk_acc=dk_loc, dv_acc=dv_loc, carry_in=False, final=False, **loc)
+    ret.wait()
+    dk = block.empty((B, c, H, D), q.dtype, q)
+    dv = block.empty((B, c, H, D), q.dtype, q)
+    for ki, (off, ln, _) in enumerate(g.own):       # fixed order: own partial, then distance 1, 2, ...
+        for w, (loc_p, dst) in enumerate(((dk_loc, dk), (dv_loc, dv))):
+            srcs = [loc_p[:, off:off + ln]] + [got[(t, ki)][w] for t in range(1, n) if (t, ki) in got]
+            block.sum_cast([s_.contiguous() for s_ in srcs], dst[:, off:off + ln])
+    return dq, dk, dv
+
+
 # ----------------------------------------------------------------- forward
 def ring_forward(block, comm, q, k, v, *, layout, causal=True, segment_ids=None, key_valid=None,
                  scale=None):
-    """Returns (out bf16 (B,c,H,D), [lse per q segment (B,H,len)])."""
+    """Returns (out bf16 (B,c,H,D), [lse per q segment (B,H,len)]) -- or, in the mesh schedule's gathered form, one lse
+    piece for the whole shard (an opaque residual between ring_forward and ring_backward of one geometry)."""
+    if _Gathered.applies(block, comm, layout, q, causal):
+        return _gathered_forward(block, comm, q, k, v, layout=layout, segment_ids=segment_ids, key_valid=key_valid, scale=scale)
     n, r = comm.size, comm.rank
     B, c, H, D = q.shape
     qsegs = layout.segments(r)
@@ -427,6 +580,9 @@ def ring_forward(block, comm, q, k, v, *, layout, causal=True, segment_ids=None,
 def ring_backward(block, comm, q, k, v, out, lses, dout, *, layout, causal=True,
                   segment_ids=None, key_valid=None, scale=None):
     """Returns (dq, dk, dv) bf16, each (B,c,H,D), for the local shard."""
+    if _Gathered.applies(block, comm, layout, q, causal):
+        return _gathered_backward(block, comm, q, k, v, out, lses, dout, layout=layout, segment_ids=segment_ids,
+                                  key_valid=key_valid, scale=scale)
     n, r = comm.size, comm.rank
     B, c, H, D = q.shape
     qsegs = layout.segments(r)

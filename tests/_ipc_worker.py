@@ -26,10 +26,16 @@ def main():
     bounds = [0, (5 * S) // 16, (17 * S) // 32, (25 * S) // 32, S]
     if packed:
         seg = torch.bucketize(torch.arange(S), torch.tensor(bounds[1:-1]), right=True).to(torch.int32)[None].contiguous()
-    lay = SeqLayout(layout, world, S)
+    if layout == "table":       # an ownership table from the document lengths: 4 chunks per rank, up to 8 messages per pair and group
+        from lwm_amd.ring import balanced_layout
+        lay = balanced_layout(world, S, [b - a for a, b in zip(bounds[:-1], bounds[1:])] if packed else None, chunks_per_rank=4)
+        assert lay.kind == "table"
+    else:
+        lay = SeqLayout(layout, world, S)
     idx = lay.global_index(rank)
     c = S // world
-    ring = CRing(dist.group.WORLD, transport="ipc", layout=layout, schedule=schedule, ipc_slot_bytes=B * c * H * D * 4)
+    ring = CRing(dist.group.WORLD, transport="ipc", layout=lay if layout == "table" else layout, schedule=schedule,
+                 ipc_slot_bytes=B * c * H * D * 4, ipc_slots=8)
     ql, kl, vl, dol = (t[:, idx].contiguous().cuda() for t in (q, k, v, do))
     segd = None if seg is None else seg.cuda()
     for _ in range(2):       # twice: message counters and slots carry over between calls

@@ -9,16 +9,27 @@ import torch
 from oracle.attention_ref import visible_mask
 
 
-def _vis(q, k, q_start, k_start, causal, seg_q, seg_k, key_valid):
+def _positions(S, start, cuts):
+    """positions of S rows under a piecewise map: rows from 0 at `start`, rows from a cut (row, position) on at its position"""
+    pos = start + np.arange(S)
+    for r, p in ([cuts] if isinstance(cuts, tuple) else list(cuts or [])):
+        pos[r:] = p + np.arange(S - r)
+    return pos
+
+
+def _vis(q, k, q_start, k_start, causal, seg_q, seg_k, key_valid, q_piece2=None, k_piece2=None):
     B, Sq = q.shape[0], q.shape[1]
     Sk = k.shape[1]
     n = lambda t: None if t is None else t.cpu().numpy()
-    m = visible_mask(Sq, Sk, causal=causal, q_start=q_start, k_start=k_start, seg_q=n(seg_q),
-                     seg_k=n(seg_k), key_valid=n(key_valid), B=B)
+    m = visible_mask(Sq, Sk, causal=False, seg_q=n(seg_q), seg_k=n(seg_k), key_valid=n(key_valid), B=B)
+    if causal:
+        m = m & (_positions(Sk, k_start, k_piece2)[None, :] <= _positions(Sq, q_start, q_piece2)[:, None])[None]
     return torch.from_numpy(m)[:, None]  # B,1,Sq,Sk
 
 
 class OracleBlockOps:
+    piece_align = 1          # piecewise position maps at any row (the HIP kernels: multiples of 256)
+
     @staticmethod
     def empty(shape, dtype, like):
         return torch.empty(shape, dtype=dtype)
@@ -46,11 +57,12 @@ class OracleBlockOps:
 
     @staticmethod
     def fwd(q, k, v, *, q_start=0, k_start=0, causal=True, seg_q=None, seg_k=None, key_valid=None,
-            scale=None, out=None, lse=None, out_acc=None, lse_acc=None, carry_in=False, final=True):
+            scale=None, out=None, lse=None, out_acc=None, lse_acc=None, carry_in=False, final=True, q_piece2=None,
+            k_piece2=None):
         D = q.shape[-1]
         scale = scale or 1.0 / math.sqrt(D)
         s = torch.einsum("bqhd,bkhd->bhqk", q.double(), k.double()) * scale
-        vis = _vis(q, k, q_start, k_start, causal, seg_q, seg_k, key_valid)
+        vis = _vis(q, k, q_start, k_start, causal, seg_q, seg_k, key_valid, q_piece2, k_piece2)
         s = s.masked_fill(~vis, float("-inf"))
         m = s.amax(dim=-1, keepdim=True)
         m = torch.where(torch.isfinite(m), m, torch.zeros_like(m))
@@ -84,11 +96,11 @@ class OracleBlockOps:
         return d
 
     @staticmethod
-    def _ds(q, k, v, dout, lse, delta, q_start, k_start, causal, seg_q, seg_k, key_valid, scale):
+    def _ds(q, k, v, dout, lse, delta, q_start, k_start, causal, seg_q, seg_k, key_valid, scale, q_piece2=None, k_piece2=None):
         D = q.shape[-1]
         scale = scale or 1.0 / math.sqrt(D)
         s = torch.einsum("bqhd,bkhd->bhqk", q.double(), k.double()) * scale
-        vis = _vis(q, k, q_start, k_start, causal, seg_q, seg_k, key_valid)
+        vis = _vis(q, k, q_start, k_start, causal, seg_q, seg_k, key_valid, q_piece2, k_piece2)
         ok = vis & torch.isfinite(lse)[..., None]
         p = torch.where(ok, torch.exp(torch.where(ok, s - lse.double()[..., None].nan_to_num(0, 0, 0), torch.zeros_like(s))),
                         torch.zeros_like(s))
@@ -98,8 +110,9 @@ class OracleBlockOps:
 
     @classmethod
     def bwd_dq(cls, q, k, v, dout, lse, delta, *, q_start=0, k_start=0, causal=True, seg_q=None,
-               seg_k=None, key_valid=None, scale=None, dq=None, dq_acc=None, carry_in=False, final=True):
-        _, ds = cls._ds(q, k, v, dout, lse, delta, q_start, k_start, causal, seg_q, seg_k, key_valid, scale)
+               seg_k=None, key_valid=None, scale=None, dq=None, dq_acc=None, carry_in=False, final=True, q_piece2=None,
+               k_piece2=None):
+        _, ds = cls._ds(q, k, v, dout, lse, delta, q_start, k_start, causal, seg_q, seg_k, key_valid, scale, q_piece2, k_piece2)
         r = torch.einsum("bhqk,bkhd->bqhd", ds, k.double())
         if carry_in:
             r = r + dq_acc.double()
@@ -114,8 +127,8 @@ class OracleBlockOps:
     @classmethod
     def bwd_dkdv(cls, q, k, v, dout, lse, delta, *, q_start=0, k_start=0, causal=True, seg_q=None,
                  seg_k=None, key_valid=None, scale=None, dk=None, dv=None, dk_acc=None, dv_acc=None,
-                 carry_in=False, final=True):
-        p, ds = cls._ds(q, k, v, dout, lse, delta, q_start, k_start, causal, seg_q, seg_k, key_valid, scale)
+                 carry_in=False, final=True, q_piece2=None, k_piece2=None):
+        p, ds = cls._ds(q, k, v, dout, lse, delta, q_start, k_start, causal, seg_q, seg_k, key_valid, scale, q_piece2, k_piece2)
         rk = torch.einsum("bhqk,bqhd->bkhd", ds, q.double())
         rv = torch.einsum("bhqk,bqhd->bkhd", p, dout.double())
         if carry_in:

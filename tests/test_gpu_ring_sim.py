@@ -131,6 +131,45 @@ def test_ring_n_equals_ring_1_on_gpu(n, layout_kind, packed, schedule):
     _check_dq(f"dq ring{n}", f(got[1]), rq, rqx)
 
 
+@pytest.mark.parametrize("n,layout_kind,packed,S", [(2, "zigzag", True, 1024), (4, "zigzag", True, 2048), (4, "contiguous", False, 1024),
+                                                     (8, "zigzag", True, 4096), (4, "balanced", True, 4096)])
+def test_mesh_gathered_form_on_gpu(n, layout_kind, packed, S, monkeypatch):
+    """lwm_amd/ring.py's own gathered form of the mesh schedule (segments of a multiple of 256 rows, B = 1, causal): the
+    fetched segments in position order in one buffer, piecewise position maps, two launches per kernel -- against the
+    single device, the fp64 oracle, and the per-pair form of the same driver (LWM_RING_FORM=pairs): same bytes."""
+    import torch
+    from lwm_amd import ring as ring_mod
+    H = 2
+    lay_kind = layout_kind
+    if layout_kind == "balanced":
+        lens = [S // 3, S // 4 + 7, S - S // 3 - S // 4 - 7]
+        real = ring_mod.SeqLayout
+        table = ring_mod.balanced_layout(n, S, lens, chunks_per_rank=4)
+        monkeypatch.setattr(ring_mod, "SeqLayout", lambda kind, n_, S_, owner=None: table if kind == "balanced" else real(kind, n_, S_, owner))
+        seg_fn = lambda S_: torch.bucketize(torch.arange(S_), torch.tensor(np.cumsum(lens)[:-1]), right=True)
+        packed = seg_fn
+    calls = {"fwd": 0}
+    real_fwd = ring_mod.HipBlockOps.fwd
+    monkeypatch.setattr(ring_mod.HipBlockOps, "fwd", staticmethod(lambda *a, **kw: (calls.__setitem__("fwd", calls["fwd"] + 1), real_fwd(*a, **kw))[1]))
+    got, ref, (q, k, v, do, seg) = _run_ring(n, lay_kind, S, H, packed, "mesh")
+    assert calls["fwd"] <= 2 * n + 1, calls            # two launches per rank (+ the single-device reference)
+    gathered_bytes = _run_ring.sent_bytes
+    f = lambda t: t.float().cpu().numpy()
+    sg = None if seg is None else seg.cpu().numpy()
+    ro, _ = R.dense_attention(f(q), f(k), f(v), causal=True, seg_q=sg, seg_k=sg)
+    rq, rk, rv, rqx = R.dense_attention_bwd(f(q), f(k), f(v), f(do), causal=True, seg_q=sg, seg_k=sg, out_saved=f(got[0]))
+    for name, a, b in zip(("out", "dk", "dv"), (got[0], got[2], got[3]), (ro, rk, rv)):
+        _check(f"{name} mesh gathered n={n} {layout_kind}", f(a), b)
+    _check_dq(f"dq mesh gathered n={n} {layout_kind}", f(got[1]), rq, rqx)
+    monkeypatch.setenv("LWM_RING_FORM", "pairs")
+    calls["fwd"] = 0
+    pairs, _, _ = _run_ring(n, lay_kind, S, H, packed, "mesh")
+    assert calls["fwd"] > 2 * n + 1 or n == 2, calls
+    assert _run_ring.sent_bytes == gathered_bytes
+    for name, a, b in zip(("out", "dq", "dk", "dv"), got, pairs):
+        assert ((a.float() - b.float()).abs().max() / b.float().abs().max()).item() <= 8e-3, name
+
+
 def _doc_windows(bounds, w=256):
     """[(doc_start, doc_end, window_start)]: the last `w` rows of every document."""
     return [(a, b, b - w) for a, b in zip(bounds[:-1], bounds[1:])]

@@ -315,6 +315,11 @@ def test_c_ring_ownership_table_vs_oracle(n, S, P):
     for name, a, b in zip(("out", "dk", "dv"), (got[0], got[2], got[3]), (ro, rk, rv)):
         check(f"{name} c-ring table n={n} P={P}", f(a), b)
     check_dq(f"dq c-ring table n={n} P={P}", f(got[1]), rq, rqx)
+    import ctypes as C
+    from lwm_amd._lib import lib
+    tab = (C.c_int32 * len(lay.owner))(*lay.owner)
+    plan = lambda r, b: lib().lwm_ring_planned_bytes_table(tab, len(lay.owner), n, r, S // n, H, 128, b)
+    assert sent == [plan(r, 0) + plan(r, 1) for r in range(n)], (sent, [plan(r, 0) + plan(r, 1) for r in range(n)])
     zz, _, _ = _run_c_ring(n, S, H, True, seg_fn, True, layout="zigzag", schedule="direct")
     for name, a, b in zip(("out", "dq", "dk", "dv"), got, zz):
         assert ((a.float() - b.float()).abs().max() / b.float().abs().max()).item() <= 8e-3, name

@@ -48,9 +48,32 @@ def _worker(rank, world, port, layout_kind, causal, packed, schedule, q_out, B=1
             lay = SeqLayout(layout_kind, world, S)
         idx = lay.global_index(rank)
         ql, kl, vl = (t[:, idx].clone().requires_grad_(True) for t in (q, k, v))
+        launches = {"fwd": 0, "dq": 0, "dkdv": 0}
+
+        class Counting(OracleBlockOps):
+            @staticmethod
+            def fwd(*a, **kw):
+                launches["fwd"] += 1
+                return OracleBlockOps.fwd(*a, **kw)
+
+            @classmethod
+            def bwd_dq(cls, *a, **kw):
+                launches["dq"] += 1
+                return super().bwd_dq(*a, **kw)
+
+            @classmethod
+            def bwd_dkdv(cls, *a, **kw):
+                launches["dkdv"] += 1
+                return super().bwd_dkdv(*a, **kw)
+
         out = ring_attention(ql, kl, vl, causal=causal, segment_ids=seg, key_valid=kv, layout=lay,
-                             block_ops=OracleBlockOps, comm=TorchRingComm(None, schedule=schedule))
+                             block_ops=Counting, comm=TorchRingComm(None, schedule=schedule))
         out.backward(do[:, idx])
+        if schedule == "mesh" and causal and B == 1:
+            # the gathered form: the local block + everything that arrived -- two launches per kernel, whatever n is
+            assert all(v_ <= 2 for v_ in launches.values()), launches
+        elif world > 2 or layout_kind != "contiguous":
+            assert launches["fwd"] > 2, launches
         q_out.put((rank, idx.numpy(), out.detach().float().numpy(), ql.grad.float().numpy(),
                    kl.grad.float().numpy(), vl.grad.float().numpy()))
         dist.barrier()

@@ -55,6 +55,13 @@ def test_ipc_ring_between_processes(n, layout, schedule, packed):
 
 
 @pytest.mark.gpu
+def test_ipc_ring_ownership_table_between_processes():
+    """an ownership table (4 chunks of 256 rows per rank, handed out by the packed documents' pair counts) between 4 real
+    processes: the gathered form's fetch and partial return by chunk through real mailboxes, 8 messages per pair and group"""
+    _launch(4, 4096, 2, "table", "direct", True, big=False)
+
+
+@pytest.mark.gpu
 def test_ipc_ring8_at_config3_shard_shape():
     """BASELINE configs[2]'s shard shape between 8 real processes: S = 131072, c = 16384 per rank, zigzag ownership, the
     direct schedule, packed documents; oracle windows at the end of every document (first, middle and last ranks)."""

@@ -56,3 +56,52 @@ def test_zigzag_balances_causal_work_and_mesh_ships_three_quarters():
     lay = SeqLayout("zigzag", n, S)
     sent = sum(len(_needed_ksegs(lay, dst, r, True)) for r in range(n) for dst in range(n) if dst != r)
     assert sent == 0.75 * (2 * n * (n - 1))                      # of the 2 segments x (n-1) peers a ring moves
+
+
+def test_ownership_tables_partition_balance_and_plan_like_the_product_library():
+    """SeqLayout("table") / balanced_layout: a partition of the sequence with P chunks per rank; for ONE document the
+    4-chunk table balances the causal triangle as zigzag does; for a packed batch it beats the best pairing of half-chunks;
+    and the bytes the C driver plans for a table (lwm_ring_planned_bytes_table, pure geometry) are what the visibility rule
+    of this module gives -- for a zigzag-shaped table exactly what the zigzag layout plans."""
+    import ctypes as C
+    from lwm_amd import _capi
+    from lwm_amd._lib import lib
+    from lwm_amd.ring import balanced_layout
+    n, S = 8, 8 * 4 * 256
+    docs = [S // 16, S // 4 + 300, S // 8 - 300, S // 2, S // 16]
+    for lens in (None, docs):
+        lay = balanced_layout(n, S, lens, chunks_per_rank=4)
+        assert lay.kind == "table" and len(lay.owner) == 4 * n and all(lay.owner.count(r) == 4 for r in range(n))
+        owned = np.concatenate([lay.global_index(r).numpy() for r in range(n)])
+        assert sorted(owned.tolist()) == list(range(S))
+        starts = np.cumsum([0] + (lens or [S])[:-1])
+        w = np.arange(S) - np.repeat(starts, lens or [S]) + 1.0
+        load = [w[lay.global_index(r).numpy()].sum() for r in range(n)]
+        assert max(load) / np.mean(load) < (1.02 if lens is None else 1.06), load
+        if lens is not None:
+            zz = SeqLayout("zigzag", n, S)
+            zload = [w[zz.global_index(r).numpy()].sum() for r in range(n)]
+            assert max(zload) / np.mean(zload) > 1.3
+        # segments: one per chunk, ascending positions, local rows in that order
+        for r in range(n):
+            segs = lay.segments(r)
+            assert [s_[0] for s_ in segs] == [i * (S // (4 * n)) for i in range(4)] and all(a[2] < b[2] for a, b in zip(segs, segs[1:]))
+    L = lib()
+    c, H, D = S // n, 2, 128
+    zig = [j if j < n else 2 * n - 1 - j for j in range(2 * n)]
+    tab = (C.c_int32 * len(zig))(*zig)
+    for r in range(n):
+        for bwd in (0, 1):
+            assert L.lwm_ring_planned_bytes_table(tab, len(zig), n, r, c, H, D, bwd) == \
+                L.lwm_ring_planned_bytes(_capi.RING_LAYOUT["zigzag"], _capi.RING_SCHEDULE["direct"], n, r, 1, c, H, D, 1, bwd)
+    lay = balanced_layout(n, S, docs, chunks_per_rank=4)
+    tab = (C.c_int32 * len(lay.owner))(*lay.owner)
+    cs = S // len(lay.owner)
+    for r in range(n):
+        last = {q: max(j for j, o in enumerate(lay.owner) if o == q) for q in range(n)}
+        fetch = sum(2 * cs * H * D * 2 for j, o in enumerate(lay.owner) if o == r for q in range(n) if q != r and j < last[q])
+        back = sum(2 * cs * H * D * 4 for j, o in enumerate(lay.owner) if o != r and j < last[r])
+        assert L.lwm_ring_planned_bytes_table(tab, len(lay.owner), n, r, c, H, D, 0) == fetch
+        assert L.lwm_ring_planned_bytes_table(tab, len(lay.owner), n, r, c, H, D, 1) == fetch + back
+    bad = (C.c_int32 * 16)(*([0] * 16))
+    assert L.lwm_ring_planned_bytes_table(bad, 16, n, 0, c, H, D, 0) == -1
