@@ -182,6 +182,15 @@ typedef struct LwmRingArgs {
      * rank owns exactly P chunks and holds them in ascending position order in its local rows.  Ignored otherwise. */
     const int32_t* chunk_owner;
     int32_t n_chunks;
+    /* Gathered form only (lwm_ring_last_form): a caller-owned device buffer of lwm_ring_kv_keep_bytes() bytes that the
+     * FORWARD gathers the fetched K/V into (instead of its workspace) and that the BACKWARD of the same layer, handed the
+     * same buffer with kv_kept = 1, reads instead of fetching K/V again: a quarter of the bytes a layer moves over xGMI
+     * (K/V twice + f32 partials once -> K/V once + partials), for (n - 1) * c * H * D * 4 bytes per layer kept between the
+     * two calls -- 0.5 GB at S = 32768 over 8 ranks, 1.9 GB at S = 131072; 288 GB per GPU is what makes that a choice.
+     * EVERY rank of the ring must make the same choice for a call (a rank that does not fetch does not send either).
+     * NULL / 0 = fetch in both calls.  Ignored by the per-pair form. */
+    void* kv_keep;
+    int32_t kv_kept;
 } LwmRingArgs;
 
 /* Ownership.  CONTIGUOUS = the reference's: rank r holds positions [r*c, (r+1)*c) (lwm/llama.py:560-562).
@@ -225,6 +234,8 @@ int64_t lwm_ring_planned_bytes(int32_t layout, int32_t schedule, int32_t n, int3
  * chunk it fetched.  -1 for an unusable table. */
 int64_t lwm_ring_planned_bytes_table(const int32_t* chunk_owner, int32_t n_chunks, int32_t n, int32_t rank, int32_t c, int32_t H,
                                      int32_t D, int32_t backward);
+/* Size of LwmRingArgs::kv_keep for a shard shape: room for the K and the V rows of every other rank, (n - 1) * c rows each. */
+int64_t lwm_ring_kv_keep_bytes(int32_t B, int32_t c, int32_t H, int32_t D, int32_t n);
 /* bytes this ring object has sent since creation (diagnostic) */
 int64_t lwm_ring_bytes_sent(const LwmRing* ring);
 /* Which form the last lwm_ring_attn_fwd / _bwd call took (diagnostic): 0 = one launch per (q segment, k segment) pair,

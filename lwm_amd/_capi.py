@@ -66,6 +66,7 @@ class LwmRingArgs(C.Structure):
         ("scale", C.c_float), ("causal", C.c_int32), ("workspace", C.c_void_p),
         ("layout", C.c_int32), ("schedule", C.c_int32),
         ("chunk_owner", C.c_void_p), ("n_chunks", C.c_int32),
+        ("kv_keep", C.c_void_p), ("kv_kept", C.c_int32),
     ]
 
 
@@ -122,6 +123,7 @@ PROTOTYPES = {
     "lwm_ring_selftest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "lwm_ring_set_fetch_groups": (C.c_int, [C.c_void_p, C.c_int32]),
     "lwm_ring_last_form": (C.c_int, [C.c_void_p]),
+    "lwm_ring_kv_keep_bytes": (C.c_int64, [C.c_int32] * 5),
     "lwm_ring_fetch_timeline": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32]),
     "lwm_ring_ipc_info_bytes": (C.c_int64, []),
     "lwm_ring_ipc_export": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -215,22 +215,45 @@ class CRing:
             a._keep_owner = owner
         return a
 
-    def forward(self, q, k, v, *, causal=True, segment_ids=None, key_valid=None, scale=None, layout=None):
+    def kv_keep_buffer(self, q):
+        """A buffer for the gathered K/V of one layer (lwm_ring_kv_keep_bytes) when keeping it between the forward and the
+        backward is within the budget -- LWM_RING_KEEP_KV_MB per layer, default 1024 (0 = never): the backward then fetches
+        no K/V again, a quarter of the layer's xGMI bytes.  A function of the geometry only, so every rank decides alike."""
+        import os
+        if self.size < 2:
+            return None
+        B, c, H, D = q.shape
+        need = int(lib().lwm_ring_kv_keep_bytes(B, c, H, D, self.size))
+        cap = float(os.environ.get("LWM_RING_KEEP_KV_MB", "1024")) * (1 << 20)
+        if need <= 0 or need > cap:
+            return None
+        buf = torch.empty(need + 256, dtype=torch.uint8, device=q.device)
+        off = (-buf.data_ptr()) % 256
+        return buf[off:off + need]
+
+    def forward(self, q, k, v, *, causal=True, segment_ids=None, key_valid=None, scale=None, layout=None, kv_keep=None):
+        """kv_keep: a buffer from kv_keep_buffer() -- the gathered form gathers the fetched K/V into it (hand it to
+        backward(kv_keep=...) of the same layer, on EVERY rank or on none)"""
         B, c, H, D = q.shape
         k, v = k.contiguous(), v.contiguous()
         out = torch.empty((B, c, H, D), dtype=torch.bfloat16, device=q.device)
         lse = torch.empty((B, H, c), dtype=torch.float32, device=q.device)
         a = self._args(q, k, v, out, lse, segment_ids, key_valid, scale, causal, False, layout)
+        if kv_keep is not None:
+            a.kv_keep = kv_keep.data_ptr()
         L = lib()
         _capi.check(L, L.lwm_ring_attn_fwd(self._h, C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
                     "lwm_ring_attn_fwd")
         return out, lse
 
-    def backward(self, q, k, v, out, lse, dout, *, causal=True, segment_ids=None, key_valid=None, scale=None, layout=None):
+    def backward(self, q, k, v, out, lse, dout, *, causal=True, segment_ids=None, key_valid=None, scale=None, layout=None,
+                 kv_keep=None):
         B, c, H, D = q.shape
         k, v, dout = k.contiguous(), v.contiguous(), dout.contiguous()
         dq, dk, dv = (torch.empty((B, c, H, D), dtype=torch.bfloat16, device=q.device) for _ in range(3))
         a = self._args(q, k, v, out, lse, segment_ids, key_valid, scale, causal, True, layout)
+        if kv_keep is not None:
+            a.kv_keep, a.kv_kept = kv_keep.data_ptr(), 1
         a.dout, a.dq, a.dk, a.dv = _t4(dout, "dout"), _t4(dq, "dq"), _t4(dk, "dk"), _t4(dv, "dv")
         L = lib()
         _capi.check(L, L.lwm_ring_attn_bwd(self._h, C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
@@ -241,9 +264,14 @@ class CRing:
 class _RingAttentionC(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, ring, causal, segment_ids, key_valid, scale, layout):
-        out, lse = ring.forward(q, k, v, causal=causal, segment_ids=segment_ids, key_valid=key_valid, scale=scale, layout=layout)
+        keep = ring.kv_keep_buffer(q)       # (None beyond the budget: the backward fetches again)
+        out, lse = ring.forward(q, k, v, causal=causal, segment_ids=segment_ids, key_valid=key_valid, scale=scale, layout=layout,
+                                kv_keep=keep)
         ctx.save_for_backward(q, k, v, out, lse)
         ctx.cfg = (ring, causal, segment_ids, key_valid, scale, layout)
+        # the gathered K/V of this layer, kept for its backward -- only when the call took the gathered form (else the
+        # buffer was not written)
+        ctx.kv_keep = keep if (keep is not None and ring.last_form == 1) else None
         return out
 
     @staticmethod
@@ -251,7 +279,8 @@ class _RingAttentionC(torch.autograd.Function):
         q, k, v, out, lse = ctx.saved_tensors
         ring, causal, segment_ids, key_valid, scale, layout = ctx.cfg
         dq, dk, dv = ring.backward(q, k, v, out, lse, dout, causal=causal, segment_ids=segment_ids,
-                                   key_valid=key_valid, scale=scale, layout=layout)
+                                   key_valid=key_valid, scale=scale, layout=layout, kv_keep=ctx.kv_keep)
+        ctx.kv_keep = None
         return dq, dk, dv, None, None, None, None, None, None
 
 

@@ -35,6 +35,7 @@ LWM_EMU_NO_RING(int, lwm_ring_attn_fwd, LwmRing*, const LwmRingArgs*, void*)
 LWM_EMU_NO_RING(int, lwm_ring_attn_bwd, LwmRing*, const LwmRingArgs*, void*)
 LWM_EMU_NO_RING(int64_t, lwm_ring_bytes_sent, const LwmRing*)
 LWM_EMU_NO_RING(int, lwm_ring_last_form, const LwmRing*)
+LWM_EMU_NO_RING(int64_t, lwm_ring_kv_keep_bytes, int32_t, int32_t, int32_t, int32_t, int32_t)
 LWM_EMU_NO_RING(int64_t, lwm_ring_planned_bytes_table, const int32_t*, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t)
 LWM_EMU_NO_RING(int64_t, lwm_ring_planned_bytes, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t)
 LWM_EMU_NO_RING(int, lwm_ring_selftest, LwmRing*, const void*, void*, int64_t, void*)

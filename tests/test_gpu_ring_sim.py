@@ -71,7 +71,7 @@ def _run_ring(n, layout_kind, S, H, packed, schedule="ring", B=1):
         seg[:, S // 3:] = 1
         seg[:, (5 * S) // 8:] = 2
         seg = seg.cuda()
-    lay = SeqLayout(layout_kind, n, S)
+    lay = layout_kind if not isinstance(layout_kind, str) else SeqLayout(layout_kind, n, S)      # (or a SeqLayout object)
     inboxes = [queue.Queue() for _ in range(n)]
     links = {(a, b): queue.Queue() for a in range(n) for b in range(n)}
     res, errs, sent = [None] * n, [], [0] * n
@@ -143,9 +143,8 @@ def test_mesh_gathered_form_on_gpu(n, layout_kind, packed, S, monkeypatch):
     lay_kind = layout_kind
     if layout_kind == "balanced":
         lens = [S // 3, S // 4 + 7, S - S // 3 - S // 4 - 7]
-        real = ring_mod.SeqLayout
-        table = ring_mod.balanced_layout(n, S, lens, chunks_per_rank=4)
-        monkeypatch.setattr(ring_mod, "SeqLayout", lambda kind, n_, S_, owner=None: table if kind == "balanced" else real(kind, n_, S_, owner))
+        lay_kind = ring_mod.balanced_layout(n, S, lens, chunks_per_rank=4)
+        assert lay_kind.kind == "table"
         seg_fn = lambda S_: torch.bucketize(torch.arange(S_), torch.tensor(np.cumsum(lens)[:-1]), right=True)
         packed = seg_fn
     calls = {"fwd": 0}

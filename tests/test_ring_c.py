@@ -147,7 +147,7 @@ class _Mailbox:
 
 
 def _run_c_ring(n, S, H, causal, packed, padded, B=1, layout="contiguous", schedule="ring", fetch_groups=None, box=None,
-                timeline=None, forms=None):
+                timeline=None, forms=None, keep_kv=False):
     import torch
     from lwm_amd.ring import SeqLayout
     from lwm_amd.ring_c import CRing
@@ -177,11 +177,13 @@ def _run_c_ring(n, S, H, causal, packed, padded, B=1, layout="contiguous", sched
                 ring.set_fetch_groups(fetch_groups)
             idx = lay.global_index(r).cuda()
             ql, kl, vl, dol = (t[:, idx].contiguous() for t in (q, k, v, do))
-            out, lse = ring.forward(ql, kl, vl, causal=causal, segment_ids=seg, key_valid=kv)
+            keep = ring.kv_keep_buffer(ql) if keep_kv else None
+            assert keep is not None or not keep_kv or n == 1
+            out, lse = ring.forward(ql, kl, vl, causal=causal, segment_ids=seg, key_valid=kv, kv_keep=keep)
             if timeline is not None:
                 timeline[r] = ring.fetch_timeline()
             f_fwd = ring.last_form
-            dq, dk, dv = ring.backward(ql, kl, vl, out, lse, dol, causal=causal, segment_ids=seg, key_valid=kv)
+            dq, dk, dv = ring.backward(ql, kl, vl, out, lse, dol, causal=causal, segment_ids=seg, key_valid=kv, kv_keep=keep)
             if forms is not None:
                 forms[r] = (f_fwd, ring.last_form)
             torch.cuda.synchronize()
@@ -281,6 +283,15 @@ def test_c_ring_gathered_form_vs_oracle(n, layout, packed, padded, S):
     for name, a, b in zip(("out", "dk", "dv"), (got[0], got[2], got[3]), (ro, rk, rv)):
         check(f"{name} c-ring gathered n={n} {layout}", f(a), b)
     check_dq(f"dq c-ring gathered n={n} {layout}", f(got[1]), rq, rqx)
+    # the forward's gathered K/V kept for the backward (LwmRingArgs::kv_keep): the same bits, the backward's K/V fetch gone
+    kept, _, sent_kept = _run_c_ring(n, S, H, True, packed, padded, layout=layout, schedule="direct", keep_kv=True)
+    for a, b in zip(got, kept):
+        assert torch.equal(a, b)
+    from lwm_amd import _capi
+    from lwm_amd._lib import lib
+    plan = lambda r, b: lib().lwm_ring_planned_bytes(_capi.RING_LAYOUT[layout], _capi.RING_SCHEDULE["direct"], n, r, 1, S // n, H, 128, 1, b)
+    assert sent == [plan(r, 0) + plan(r, 1) for r in range(n)]
+    assert sent_kept == [plan(r, 1) for r in range(n)], (sent_kept, [plan(r, 1) for r in range(n)])      # K/V once + the partials
     if n > 2:       # (n = 2 has one peer: one fetch group whatever is asked for)
         pair, _, sent_pair = _run_c_ring(n, S, H, True, packed, padded, layout=layout, schedule="direct", fetch_groups=n - 1, forms=forms_pair)
         assert all(forms_pair[r] == (0, 0) for r in range(n)), forms_pair
