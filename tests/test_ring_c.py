@@ -443,15 +443,9 @@ def test_c_ring8_at_configs3_and_4_shard_shapes_vs_oracle(S, packed):
     check("dv c-ring8@256K last keys", f(dv, slice(K0 + 256, S)), rv[:, K0 + 256:])
 
 
-@pytest.mark.gpu
-def test_c_ring_direct_hands_blocks_over_as_they_land(monkeypatch):
-    """The direct schedule's K/V fetch in one group per rank distance (lwm_ring_set_fetch_groups(n - 1)): step t waits for
-    the block of distance t only.  Rank 0's link from the FARTHEST rank is held back by ~100 ms of GPU time: the kernels
-    of its steps 1 and 2 must have finished long before that block lands (timestamps of the driver's own events,
-    lwm_ring_fetch_timeline), the result is unchanged, and with ONE group (the bulk-synchronous RCCL default) every step
-    waits for the late block."""
+def _hands_blocks_over_body():
+    """(runs in its own process, see the test below)"""
     import torch
-    monkeypatch.setenv("LWM_RING_TIMING", "1")
     n, S, H = 4, 2048, 2
     cycles = int(0.1 * 1.5e9)
     ref = _run_c_ring(n, S, H, False, False, False, layout="zigzag", schedule="direct")[0]
@@ -468,6 +462,26 @@ def test_c_ring_direct_hands_blocks_over_as_they_land(monkeypatch):
             assert kv_ms[1] < 0.5 * kv_ms[n - 1], kv_ms
         else:
             assert kern_ms[1] >= kv_ms[n - 1] - 1.0, (kv_ms, kern_ms)
+    print("HANDS_OVER_OK")
+
+
+@pytest.mark.gpu
+def test_c_ring_direct_hands_blocks_over_as_they_land():
+    """The direct schedule's K/V fetch in one group per rank distance (lwm_ring_set_fetch_groups(n - 1)): step t waits for
+    the block of distance t only.  Rank 0's link from the FARTHEST rank is held back by ~100 ms of GPU time: the kernels
+    of its steps 1 and 2 must have finished long before that block lands (timestamps of the driver's own events,
+    lwm_ring_fetch_timeline), the result is unchanged, and with ONE group (the bulk-synchronous RCCL default) every step
+    waits for the late block.
+    In its OWN process: the four ranks are threads here, each with a compute and a side stream, and HIP multiplexes a
+    process's streams onto a few hardware queues -- after the dozens of rings the tests above have made in this process a
+    rank's compute stream can share a hardware queue with the side stream that holds the delay kernel, and then waits
+    behind it (a property of thread-played ranks, not of the driver: a real rank is a process with two streams)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, PYTHONPATH=ROOT, LWM_RING_TIMING="1")
+    p = subprocess.run([sys.executable, "-c", "import tests.test_ring_c as t; t._hands_blocks_over_body()"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "HANDS_OVER_OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
 
 
 _RCCL_FIRST_CONTACT = r'''
