@@ -35,19 +35,20 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _argv(n, dump, extra=()):
+def _argv(n, dump, extra=(), vision=False):
+    kind = "json_vision" if vision else "json"
     return [sys.executable, "-m", "lwm_amd.cli.train", f"--mesh_dim=1,1,1,{n}", "--dtype=bf16", "--total_steps=1",
             "--log_freq=1", "--load_llama_config=debug", "--seed=11",
-            f"--update_llama_config=dict(vocab_size=512,max_sequence_length={S},theta=1000000)",
-            "--train_dataset.type=json", f"--train_dataset.json_dataset.seq_length={S}",
-            "--train_dataset.json_dataset.batch_size=1", "--optimizer.adamw_optimizer.lr=1e-4",
-            f"--lwm_dump_grads={dump}", *extra]
+            f"--update_llama_config=dict(vocab_size=512,max_sequence_length={S},theta=1000000" + (",vision_vocab_size=256" if vision else "") + ")",
+            f"--train_dataset.type={kind}", f"--train_dataset.{kind}_dataset.seq_length={S}",
+            f"--train_dataset.{kind}_dataset.batch_size=1", "--optimizer.adamw_optimizer.lr=1e-4",
+            f"--lwm_dump_grads={dump}", *(["--modality=vision,text"] if vision else []), *extra]
 
 
-def _run(n, dump, env_extra=None, extra=(), timeout=900):
+def _run(n, dump, env_extra=None, extra=(), timeout=900, vision=False):
     base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     if n == 1:
-        r = subprocess.run(_argv(1, dump, extra), cwd=ROOT, env=base, capture_output=True, text=True, timeout=timeout)
+        r = subprocess.run(_argv(1, dump, extra, vision), cwd=ROOT, env=base, capture_output=True, text=True, timeout=timeout)
         assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
         return [r.stdout + r.stderr]
     port = _free_port()
@@ -56,7 +57,7 @@ def _run(n, dump, env_extra=None, extra=(), timeout=900):
         env = dict(base, RANK=str(rank), WORLD_SIZE=str(n), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", GLOO_SOCKET_IFNAME="lo",
                    LWM_DIST_BACKEND="gloo", LWM_RING_TRANSPORT="ipc", **(env_extra or {}))
-        procs.append(subprocess.Popen(_argv(n, dump, extra), cwd=ROOT, env=env, stdout=subprocess.PIPE,
+        procs.append(subprocess.Popen(_argv(n, dump, extra, vision), cwd=ROOT, env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = []
     try:
@@ -143,3 +144,23 @@ def test_train_cli_contiguous_ownership_is_the_unbalanced_control(tmp_path):
     assert abs(ring["loss"] - ref["loss"]) <= 2e-3 * abs(ref["loss"])
     bal = _balance(outs[0])
     assert bal["layout"] == "contiguous" and bal["max_over_mean"] >= 1.3, bal
+
+
+@pytest.mark.gpu
+def test_train_cli_vision_text_on_a_ring(tmp_path):
+    """--modality=vision,text over 4 ranks: two embedding tables, two heads, two masked losses whose target counts differ
+    from rank to rank (the vision block sits mid-sequence) -- each rank's loss is its share of the per-sequence means
+    (the counts are summed over the ring), RoPE positions come from the ownership rule: the 1-process figures."""
+    import torch
+    ref_f, ring_f = str(tmp_path / "ref.pt"), str(tmp_path / "ring.pt")
+    _run(1, ref_f, vision=True)
+    outs = _run(4, ring_f, vision=True)
+    assert "layout zigzag" in outs[0]
+    ref, ring = torch.load(ref_f), torch.load(ring_f)
+    assert abs(ring["loss"] - ref["loss"]) <= 2e-3 * abs(ref["loss"]), (ring["loss"], ref["loss"])
+    for k in ("vision_loss", "text_loss", "vision_acc", "text_acc"):
+        assert abs(ring["metrics"][k] - ref["metrics"][k]) <= 2e-3 * max(1.0, abs(ref["metrics"][k])), (k, ring["metrics"][k], ref["metrics"][k])
+    for name, g_ref in ref["grads"].items():
+        a, b = ring["grads"][name].double().flatten(), g_ref.double().flatten()
+        cos = float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-30))
+        assert cos >= 0.9999, (name, cos)
