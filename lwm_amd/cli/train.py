@@ -164,18 +164,22 @@ def main(argv=None):
     return history
 
 
-def balance_report(cfg, B, c, n, dev, reps=3, heads=None, windows=3):
+def balance_report(cfg, B, c, n, dev, reps=3, heads=None, windows=3, layout=None):
     """Per-rank attention time of ONE layer of this job's shard shape, measured without the other ranks in the way: every
     rank of the sp ring is played in turn on the GPU of sp rank 0 by the C ring driver over a transport that moves nothing
     (CRing.null) -- the launch list of rank r under the ownership rule in force, forward + backward -- while the other
     processes wait at a barrier (they may share that GPU).  The chip runs at its power limit under these kernels and the
     clock wanders: a rank's figure is the best of `windows` timing windows of `reps` layers.
+    CAVEAT: when the job's processes SHARE a GPU (a dry run), their idle contexts still cost the measuring one scheduler
+    time slices -- 43 ms and erratic where the same launch lists take 15 ms alone (scripts/gpu_balance_probe.py): inside such a
+    job the figures are indicative only; call this function from a process that has the GPU to itself (layout="zigzag" |
+    "contiguous" names the rule when no "sp" axis is bound) for the real ones, as tests/test_gpu_cli_ring.py does.
     -> {"ms_per_rank": [...], "max_over_mean"} on every rank"""
     import torch.distributed as dist
     from ..ring_c import CRing
     from ..ringattention import sp_layout, sp_size_rank
     H, D = heads or cfg.num_attention_heads, cfg.hidden_size // cfg.num_attention_heads
-    kind = sp_layout("sp", c)
+    kind = layout or sp_layout("sp", c)
     me = sp_size_rank("sp")[1]
     multi = dist.is_available() and dist.is_initialized()
     ms = [0.0] * n

@@ -78,8 +78,20 @@ def _run(n, dump, env_extra=None, extra=(), timeout=900, vision=False):
 
 
 def _balance(out):
+    """The ownership rule the job ran under (its own report line names it), then the per-rank attention time of that rule's
+    launch lists measured HERE, in a process that has the GPU to itself: inside the job the ranks' processes share the one
+    GPU of a test box, and their idle contexts cost the measuring process scheduler time slices (the job's own figures
+    are 3x too long and erratic: lwm_amd/cli/train.py::balance_report)."""
+    import torch
+    from lwm_amd.cli.train import balance_report
+    from lwm_amd.llama import LLaMAConfig
     line = [l for l in out.splitlines() if l.startswith("LWM_BALANCE ")][-1]
-    return json.loads(line[len("LWM_BALANCE "):])
+    job = json.loads(line[len("LWM_BALANCE "):])
+    n = len(job["ms_per_rank"])
+    cfg = LLaMAConfig.load_config("debug")
+    bal = balance_report(cfg, 1, S_BALANCE // n, n, torch.device("cuda", 0), heads=H_BALANCE, layout=job["layout"])
+    bal["inside_the_job_on_a_shared_gpu"] = job
+    return bal
 
 
 @pytest.mark.gpu
