@@ -358,6 +358,11 @@ LWM_DEVICE void d4_drain(const D4Ctx& cx, D4Regs& rg, f32x16 (&dk)[4], f32x16 (&
 
 template <bool HAS_META>
 LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
+#ifdef LWM_PROF
+    // (dump slots 11..13: entry -> last store issued, entry -> first step of the walk, entry -> first store of the epilogue)
+    const unsigned long long d4_entry = __builtin_amdgcn_s_memtime();
+    unsigned long long d4_head = 0, d4_epi = 0;
+#endif
     const lds_t lds = dyn_lds();
     const int tid = thread_idx();
     const int wave = wave_uniform(tid >> 6), lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -389,7 +394,8 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
     for (int s = 0; s < 8; ++s) kf[s] = f4_load_agpr(kb + (int64_t)kr * p.k_ss + 16 * s + 8 * hi);
     for (int s = 0; s < 8; ++s) vf[s] = f4_load_agpr(vb + (int64_t)kr * p.v_ss + 16 * s + 8 * hi);
     const PosMap qm = q_map(p);
-    const int64_t k_base = pos_base(k_map(p), kbi * kD4BK);       // position of key row r of this workgroup = k_base + r
+    const PosTab qt_ = load_postab(qm);                           // (register copies of the tables: prologue only)
+    const int64_t k_base = pos_base(load_postab(k_map(p)), kbi * kD4BK);       // position of key row r of this workgroup = k_base + r
     const int64_t k_pos = k_base + k_row;
     int32_t kseg = 0;
     if (HAS_META) {
@@ -403,7 +409,7 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
     // ---- step range of the walk (steps of 64 queries; causal: skip steps wholly before this key block)
     int nst = (p.Sq + kD4BQ - 1) / kD4BQ;
     int st0 = 0;
-    if (p.causal) st0 = tiles_below(qm, kD4BQ, nst, k_base + (int64_t)kbi * kD4BK - 1);   // steps wholly before the block's key 0
+    if (p.causal) st0 = tiles_below(qt_, kD4BQ, nst, k_base + (int64_t)kbi * kD4BK - 1);   // steps wholly before the block's key 0
     if (HAS_META && p.segb_q && p.segb_k && st0 < nst) {     // packed sequences: skip other documents' query steps
         const int nbq = (p.Sq + 31) >> 5, nbk = (p.Sk + 31) >> 5;
         int smin, smax, lo, hi2;
@@ -497,14 +503,14 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
         auto clamp32 = [](int64_t x) -> int { return x > (1 << 30) ? (1 << 30) : (x < -(1 << 30) ? -(1 << 30) : (int)x); };
         // positions relative to q_start; a unit's first query (row ub of the q block) sits at rel_pos(qm, ub)
         const int k_rel = clamp32(k_pos - p.q_start) - 4 * hi;                                     // this lane's key
-        PosCursor qc = cursor_begin(qm);
+        PosCursor qc = cursor_begin(qt_);
         auto q_rel_of = [&](int ub) -> int {             // (the walk descends: a compare while the unit is inside the piece)
             cursor_seek(qm, qc, ub);
             return clamp32(qc.base + ub - p.q_start);
         };
         // positions ascend with the row: the units that begin before the wave's last key -- the ones that need the mask
         // code -- are the first mask_end rows of the q block (one compare per unit in the walk)
-        const int mask_end = p.causal ? 32 * tiles_reaching(qm, 32, (p.Sq + 31) / 32, k_base + (int64_t)kbi * kD4BK + wave * 32 + 31 - 1) : 0;
+        const int mask_end = p.causal ? 32 * tiles_reaching(qt_, 32, (p.Sq + 31) / 32, k_base + (int64_t)kbi * kD4BK + wave * 32 + 31 - 1) : 0;
         auto needs_causal = [&](int ub) -> bool { return ub < mask_end; };
         // the wave's 32 keys all valid and of one segment?  (then a step whose 64 queries carry it needs no segment test)
         const int32_t own_seg = wave_uniform(kseg);
@@ -558,6 +564,7 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
 #ifdef LWM_PROF
         unsigned long long d4p[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, d4t = __builtin_amdgcn_s_memtime();
         const unsigned long long d4t0 = d4t;
+        d4_head = d4t - d4_entry;
 #define D4_LAP(slot)                                                  \
     do {                                                              \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
@@ -640,7 +647,7 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
 #ifdef LWM_PROF
             if (!HAS_META && hb == 0 && kbi == 0 && lane == 0 && p.out_acc) {
                 d4p[10] = __builtin_amdgcn_s_memtime() - d4t0;
-                for (int j = 0; j < 12; ++j) ((unsigned long long*)p.out_acc)[wave * 12 + j] = d4p[j];
+                for (int j = 0; j < 11; ++j) ((unsigned long long*)p.out_acc)[wave * 16 + j] = d4p[j];
             }
 #endif
             for (; i < n; ++i) LWM_D4_STEP(i, false, false);
@@ -659,6 +666,9 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
 
     // ---- epilogue: scale, merge with the ring carries, store
     d4_settle_acc(dk, dv);
+#ifdef LWM_PROF
+    d4_epi = __builtin_amdgcn_s_memtime() - d4_entry;
+#endif
     if (k_ok) {
         const float ksc = p.scale;
         const int64_t krow_o = (int64_t)b * p.dk_sb + (int64_t)k_row * p.dk_ss + (int64_t)h * p.dk_sh;
@@ -690,6 +700,15 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
                 }
             }
     }
+#ifdef LWM_PROF
+    if (!HAS_META && hb == 0 && kbi == 0 && lane == 0 && p.out_acc) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the stores have left)
+        unsigned long long* o_ = (unsigned long long*)p.out_acc + wave * 16;
+        o_[11] = __builtin_amdgcn_s_memtime() - d4_entry;
+        o_[12] = d4_head;
+        o_[13] = d4_epi;
+    }
+#endif
 }
 
 LWM_KERNEL(kD4Threads) void attn_bwd_dkdv4_kernel(AttnParams p) { attn_bwd_dkdv4_body<false>(p); }
@@ -961,13 +980,14 @@ LWM_DEVICE void attn_bwd_dq4_body(const AttnParams& p) {
     cx.c = p.scale * kLog2e;
     const int32_t seg_q = (HAS_META && q_ok && p.seg_q) ? p.seg_q[(int64_t)b * p.Sq + q_row] : 0;
     const PosMap km = k_map(p);
-    const int64_t q_base = pos_base(q_map(p), qbi * kQ4BQ);       // position of query row r of this workgroup = q_base + r
+    const PosTab kt_ = load_postab(km);                           // (register copies of the tables: prologue only)
+    const int64_t q_base = pos_base(load_postab(q_map(p)), qbi * kQ4BQ);       // position of query row r of this workgroup = q_base + r
 
     // ---- key step range of the walk (steps of 64 keys; causal: up to the diagonal of the workgroup's last query)
     const int nst_all = (p.Sk + kQ4BK - 1) / kQ4BK;
     int nst = nst_all, st0 = 0;
     const int q_last = (qbi * kQ4BQ + kQ4BQ < p.Sq ? qbi * kQ4BQ + kQ4BQ : p.Sq) - 1;
-    if (p.causal) nst = tiles_reaching(km, kQ4BK, nst_all, q_base + q_last);      // up to the step of the last visible key
+    if (p.causal) nst = tiles_reaching(kt_, kQ4BK, nst_all, q_base + q_last);      // up to the step of the last visible key
     if (HAS_META && p.segb_q && p.segb_k && nst > 0) {     // packed sequences: skip other documents' key steps
         const int nbq = (p.Sq + 31) >> 5, nbk = (p.Sk + 31) >> 5;
         int smin, smax, lo, hi2;
@@ -1041,14 +1061,14 @@ LWM_DEVICE void attn_bwd_dq4_body(const AttnParams& p) {
         auto clamp32 = [](int64_t x) -> int { return x > (1 << 30) ? (1 << 30) : (x < -(1 << 30) ? -(1 << 30) : (int)x); };
         // positions relative to k_start; a unit's first key (row ub of the K/V block) sits at rel_pos(km, ub)
         const int q_rel = clamp32(q_base + q_row - p.k_start) - 4 * hi;                         // this lane's query
-        PosCursor kc = cursor_begin(km);
+        PosCursor kc = cursor_begin(kt_);
         auto k_rel_of = [&](int ub) -> int {             // (the walk ascends)
             cursor_seek(km, kc, ub);
             return clamp32(kc.base + ub - p.k_start);
         };
         // a unit needs the mask code when its last key lies after the wave's first query: positions ascend with the row,
         // so those are the units from row mask_from of the K/V block on (one compare per unit in the walk)
-        const int mask_from = p.causal ? 32 * tiles_below(km, 32, (p.Sk + 31) / 32, q_base + (int64_t)qbi * kQ4BQ + wave * 32) : 0x7fffffff;
+        const int mask_from = p.causal ? 32 * tiles_below(kt_, 32, (p.Sk + 31) / 32, q_base + (int64_t)qbi * kQ4BQ + wave * 32) : 0x7fffffff;
         auto needs_causal = [&](int ub) -> bool { return ub >= mask_from; };
         // the wave's 32 queries of one segment?  (then a step whose 64 keys carry it needs no segment test; rows past Sq
         // are never stored and do not count)

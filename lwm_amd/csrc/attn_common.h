@@ -90,37 +90,67 @@ struct PosMap {
 };
 LWM_DEVICE PosMap q_map(const AttnParams& p) { return PosMap{p.q_row, p.q_pos, p.q_np, p.Sq}; }
 LWM_DEVICE PosMap k_map(const AttnParams& p) { return PosMap{p.k_row, p.k_pos, p.k_np, p.Sk}; }
-// position of row r = pos_base(m, row0) + r for every row r of a tile that begins at row0
-LWM_DEVICE int64_t pos_base(const PosMap& m, int row0) {
-    int64_t base = m.pos[0];
-    for (int i = 1; i < m.n; ++i)
-        if (row0 >= m.row[i]) base = m.pos[i] - m.row[i];
+// The prologue's copy of a table: every entry in scalar registers, loaded by ONE clause of kernel-argument loads behind
+// one wait (the empty asm pins all 24 values at this point; left to itself hipcc loads each entry where it is first used,
+// behind its own wait and often its own branch: 46 scalar loads, 31 waits and 34 branches before a workgroup's first
+// barrier -- 3000 to 5000 cycles, 3-5 % of a 32-step walk).  Dead after the prologue: nothing of it is live in a tile loop.
+struct PosTab {
+    int32_t row[kMaxPieces];
+    int64_t pos[kMaxPieces];
+    int32_t S;
+};
+LWM_DEVICE PosTab load_postab(const PosMap& m) {
+    PosTab t;
+    t.S = m.S;
+#pragma unroll
+    for (int i = 0; i < kMaxPieces; ++i) {
+        t.row[i] = m.row[i];
+        t.pos[i] = m.pos[i];
+    }
+#ifndef LWM_EMU
+    asm volatile("" : "+s"(t.row[0]), "+s"(t.row[1]), "+s"(t.row[2]), "+s"(t.row[3]), "+s"(t.row[4]), "+s"(t.row[5]), "+s"(t.row[6]),
+                      "+s"(t.row[7]), "+s"(t.pos[0]), "+s"(t.pos[1]), "+s"(t.pos[2]), "+s"(t.pos[3]), "+s"(t.pos[4]), "+s"(t.pos[5]),
+                      "+s"(t.pos[6]), "+s"(t.pos[7]));
+#endif
+    return t;
+}
+// position of row r = pos_base(t, row0) + r for every row r of a tile that begins at row0 (unused entries: row = INT32_MAX)
+LWM_DEVICE int64_t pos_base(const PosTab& t, int row0) {
+    int64_t base = t.pos[0];
+#pragma unroll
+    for (int i = 1; i < kMaxPieces; ++i) base = row0 >= t.row[i] ? t.pos[i] - t.row[i] : base;
     return base;
 }
 // How many LEADING tiles (of `per` rows; n_tiles = ceil(S / per)) begin at a position <= P -- positions ascend with the
 // row, so those are the tiles a query at P can see a key of (or, mirrored, the query steps that lie wholly before a key
-// at P + 1 when asked with P = key - per).
-LWM_DEVICE int tiles_reaching(const PosMap& m, int per, int n_tiles, int64_t P) {
+// at P + 1 when asked with P = key - per).  Branch-free over the register copy.
+LWM_DEVICE int tiles_reaching(const PosTab& t, int per, int n_tiles, int64_t P) {
     int total = 0;
-    for (int i = 0; i < m.n; ++i) {
-        const int r0 = m.row[i], r1 = i + 1 < m.n ? m.row[i + 1] : m.S;
-        const int t_i = (r1 - r0 + per - 1) / per;
-        const int64_t p0 = m.pos[i];
-        const int64_t c = P < p0 ? 0 : (P - p0) / per + 1;
-        if (c < t_i) return total + (int)c;       // the piece is not reached to its end: the later ones lie above P
-        total += t_i;
+    bool open = true;       // every piece so far was reached to its end
+#pragma unroll
+    for (int i = 0; i < kMaxPieces; ++i) {
+        const int r0 = i == 0 ? 0 : t.row[i];
+        const int rn = i + 1 < kMaxPieces ? t.row[i + 1] : 0x7fffffff;
+        const bool live = r0 < t.S;
+        const int r1 = rn < t.S ? rn : t.S;
+        const int t_i = live ? (r1 - r0 + per - 1) / per : 0;
+        const int64_t d = P - t.pos[i];
+        const int64_t c = d < 0 ? 0 : d / per + 1;
+        const int take = (open & live) ? (int)(c < t_i ? c : t_i) : 0;
+        total += take;
+        open = open & (take == t_i);
     }
     return total < n_tiles ? total : n_tiles;
 }
 // ... whose EVERY row lies at a position <= P
-LWM_DEVICE int tiles_below(const PosMap& m, int per, int n_tiles, int64_t P) { return tiles_reaching(m, per, n_tiles, P - (per - 1)); }
+LWM_DEVICE int tiles_below(const PosTab& t, int per, int n_tiles, int64_t P) { return tiles_reaching(t, per, n_tiles, P - (per - 1)); }
 // A cursor over the pieces for a walk that moves monotonically through the rows: rows [lo, hi) sit at base + row.
 // seek() is called where a position is needed (a masked tile); it costs a compare when the row is still inside the piece.
 struct PosCursor {
     int64_t base;
     int32_t lo, hi, i;
 };
-LWM_DEVICE PosCursor cursor_begin(const PosMap& m) { return PosCursor{m.pos[0], 0, m.n > 1 ? m.row[1] : m.S, 0}; }
+LWM_DEVICE PosCursor cursor_begin(const PosTab& t) { return PosCursor{t.pos[0], 0, t.row[1] < t.S ? t.row[1] : t.S, 0}; }
 LWM_DEVICE void cursor_seek(const PosMap& m, PosCursor& c, int row) {
     while (row >= c.hi && c.i + 1 < m.n) {
         ++c.i;

@@ -470,7 +470,8 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
     int32_t seg_q[2];
     int64_t q_pos[2];
     const PosMap km = k_map(p);
-    const int64_t q_base = pos_base(q_map(p), qt * kF4BQ);       // position of row r of this workgroup = q_base + r
+    const PosTab kt_ = load_postab(km);                          // (register copies of the tables: prologue only)
+    const int64_t q_base = pos_base(load_postab(q_map(p)), qt * kF4BQ);       // position of row r of this workgroup = q_base + r
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         q_row[qb] = qt * kF4BQ + wave * 64 + 32 * qb + l31;
@@ -494,7 +495,7 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
     const int nkt_all = (p.Sk + kF4BK - 1) / kF4BK;
     int nkt = nkt_all, kt0 = 0;
     const int q_last = (qt * kF4BQ + kF4BQ < p.Sq ? qt * kF4BQ + kF4BQ : p.Sq) - 1;
-    if (p.causal) nkt = tiles_reaching(km, kF4BK, nkt_all, q_base + q_last);      // up to the tile of the last visible key
+    if (p.causal) nkt = tiles_reaching(kt_, kF4BK, nkt_all, q_base + q_last);      // up to the tile of the last visible key
     if (HAS_META && p.segb_q && p.segb_k && nkt > 0) {      // packed sequences: skip other documents' key tiles
         const int nbq = (p.Sq + 31) >> 5, nbk = (p.Sk + 31) >> 5;
         int smin, smax, lo, hi2;
@@ -513,7 +514,7 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
     // tiles this WAVE computes: [kt0, kt0 + n_w) -- its rows see nothing beyond its own diagonal tile
     int n_w = n_wg;
     if (p.causal) {
-        const int nw = tiles_reaching(km, kF4BK, nkt_all, wq_max) - kt0;
+        const int nw = tiles_reaching(kt_, kF4BK, nkt_all, wq_max) - kt0;
         n_w = nw < 0 ? 0 : (nw < n_wg ? nw : n_wg);
     }
     if (wave_uniform(qt * kF4BQ + wave * 64 >= p.Sq ? 1 : 0)) n_w = 0;    // a wave past the ragged end of Sq
@@ -567,7 +568,7 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
             }
             if (HAS_META && i + 2 < n_wg) f4_meta_stage(p, cx, b, kt0 + i + 2, (i + 2) % 3);
         };
-        PosCursor kc = cursor_begin(km);
+        PosCursor kc = cursor_begin(kt_);
         auto rel_of = [&](int rel, int (&r)[2]) {       // mask offsets of tile `rel` for the two query blocks
             const int krow0 = (kt0 + rel) * kF4BK;
             cursor_seek(km, kc, krow0);                 // (the walk ascends: a compare while the tile is inside the piece)
@@ -581,7 +582,7 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
         // another reason than causality): from tile first_mask on -- one integer compare per half step in the loop
         int first_mask = 0x7fffffff;
         if (p.causal) {
-            const int ft = tiles_below(km, kF4BK, nkt_all, wq_min) - kt0;     // the tiles before it lie wholly at or below wq_min
+            const int ft = tiles_below(kt_, kF4BK, nkt_all, wq_min) - kt0;     // the tiles before it lie wholly at or below wq_min
             first_mask = ft < 0 ? 0 : ft;
         }
         auto needs_causal = [&](int rel) -> bool { return rel >= first_mask; };

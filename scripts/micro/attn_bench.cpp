@@ -153,7 +153,10 @@ int main(int argc, char** argv) {
                 printf(" %7.1f", (double)h[w * slots + i] / cnt);
                 sum += (double)h[w * slots + i] / cnt;
             }
-            printf(" = %7.1f | %llu %llu\n", sum, h[w * slots + it_slot], h[w * slots + it_slot + 1]);
+            printf(" = %7.1f | %llu %llu", sum, h[w * slots + it_slot], h[w * slots + it_slot + 1]);
+            if (it_slot + 4 < slots)      // (dK/dV: the whole workgroup)
+                printf(" | %llu %llu %llu", h[w * slots + it_slot + 2], h[w * slots + it_slot + 3], h[w * slots + it_slot + 4]);
+            printf("\n");
         }
         CK(hipFree(prof));
     };
@@ -162,18 +165,8 @@ int main(int argc, char** argv) {
         laps(fwd, "forward, last q tile of head 0: cycles per tile iteration (phase1a, mask+toggle, phase2a, phase1b, mask, phase2b, dma wait, barrier | iterations, total)", 10, 8, 8);
     const float ms_delta = time_ms([&] { must(bdelta(&a, nullptr), "delta"); });
     if (dump > 0)
-        laps(bdkdv, "dK/dV, key block 0 of head 0: cycles per step (X0, mask, Y0, X1, mask, Y1, wait, barrier, addresses | steps, total)", 12, 9, 9);
-    // LWM_BENCH_DS=1 with a -DLWM_D4X_STOREDS build: a scratch buffer for the dS spill experiment rides in dq_acc
-    float* ds_scratch = nullptr;
-    if (getenv("LWM_BENCH_DS") && atoi(getenv("LWM_BENCH_DS"))) {
-        const size_t bytes = (size_t)H * ((S + 127) / 128) * ((S + 63) / 64) * 16384;
-        CK(hipMalloc(&ds_scratch, bytes));
-        fprintf(stderr, "dS scratch: %.1f GB\n", bytes * 1e-9);
-    }
-    float* const dq_acc_saved = a.dq_acc;
-    a.dq_acc = ds_scratch ? ds_scratch : a.dq_acc;
+        laps(bdkdv, "dK/dV, key block 0 of head 0: cycles per step (X0, mask, Y0, X1, mask, Y1, wait, barrier, addresses | steps, cycles of the pipelined steps | entry->stores done, entry->first step, entry->epilogue)", 16, 9, 9);
     const float ms_dkdv = time_ms([&] { must(bdkdv(&a, nullptr), "dkdv"); });
-    a.dq_acc = dq_acc_saved;
     const float ms_dq = time_ms([&] { must(bdq(&a, nullptr), "dq"); });
     printf("%-34s S=%d H=%d  fwd %.3f  delta %.3f  dkdv %.3f  dq %.3f ms   |dq| %.6f |dk| %.6f |dv| %.6f\n", argv[1], S, H, ms_fwd,
            ms_delta, ms_dkdv, ms_dq, checksum(dq), checksum(dk), checksum(dv));
