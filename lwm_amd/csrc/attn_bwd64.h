@@ -669,36 +669,38 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
 #ifdef LWM_PROF
     d4_epi = __builtin_amdgcn_s_memtime() - d4_entry;
 #endif
-    if (k_ok) {
-        const float ksc = p.scale;
-        const int64_t krow_o = (int64_t)b * p.dk_sb + (int64_t)k_row * p.dk_ss + (int64_t)h * p.dk_sh;
-        const int64_t vrow_o = (int64_t)b * p.dv_sb + (int64_t)k_row * p.dv_ss + (int64_t)h * p.dv_sh;
-        const int64_t arow = (((int64_t)b * p.Sk + k_row) * p.H + h) * kHeadDim;
-        for (int db = 0; db < 4; ++db)
-            for (int rq = 0; rq < 4; ++rq) {
-                const int d0 = 32 * db + 8 * rq + 4 * hi;
-                float k0 = dk[db][4 * rq + 0] * ksc, k1 = dk[db][4 * rq + 1] * ksc;
-                float k2 = dk[db][4 * rq + 2] * ksc, k3 = dk[db][4 * rq + 3] * ksc;
-                float v0 = dv[db][4 * rq + 0], v1 = dv[db][4 * rq + 1];
-                float v2 = dv[db][4 * rq + 2], v3 = dv[db][4 * rq + 3];
-                if (p.carry_in) {
-                    const float* ka = p.dk_acc + arow + d0;
-                    const float* va = p.dv_acc + arow + d0;
-                    k0 += ka[0]; k1 += ka[1]; k2 += ka[2]; k3 += ka[3];
-                    v0 += va[0]; v1 += va[1]; v2 += va[2]; v3 += va[3];
-                }
-                if (p.final_out) {
-                    global_store_b64(p.dk + krow_o + d0, u32x2{pack_bf16x2(k0, k1), pack_bf16x2(k2, k3)});
-                    global_store_b64(p.dv + vrow_o + d0, u32x2{pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)});
-                } else {
-                    global_store_b128(p.dk_acc + arow + d0,
-                                      u32x4{__builtin_bit_cast(uint32_t, k0), __builtin_bit_cast(uint32_t, k1),
-                                            __builtin_bit_cast(uint32_t, k2), __builtin_bit_cast(uint32_t, k3)});
-                    global_store_b128(p.dv_acc + arow + d0,
-                                      u32x4{__builtin_bit_cast(uint32_t, v0), __builtin_bit_cast(uint32_t, v1),
-                                            __builtin_bit_cast(uint32_t, v2), __builtin_bit_cast(uint32_t, v3)});
+    // The tiles leave as whole rows (attn_common.h, "epilogue staging"): the walk is over for every wave behind the
+    // barrier, so the tile slots are free; a wave passes dK^T, then dV^T through its own 16.5 KiB of them.
+    block_sync_lds();
+    {
+        const lds_t tb = lds + (uint32_t)wave * kEpiTileBytes;
+        const int col = (lane & 31) * 4;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            if (which) wave_lds_fence();        // (dK^T's rows have been read)
+            epi_tile_write(tb, which ? dv : dk, which ? 1.0f : p.scale, l31, hi);
+            wave_lds_fence();
+            float* const acc_base = which ? p.dv_acc : p.dk_acc;
+            bf16_t* const out_base = which ? p.dv : p.dk;
+            const int64_t o_sb = which ? p.dv_sb : p.dk_sb, o_ss = which ? p.dv_ss : p.dk_ss, o_sh = which ? p.dv_sh : p.dk_sh;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                f32x4 x = epi_tile_read(tb, i, lane);
+                const int row = kbi * kD4BK + wave * 32 + 2 * i + (lane >> 5);
+                if (row < p.Sk) {
+                    const int64_t arow = (((int64_t)b * p.Sk + row) * p.H + h) * kHeadDim + col;
+                    if (p.carry_in) {
+                        const f32x4 c = global_load_f32x4(acc_base + arow);
+                        x[0] += c[0]; x[1] += c[1]; x[2] += c[2]; x[3] += c[3];
+                    }
+                    if (p.final_out)
+                        global_store_b64(out_base + (int64_t)b * o_sb + (int64_t)row * o_ss + (int64_t)h * o_sh + col,
+                                         u32x2{pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])});
+                    else
+                        global_store_f32x4(acc_base + arow, x);
                 }
             }
+        }
     }
 #ifdef LWM_PROF
     if (!HAS_META && hb == 0 && kbi == 0 && lane == 0 && p.out_acc) {

@@ -252,6 +252,28 @@ LWM_DEVICE bf16x8 cvt_frag(const f32x16& x, int base) {
     return o;
 }
 
+// ---- epilogue staging.  A wave's 32 x 128 f32 result tile sits in its C/D fragments with one ROW per lane pair: lane
+// (l31, hi) holds, for d block db and register quad rq, the four columns 32 db + 8 rq + 4 hi + 0..3 of row l31 -- stored
+// from there a wave instruction touches 32 rows x 32 bytes (8.9 k cycles for the 128 KiB of a dK/dV workgroup's f32
+// partials).  Through LDS the tile leaves as whole rows: written at a row stride of 528 bytes (16 bytes of padding: the
+// 16 lanes of a ds_write_b128 pass hit 16 x 4 distinct banks), read back two rows per instruction -- lanes 0..31 the 512
+// contiguous bytes of row 2 i, lanes 32..63 of row 2 i + 1.  Same values, same roundings: only the order of the stores.
+constexpr int kEpiRowBytes = kHeadDim * 4 + 16;
+constexpr int kEpiTileBytes = 32 * kEpiRowBytes;       // 16 896 B per wave
+LWM_DEVICE void epi_tile_write(lds_t tb, const f32x16 (&acc)[4], float scale, int l31, int hi) {
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+            lds_write_f32x4(tb + (uint32_t)(l31 * kEpiRowBytes + (32 * db + 8 * rq + 4 * hi) * 4),
+                            f32x4{acc[db][4 * rq + 0] * scale, acc[db][4 * rq + 1] * scale, acc[db][4 * rq + 2] * scale,
+                                  acc[db][4 * rq + 3] * scale});
+}
+// read instruction i (0..15): row 2 i + (lane >> 5) of the tile, columns 4 (lane & 31) + 0..3
+LWM_DEVICE f32x4 epi_tile_read(lds_t tb, int i, int lane) {
+    return lds_read_f32x4(tb + (uint32_t)((2 * i + (lane >> 5)) * kEpiRowBytes + (lane & 31) * 16));
+}
+
 // ---- packed sequences: narrow a tile loop to the tiles whose segment range can meet
 // the workgroup's own.  `blk` = (min,max) per 32-row block of the OTHER operand (one batch
 // row), a tile = `per` consecutive blocks; the workgroup's own range is [smin, smax].

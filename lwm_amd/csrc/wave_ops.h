@@ -58,6 +58,13 @@ LWM_DEVICE void block_sync_lds() {
     asm volatile("" ::: "memory");
 }
 
+// Orders one wave's LDS accesses among its own lanes (a wave's private staging area: written by some lanes, read by
+// others).  The LDS queue of a wave is in order, so this is a compiler fence only.
+LWM_DEVICE void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // D = A(32x16) * B(16x32) + C(32x32), bf16 in / f32 accumulate.
 //   A: lane l holds A[row = l&31][k = 8*(l>>5) + j], j = 0..7
 //   B: lane l holds B[k = 8*(l>>5) + j][col = l&31]

@@ -208,6 +208,7 @@ LWM_DEVICE int grid_dim_x() { return emu::g_blk->gx; }
 LWM_DEVICE lds_t dyn_lds() { return emu::kLdsBase; }
 LWM_DEVICE void block_sync() { emu::block_barrier(); }
 LWM_DEVICE void block_sync_lds() { emu::block_barrier(); }
+LWM_DEVICE void wave_lds_fence() { emu::wave_sync(); }
 
 LWM_DEVICE f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
     emu::Wave& w = emu::g_blk->waves[emu::g_lane->tid >> 6];
