@@ -740,6 +740,47 @@ def fail_line(args, stage, err, extra=None):
     traceback.print_exception(type(err), err, err.__traceback__, file=sys.stderr)
 
 
+class Watchdog:
+    """A hang becomes a diagnosable line.  The ring exchange has met RCCL on one GPU and real processes over the IPC
+    transport, never several GPUs: a stuck peer exchange there would block every rank inside a stream wait or a collective,
+    where no exception can reach it.  While a stage is armed, a timer thread that finds it unfinished after `seconds` prints
+    the {"error": ...} line (rank 0 on stdout, the others on stderr only) and leaves the process without waiting for the
+    GPU -- the launcher then ends the job instead of the driver's clock."""
+
+    def __init__(self, args, seconds):
+        self.args, self.seconds, self.limit, self.timer, self.stage, self.on_fire = args, seconds, seconds, None, None, None
+
+    def arm(self, stage, seconds=None, on_fire=None):
+        """on_fire(stage, error) -> exit code replaces the error line (a stage after which the line's value exists)"""
+        import threading
+        self.disarm()
+        self.stage, self.on_fire, self.limit = stage, on_fire, seconds or self.seconds
+        self.timer = threading.Timer(self.limit, self._fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+        self.timer = None
+
+    def _fire(self):
+        err = TimeoutError(f"stage '{self.stage}' did not finish within {self.limit:.0f} s on this rank "
+                           f"(LWM_BENCH_WATCHDOG_S sets the limit; --driver python takes the torch.distributed ring)")
+        if self.on_fire is not None:
+            code = 7
+            try:
+                code = self.on_fire(self.stage, err)
+                sys.stdout.flush()
+            finally:
+                os._exit(code)
+        if int(os.environ.get("RANK", "0")) == 0:
+            fail_line(self.args, "watchdog: " + self.stage, err)
+        else:
+            print(f"[bench] rank {os.environ.get('RANK')}: {err}", file=sys.stderr, flush=True)
+        os._exit(7)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -886,6 +927,9 @@ def main():
 
     c_ring = None
     sched_c = "ring" if args.schedule == "ring" else "direct"
+    dog = Watchdog(args, float(os.environ.get("LWM_BENCH_WATCHDOG_S", "600")))
+    if world > 1:
+        dog.arm(f"ring set-up and first layer ({args.driver} driver, {args.backend})")
     S2 = 131072                     # BASELINE configs[2]'s sequence: a second leg of every N > 1 line
     if args.driver == "c" and world > 1:
         from lwm_amd.ring_c import CRing
@@ -969,6 +1013,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    if world > 1:
+        dog.arm("warm-up and timed steps")
+    def all_ranks_ok(ok):
+        """a collective every rank enters whatever happened on it before: one rank's failure (an allocation, say) must
+        skip a leg everywhere instead of leaving the others inside the leg's exchange"""
+        if world == 1:
+            return bool(ok)
+        vote = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if shared else dev)
+        dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+        return int(vote.item()) == 1
+
     for _ in range(args.warmup):
         step()
     barrier()
@@ -979,7 +1034,64 @@ def main():
         step()
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
+    dog.disarm()
     sent_timed = (c_ring.bytes_sent - sent_before) if c_ring is not None else 0
+    exchange = configs2 = configs3 = configs4 = None
+
+    def main_line():
+        """the line as far as it is known: the timed region is over when this is first called; the secondary
+        configurations of an N > 1 run are whatever they are at that moment (the watchdog may call it early)"""
+        ms_per_step = elapsed * 1e3 / args.steps
+        tokens_per_s = S * args.steps / elapsed
+        unit = gemm_unit_flops(S) if doc_sq is None else doc_sq * D_MODEL   # visible pairs only when packed
+        algo_flops_step = 7.0 * unit * args.layers
+        res = {
+            "metric": "tokens/sec fwd+bwd, LWM-7B RingAttention hot path (32 layers x 32 heads x 128)",
+            "value": tokens_per_s,
+            "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "bf16 (f32 logits/softmax/accumulate)",
+            "data": "synthetic N(0,1) q/k/v/dO, seed 1234, resident in HBM",
+            "config": {
+                "workload": (f"LWM-7B attention fwd+bwd, {args.layers} layers, B=1, S={S}, H=32, D=128, "
+                             f"causal, ring={world}" + (f", layout={layout.kind}" if world > 1 else "")
+                             + (f", masked packing ({len(lens)} documents)" if args.packed else "")
+                             + (" [BASELINE configs[1]]" if world == 1 and S == 32768 and not args.packed else "")
+                             + (" [BASELINE configs[2] problem]" if world > 1 and S == 131072 else "")
+                             + (" [BASELINE configs[1] problem, ring-sharded]" if world > 1 and S == 32768 else "")),
+                "seq_len": S, "ring": world, "layers": args.layers,
+                "exchange_schedule": (f"{sched_c} (C-ABI driver, {args.transport} on a side stream)" if c_ring is not None else
+                                      getattr(comm, "schedule", None)) if world > 1 else None,
+            },
+            "tokens_per_s_per_gpu": tokens_per_s / world,
+            "exchange": exchange,
+            "configs2": configs2,
+            "configs3": configs3,
+            "configs4": configs4,
+            "driver_fallback": driver_fallback,
+            "rccl_ranks_seen": rccl_ranks_seen,
+            "bootstrap_ranks_seen": ranks_seen if world > 1 else None,
+            "bootstrap_backend": dist.get_backend() if world > 1 else None,
+            "dry_run": ("ranks share devices, messages staged through host memory; timings are not xGMI" if dry else
+                        "ranks share devices (IPC transport inside one GPU); timings are not xGMI" if shared and world > 1 else None),
+            "path_algorithmic_tflops_per_gpu": algo_flops_step / (ms_per_step * 1e-3) / 1e12 / world,
+        }
+        return res
+
+    if world > 1:
+        # From here on the line's value exists: a secondary configuration that hangs must not cost it.  Rank 0 prints the
+        # line as far as it is known and every rank leaves with code 0.
+        def late(stage, err):
+            if rank == 0:
+                print(json.dumps(dict(main_line(), secondary_legs_error={"stage": stage, "message": str(err)})), flush=True)
+            return 0
+        dog.arm("secondary configurations of the N > 1 line (configs2 / configs3 / configs4)",
+                float(os.environ.get("LWM_BENCH_WATCHDOG_LATE_S", "900")), on_fire=late)
+
 
     exchange = None
     if world > 1:
@@ -1048,12 +1160,20 @@ def main():
     if world > 1 and not args.no_configs2 and S != S2 and not args.packed:
         # BASELINE configs[2] (S = 131072 over the ring) at THIS N, in the same line: `value` stays the S = 32768 strong-scaling
         # series, this object is the configuration the metric names.
+        err2, ten2 = None, None
         try:
             lay2 = SeqLayout(args.layout, world, S2)
             c2 = lay2.local_len
             g2 = torch.Generator(device=dev).manual_seed(4321 + rank)
             ten2 = [torch.randn(1, c2, N_HEADS, HEAD_DIM, generator=g2, device=dev, dtype=torch.float32).to(torch.bfloat16)
                     for _ in range(4)]
+        except Exception as e:      # noqa: BLE001
+            err2 = repr(e)[:500]
+        if not all_ranks_ok(err2 is None):
+            ten2 = None
+            configs2 = {"error": err2 or "the set-up failed on another rank", "skipped_on_every_rank": True}
+    if world > 1 and not args.no_configs2 and S != S2 and not args.packed and configs2 is None:
+        try:
             sent0 = c_ring.bytes_sent if c_ring is not None else None
             step(ten=ten2, lay=lay2)
             barrier()
@@ -1073,8 +1193,14 @@ def main():
                               "bytes_sent_per_rank_per_step": (c_ring.bytes_sent - sent0) / (n2 + 1)} if c_ring is not None
                              else {"schedule": getattr(comm, "schedule", None)}),
             }
-            del ten2
-            # the same problem on one GPU, one layer
+        except Exception as e:      # noqa: BLE001 -- a secondary leg must not cost the line
+            configs2 = dict(configs2 or {}, error=repr(e)[:500])
+        ten2 = None
+        torch.cuda.empty_cache()
+        # the same problem on one GPU, one layer: local work on every rank (no collective inside the guarded part; a dry
+        # run with N ranks on ONE GPU may not have room for N copies of it)
+        err1, tl, t1 = None, 0.0, None
+        try:
             g1 = torch.Generator(device=dev).manual_seed(98)
             t1 = [torch.randn(1, S2, N_HEADS, HEAD_DIM, generator=g1, device=dev, dtype=torch.float32).to(torch.bfloat16)
                   for _ in range(4)]
@@ -1089,14 +1215,20 @@ def main():
             t0 = time.perf_counter()
             one_layer2()
             torch.cuda.synchronize()
-            tl = max_over_ranks(time.perf_counter() - t0)
+            tl = time.perf_counter() - t0
+        except Exception as e:      # noqa: BLE001
+            err1 = repr(e)[:500]
+        t1 = None
+        torch.cuda.empty_cache()
+        ok1 = all_ranks_ok(err1 is None)
+        tl = max_over_ranks(tl)
+        if ok1 and "tokens_per_s" in configs2:
             tps1 = S2 / (tl * args.layers)
             configs2["same_problem_on_1_gpu"] = {"ms_per_layer": tl * 1e3, "tokens_per_s": tps1,
                                                  "speedup": configs2["tokens_per_s"] / tps1,
                                                  "strong_scaling_efficiency": configs2["tokens_per_s"] / tps1 / world}
-            del t1
-        except Exception as e:
-            configs2 = dict(configs2 or {}, error=repr(e))
+        elif not ok1:
+            configs2["same_problem_on_1_gpu"] = {"error": err1 or "failed on another rank"}
 
     def other_config(tag, Sx, layers_x, packed_docs):
         """One more configuration of BASELINE.json in the same N > 1 line: the sequence ring at S = Sx over these N GPUs,
@@ -1161,46 +1293,11 @@ def main():
         torch.cuda.empty_cache()
         configs4 = other_config("configs[4]", 1 << 20, 2, True)
 
+    dog.disarm()
     if rank == 0:
-        ms_per_step = elapsed * 1e3 / args.steps
-        tokens_per_s = S * args.steps / elapsed
-        unit = gemm_unit_flops(S) if doc_sq is None else doc_sq * D_MODEL   # visible pairs only when packed
-        algo_flops_step = 7.0 * unit * args.layers
-        res = {
-            "metric": "tokens/sec fwd+bwd, LWM-7B RingAttention hot path (32 layers x 32 heads x 128)",
-            "value": tokens_per_s,
-            "unit": "tokens/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "bf16 (f32 logits/softmax/accumulate)",
-            "data": "synthetic N(0,1) q/k/v/dO, seed 1234, resident in HBM",
-            "config": {
-                "workload": (f"LWM-7B attention fwd+bwd, {args.layers} layers, B=1, S={S}, H=32, D=128, "
-                             f"causal, ring={world}" + (f", layout={layout.kind}" if world > 1 else "")
-                             + (f", masked packing ({len(lens)} documents)" if args.packed else "")
-                             + (" [BASELINE configs[1]]" if world == 1 and S == 32768 and not args.packed else "")
-                             + (" [BASELINE configs[2] problem]" if world > 1 and S == 131072 else "")
-                             + (" [BASELINE configs[1] problem, ring-sharded]" if world > 1 and S == 32768 else "")),
-                "seq_len": S, "ring": world, "layers": args.layers,
-                "exchange_schedule": (f"{sched_c} (C-ABI driver, {args.transport} on a side stream)" if c_ring is not None else
-                                      getattr(comm, "schedule", None)) if world > 1 else None,
-            },
-            "tokens_per_s_per_gpu": tokens_per_s / world,
-            "exchange": exchange,
-            "configs2": configs2,
-            "configs3": configs3,
-            "configs4": configs4,
-            "driver_fallback": driver_fallback,
-            "rccl_ranks_seen": rccl_ranks_seen,
-            "bootstrap_ranks_seen": ranks_seen if world > 1 else None,
-            "bootstrap_backend": dist.get_backend() if world > 1 else None,
-            "dry_run": ("ranks share devices, messages staged through host memory; timings are not xGMI" if dry else
-                        "ranks share devices (IPC transport inside one GPU); timings are not xGMI" if shared and world > 1 else None),
-            "path_algorithmic_tflops_per_gpu": algo_flops_step / (ms_per_step * 1e-3) / 1e12 / world,
-        }
+        res = main_line()
+        ms_per_step = res["ms_per_step"]
+        unit = gemm_unit_flops(S) if doc_sq is None else doc_sq * D_MODEL
         if world == 1:
             ks = timer.summary()
             res["kernels"] = ks

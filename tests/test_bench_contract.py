@@ -109,3 +109,28 @@ def test_bench_cli_contract_without_a_gpu():
     for flag in ("--gpus", "--steps", "--warmup", "--driver", "--transport", "--schedule", "--layout", "--no-configs2",
                  "--no-configs34", "--no-packed-1m"):
         assert flag in h.stdout
+
+
+def test_bench_watchdog_turns_a_hang_into_an_error_line():
+    """A stage of the N > 1 path that never returns (a stuck peer exchange cannot raise) ends the process with the
+    {"error": ...} line on rank 0's stdout, a note on the other ranks' stderr, and exit code 7."""
+    body = ("import sys, time, argparse; sys.path.insert(0, %r); import bench; "
+            "d = bench.Watchdog(argparse.Namespace(gpus=2, steps=1, warmup=0), 0.3); d.arm('quick stage'); d.disarm(); "
+            "d.arm('stuck stage'); time.sleep(30)" % ROOT)
+    for rank in ("0", "1"):
+        env = dict(os.environ, RANK=rank, WORLD_SIZE="2")
+        r = subprocess.run([sys.executable, "-c", body], capture_output=True, text=True, env=env, timeout=120)
+        assert r.returncode == 7
+        lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+        if rank == "0":
+            assert len(lines) == 1 and lines[0]["value"] is None
+            assert lines[0]["error"]["stage"] == "watchdog: stuck stage" and lines[0]["error"]["type"] == "TimeoutError"
+        else:
+            assert not lines and "stuck stage" in r.stderr
+    # a stage after which the line's value exists: the callback prints what is known and chooses the exit code
+    body = ("import sys, time, json, argparse; sys.path.insert(0, %r); import bench; "
+            "d = bench.Watchdog(argparse.Namespace(gpus=2, steps=1, warmup=0), 60.0); "
+            "d.arm('late stage', 0.3, on_fire=lambda stage, err: (print(json.dumps({'value': 1.0, 'late': stage})), 0)[1]); "
+            "time.sleep(30)" % ROOT)
+    r = subprocess.run([sys.executable, "-c", body], capture_output=True, text=True, env=dict(os.environ, RANK="0"), timeout=120)
+    assert r.returncode == 0 and json.loads(r.stdout.strip()) == {"value": 1.0, "late": "late stage"}
