@@ -357,34 +357,51 @@ LWM_DEVICE void d4_drain(const D4Ctx& cx, D4Regs& rg, f32x16 (&dk)[4], f32x16 (&
 }
 
 // The epilogue of a key block: the wave's dK^T (scaled) and dV^T tiles, rows row0 .. row0 + 31 of (b, h), through the
-// wave's 16 KiB of LDS at tb (free of other readers and writers: the caller's barrier), merged with the ring carries,
-// stored as whole rows -- bf16 results or f32 partials.
+// wave's LDS staging tile at tb (attn_common.h, "epilogue staging"; free of other readers and writers: the caller's
+// barrier), merged with the ring carries, stored as whole rows -- bf16 results or f32 partials.  Everything the 32 store
+// instructions share is read and computed ONCE (kernel arguments, the lane's first address of each buffer, the
+// strides): left inside the row loop, hipcc re-read carry_in / final_out / Sk behind a wait per row and rebuilt the
+// 64-bit address products -- 15 k cycles per key block (s_memtime), five times the data movement.
 LWM_DEVICE void d4_store_tiles(const AttnParams& p, lds_t tb, const f32x16 (&dk)[4], const f32x16 (&dv)[4], int b, int h,
                                int row0, int lane) {
     const int l31 = lane & 31, hi = lane >> 5, col = l31 * 4;
+    const int Sk = p.Sk;
+    const bool carry = p.carry_in != 0, fin = p.final_out != 0;
+    const int rows = Sk - (row0 + hi);                              // this lane stores rows row0 + hi + 2 i while 2 i < rows
+    const int64_t acc0 = ((((int64_t)b * Sk + row0 + hi) * p.H + h) * kHeadDim + col) * 4;       // bytes
+    const int64_t acc_step = (int64_t)2 * p.H * kHeadDim * 4;
 #pragma unroll
     for (int which = 0; which < 2; ++which) {
         if (which) wave_lds_fence();        // (dK^T's rows have been read)
         epi_tile_write(tb, which ? dv : dk, which ? 1.0f : p.scale, l31, hi);
         wave_lds_fence();
-        float* const acc_base = which ? p.dv_acc : p.dk_acc;
-        bf16_t* const out_base = which ? p.dv : p.dk;
-        const int64_t o_sb = which ? p.dv_sb : p.dk_sb, o_ss = which ? p.dv_ss : p.dk_ss, o_sh = which ? p.dv_sh : p.dk_sh;
+        char* ap = (char*)(which ? p.dv_acc : p.dk_acc) + acc0;
+        const int64_t o_ss = which ? p.dv_ss : p.dk_ss;
+        char* op = (char*)((which ? p.dv : p.dk) + (int64_t)b * (which ? p.dv_sb : p.dk_sb) + (int64_t)(row0 + hi) * o_ss +
+                           (int64_t)h * (which ? p.dv_sh : p.dk_sh) + col);
+        const int64_t out_step = 2 * o_ss * 2;
+        if (fin && !carry) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            f32x4 x = epi_tile_read(tb, i, lane);
-            const int row = row0 + 2 * i + hi;
-            if (row < p.Sk) {
-                const int64_t arow = (((int64_t)b * p.Sk + row) * p.H + h) * kHeadDim + col;
-                if (p.carry_in) {
-                    const f32x4 c = global_load_f32x4(acc_base + arow);
+            for (int i = 0; i < 16; ++i) {
+                const f32x4 x = epi_tile_read(tb, i, lane);
+                if (2 * i < rows) global_store_b64(op + i * out_step, u32x2{pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])});
+            }
+        } else if (!fin && !carry) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const f32x4 x = epi_tile_read(tb, i, lane);
+                if (2 * i < rows) global_store_f32x4((float*)(ap + i * acc_step), x);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                f32x4 x = epi_tile_read(tb, i, lane);
+                if (2 * i < rows) {
+                    const f32x4 c = global_load_f32x4((const float*)(ap + i * acc_step));
                     x[0] += c[0]; x[1] += c[1]; x[2] += c[2]; x[3] += c[3];
+                    if (fin) global_store_b64(op + i * out_step, u32x2{pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])});
+                    else global_store_f32x4((float*)(ap + i * acc_step), x);
                 }
-                if (p.final_out)
-                    global_store_b64(out_base + (int64_t)b * o_sb + (int64_t)row * o_ss + (int64_t)h * o_sh + col,
-                                     u32x2{pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])});
-                else
-                    global_store_f32x4(acc_base + arow, x);
             }
         }
     }
@@ -719,330 +736,8 @@ LWM_DEVICE void attn_bwd_dkdv4_body(const AttnParams& p) {
 }
 
 
-// ====================================================================================================== dK/dV, chained
-// The same walk with the key blocks of a workgroup CHAINED (no key meta, Sq a multiple of 64: api.inc chooses).  A key
-// block on its own pays, beside its steps, a head -- kernel arguments, K / V fragments and two staged steps behind one
-// exposed memory latency, 10-12 k cycles -- that nothing hides: one workgroup fits a CU.  On the 32-step walks of a ring
-// shard that is a tenth of the block.  Here a launch has as many workgroups as the device has CUs, and workgroup w walks
-// the blocks w, w + G, w + 2 G, ... of the launch's block order (odd rounds mirrored inside their XCD, so that walks that
-// shorten with the block index add up to the same length everywhere) as ONE pipeline:
-//   * the staging stream runs two steps ahead of the walk ACROSS blocks: the last two steps of a block stage the first
-//     two of the next one (empty blocks skipped), every step of the walk is a staging step;
-//   * the next block's K / V fragments are requested where the walk of the current one ends -- the registers are dead
-//     from there on -- and land under its drain and epilogue;
-//   * the epilogue passes the tiles through the two slots the walk has just left (attn_common.h, "epilogue staging");
-//     the two ahead of it already hold the next block's first steps.
-// Per block that leaves the drain, the epilogue and some scalar arithmetic.  Results are bit-identical to the
-// one-block-per-workgroup kernel (same products in the same order).
-LWM_DEVICE void attn_bwd_dkdv4_chain_body(const AttnParams& p) {
-#ifdef LWM_PROF
-    unsigned long long c4p[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, c4t = __builtin_amdgcn_s_memtime();
-    const unsigned long long c4t0 = c4t;
-#define C4_LAP(slot)                                                  \
-    do {                                                              \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-        c4p[slot] += now_ - c4t;                                      \
-        c4t = now_;                                                   \
-    } while (0)
-#else
-#define C4_LAP(slot)
-#endif
-    const lds_t lds = dyn_lds();
-    const int tid = thread_idx();
-    const int wave = wave_uniform(tid >> 6), lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-    // Everything a block switch needs is derived again from the kernel arguments where it is needed (`again`): only the
-    // stream's pointers and the walk's counters are live in the tile loop.
-
-    // the block of round r of this workgroup (launch order: all key blocks of one (b,h) on one XCD, longest walks first)
-    auto block_of = [&](const AttnParams& a, int r, int& hb, int& kbi) -> bool {
-        const int nkb = (a.Sk + kD4BK - 1) / kD4BK, HB = a.H * a.B;
-        const int G = grid_dim_x(), w = block_idx_x();
-        const bool xcd_map = (HB & 7) == 0;
-        const int w_flip = (xcd_map && (G & 7) == 0) ? ((((G >> 3) - 1 - (w >> 3)) << 3) | (w & 7)) : G - 1 - w;
-        const int v = r * G + ((r & 1) ? w_flip : w);
-        if (v >= nkb * HB) return false;
-        if (xcd_map) {
-            const int i = v >> 3;
-            hb = (v & 7) + 8 * (i / nkb);
-            kbi = i % nkb;
-        } else {
-            hb = v / nkb;
-            kbi = v % nkb;
-        }
-        return true;
-    };
-    // its walk: steps nst - 1 down to nst - n (causal: the steps wholly before the block's key 0 are not walked)
-    auto walk_of = [&](const AttnParams& a, int kbi, int64_t& k_base) -> int {
-        const int nst = a.Sq / kD4BQ;
-        k_base = pos_base(load_postab(k_map(a)), kbi * kD4BK);
-        const int st0 = a.causal ? tiles_below(load_postab(q_map(a)), kD4BQ, nst, k_base + (int64_t)kbi * kD4BK - 1) : 0;
-        return nst > st0 ? nst - st0 : 0;
-    };
-    // a block nobody sees: zeros (or the carries) leave from the registers
-    auto store_empty = [&](const AttnParams& a, int hb, int kbi) {
-        const int b = hb / a.H, h = hb % a.H;
-        const int row = kbi * kD4BK + wave * 32 + l31;
-        if (row >= a.Sk) return;
-        const int64_t arow = (((int64_t)b * a.Sk + row) * a.H + h) * kHeadDim;
-        for (int which = 0; which < 2; ++which) {
-            float* const acc_base = which ? a.dv_acc : a.dk_acc;
-            bf16_t* const out_row = which ? a.dv + (int64_t)b * a.dv_sb + (int64_t)row * a.dv_ss + (int64_t)h * a.dv_sh
-                                          : a.dk + (int64_t)b * a.dk_sb + (int64_t)row * a.dk_ss + (int64_t)h * a.dk_sh;
-            for (int c = 64 * hi; c < 64 * hi + 64; c += 4) {
-                f32x4 x = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                if (a.carry_in) x = global_load_f32x4(acc_base + arow + c);
-                if (a.final_out) global_store_b64(out_row + c, u32x2{pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])});
-                else global_store_f32x4(acc_base + arow + c, x);
-            }
-        }
-    };
-
-    // ---- the staging stream: the next step to stage (pointers walk down inside a block, then move to the top of the
-    // next non-empty one; exhausted: a valid address is staged again, into a slot nobody will read)
-    int rs = -1, s_rem = 0;
-    const char *q_src2 = nullptr, *do_src2 = nullptr, *st_src2 = nullptr;
-    int64_t q_dec = 0, do_dec = 0;
-    int st_dec = 0;
-    auto stream_block = [&]() {
-        const AttnParams& a = again(p);
-        const int64_t Sqp = bwd_stat_pad(a.Sq);
-        const int nst = a.Sq / kD4BQ;
-        for (;;) {
-            ++rs;
-            int hb_, kbi_;
-            if (!block_of(a, rs, hb_, kbi_)) {
-                q_src2 = (const char*)a.q;
-                do_src2 = (const char*)a.dout;
-                st_src2 = (const char*)(a.delta + (wave == 1 ? Sqp : 0));
-                q_dec = do_dec = 0;
-                st_dec = 0;
-                s_rem = 0x3fffffff;
-                return;
-            }
-            int64_t kb_;
-            const int n_ = walk_of(a, kbi_, kb_);
-            if (n_ == 0) continue;
-            const int b_ = hb_ / a.H, h_ = hb_ % a.H;
-            q_dec = (int64_t)kD4BQ * a.q_ss * 2;
-            do_dec = (int64_t)kD4BQ * a.do_ss * 2;
-            st_dec = kD4BQ * 4;
-            q_src2 = (const char*)(a.q + (int64_t)b_ * a.q_sb + (int64_t)h_ * a.q_sh) + (int64_t)(nst - 1) * q_dec;
-            do_src2 = (const char*)(a.dout + (int64_t)b_ * a.do_sb + (int64_t)h_ * a.do_sh) + (int64_t)(nst - 1) * do_dec;
-            st_src2 = (const char*)(a.delta + bwd_stat_row((int64_t)b_ * a.H + h_, Sqp) + (wave == 1 ? Sqp : 0)) +
-                      (int64_t)(nst - 1) * kD4BQ * 4;
-            s_rem = n_;
-            return;
-        }
-    };
-    const bool stat_on = wave < 2;
-    const lds_t stat_dst = lds + kD4OffStat + (uint32_t)(wave < 2 ? wave : 0) * kD4BQ * 4;
-    const uint32_t vstat = (uint32_t)lane * 4;
-    uint32_t vq[4], vdo[4];
-    d4_stage_offsets(p, wave, lane, 0, vq, vdo);      // full steps: nothing is clamped
-
-    D4Ctx cx;
-    cx.hi = hi;
-    cx.c = p.scale * kLog2e;
-    for (int s = 0; s < 8; ++s) cx.qa[s] = lds + tile_off(l31, 2 * s + hi);
-    {
-        const TrFragAddr t = frag_tr_addr(lds, lane);
-        for (int db = 0; db < 4; ++db) {
-            cx.tlo[db] = t.lo[db];
-            cx.tup[db] = t.up[db];
-            cx.plo[db] = t.lo[db];
-            cx.pup[db] = t.up[db];
-        }
-    }
-    cx.stat = lds + kD4OffStat + 16 * hi;
-    auto clamp32 = [](int64_t x) -> int { return x > (1 << 30) ? (1 << 30) : (x < -(1 << 30) ? -(1 << 30) : (int)x); };
-
-    // ---- the first block with a walk (the empty ones before it are stored on the way)
-    int rc = 0, hb = 0, kbi = 0, n = 0;
-    int64_t k_base = 0;
-    auto next_block = [&](int r_from) -> bool {
-        const AttnParams& a = again(p);
-        for (rc = r_from;; ++rc) {
-            if (!block_of(a, rc, hb, kbi)) return false;
-            n = walk_of(a, kbi, k_base);
-            if (n > 0) return true;
-            store_empty(a, hb, kbi);
-        }
-    };
-    if (!next_block(0)) return;
-    bf16x8 kf[8], vf[8];
-    auto request_fragments = [&]() {       // this lane's key of block (hb, kbi): fragments straight into the accumulator file
-        const AttnParams& a = again(p);
-        const int b = hb / a.H, h = hb % a.H;
-        const int k_row = kbi * kD4BK + wave * 32 + l31;
-        const int kr = k_row < a.Sk ? k_row : a.Sk - 1;       // (a row past Sk re-reads the last row: never stored)
-        const bf16_t* kb = a.k + (int64_t)b * a.k_sb + (int64_t)h * a.k_sh + (int64_t)kr * a.k_ss + 8 * hi;
-        const bf16_t* vb = a.v + (int64_t)b * a.v_sb + (int64_t)h * a.v_sh + (int64_t)kr * a.v_ss + 8 * hi;
-        for (int s = 0; s < 8; ++s) kf[s] = f4_load_agpr(kb + 16 * s);
-        for (int s = 0; s < 8; ++s) vf[s] = f4_load_agpr(vb + 16 * s);
-    };
-    request_fragments();
-    // prologue: the stream's first two steps -> slots 0 and 1
-    for (int j = 0; j < 2; ++j) {
-        if (s_rem == 0) stream_block();
-        const lds_t dst = lds + j * kD4SlotBytes + (uint32_t)wave * 1024;
-        if (stat_on) glds_load_b32(st_src2 + (int64_t)lane * 4, stat_dst + j * kD4StatBytes);
-        f4_dma<4>(vq, q_src2, dst);
-        f4_dma<4>(vdo, do_src2, dst + kD4TileBytes);
-        q_src2 -= q_dec;
-        do_src2 -= do_dec;
-        st_src2 -= st_dec;
-        --s_rem;
-    }
-    f4_load_agpr_wait8(kf);      // vmcnt(0): everything requested so far
-    f4_load_agpr_wait8(vf);
-    block_sync();
-    C4_LAP(6);      // (head of the chain)
-
-    D4Regs rg;
-    D4Dma dm = {};
-    int g = 0;                   // steps walked so far: step g lives in slot g & 3
-    for (;;) {
-        // ---- this block's masks (see attn_bwd_dkdv4_body)
-        int ub, mask_end, k_rel;
-        PosCursor qc;
-        {
-            const AttnParams& a = again(p);
-            const PosTab qt_ = load_postab(q_map(a));
-            const int k_row = kbi * kD4BK + wave * 32 + l31;
-            k_rel = clamp32(k_base + k_row - a.q_start) - 4 * hi;
-            qc = cursor_begin(qt_);
-            mask_end = a.causal ? 32 * tiles_reaching(qt_, 32, (a.Sq + 31) / 32, k_base + (int64_t)kbi * kD4BK + wave * 32 + 31 - 1) : 0;
-            ub = (a.Sq / kD4BQ - 1) * kD4BQ;
-        }
-        const PosMap qm = q_map(p);
-        auto q_rel_of = [&](int ub_) -> int {
-            cursor_seek(qm, qc, ub_);
-            return clamp32(qc.base + ub_ - p.q_start);
-        };
-        auto needs_causal = [&](int ub_) -> bool { return ub_ < mask_end; };
-        auto rel_of = [&](int ub_) -> int {
-            if (!p.causal) return -64;
-            const int64_t d = (int64_t)k_rel - q_rel_of(ub_);
-            return d > 64 ? 64 : (d < -64 ? -64 : (int)d);
-        };
-        rg.s = zero_f32x16();
-        rg.dp[0] = zero_f32x16();
-        rg.dp[1] = zero_f32x16();
-        for (int r = 0; r < 16; ++r) {
-            rg.nl[r] = 0.0f;
-            rg.t[r] = 0.0f;
-            rg.ds[r] = 0.0f;
-        }
-        for (int t = 0; t < 2; ++t) {
-            rg.pb[t] = zero_bf16x8();
-            rg.dsb[t] = zero_bf16x8();
-        }
-        for (int j = 0; j < 8; ++j) rg.fr[j] = zero_bf16x8();
-        // the first unit's fragments and -delta (every later unit finds them requested by the unit before it)
-        for (int j = 0; j < kD4Ahead; ++j) rg.fr[j] = d4_frag<0>(cx, j);
-        for (int q4 = 0; q4 < 4; ++q4) d4_load_ndelta<0>(cx.stat, rg.dp[0], q4);
-        f32x16 dk[4], dv[4];       // defined by the first products of the walk (d4_y<.., INIT>)
-
-#define LWM_D4C_MASK(HALF_, HAS_PREV_, ub_)                                           \
-    do {                                                                              \
-        if (!(HAS_PREV_)) d4_settle_t(rg.s);                                          \
-        if (needs_causal(ub_)) {                                                      \
-            if (HAS_PREV_) d4_settle_t(rg.s);                                         \
-            d4_mask<HALF_, false>(cx, rg, rel_of(ub_), 0);                            \
-        }                                                                             \
-    } while (0)
-        // step g of the workgroup (= step `ub / 64` of this block): see LWM_D4_STEP; every step stages the stream's next one
-#define LWM_D4C_STEP(FIRST)                                                                                         \
-    do {                                                                                                            \
-        if (s_rem == 0) {                                                                                           \
-            C4_LAP(1);                                                                                              \
-            stream_block();                                                                                         \
-            C4_LAP(2);                                                                                              \
-        }                                                                                                           \
-        if (stat_on) d4_dma_b32(vstat, st_src2, stat_dst + ((g + 2) & 3) * kD4StatBytes);                           \
-        dm.q_src = q_src2;                                                                                          \
-        dm.do_src = do_src2;                                                                                        \
-        dm.dst = lds + ((g + 2) & 3) * kD4SlotBytes + (uint32_t)wave * 1024;                                        \
-        q_src2 -= q_dec;                                                                                            \
-        do_src2 -= do_dec;                                                                                          \
-        st_src2 -= st_dec;                                                                                          \
-        --s_rem;                                                                                                    \
-        const uint32_t d_ = ((g & 3) == 3) ? (uint32_t)(-3 * kD4SlotBytes) : (uint32_t)kD4SlotBytes;                \
-        const uint32_t e_ = ((g & 3) == 3) ? (uint32_t)(-3 * kD4StatBytes) : (uint32_t)kD4StatBytes;                \
-        d4_x<0, !(FIRST), true>(cx, rg, kf, vf, vq, vdo, dm);                                                       \
-        LWM_D4C_MASK(0, !(FIRST), ub);                                                                              \
-        d4_y<0, !(FIRST), true, false>(cx, rg, dk, dv, cx.stat);                                                    \
-        d4_x<1, true, false>(cx, rg, kf, vf, vq, vdo, dm);                                                          \
-        for (int s_ = 0; s_ < 8; ++s_) cx.qa[s_] += d_;                                                             \
-        LWM_D4C_MASK(1, true, ub + 32);                                                                             \
-        d4_y<1, true, true, FIRST>(cx, rg, dk, dv, cx.stat + e_);                                                   \
-        ub -= kD4BQ;                                                                                                \
-        if (FIRST) d4_settle_acc(dk, dv);                                                                           \
-        glds_wait_all();                                                                                            \
-        block_sync_lds();                                                                                           \
-        for (int db_ = 0; db_ < 4; ++db_) {                                                                         \
-            cx.plo[db_] = cx.tlo[db_];                                                                              \
-            cx.pup[db_] = cx.tup[db_];                                                                              \
-            cx.tlo[db_] += d_;                                                                                      \
-            cx.tup[db_] += d_;                                                                                      \
-        }                                                                                                           \
-        cx.stat += e_;                                                                                              \
-        ++g;                                                                                                        \
-    } while (0)
-
-        C4_LAP(0);      // (block start: masks, first fragments)
-        LWM_D4C_STEP(true);
-        for (int i = 1; i < n; ++i) LWM_D4C_STEP(false);
-        C4_LAP(1);      // (the walk)
-#undef LWM_D4C_STEP
-#undef LWM_D4C_MASK
-        d4_settle_acc(dk, dv);      // (the loop's exit merges paths)
-
-        // ---- the block that follows: its fragments are requested now (kf / vf are dead: the drain multiplies P and dS
-        // by LDS fragments) and land under the drain and the epilogue
-        const int hb_done = hb, kbi_done = kbi;
-        const bool more = next_block(rc + 1);
-        if (more) request_fragments();
-        C4_LAP(5);
-
-        // the last unit's products: its tiles are the second half of the PREVIOUS slot now (the registers moved on)
-        d4_drain<1>(cx, rg, dk, dv);
-        d4_settle_acc(dk, dv);
-        C4_LAP(4);
-
-        // ---- epilogue through the two slots the walk has left: (g - 2) & 3 for waves 0 and 1, (g - 1) & 3 for waves 2 and 3
-        block_sync_lds();
-        {
-            const AttnParams& a = again(p);
-            const int bd = hb_done / a.H, hd = hb_done % a.H;
-            const lds_t tb = lds + (uint32_t)((g + 2 + (wave >> 1)) & 3) * kD4SlotBytes + (uint32_t)(wave & 1) * kEpiTileBytes;
-            d4_store_tiles(a, tb, dk, dv, bd, hd, kbi_done * kD4BK + wave * 32, lane);
-        }
-        C4_LAP(3);
-#ifdef LWM_PROF
-        c4p[9] += 1;
-#endif
-        if (!more) break;
-        f4_load_agpr_wait8(kf);      // vmcnt(0)
-        f4_load_agpr_wait8(vf);
-        block_sync_lds();            // (the next step stages into a slot the epilogue has just read)
-        C4_LAP(7);      // (fragments landed, barrier)
-    }
-#ifdef LWM_PROF
-    // laps per block of workgroup LWM_PROF_WG's chain: 0 block start, 1 walk, 2 stream switch, 3 epilogue, 4 drain, 5 next block +
-    // fragment requests, 6 head of the chain, 7 fragment wait + barrier; 9 blocks, 10 total cycles, 11 steps
-    if (block_idx_x() == 0 && lane == 0 && p.out_acc) {
-        c4p[10] = __builtin_amdgcn_s_memtime() - c4t0;
-        c4p[11] = (unsigned long long)g;
-        for (int j = 0; j < 16; ++j) ((unsigned long long*)p.out_acc)[wave * 16 + j] = c4p[j];
-    }
-#endif
-#undef C4_LAP
-}
-
 LWM_KERNEL(kD4Threads) void attn_bwd_dkdv4_kernel(AttnParams p) { attn_bwd_dkdv4_body<false>(p); }
 LWM_KERNEL(kD4Threads) void attn_bwd_dkdv4_meta_kernel(AttnParams p) { attn_bwd_dkdv4_body<true>(p); }
-LWM_KERNEL(kD4Threads) void attn_bwd_dkdv4_chain_kernel(AttnParams p) { attn_bwd_dkdv4_chain_body(p); }
 
 
 // ====================================================================================================== dQ

@@ -80,24 +80,6 @@ struct AttnParams {
     const int32_t* segb_k;
 };
 
-// The kernel arguments again, through an offset the optimiser cannot see through (it is 0): loads behind it stay where
-// they are written.  hipcc hoists loads of kernel arguments out of every loop and keeps the values in scalar registers
-// from the top of the kernel on; a kernel whose outer loop needs sixty of them once per key block spills them across its
-// tile loop.  `p` must be the kernel's FIRST argument (the kernarg segment begins with it); the pointer keeps the
-// constant address space up to the cast, so the loads stay scalar loads.
-LWM_DEVICE const AttnParams& again(const AttnParams& p) {
-#ifdef LWM_EMU
-    return p;
-#else
-    int z = 0;
-    asm volatile("" : "+s"(z));
-    const __attribute__((address_space(4))) char* k =
-        (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_amdgcn_readfirstlane(z);
-    (void)p;
-    return *(const AttnParams*)k;
-#endif
-}
-
 // ---- position maps (see AttnParams): everything below is wave-uniform scalar arithmetic over the piece tables in the
 // kernel arguments, read with scalar loads where they are needed (prologue; the rare masked tile) -- nothing of them
 // stays in registers across the tile loops.
@@ -273,25 +255,23 @@ LWM_DEVICE bf16x8 cvt_frag(const f32x16& x, int base) {
 // ---- epilogue staging.  A wave's 32 x 128 f32 result tile sits in its C/D fragments with one ROW per lane pair: lane
 // (l31, hi) holds, for d block db and register quad rq, the four columns 32 db + 8 rq + 4 hi + 0..3 of row l31 -- stored
 // from there a wave instruction touches 32 rows x 32 bytes (8.9 k cycles for the 128 KiB of a dK/dV workgroup's f32
-// partials, and partial-line writes: 4.77 GB of HBM traffic per full-size launch instead of 3.83).  Through LDS the tile
-// leaves as whole rows: 16 KiB per wave, row r at r * 512 with its 16-byte column c at physical column c ^ r (the 16
-// lanes of a ds_write_b128 / ds_read_b128 pass hit 16 x 4 distinct banks both ways), read back two rows per instruction
-// -- lanes 0..31 the 512 contiguous bytes of row 2 i, lanes 32..63 of row 2 i + 1.  Same values, same roundings: only the
-// order of the stores.
-constexpr int kEpiTileBytes = 32 * kHeadDim * 4;       // 16 KiB per wave
+// partials).  Through LDS the tile leaves as whole rows: written at a row stride of 528 bytes (16 bytes of padding: the
+// 16 lanes of a ds_write_b128 pass hit 16 x 4 distinct banks), read back two rows per instruction -- lanes 0..31 the 512
+// contiguous bytes of row 2 i, lanes 32..63 of row 2 i + 1.  Same values, same roundings: only the order of the stores.
+constexpr int kEpiRowBytes = kHeadDim * 4 + 16;
+constexpr int kEpiTileBytes = 32 * kEpiRowBytes;       // 16 896 B per wave
 LWM_DEVICE void epi_tile_write(lds_t tb, const f32x16 (&acc)[4], float scale, int l31, int hi) {
 #pragma unroll
     for (int db = 0; db < 4; ++db)
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq)
-            lds_write_f32x4(tb + (uint32_t)(l31 * (kHeadDim * 4) + (((8 * db + 2 * rq + hi) ^ l31) << 4)),
+            lds_write_f32x4(tb + (uint32_t)(l31 * kEpiRowBytes + (32 * db + 8 * rq + 4 * hi) * 4),
                             f32x4{acc[db][4 * rq + 0] * scale, acc[db][4 * rq + 1] * scale, acc[db][4 * rq + 2] * scale,
                                   acc[db][4 * rq + 3] * scale});
 }
 // read instruction i (0..15): row 2 i + (lane >> 5) of the tile, columns 4 (lane & 31) + 0..3
 LWM_DEVICE f32x4 epi_tile_read(lds_t tb, int i, int lane) {
-    const int row = 2 * i + (lane >> 5);
-    return lds_read_f32x4(tb + (uint32_t)(row * (kHeadDim * 4) + (((lane & 31) ^ row) << 4)));
+    return lds_read_f32x4(tb + (uint32_t)((2 * i + (lane >> 5)) * kEpiRowBytes + (lane & 31) * 16));
 }
 
 // ---- packed sequences: narrow a tile loop to the tiles whose segment range can meet

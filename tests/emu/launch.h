@@ -18,12 +18,7 @@ inline int zero_device(void* p, size_t bytes, void* stream) {
     memset(p, 0, bytes);
     return 0;
 }
-// a few "XCDs" worth of persistent workgroups; LWM_EMU_CUS plays another device (chained kernels: rounds, mirrored rounds)
-inline long device_cu_count() {
-    const char* e = getenv("LWM_EMU_CUS");
-    const long n = e ? atol(e) : 24;
-    return n > 0 ? n : 24;
-}
+inline long device_cu_count() { return 24; }   // a few "XCDs" worth of persistent workgroups
 
 template <class... KArgs, class... Args>
 inline int launch(const char* name, void (*kernel)(KArgs...), long grid, int threads,

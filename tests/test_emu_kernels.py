@@ -322,73 +322,3 @@ def test_two_piece_maps_are_validated():
     a.lse, a.delta, a.delta_bytes, a.final_out = lse.ctypes.data, small.ctypes.data, small.nbytes, 1
     assert L.lwm_attn_bwd_delta(C.byref(a), None) == _capi.LWM_EINVAL and b"lwm_attn_bwd_delta_bytes" in L.lwm_last_error()
     assert L.lwm_attn_bwd_dq(C.byref(a), None) == _capi.LWM_EINVAL
-
-
-def _chain_case(monkeypatch, cus, B, H, Sq, Sk, causal, q_start, k_start, carry, final, k_piece2=None, q_piece2=None):
-    monkeypatch.setenv("LWM_EMU_CUS", str(cus))
-    q, k, v, do = (_rnd((B, Sq, H, 128), 61), _rnd((B, Sk, H, 128), 62), _rnd((B, Sk, H, 128), 63), _rnd((B, Sq, H, 128), 64))
-    kw = dict(causal=causal, q_start=q_start, k_start=k_start, q_piece2=q_piece2, k_piece2=k_piece2)
-    out, lse = _emu.attn_fwd(q, k, v, **kw)
-    c = None
-    if carry:
-        rng = np.random.default_rng(65)
-        c = tuple(_emu.aligned(s, np.float32) for s in ((B, Sq, H, 128), (B, Sk, H, 128), (B, Sk, H, 128)))
-        for a in c:
-            a[...] = rng.standard_normal(a.shape).astype(np.float32)
-        c0 = tuple(a.copy() for a in c)
-    got = _emu.attn_bwd(q, k, v, out, lse, do, carry=c, final=final, **kw)
-    got = tuple(np.array(g, dtype=np.float32, copy=True) for g in got)
-    return (q, k, v, do, kw, (c0 if carry else None)), got
-
-
-@pytest.mark.parametrize("name,B,H,Sq,Sk,causal,q_start,k_start,carry,final", [
-    ("causal, 3 heads x 6 key blocks", 1, 3, 768, 768, True, 0, 0, False, True),
-    ("8 slices: XCD-mirrored rounds", 2, 4, 256, 512, True, 256, 0, False, True),
-    ("f32 partials with carries", 1, 2, 256, 640, True, 384, 0, True, False),
-    ("bf16 results with carries, ragged last key block", 1, 2, 128, 300, False, 0, 0, True, True),
-    ("key blocks nobody sees + one-step walks", 1, 2, 256, 768, True, 0, 192, False, False),
-])
-def test_emulated_dkdv_chain(monkeypatch, name, B, H, Sq, Sk, causal, q_start, k_start, carry, final):
-    """The chained dK/dV kernel (whole steps of 64 queries, no key meta): workgroups that walk several key blocks as one
-    pipeline -- the staging stream crossing blocks (and empty blocks), fragments requested at the end of a walk, the
-    epilogue in the two slots the walk has left -- against the oracle, and bit for bit the same whatever the number of
-    workgroups: 1 (every block of the launch in ONE chain), 3 (odd: mirrored rounds without XCDs), 8 (mirrored inside
-    XCDs when the slices are a multiple of 8), 24."""
-    ref = None
-    for cus in (1, 3, 8, 24):
-        (q, k, v, do, kw, c0), got = _chain_case(monkeypatch, cus, B, H, Sq, Sk, causal, q_start, k_start, carry, final)
-        if ref is None:
-            rq, rk, rv = R.dense_attention_bwd(q, k, v, do, causal=causal, q_start=q_start, k_start=k_start)
-            if carry:
-                rq, rk, rv = rq + c0[0], rk + c0[1], rv + c0[2]
-            for a, r in zip(got, (rq, rk, rv)):
-                assert _rel(a, r) < 1e-2, name
-            ref = got
-        else:
-            for a, r in zip(got, ref):
-                assert np.array_equal(a, r), (name, cus)
-
-
-def test_emulated_dkdv_chain_with_piecewise_maps(monkeypatch):
-    """... and under piecewise position maps (the gathered form of the ring: a low query stops at the run its position
-    reaches, key blocks of the far run have short or empty walks)."""
-    B, H, Sq, Sk = 1, 2, 512, 1024
-    ref = None
-    for cus in (1, 3, 24):
-        # queries: rows 0..255 at positions 256.., rows 256.. at 1792..; keys: rows 0..511 at 0.., rows 512.. at 1024..
-        (q, k, v, do, kw, _), got = _chain_case(monkeypatch, cus, B, H, Sq, Sk, True, 256, 0, False, False,
-                                                q_piece2=(256, 1792), k_piece2=(512, 1024))
-        if ref is None:
-            qpos = np.concatenate([256 + np.arange(256), 1792 + np.arange(256)])
-            kpos = np.concatenate([np.arange(512), 1024 + np.arange(512)])
-            n = 2048
-            present = np.zeros((1, n), np.uint8)
-            present[:, kpos] = 1
-            rq, rk, rv = R.dense_attention_bwd(_embed(q, qpos, n), _embed(k, kpos, n), _embed(v, kpos, n), _embed(do, qpos, n),
-                                               causal=True, key_valid=present)
-            for a, r in zip(got, (rq[:, qpos], rk[:, kpos], rv[:, kpos])):
-                assert _rel(a, r) < 1e-2
-            ref = got
-        else:
-            for a, r in zip(got, ref):
-                assert np.array_equal(a, r), cus
