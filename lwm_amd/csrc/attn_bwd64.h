@@ -1193,26 +1193,36 @@ LWM_DEVICE void attn_bwd_dq4_body(const AttnParams& p) {
 
     // ---- epilogue: scale, merge with the ring carry, store (one query row per lane)
     d4_settle_acc4(dq);
+    // (what the 16 stores share is read once and the three cases are three loops: left inside one loop, hipcc re-read
+    // carry_in / final_out behind a wait per store -- see d4_store_tiles)
     if (q_ok) {
-        const int64_t orow = (int64_t)b * p.dq_sb + (int64_t)q_row * p.dq_ss + (int64_t)h * p.dq_sh;
-        const int64_t arow = (int64_t)b * p.dqa_sb + (int64_t)q_row * p.dqa_ss + (int64_t)h * p.dqa_sh;
-        for (int db = 0; db < 4; ++db)
-            for (int rq = 0; rq < 4; ++rq) {
-                const int d0 = 32 * db + 8 * rq + 4 * hi;
-                float o0 = dq[db][4 * rq + 0] * p.scale, o1 = dq[db][4 * rq + 1] * p.scale;
-                float o2 = dq[db][4 * rq + 2] * p.scale, o3 = dq[db][4 * rq + 3] * p.scale;
-                if (p.carry_in) {
-                    const float* a = p.dq_acc + arow + d0;
-                    o0 += a[0]; o1 += a[1]; o2 += a[2]; o3 += a[3];
+        const bool carry = p.carry_in != 0, fin = p.final_out != 0;
+        const float sc = p.scale;
+        bf16_t* const op = p.dq + (int64_t)b * p.dq_sb + (int64_t)q_row * p.dq_ss + (int64_t)h * p.dq_sh + 4 * hi;
+        float* const ap = p.dq_acc + (int64_t)b * p.dqa_sb + (int64_t)q_row * p.dqa_ss + (int64_t)h * p.dqa_sh + 4 * hi;
+        if (fin && !carry) {
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq)
+                    global_store_b64(op + 32 * db + 8 * rq, u32x2{pack_bf16x2(dq[db][4 * rq + 0] * sc, dq[db][4 * rq + 1] * sc),
+                                                                  pack_bf16x2(dq[db][4 * rq + 2] * sc, dq[db][4 * rq + 3] * sc)});
+        } else {
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int d0 = 32 * db + 8 * rq;
+                    float o0 = dq[db][4 * rq + 0] * sc, o1 = dq[db][4 * rq + 1] * sc;
+                    float o2 = dq[db][4 * rq + 2] * sc, o3 = dq[db][4 * rq + 3] * sc;
+                    if (carry) {
+                        const f32x4 a = global_load_f32x4(ap + d0);
+                        o0 += a[0]; o1 += a[1]; o2 += a[2]; o3 += a[3];
+                    }
+                    if (fin) global_store_b64(op + d0, u32x2{pack_bf16x2(o0, o1), pack_bf16x2(o2, o3)});
+                    else global_store_f32x4(ap + d0, f32x4{o0, o1, o2, o3});
                 }
-                if (p.final_out) {
-                    global_store_b64(p.dq + orow + d0, u32x2{pack_bf16x2(o0, o1), pack_bf16x2(o2, o3)});
-                } else {
-                    global_store_b128(p.dq_acc + arow + d0,
-                                      u32x4{__builtin_bit_cast(uint32_t, o0), __builtin_bit_cast(uint32_t, o1),
-                                            __builtin_bit_cast(uint32_t, o2), __builtin_bit_cast(uint32_t, o3)});
-                }
-            }
+        }
     }
 }
 

@@ -762,6 +762,7 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
     if (n_wg <= 0) f4_load_agpr_wait(qf);      // (no walk: the fragments are unused, their loads are not left in flight)
     // ---- epilogue: normalise, merge with the ring carry, store (per query block)
     f4_settle_acc(acc);
+    const bool carry = p.carry_in != 0, fin = p.final_out != 0;
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const float l_tot = cx.lsum[qb] + xhalf(cx.lsum[qb]);
@@ -772,7 +773,7 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
         }
         float w_a = 0.0f, w_b = 1.0f, lse_new = lse_b;
         const int64_t lse_idx = ((int64_t)b * p.H + h) * p.Sq + q_row[qb];
-        if (p.carry_in && q_ok[qb]) {
+        if (carry && q_ok[qb]) {
             const float lse_a = p.lse_acc[lse_idx];
             const float mxl = fmaxf(lse_a, lse_b);
             if (mxl == -INFINITY) {
@@ -787,28 +788,37 @@ LWM_DEVICE void attn_fwd64_body(const AttnParams& p) {
             }
         }
         if (q_ok[qb]) {
+            // (what the 16 stores share is read once and the common case is its own loop: left inside one loop, hipcc
+            // re-read carry_in / final_out behind a wait per store -- attn_bwd64.h, d4_store_tiles)
             const float sc = inv * w_b;
-            const int64_t orow = (int64_t)b * p.o_sb + (int64_t)q_row[qb] * p.o_ss + (int64_t)h * p.o_sh;
-            const int64_t arow = (((int64_t)b * p.Sq + q_row[qb]) * p.H + h) * kHeadDim;   // the f32 carry is dense [B,Sq,H,D]
-            for (int db = 0; db < 4; ++db)
-                for (int rq = 0; rq < 4; ++rq) {
-                    const int d0 = 32 * db + 8 * rq + 4 * hi;
-                    float o0 = acc[qb][db][4 * rq + 0] * sc, o1 = acc[qb][db][4 * rq + 1] * sc;
-                    float o2 = acc[qb][db][4 * rq + 2] * sc, o3 = acc[qb][db][4 * rq + 3] * sc;
-                    if (p.carry_in) {
-                        const float* a = p.out_acc + arow + d0;
-                        o0 += a[0] * w_a; o1 += a[1] * w_a; o2 += a[2] * w_a; o3 += a[3] * w_a;
+            bf16_t* const op = p.out + (int64_t)b * p.o_sb + (int64_t)q_row[qb] * p.o_ss + (int64_t)h * p.o_sh + 4 * hi;
+            float* const ap = p.out_acc + (((int64_t)b * p.Sq + q_row[qb]) * p.H + h) * kHeadDim + 4 * hi;   // the f32 carry is dense [B,Sq,H,D]
+            if (fin && !carry) {
+#pragma unroll
+                for (int db = 0; db < 4; ++db)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq)
+                        global_store_b64(op + 32 * db + 8 * rq,
+                                         u32x2{pack_bf16x2(acc[qb][db][4 * rq + 0] * sc, acc[qb][db][4 * rq + 1] * sc),
+                                               pack_bf16x2(acc[qb][db][4 * rq + 2] * sc, acc[qb][db][4 * rq + 3] * sc)});
+            } else {
+#pragma unroll
+                for (int db = 0; db < 4; ++db)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const int d0 = 32 * db + 8 * rq;
+                        float o0 = acc[qb][db][4 * rq + 0] * sc, o1 = acc[qb][db][4 * rq + 1] * sc;
+                        float o2 = acc[qb][db][4 * rq + 2] * sc, o3 = acc[qb][db][4 * rq + 3] * sc;
+                        if (carry) {
+                            const f32x4 a = global_load_f32x4(ap + d0);
+                            o0 += a[0] * w_a; o1 += a[1] * w_a; o2 += a[2] * w_a; o3 += a[3] * w_a;
+                        }
+                        if (fin) global_store_b64(op + d0, u32x2{pack_bf16x2(o0, o1), pack_bf16x2(o2, o3)});
+                        else global_store_f32x4(ap + d0, f32x4{o0, o1, o2, o3});
                     }
-                    if (p.final_out) {
-                        global_store_b64(p.out + orow + d0, u32x2{pack_bf16x2(o0, o1), pack_bf16x2(o2, o3)});
-                    } else {
-                        global_store_b128(p.out_acc + arow + d0,
-                                          u32x4{__builtin_bit_cast(uint32_t, o0), __builtin_bit_cast(uint32_t, o1),
-                                                __builtin_bit_cast(uint32_t, o2), __builtin_bit_cast(uint32_t, o3)});
-                    }
-                }
+            }
             if (hi == 0) {
-                if (p.final_out) p.lse[lse_idx] = lse_new;
+                if (fin) p.lse[lse_idx] = lse_new;
                 else p.lse_acc[lse_idx] = lse_new;
             }
         }
