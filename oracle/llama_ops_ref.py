@@ -1,8 +1,11 @@
 """CPU oracle for RoPE and RMSNorm -- TEST INFRASTRUCTURE, NOT PRODUCT.
 
-Restates lwm/llama.py:320-375 in numpy.  PARITY UNPINNED (jax cannot be imported
-here, the reference ships no vectors); the restatement follows the in-tree source
-line by line, float32 where the reference computes in float32, and float64 variants
+Restates lwm/llama.py:320-375 in numpy.  PINNED (round 5) to a run of the reference's own lines:
+tests/golden/gen_ref_run_golden.py executes precompute_freqs_cis, apply_rotary_emb and RMSNorm._norm / __call__ where they lie
+in /root/reference (numpy standing in for the jax.numpy names they use) and commits tests/golden/ref_run.npz;
+tests/test_golden.py holds precompute_freqs_cis / apply_rotary_emb below to those vectors bit for bit and rmsnorm to 4 f32
+ulps (the mean of squares is taken in float64 here).  XLA's own rounding is not pinned (jax cannot be imported here).  The
+cross-entropy below restates tux (absent): unpinned.  float32 where the reference computes in float32; float64 variants
 are provided for gradient checks.
 """
 import numpy as np

@@ -3,8 +3,11 @@
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this module.  Nothing under lwm_amd/ does.
 
-PARITY UNPINNED (see oracle/vqgan_ref.c): lwm/vqgan.py is flax code that cannot
-be executed here (the encoder + quantiser are checked against HF transformers'
+PARITY UNPINNED for the networks (see oracle/vqgan_ref.c); the QUANTISER is pinned (round 5) to a run of the
+reference's own VectorQuantizer.__call__ (lwm/vqgan.py:192-221 executed where it lies with numpy standing in for
+jax.numpy: tests/golden/gen_ref_run_golden.py -> tests/golden/ref_run.npz; vq_argmin / vq_gather below reproduce its
+indices, its lookup and its straight-through forward value exactly, tests/test_golden.py).  The rest of lwm/vqgan.py is
+flax code that cannot be executed here (the encoder + quantiser are checked against HF transformers'
 ChameleonVQVAE and the decoder network against HF's JanusVQVAEDecoder, third-party
 implementations of the same architecture: tests/golden/gen_hf_vqvae_golden.py,
 tests/test_golden.py); the arithmetic primitives are restated in C (libvqgan_ref.so,
