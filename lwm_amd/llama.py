@@ -135,6 +135,24 @@ def _dense(i, o, std, dtype):
     return torch.nn.Parameter(torch.randn(i, o, dtype=torch.float32).mul_(std).to(dtype))
 
 
+def key_padding_bias(attention_mask):
+    """lwm/llama.py:527-537: the (B, S_global) key mask as the additive bias the blockwise branch hands to ringattention,
+    (B,1,1,S_global) with 0 where attention_mask > 0 and finfo.min elsewhere."""
+    B, S = attention_mask.shape
+    return torch.where(attention_mask.reshape(B, 1, 1, S) > 0, 0.0, torch.finfo(torch.float32).min)
+
+
+def cached_visibility(B, Q, max_len, q0, attention_mask, device):
+    """lwm/llama.py:574-592 with a cache present: key j of the max_len cache rows is visible to query i of the block iff
+    j <= q0 + i (q0 = cache_index, plus the block's offset when the update is sharded) and attention_mask[b, j] > 0
+    (attention_mask: (B, >= max_len) or None).  -> (B,1,Q,max_len) bool."""
+    ar = torch.arange(max_len, device=device)
+    mask = (ar[None, :] <= (torch.arange(Q, device=device) + q0)[:, None])[None, None].expand(B, 1, Q, max_len)
+    if attention_mask is not None:
+        mask = mask & (attention_mask[:, None, None, :max_len] > 0)
+    return mask
+
+
 class LLaMAAttention(torch.nn.Module):
     """FlaxLLaMAAttention.__call__, training branch (lwm/llama.py:494-570, :616-617)."""
 
@@ -159,8 +177,7 @@ class LLaMAAttention(torch.nn.Module):
             if attention_mask.shape[-1] != S * n_sp:
                 raise ValueError(f"attention_mask covers {attention_mask.shape[-1]} positions; the sequence ring "
                                  f"needs the global length {S * n_sp} (= local {S} x sp {n_sp}) on every rank")
-            m = attention_mask.reshape(B, 1, 1, S * n_sp)
-            bias = torch.where(m > 0, 0.0, torch.finfo(torch.float32).min)
+            bias = key_padding_bias(attention_mask.reshape(B, S * n_sp))
         out = ringattention(xq, xk, xv.contiguous(), bias, segment_ids, axis_name="sp", float32_logits=True,
                             cache_idx=None,
                             blockwise_kwargs=dict(causal_block_size=1, deterministic=True, attn_pdrop=0.0,
@@ -193,13 +210,10 @@ class LLaMAAttention(torch.nn.Module):
             kvld = None if attention_mask is None else attention_mask[:, :max_len]
             return ringattention_inference(xq.contiguous(), ck, cv, None, axis_name="sp", causal_offset=idx,
                                            key_valid=kvld)
-        ar = torch.arange(max_len, device=xq.device)
         # a sharded prefill block (Q > 1) holds the queries [r*Q, (r+1)*Q) of the update; a decode query
         # is replicated (lwm/llama.py:599)
         q0 = idx + (r_sp * Q if Q > 1 else 0)
-        mask = (ar[None, :] <= (torch.arange(Q, device=xq.device) + q0)[:, None])[None, None].expand(B, 1, Q, max_len)
-        if attention_mask is not None:
-            mask = mask & (attention_mask[:, None, None, :max_len] > 0)
+        mask = cached_visibility(B, Q, max_len, q0, attention_mask, xq.device)
         cache["cache_index"] = concatenate_to_cache(ck, cv, xk.contiguous(), xv, idx, axis_name="sp")
         return ringattention_inference(xq.contiguous(), ck, cv, mask, axis_name="sp")
 

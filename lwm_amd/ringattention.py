@@ -122,6 +122,15 @@ def sp_all_reduce_sum(t, axis_name="sp"):
     return t
 
 
+def key_valid_from_bias(attn_bias):
+    """The additive key-padding bias of lwm/llama.py:527-537 -- (B,1,1,S_global), 0 where attention_mask > 0 and
+    finfo(dtype).min elsewhere (-3.4028e38 at fp32, -3.3895e38 at bf16) -- back to the key mask it was made from, which is
+    what the kernels evaluate: (B, S_global) uint8."""
+    if attn_bias.dim() != 4 or attn_bias.shape[1] != 1 or attn_bias.shape[2] != 1:
+        raise ValueError("attn_bias must be (B,1,1,S_global) as built at lwm/llama.py:527-537")
+    return (attn_bias[:, 0, 0, :].float() > -1e30).to(torch.uint8).contiguous()
+
+
 def ringattention(q, k, v, attn_bias, segment_ids, axis_name="sp", float32_logits=True,
                   cache_idx=None, blockwise_kwargs=None, layout=None):
     """q,k,v: local (B, S/sp, H, D) bf16 shards.  attn_bias: (B,1,1,S_global)
@@ -142,11 +151,7 @@ def ringattention(q, k, v, attn_bias, segment_ids, axis_name="sp", float32_logit
     if not float32_logits:
         # logits are always f32 here; float32_logits=False would only lower precision
         pass
-    key_valid = None
-    if attn_bias is not None:
-        if attn_bias.dim() != 4 or attn_bias.shape[1] != 1 or attn_bias.shape[2] != 1:
-            raise ValueError("attn_bias must be (B,1,1,S_global) as built at lwm/llama.py:527-537")
-        key_valid = (attn_bias[:, 0, 0, :].float() > -1e30).to(torch.uint8).contiguous()
+    key_valid = None if attn_bias is None else key_valid_from_bias(attn_bias)
     if layout is None:
         layout = sp_layout(axis_name, q.shape[1])
     return ring_attention(q, k, v, group=_resolve_axis(axis_name), causal=cbs == 1,

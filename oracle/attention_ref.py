@@ -30,6 +30,11 @@ That pins the dense semantics, not the JAX package's blockwise order of operatio
 and anchors parity on the structural identities the reference's own code
 implies: blockwise == dense branch, ring n == ring 1, packed == per-segment.
 
+PINNED since round 5: the MASK.  tests/golden/gen_ref_run_golden.py executes the reference's own mask statements
+(lwm/llama.py:425, :527-537, :572-592, where they lie, numpy standing in for jax.numpy) and commits the visibility they
+produce (tests/golden/ref_run.npz); visible_mask() / decode_mask() below reproduce it pair by pair
+(tests/test_golden.py::test_mask_oracle_reproduces_the_reference_run).  The softmax-attention ARITHMETIC stays unpinned.
+
 Layouts follow the reference: q,k,v,out are (B, S, H, D) (heads split by
 reshape, lwm/llama.py:434-438); segment_ids (B, S); key-padding mask (B, S).
 Rows with no visible key are defined to give out = 0, lse = -inf (the reference
@@ -107,7 +112,7 @@ def dense_attention(q, k, v, *, causal=True, q_start=0, k_start=0, seg_q=None, s
 
 
 def dense_attention_bwd(q, k, v, dout, *, causal=True, q_start=0, k_start=0, seg_q=None,
-                        seg_k=None, key_valid=None, scale=None, dtype=np.float64, out_saved=None):
+                        seg_k=None, key_valid=None, scale=None, dtype=np.float64, out_saved=None, dense_mask=None):
     """Analytic gradients of dense_attention w.r.t. q, k, v (float64 by default): (dq, dk, dv).
 
     out_saved: the forward output AS THE IMPLEMENTATION SAVED IT (bf16, the reference saves `out` cast to v.dtype for
@@ -126,10 +131,10 @@ def dense_attention_bwd(q, k, v, dout, *, causal=True, q_start=0, k_start=0, seg
         scale = 1.0 / np.sqrt(D)
     out, lse = dense_attention(q, k, v, causal=causal, q_start=q_start, k_start=k_start,
                                seg_q=seg_q, seg_k=seg_k, key_valid=key_valid, scale=scale,
-                               dtype=dtype)
+                               dtype=dtype, dense_mask=dense_mask)
     s = _scores(q, k) * dtype(scale)
     vis = visible_mask(Sq, Sk, causal=causal, q_start=q_start, k_start=k_start, seg_q=seg_q,
-                       seg_k=seg_k, key_valid=key_valid, B=B)[:, None]
+                       seg_k=seg_k, key_valid=key_valid, B=B, dense_mask=dense_mask)[:, None]
     lse_safe = np.where(np.isfinite(lse), lse, 0.0)[..., None]
     p = np.where(vis & np.isfinite(lse)[..., None], np.exp(np.where(vis, s, 0.0) - lse_safe), 0.0)
     dv = _apply_t(p, dout)
