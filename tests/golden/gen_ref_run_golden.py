@@ -12,7 +12,19 @@ for the handful of `jax.numpy` / `jax.lax` names they use:
       setup:     self.causal_mask = make_causal_mask(...)                                   lwm/llama.py:425
       __call__:  blockwise branch, attention_mask -> additive key-padding bias               lwm/llama.py:526-537
                  dense branch, causal (with the cache's shift) AND segment AND key mask      lwm/llama.py:573-592
-    These are statement RANGES inside larger methods (the rest of the methods builds flax layers and calls ringattention):
+  FlaxLLaMAAttention._concatenate_to_cache  lwm/llama.py:441-492  the whole method (row a6): first call creates the cache
+      variables, later calls with a block of Q > 1 tokens write it at cache_index (lax.dynamic_update_slice stood in from
+      XLA's documented semantics: the start index is clamped so that the update fits) and advance the index; the one-token
+      branch (:452-483) is shard_map / lax.cond / .at[].set code and is not executed
+  FlaxVideoLLaMAModule.__call__, the embedding choice   lwm/vision_llama.py:308-311 (text ids -> wte, vision ids -> vte, mixed
+      by the vision mask; nn.Embed stood in by a table lookup)
+  train_step.loss_and_accuracy, modality 'vision,text'   lwm/train.py:185-202: which targets and which masks go to which head, and
+      0.5 * (vision_loss + text_loss); model.apply returns the logits handed in, tux's cross_entropy_loss_and_accuracy (absent)
+      is stood in by a function that RECORDS its arguments and returns oracle/llama_ops_ref's restatement
+  VQGANModel.encode / .decode   lwm/vqgan.py:117-141 (row v7): 5-D video folded into the batch and unfolded again, the final
+      clip; the sub-modules (encoder, quant_conv, quantize, post_quant_conv, decoder) are the ORACLE's, so the vectors pin the
+      glue, not the networks
+    The mask statements are statement RANGES inside larger methods (the rest of the methods builds flax layers and calls ringattention):
     the ranges are located in the syntax tree by what they assign, compiled as they are and executed with the locals the
     method would hold (xq, xk, hidden_states, attention_mask, segment_ids; `self` = a plain object with has_variable /
     variables / causal_mask / config / dtype).  Two flax helpers they call are stood in from flax's documented behaviour
@@ -256,12 +268,157 @@ def masks(out):
     out["mask_bias"] = bias
 
 
+def cache(out):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    fn, a0, a1 = cut(f"{REF}/llama.py", "FlaxLLaMAAttention", "_concatenate_to_cache")
+    out["cache_lines"] = np.array([[a0, a1]], np.int32)
+
+    def dynamic_update_slice(operand, update, start):          # jax.lax.dynamic_update_slice: clamped start, copy
+        res = np.array(operand, copy=True)
+        st = [int(np.clip(int(s0), 0, d - u)) for s0, d, u in zip(start, operand.shape, update.shape)]
+        res[tuple(slice(a, a + u) for a, u in zip(st, update.shape))] = update
+        return res
+    fn.__globals__["lax"].dynamic_update_slice = dynamic_update_slice
+    fn.__globals__["jnp"].zeros = np.zeros
+    fn.__globals__["jnp"].array = np.array
+    fn.__globals__["jnp"].int32 = np.int32
+
+    class Var:                                                 # flax's self.variable(collection, name, init_fn, *args)
+        def __init__(self, value):
+            self.value = value
+    store = {}
+    self = types.SimpleNamespace(config=None)
+    self.has_variable = lambda col, name: (col, name) in store
+    def variable(col, name, init, *args):
+        if (col, name) not in store:
+            store[(col, name)] = Var(init(*args))
+        return store[(col, name)]
+    self.variable = variable
+    g = np.random.default_rng(440)
+    B, L, H, D = 2, 16, 2, 4
+    am = np.ones((B, L), np.int32)
+    # init_cache: the module runs once on max_length rows (lwm/llama.py:876-895) -- creates zeros, returns its arguments
+    k0, v0 = np.ones((B, L, H, D), np.float32), np.ones((B, L, H, D), np.float32)
+    rk, rv, rm = fn(self, k0, v0, np.zeros((B, L, H, D), np.float32), am)
+    assert rk is k0 and rv is v0 and rm is am and not store[("cache", "cached_key")].value.any()
+    steps = []
+    for Q in (5, 3, 8):                                        # prefill blocks at cache_index 0, 5, 8 (the last one ends at max_length)
+        key, value = (g.standard_normal((B, Q, H, D)).astype(np.float32) for _ in range(2))
+        idx = int(store[("cache", "cache_index")].value)
+        rk, rv, rm = fn(self, key, value, np.zeros((B, Q, H, D), np.float32), am)
+        assert rk.shape == (B, L, H, D) and rm is am                  # attention runs over the WHOLE cache: kv_len = max_length
+        steps.append((idx, key, value, rk.copy(), rv.copy(), int(store[("cache", "cache_index")].value)))
+    for i, (idx, key, value, ck, cv, nxt) in enumerate(steps):
+        out.update({f"cache_{i}_index": np.int32(idx), f"cache_{i}_key": key, f"cache_{i}_value": value,
+                    f"cache_{i}_k": ck, f"cache_{i}_v": cv, f"cache_{i}_next": np.int32(nxt)})
+    out["cache_steps"] = np.int32(len(steps))
+
+
+def vision_text(out):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import llama_ops_ref as R
+    g = np.random.default_rng(307)
+    # (1) the embedding choice, lwm/vision_llama.py:308-311
+    def emb_pick(f, src):
+        iff = next(n for n in f.body if isinstance(n, ast.If) and "input_ids.shape[1] == 1" in ast.get_source_segment(src, n.test))
+        return iff.orelse
+    code, e0, e1 = statements(f"{REF}/vision_llama.py", "FlaxVideoLLaMAModule", "__call__", emb_pick)
+    B, S, V, VV, d = 2, 12, 11, 7, 8
+    wte, vte = g.standard_normal((V, d)).astype(np.float32), g.standard_normal((VV, d)).astype(np.float32)
+    vm = g.random((B, S)) < 0.5
+    ids = np.where(vm, g.integers(0, VV, (B, S)), g.integers(0, V, (B, S))).astype(np.int32)
+    ns = shims()
+    ns["jnp"].where = np.where
+    loc = dict(ns, self=types.SimpleNamespace(wte=lambda i: wte[i], vte=lambda i: vte[i]), input_ids=ids, vision_masks=vm)
+    exec(code, loc)
+    out.update({"vt_embed_lines": np.array([[e0, e1]], np.int32), "vt_wte": wte, "vt_vte": vte, "vt_ids": ids, "vt_vm": vm,
+                "vt_embeds": np.asarray(loc["input_embeds"], np.float32)})
+    # (2) the objective, lwm/train.py:185-202
+    src = open(f"{REF}/train.py").read()
+    f = next(n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.FunctionDef) and n.name == "loss_and_accuracy")
+    top = next(n for n in f.body if isinstance(n, ast.If))
+    branch = top.orelse[0]
+    assert "vision,text" in ast.get_source_segment(src, branch.test)
+    last = max(i for i, n in enumerate(branch.body) if assigns(n, "loss"))
+    stmts = branch.body[:last + 1]
+    code = compile(ast.Module(body=stmts, type_ignores=[]), f"{REF}/train.py:{stmts[0].lineno}", "exec")
+    out["vt_loss_lines"] = np.array([[stmts[0].lineno, stmts[-1].end_lineno]], np.int32)
+    vl, tl = g.standard_normal((B, S, VV)).astype(np.float32), g.standard_normal((B, S, V)).astype(np.float32)
+    tvm = g.random((B, S)) < 0.4
+    tgt = np.where(tvm, g.integers(0, VV, (B, S)), g.integers(0, V, (B, S))).astype(np.int32)
+    lm = (g.random((B, S)) < 0.8).astype(np.float32)
+    calls, applied = [], []
+
+    def ce(logits, tokens, valid=None):
+        calls.append((np.asarray(logits), np.asarray(tokens), np.asarray(valid)))
+        loss, acc, _ = R.cross_entropy_loss_and_accuracy(logits, tokens, valid)
+        return loss, acc
+
+    def apply(params, *args, **kw):
+        applied.append(args)
+        return types.SimpleNamespace(logits=(vl, tl))
+    batch = {"input_tokens": ids, "input_vision_masks": vm, "target_tokens": tgt, "target_vision_masks": tvm, "loss_masks": lm}
+    loc = dict(ns, params=None, batch=batch, model=types.SimpleNamespace(apply=apply), cross_entropy_loss_and_accuracy=ce,
+               rng_generator=lambda keys: None, llama_config=types.SimpleNamespace(rng_keys=lambda: ()))
+    exec(code, loc)
+    assert len(calls) == 2 and calls[0][0] is vl and calls[1][0] is tl and applied[0][0] is ids and applied[0][1] is vm
+    out.update({"vt_vision_logits": vl, "vt_text_logits": tl, "vt_targets": tgt, "vt_tvm": tvm, "vt_loss_masks": lm,
+                "vt_vision_targets": calls[0][1], "vt_vision_valid": calls[0][2].astype(np.float32),
+                "vt_text_targets": calls[1][1], "vt_text_valid": calls[1][2].astype(np.float32),
+                "vt_loss": np.float64(loc["loss"]), "vt_vision_loss": np.float64(loc["vision_loss"]),
+                "vt_text_loss": np.float64(loc["text_loss"]), "vt_vision_acc": np.float64(loc["vision_acc"]),
+                "vt_text_acc": np.float64(loc["text_acc"])})
+
+
+def video(out):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import vqgan_ref as V
+    from lwm_amd.vqgan import VQGANConfig, random_params
+    enc, a0, a1 = cut(f"{REF}/vqgan.py", "VQGANModel", "encode")
+    dec, b0, b1 = cut(f"{REF}/vqgan.py", "VQGANModel", "decode")
+    dec.__globals__["jnp"].clip = np.clip
+    out["video_lines"] = np.array([[a0, a1], [b0, b1]], np.int32)
+    cfgo = VQGANConfig.get_default_config(dict(resolution=32, channel_mult=(1, 2, 4), num_embeddings=1024))
+    params = random_params(cfgo, seed=11)
+    cfg = cfgo.as_dict()
+    # make the decoder overshoot [-1, 1] so that the clip has something to do
+    params["decoder"]["Conv_1"]["kernel"] = params["decoder"]["Conv_1"]["kernel"] * 40.0
+    cb = params["quantize"]["embeddings"]
+
+    def quantize(z, encoding_indices=None):                    # the oracle's quantiser (the reference's own: vq(), above)
+        if encoding_indices is not None:
+            return V.vq_gather(cb, encoding_indices)
+        idx = V.vq_argmin(z, cb)
+        return V.vq_gather(cb, idx, z=z), idx
+    self = types.SimpleNamespace(encoder=lambda x: V.encoder(params["encoder"], x, cfg),
+                                 quant_conv=lambda h: V._conv(params["quant_conv"], h), quantize=quantize,
+                                 post_quant_conv=lambda h: V._conv(params["post_quant_conv"], h),
+                                 decoder=lambda h: V.decoder(params["decoder"], h, cfg, clip=False))
+    g = np.random.default_rng(117)
+    px = g.uniform(-1, 1, (2, 3, 32, 32, 3)).astype(np.float32)       # (B, T, H, W, C): a video
+    zq, idx = enc(self, px)
+    rec = dec(self, idx)
+    assert idx.shape == (2, 3, 8, 8) and zq.shape == (2, 3, 8, 8, cfg["quantized_embed_dim"]) and rec.shape == px.shape
+    frac = float(np.mean(np.abs(rec) == 1.0))
+    assert 0.01 < frac < 0.99, frac
+    zq4, idx4 = enc(self, px[:, 0])                                   # (B, H, W, C): images
+    out.update({"video_px": px, "video_zq": zq, "video_idx": idx.astype(np.int32), "video_rec": rec, "video_seed": np.int32(11),
+                "video_kernel_gain": np.float32(40.0), "video_zq_image": zq4, "video_idx_image": idx4.astype(np.int32),
+                "video_clipped_fraction": np.float64(frac)})
+
+
 def main():
     out = {}
     rope(out)
     rmsnorm(out)
     vq(out)
     masks(out)
+    cache(out)
+    vision_text(out)
+    video(out)
     np.savez_compressed(os.path.join(HERE, "ref_run.npz"), **out)
     print("wrote ref_run.npz;", "lines", {k: out[k].tolist() for k in out if k.endswith("_lines")}, "vq margin", float(out["vq_min_margin"]))
 
