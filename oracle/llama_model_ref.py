@@ -1,7 +1,12 @@
 """CPU float32 reference of the LLaMA harness (lwm/llama.py restated with plain PyTorch-CPU
 ops: dense masked attention, interleaved RoPE, RMSNorm, SwiGLU, tux cross entropy) --
 TEST INFRASTRUCTURE, NOT PRODUCT.  BASELINE config #1 (2-layer slice, S = 4096, fp32 on CPU).
-PARITY UNPINNED (see oracle/attention_ref.py): this follows the in-tree source line by line."""
+The softmax-attention arithmetic is UNPINNED (see oracle/attention_ref.py: it lives in the absent `ringattention`
+package).  Everything around it is PINNED (round 5) to a run of the reference's own lines: one whole layer --
+FlaxLLaMABlock.__call__, FlaxLLaMAAttention.__call__ (both branches), FlaxLLaMAMLP.__call__, RMSNorm, RoPE -- executed out
+of /root/reference with numpy standing in for jax.numpy (tests/golden/gen_ref_run_golden.py, ref_run.npz); forward_hidden()
+below reproduces it to 4e-7 (tests/test_golden.py::test_oracle_model_layer_reproduces_the_reference_run), as it
+reproduces HF transformers' LlamaForCausalLM (tests/test_weights.py)."""
 import math
 
 import numpy as np

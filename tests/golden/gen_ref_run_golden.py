@@ -24,6 +24,17 @@ for the handful of `jax.numpy` / `jax.lax` names they use:
   VQGANModel.encode / .decode   lwm/vqgan.py:117-141 (row v7): 5-D video folded into the batch and unfolded again, the final
       clip; the sub-modules (encoder, quant_conv, quantize, post_quant_conv, decoder) are the ORACLE's, so the vectors pin the
       glue, not the networks
+  ONE WHOLE LAYER (BASELINE configs[0]'s arithmetic around the op): FlaxLLaMABlock.__call__ (lwm/llama.py:705-744),
+      FlaxLLaMAAttention.__call__ (:494-620, both branches), ._split_heads / ._merge_heads (:434-438), FlaxLLaMAMLP.__call__
+      (:658-661) and RMSNorm executed as they are, composed the way the reference composes them.  Stood in: flax's nn.Dense (x @
+      kernel, no bias: use_bias=False), nn.Dropout (identity: deterministic), nn.silu (x * sigmoid(x)), tux's
+      with_sharding_constraint (identity), jax's shard_map (returns the function: one device), and -- the arithmetic that IS
+      NOT the reference's here -- the two ops of the absent `ringattention` package: `ringattention(...)` is the oracle's f32
+      blockwise restatement (after asserting the keyword arguments the call site passes), `ringattention_inference(...)` the
+      oracle's dense-mask restatement, `blockwise_feedforward(module, x, chunk, pre_remat=True)` = module(x) recorded.  What
+      this pins for oracle/llama_model_ref.py: projections on the NORMALISED input, heads split by reshape, RoPE on q and k
+      (not v) at the given positions, which branch runs when (S > max(chunk sizes)), what each branch hands the op (bias vs
+      combined mask), merge, wo, both residual adds, the FFN's structure and when it goes blockwise.
     The mask statements are statement RANGES inside larger methods (the rest of the methods builds flax layers and calls ringattention):
     the ranges are located in the syntax tree by what they assign, compiled as they are and executed with the locals the
     method would hold (xq, xk, hidden_states, attention_mask, segment_ids; `self` = a plain object with has_variable /
@@ -410,6 +421,103 @@ def video(out):
                 "video_clipped_fraction": np.float64(frac)})
 
 
+def layer(out):
+    import functools
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import attention_ref as A
+    path = f"{REF}/llama.py"
+    pre, _, _ = cut(path, None, "precompute_freqs_cis")
+    rot, _, _ = cut(path, None, "apply_rotary_emb")
+    norm, _, _ = cut(path, "RMSNorm", "_norm")
+    norm_call, _, _ = cut(path, "RMSNorm", "__call__")
+    split, h0, h1 = cut(path, "FlaxLLaMAAttention", "_split_heads")
+    merge, m0, m1 = cut(path, "FlaxLLaMAAttention", "_merge_heads")
+    attn, a0, a1 = cut(path, "FlaxLLaMAAttention", "__call__")
+    mlp, f0, f1 = cut(path, "FlaxLLaMAMLP", "__call__")
+    block, b0, b1 = cut(path, "FlaxLLaMABlock", "__call__")
+    out["layer_lines"] = np.array([[h0, h1], [m0, m1], [a0, a1], [f0, f1], [b0, b1]], np.int32)
+    setup_code, _, _ = statements(path, "FlaxLLaMAAttention", "setup", lambda f, src: [n for n in f.body if assigns(n, "causal_mask")])
+
+    g = np.random.default_rng(664)
+    B, S, H, D, F, L = 2, 24, 2, 16, 48, 32
+    d = H * D
+    W = {n: (g.standard_normal(shp) * 0.2).astype(np.float32) for n, shp in
+         (("wq", (d, d)), ("wk", (d, d)), ("wv", (d, d)), ("wo", (d, d)), ("w1", (d, F)), ("w2", (F, d)), ("w3", (d, F)))}
+    W["attention_norm"] = (1 + 0.1 * g.standard_normal(d)).astype(np.float32)
+    W["ffn_norm"] = (1 + 0.1 * g.standard_normal(d)).astype(np.float32)
+    x = g.standard_normal((B, S, d)).astype(np.float32)
+    am = np.ones((B, S), np.int32)
+    am[0, :3] = 0
+    seg = np.zeros((B, S), np.int32)
+    seg[1, 9:] = 1
+    seg[1, 17:] = 2
+    pos = np.tile(np.arange(S, dtype=np.int32), (B, 1))
+    record = []
+
+    def ringattention(q, k, v, attn_bias, segment_ids, axis_name=None, float32_logits=None, cache_idx=None, blockwise_kwargs=None):
+        kw = blockwise_kwargs
+        assert axis_name == "sp" and float32_logits is True and cache_idx is None and kw["causal_block_size"] == 1
+        assert attn_bias.shape == (B, 1, 1, S) and set(np.unique(attn_bias)) <= {0.0, float(np.finfo(np.float32).min)}
+        record.append(("ringattention", kw["query_chunk_size"], kw["key_chunk_size"], segment_ids is not None))
+        return A.blockwise_ring_attention(q, k, v, ring=1, q_chunk=kw["query_chunk_size"], k_chunk=kw["key_chunk_size"], causal=True,
+                                          segment_ids=segment_ids, key_valid=(attn_bias[:, 0, 0] == 0).astype(np.uint8))
+
+    def ringattention_inference(q, k, v, attn_mask, axis_name=None):
+        assert axis_name == "sp" and attn_mask.shape == (B, 1, S, S)
+        record.append(("ringattention_inference",))
+        return A.ring_inference(q, k, v, attn_mask[:, 0])
+
+    def blockwise_feedforward(module, xx, chunk_size, pre_remat=None):
+        assert pre_remat is True
+        record.append(("blockwise_feedforward", int(chunk_size)))
+        return module(xx)
+
+    def build(theta, q_chunk, k_chunk, scan_mlp, mlp_chunk):
+        cfg = types.SimpleNamespace(max_sequence_length=L, scan_attention=True, scan_query_chunk_size=q_chunk, scan_key_chunk_size=k_chunk,
+                                    attn_pdrop=0.0, mesh_dim="1,1,1,1", scan_layers=False, scan_mlp=scan_mlp, scan_mlp_chunk_size=mlp_chunk)
+        ns = shims()
+        ns["jnp"].take, ns["jnp"].where = np.take, np.where
+        sa = types.SimpleNamespace(config=cfg, dtype=np.float32, precision=None, embed_dim=d, num_heads=H, head_dim=D, variables={},
+                                   wq=lambda t: t @ W["wq"], wk=lambda t: t @ W["wk"], wv=lambda t: t @ W["wv"], wo=lambda t: t @ W["wo"],
+                                   resid_dropout=lambda t, deterministic=True: t, has_variable=lambda c, n: False)
+        sa._split_heads, sa._merge_heads = types.MethodType(split, sa), types.MethodType(merge, sa)
+        sa.freqs_cis = pre(D, L, theta=theta, dtype=np.float32)
+        exec(setup_code, dict(ns, self=sa, config=cfg))
+        glob = attn.__globals__
+        glob.update(ns)
+        glob.update(apply_rotary_emb=rot, with_sharding_constraint=lambda t, spec: t, PS=lambda *a: a, partial=functools.partial,
+                    shard_map=lambda fn, mesh=None, in_specs=None, out_specs=None, check_rep=None: fn,
+                    ringattention=ringattention, ringattention_inference=ringattention_inference,
+                    LLaMAConfig=types.SimpleNamespace(get_jax_mesh=lambda mesh_dim: None))
+        glob["jax"].checkpoint_policies = types.SimpleNamespace(nothing_saveable=None)
+
+        def rms(weight):
+            o = types.SimpleNamespace(eps=1e-6, dtype=np.float32, param_dtype=np.float32, weight=weight)
+            o._norm = types.MethodType(norm, o)
+            return lambda t: norm_call(o, t)
+        sm = types.SimpleNamespace(w1=lambda t: t @ W["w1"], w2=lambda t: t @ W["w2"], w3=lambda t: t @ W["w3"],
+                                   dropout=lambda t, deterministic=True: t)
+        mlp.__globals__["nn"] = types.SimpleNamespace(silu=lambda t: t * (1.0 / (1.0 + np.exp(-t))).astype(t.dtype))
+        block.__globals__.update(blockwise_feedforward=blockwise_feedforward, with_sharding_constraint=lambda t, spec: t, PS=lambda *a: a)
+        sb = types.SimpleNamespace(config=cfg, attention=lambda *a: attn(sa, *a), attention_norm=rms(W["attention_norm"]),
+                                   ffn_norm=rms(W["ffn_norm"]), feed_forward=lambda t, deterministic=True: mlp(sm, t, deterministic))
+        return sb, rms
+
+    for tag, theta, qc, kc, scan_mlp, mlp_chunk, use_seg in (("dense", 1e4, 1024, 1024, False, 8, True),      # S <= chunk: dense branch, plain FFN
+                                                              ("blockwise", 1e7, 8, 8, True, 8, True),        # S > chunk: ringattention, blockwise FFN
+                                                              ("blockwise_noseg", 1e4, 12, 8, True, 64, False)):   # scan_mlp but S < its chunk: plain FFN
+        sb, rms = build(theta, qc, kc, scan_mlp, mlp_chunk)
+        record.clear()
+        y = block(sb, x, am, seg if use_seg else None, pos)
+        assert y.shape == x.shape and y.dtype == np.float32
+        out.update({f"layer_{tag}_out": y, f"layer_{tag}_final": rms(np.ones(d, np.float32))(y),    # ... and ln_f with a unit weight (lwm/llama.py:1034)
+                    f"layer_{tag}_calls": np.array([r[0] for r in record]), f"layer_{tag}_theta": np.float64(theta),
+                    f"layer_{tag}_chunks": np.array([qc, kc, int(scan_mlp), mlp_chunk, int(use_seg)], np.int32)})
+    out.update({f"layer_W_{n}": w for n, w in W.items()})
+    out.update({"layer_x": x, "layer_am": am, "layer_seg": seg, "layer_pos": pos, "layer_dims": np.array([B, S, H, D, F, L], np.int32)})
+
+
 def main():
     out = {}
     rope(out)
@@ -419,6 +527,7 @@ def main():
     cache(out)
     vision_text(out)
     video(out)
+    layer(out)
     np.savez_compressed(os.path.join(HERE, "ref_run.npz"), **out)
     print("wrote ref_run.npz;", "lines", {k: out[k].tolist() for k in out if k.endswith("_lines")}, "vq margin", float(out["vq_min_margin"]))
 
