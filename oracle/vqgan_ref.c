@@ -71,6 +71,13 @@ static inline float ref_silu(float y) {
     return y * sig;
 }
 
+/* nn.silu on its own (lwm/vqgan.py:162,182,252,255 apply it to the GroupNorm's output): the same arithmetic as the fused
+ * form of ref_groupnorm below -- used where the reference's own module code is executed with these primitives standing in
+ * for flax's (tests/golden/gen_ref_run_golden.py). */
+void ref_silu_array(const float* x, float* y, long n) {
+    for (long i = 0; i < n; ++i) y[i] = ref_silu(x[i]);
+}
+
 /* x: [B,Hin,Win,Cin]  w: [KH,KW,Cin,Cout]  bias: [Cout] or NULL
  * residual: [B,Ho,Wo,Cout] or NULL   y: [B,Ho,Wo,Cout]
  * virtual input = x upsampled (nearest) by 2^up_shift; tap (kh,kw) of output

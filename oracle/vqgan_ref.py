@@ -3,7 +3,11 @@
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this module.  Nothing under lwm_amd/ does.
 
-PARITY UNPINNED for the networks (see oracle/vqgan_ref.c); the QUANTISER is pinned (round 5) to a run of the
+The ARITHMETIC of conv / GroupNorm is this oracle's own contract (see oracle/vqgan_ref.c: XLA's is not reproducible);
+the WIRING of the networks is pinned (round 5) to the reference's own module code: every class of lwm/vqgan.py:105-351 executed
+under a minimal emulation of flax.linen.Module with the primitives below standing in for nn.Conv / nn.GroupNorm / nn.silu
+(tests/golden/gen_ref_run_golden.py: MiniFlax) gives bit for bit what encode() / decode() below give
+(tests/test_golden.py::test_vqgan_oracle_network_reproduces_the_reference_run).  The QUANTISER is pinned to a run of the
 reference's own VectorQuantizer.__call__ (lwm/vqgan.py:192-221 executed where it lies with numpy standing in for
 jax.numpy: tests/golden/gen_ref_run_golden.py -> tests/golden/ref_run.npz; vq_argmin / vq_gather below reproduce its
 indices, its lookup and its straight-through forward value exactly, tests/test_golden.py).  The rest of lwm/vqgan.py is
@@ -55,6 +59,8 @@ def lib():
         L.ref_vq_argmin.restype = None
         L.ref_vq_gather.argtypes = [fp, ip, fp, fp, C.c_long, C.c_int]
         L.ref_vq_gather.restype = None
+        L.ref_silu_array.argtypes = [fp, fp, C.c_long]
+        L.ref_silu_array.restype = None
         L.ref_expf_scalar.argtypes = [C.c_float]
         L.ref_expf_scalar.restype = C.c_float
         _lib = L
@@ -124,6 +130,14 @@ def vq_gather(codebook, idx, z=None):
     lib().ref_vq_gather(_f(codebook), idx.ctypes.data_as(C.POINTER(C.c_int32)), _f(z), _f(out),
                         idx.size, D)
     return out
+
+
+def silu(x):
+    """nn.silu with the arithmetic of the fused GroupNorm + SiLU above (x * (1 / (1 + exp(-x))), the oracle's exp)."""
+    x = _c(x)
+    y = np.empty_like(x)
+    lib().ref_silu_array(_f(x), _f(y), x.size)
+    return y
 
 
 def expf(x):

@@ -35,6 +35,18 @@ for the handful of `jax.numpy` / `jax.lax` names they use:
       this pins for oracle/llama_model_ref.py: projections on the NORMALISED input, heads split by reshape, RoPE on q and k
       (not v) at the given positions, which branch runs when (S > max(chunk sizes)), what each branch hands the op (bias vs
       combined mask), merge, wo, both residual adds, the FFN's structure and when it goes blockwise.
+  THE WHOLE TOKENISER NETWORK (rows v1-v5, v7; the parameter tree of f.4): every class of lwm/vqgan.py from VQGANModel to
+      MidBlock (lines 105-351: VQGANModel, Encoder, Decoder, VectorQuantizer, DownsamplingBlock, ResnetBlock, AttnBlock,
+      Downsample, Upsample, UpsamplingBlock, MidBlock) executed as CLASS DEFINITIONS under a ~60-line emulation of
+      flax.linen.Module (MiniFlax below: dataclass-style fields from the annotations, setup(), @nn.compact, and flax's
+      naming rule -- a submodule made in setup() is named by its attribute, one made inside a compact __call__ gets
+      ClassName_<n>, n counting that class within the parent).  nn.Conv / nn.GroupNorm are the ORACLE's primitives fed the
+      {'kernel','bias'} / {'scale','bias'} leaves the naming rule leads to, nn.silu the oracle's, jnp.pad numpy's,
+      jax.image.resize(method='nearest') an integer repeat.  What this pins: the wiring of the reference's own module code --
+      block order, channel widths, where Downsample / Upsample sit, the shortcut rule and its position in the creation
+      order, the literal jnp.pad [(0,0),(0,1),(0,1),(0,0)] before the VALID stride-2 conv, GroupNorm -> silu -> conv order --
+      and that the parameter tree lwm_amd.vqgan builds (random_params: the layout of the pickles of lwm/vqgan.py:19) is the
+      tree this code asks for: every leaf is read, none is missing.
     The mask statements are statement RANGES inside larger methods (the rest of the methods builds flax layers and calls ringattention):
     the ranges are located in the syntax tree by what they assign, compiled as they are and executed with the locals the
     method would hold (xq, xk, hidden_states, attention_mask, segment_ids; `self` = a plain object with has_variable /
@@ -518,6 +530,166 @@ def layer(out):
     out.update({"layer_x": x, "layer_am": am, "layer_seg": seg, "layer_pos": pos, "layer_dims": np.array([B, S, H, D, F, L], np.int32)})
 
 
+class MiniFlax:
+    """The part of flax.linen the classes of lwm/vqgan.py use, over a parameter tree handed in."""
+
+    def __init__(self, conv, groupnorm, silu):
+        mf = self
+        self.stack, self.read = [], set()          # scopes: [tree, path, per-class counters]; leaves that were read
+
+        class Module:
+            _fields = ()
+
+            def __init_subclass__(cls):
+                ann = {}
+                for c in reversed(cls.__mro__):
+                    ann.update({k: v for k, v in getattr(c, "__annotations__", {}).items() if not k.startswith("_")})
+                cls._fields = tuple(ann)
+                for meth in ("__call__", "encode", "decode"):
+                    if meth in cls.__dict__:
+                        setattr(cls, meth, mf._scoped(cls.__dict__[meth]))
+
+            def __init__(self, *args, **kw):
+                vals = dict(zip(self._fields, args), **kw)
+                for f in self._fields:
+                    object.__setattr__(self, f, vals[f] if f in vals else getattr(type(self), f))
+                object.__setattr__(self, "_name", None)
+                object.__setattr__(self, "_set_up", False)
+                if mf.stack and mf.stack[-1][3] == "compact":     # made inside a compact __call__: ClassName_<n>
+                    cnt = mf.stack[-1][2]
+                    n = cnt.get(type(self).__name__, 0)
+                    cnt[type(self).__name__] = n + 1
+                    object.__setattr__(self, "_name", f"{type(self).__name__}_{n}")
+
+            def __setattr__(self, k, v):
+                if isinstance(v, Module) and v._name is None:     # made in setup(): named by the attribute
+                    object.__setattr__(v, "_name", k)
+                object.__setattr__(self, k, v)
+
+            def param(self, name, init, *args):
+                tree, path = mf.stack[-1][0], mf.stack[-1][1]
+                mf.read.add(path + (name,))
+                return tree[name]
+
+        class Conv(Module):
+            features: int
+            kernel_size: object
+            strides: object = None
+            padding: object = "SAME"
+
+            def __call__(self, x):
+                w, b = self.param("kernel", None), self.param("bias", None)
+                assert w.shape[:2] == tuple(self.kernel_size) and w.shape[3] == self.features and w.shape[2] == x.shape[-1]
+                if self.padding == "VALID":
+                    st = self.strides[0]
+                    return conv(x, w, b, stride=st, pad=0, out_hw=((x.shape[1] - w.shape[0]) // st + 1, (x.shape[2] - w.shape[1]) // st + 1))
+                assert self.padding == "SAME" and self.strides is None
+                return conv(x, w, b)
+
+        class GroupNorm(Module):                       # flax defaults: num_groups 32, epsilon 1e-6, scale and bias
+            def __call__(self, x):
+                return groupnorm(x, self.param("scale", None), self.param("bias", None), groups=32, eps=1e-6, silu=False)
+
+        class Dropout(Module):
+            rate: float
+            deterministic: bool = None
+
+            def __call__(self, x):
+                assert self.deterministic is True
+                return x
+
+        self.Module = Module
+        self.nn = types.SimpleNamespace(Module=Module, compact=lambda f: f, Conv=Conv, GroupNorm=GroupNorm, Dropout=Dropout, silu=silu)
+
+    def _scoped(self, fn):
+        mf = self
+
+        def call(obj, *a, **kw):
+            if not obj._set_up:
+                object.__setattr__(obj, "_set_up", True)
+                if hasattr(obj, "setup"):
+                    mf.stack.append((None, None, {}, "setup"))
+                    obj.setup()
+                    mf.stack.pop()
+            tree, path = mf.stack[-1][0], mf.stack[-1][1]
+            if obj._name is not None:
+                tree, path = tree.get(obj._name, {}), path + (obj._name,)     # (a module without parameters has no subtree)
+            mf.stack.append((tree, path, {}, "compact"))
+            try:
+                return fn(obj, *a, **kw)
+            finally:
+                mf.stack.pop()
+        return call
+
+    def run(self, params, thunk):
+        self.stack.append((params, (), {}, "root"))
+        try:
+            return thunk()
+        finally:
+            self.stack.pop()
+
+
+def leaves(tree, path=()):
+    for k, v in tree.items():
+        if isinstance(v, dict):
+            yield from leaves(v, path + (k,))
+        else:
+            yield path + (k,)
+
+
+def network(out):
+    import sys
+    from typing import Optional
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import vqgan_ref as V
+    from lwm_amd.vqgan import VQGANConfig, random_params
+    src = open(f"{REF}/vqgan.py").read()
+    body = ast.parse(src).body
+    first = next(n for n in body if isinstance(n, ast.ClassDef) and n.name == "VQGANModel")
+    classes = [n for n in body if isinstance(n, ast.ClassDef) and n.lineno >= first.lineno]
+    assert [c.name for c in classes] == ["VQGANModel", "Encoder", "Decoder", "VectorQuantizer", "DownsamplingBlock", "ResnetBlock",
+                                         "AttnBlock", "Downsample", "Upsample", "UpsamplingBlock", "MidBlock"]
+    out["network_lines"] = np.array([[classes[0].lineno, classes[-1].end_lineno]], np.int32)
+    mf = MiniFlax(V.conv2d, V.groupnorm, V.silu)
+    ns = shims()
+    ns["jnp"].pad, ns["jnp"].clip = np.pad, np.clip
+    ns["jax"].image = types.SimpleNamespace(resize=None)
+
+    def resize(x, shape, method=None):
+        assert method == "nearest" and shape[0] == x.shape[0] and shape[3] == x.shape[3]
+        fy, fx = shape[1] // x.shape[1], shape[2] // x.shape[2]
+        assert (fy * x.shape[1], fx * x.shape[2]) == tuple(shape[1:3])
+        return np.repeat(np.repeat(x, fy, axis=1), fx, axis=2)
+    ns["jax"].image.resize = resize
+    ns.update(nn=mf.nn, Optional=Optional, VQGANConfig=object)
+    code = compile(ast.Module(body=classes, type_ignores=[]), f"{REF}/vqgan.py:{classes[0].lineno}", "exec")
+    exec(code, ns)                                                  # the reference's class definitions, as they are
+
+    cfgo = VQGANConfig.get_default_config(dict(resolution=32, channel_mult=(1, 2, 4), num_embeddings=1024))
+    cfg = cfgo.as_dict()
+    params = random_params(cfgo, seed=105)
+    conf = types.SimpleNamespace(**cfg)
+    conf.num_resolutions = len(cfg["channel_mult"])                # VQGANConfig.get_default_config, lwm/vqgan.py:97
+    conf.dropout = 0.0
+    g = np.random.default_rng(105)
+    px = g.uniform(-1, 1, (2, 32, 32, 3)).astype(np.float32)
+    # codes placed ON the encoder's outputs (plus far-away ones): every summation order finds the same index
+    z = V._conv(params["quant_conv"], V.encoder(params["encoder"], px, cfg))
+    zf = z.reshape(-1, z.shape[-1])
+    cb = (zf.mean(0) + 50.0 * zf.std() * g.standard_normal(params["quantize"]["embeddings"].shape)).astype(np.float32)
+    slots = g.permutation(cb.shape[0])[:zf.shape[0]]
+    cb[slots] = zf
+    params["quantize"]["embeddings"] = cb
+    model = ns["VQGANModel"](conf)
+    zq, idx = mf.run(params, lambda: model.encode(px))
+    assert np.array_equal(idx.reshape(-1), slots)
+    rec = mf.run(params, lambda: model.decode(idx))
+    want = set(leaves(params))
+    assert mf.read == want, (sorted(want - mf.read)[:5], sorted(mf.read - want)[:5])      # every leaf read, none missing
+    out.update({"network_px": px, "network_idx": idx.astype(np.int32), "network_zq": np.asarray(zq, np.float32), "network_rec": rec,
+                "network_seed": np.int32(105), "network_codebook": cb, "network_leaves": np.int32(len(want))})
+
+
 def main():
     out = {}
     rope(out)
@@ -528,6 +700,7 @@ def main():
     vision_text(out)
     video(out)
     layer(out)
+    network(out)
     np.savez_compressed(os.path.join(HERE, "ref_run.npz"), **out)
     print("wrote ref_run.npz;", "lines", {k: out[k].tolist() for k in out if k.endswith("_lines")}, "vq margin", float(out["vq_min_margin"]))
 
