@@ -10,7 +10,9 @@ Three on-disk formats reach the reference's hot path:
     (`lwm_amd.llama.hf_rotary_to_interleaved`).
   * the flax-msgpack stream that `tux.StreamingCheckpointer` writes (lwm/train.py:104-107,
     lwm/vision_chat.py:182-185 `load_trainstate_checkpoint`): a concatenation of msgpack
-    records `(key_tuple, flax.serialization.to_bytes(leaf))`.  [upstream, unverifiable here:
+    records `(key_tuple, flax.serialization.to_bytes(leaf))`.  [The parameter NAMES and the stacked
+    `scan_decoder` layout are verified against a run of the reference's own model classes
+    (tests/golden/gen_ref_run_golden.py::model, tests/test_golden.py); the byte format is upstream and unverifiable here:
     `tux` and `flax` are not in this image; the record layout below restates
     flax/serialization.py (`_ndarray_to_bytes`, ext type 1 = (shape, dtype name, raw bytes);
     `__msgpack_chunks__` for leaves > 2**30 bytes) and tux/checkpoint.py.]

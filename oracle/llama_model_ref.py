@@ -75,7 +75,11 @@ def forward_hidden(state, cfg, input_tokens, attention_mask=None, segment_ids=No
         q, k = _rope(q, fc, pos), _rope(k, fc, pos)
         s = torch.einsum("bqhd,bkhd->bhqk", q, k) / math.sqrt(D)
         s = s.masked_fill(~vis, float("-inf"))
-        a = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, dim=-1), v).reshape(B, S, H * D)
+        # a query with no visible key (left padding) gives 0, as in oracle/attention_ref.py and in the kernels -- not NaN,
+        # which a second layer would spread over the whole batch row through 0 * NaN (the reference returns an average of
+        # masked keys there and never uses it, lwm/vision_chat.py:138-140)
+        pr = torch.where(vis.any(-1, keepdim=True), torch.softmax(s, dim=-1), torch.zeros(()))
+        a = torch.einsum("bhqk,bkhd->bqhd", pr, v).reshape(B, S, H * D)
         x = x + a @ state[p + "attention.wo"]
         hn = _rmsnorm(x, state[p + "ffn_norm.kernel"], cfg.rms_norm_eps)
         ff = (torch.nn.functional.silu(hn @ state[p + "feed_forward.w1"]) * (hn @ state[p + "feed_forward.w3"])) \

@@ -549,13 +549,14 @@ class MiniFlax:
                     if meth in cls.__dict__:
                         setattr(cls, meth, mf._scoped(cls.__dict__[meth]))
 
-            def __init__(self, *args, **kw):
+            def __init__(self, *args, name=None, **kw):
                 vals = dict(zip(self._fields, args), **kw)
                 for f in self._fields:
                     object.__setattr__(self, f, vals[f] if f in vals else getattr(type(self), f))
-                object.__setattr__(self, "_name", None)
+                object.__setattr__(self, "_name", name)           # name=...: explicit (lwm/llama.py:953: name=str(i))
                 object.__setattr__(self, "_set_up", False)
-                if mf.stack and mf.stack[-1][3] == "compact":     # made inside a compact __call__: ClassName_<n>
+                object.__setattr__(self, "variables", {})          # no 'cache' collection: training / prefill without a cache
+                if name is None and mf.stack and mf.stack[-1][3] == "compact":     # made inside a compact __call__: ClassName_<n>
                     cnt = mf.stack[-1][2]
                     n = cnt.get(type(self).__name__, 0)
                     cnt[type(self).__name__] = n + 1
@@ -570,6 +571,12 @@ class MiniFlax:
                 tree, path = mf.stack[-1][0], mf.stack[-1][1]
                 mf.read.add(path + (name,))
                 return tree[name]
+
+            def has_variable(self, collection, name):
+                return False
+
+            def is_mutable_collection(self, collection):
+                return False
 
         class Conv(Module):
             features: int
@@ -590,30 +597,84 @@ class MiniFlax:
             def __call__(self, x):
                 return groupnorm(x, self.param("scale", None), self.param("bias", None), groups=32, eps=1e-6, silu=False)
 
-        class Dropout(Module):
+        class Dense(Module):                           # x @ kernel (every Dense of lwm/llama.py has use_bias=False)
+            features: int
+            use_bias: bool = True
+            dtype: object = None
+            param_dtype: object = None
+            kernel_init: object = None
+            precision: object = None
+
+            def __call__(self, x):
+                assert self.use_bias is False
+                w = self.param("kernel", None)
+                assert w.shape == (x.shape[-1], self.features)
+                return x @ w
+
+        class Embed(Module):
+            num_embeddings: int
+            features: int
+            embedding_init: object = None
+            dtype: object = None
+            param_dtype: object = None
+
+            def __call__(self, ids):
+                e = self.param("embedding", None)
+                assert e.shape == (self.num_embeddings, self.features)
+                return e[ids]
+
+        class Dropout(Module):                         # (redefined for lwm/llama.py: Dropout(rate=...)(x, deterministic=...))
             rate: float
             deterministic: bool = None
 
-            def __call__(self, x):
-                assert self.deterministic is True
+            def __call__(self, x, deterministic=None):
+                assert deterministic is True or self.deterministic is True
                 return x
 
+        def scan(target, variable_axes=None, split_rngs=None, in_axes=None, length=None, metadata_params=None):
+            """flax.linen.scan as lwm/llama.py:927-941 uses it: `length` applications of `target` whose parameters are ONE
+            stacked leaf per parameter, layer i = index i of axis variable_axes['params']; the module returns (carry, out)."""
+            axis = variable_axes["params"]
+
+            def cut_layer(tree, i):
+                return {k: cut_layer(v, i) if isinstance(v, dict) else np.take(v, i, axis=axis) for k, v in tree.items()}
+
+            class Scanned(Module):
+                def __call__(self_, carry, *bcast):
+                    tree, path = mf.stack[-1][0], mf.stack[-1][1]
+                    for i in range(length):
+                        mf.stack.append((cut_layer(tree, i), path, {}, "scan"))
+                        try:
+                            carry, _ = target(*self_._args, **self_._kw)(carry, *bcast)
+                        finally:
+                            mf.stack.pop()
+                    return carry, None
+
+            def make(*args, name=None, **kw):
+                m = Scanned(name=name)
+                object.__setattr__(m, "_args", args)
+                object.__setattr__(m, "_kw", kw)
+                return m
+            return make
+
         self.Module = Module
-        self.nn = types.SimpleNamespace(Module=Module, compact=lambda f: f, Conv=Conv, GroupNorm=GroupNorm, Dropout=Dropout, silu=silu)
+        self.nn = types.SimpleNamespace(Module=Module, compact=lambda f: f, Conv=Conv, GroupNorm=GroupNorm, Dropout=Dropout, silu=silu,
+                                        Dense=Dense, Embed=Embed, scan=scan, broadcast=object(), PARTITION_NAME="partition_name",
+                                        initializers=types.SimpleNamespace(ones=None))
 
     def _scoped(self, fn):
         mf = self
 
         def call(obj, *a, **kw):
-            if not obj._set_up:
-                object.__setattr__(obj, "_set_up", True)
-                if hasattr(obj, "setup"):
-                    mf.stack.append((None, None, {}, "setup"))
-                    obj.setup()
-                    mf.stack.pop()
             tree, path = mf.stack[-1][0], mf.stack[-1][1]
             if obj._name is not None:
                 tree, path = tree.get(obj._name, {}), path + (obj._name,)     # (a module without parameters has no subtree)
+            if not obj._set_up:
+                object.__setattr__(obj, "_set_up", True)
+                if hasattr(obj, "setup"):                                     # setup() runs in the module's own scope
+                    mf.stack.append((tree, path, {}, "setup"))
+                    obj.setup()
+                    mf.stack.pop()
             mf.stack.append((tree, path, {}, "compact"))
             try:
                 return fn(obj, *a, **kw)
@@ -690,6 +751,114 @@ def network(out):
                 "network_seed": np.int32(105), "network_codebook": cb, "network_leaves": np.int32(len(want))})
 
 
+def model(out):
+    """BASELINE configs[0] in miniature: the reference's own model classes produce logits on the CPU."""
+    import functools
+    import sys
+    from typing import Any, Dict, List, Optional, Union
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import attention_ref as A
+    path = f"{REF}/llama.py"
+    src = open(path).read()
+    want = ["RMSNorm", "precompute_freqs_cis", "apply_rotary_emb", "FlaxLLaMAAttention", "FlaxLLaMAMLP", "FlaxLLaMABlock",
+            "FlaxLLaMABlockCollection", "FlaxLLaMAModule", "FlaxLLaMAForCausalLMModule"]
+    nodes = [n for n in ast.parse(src).body if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name in want]
+    assert [n.name for n in nodes] == want
+    out["model_lines"] = np.array([[n.lineno, n.end_lineno] for n in nodes], np.int32)
+    mf = MiniFlax(None, None, lambda t: t * (1.0 / (1.0 + np.exp(-t))).astype(t.dtype))
+    ns = shims()
+    jnp = ns["jnp"]
+    jnp.take, jnp.where, jnp.zeros, jnp.array, jnp.int32, jnp.ones_like = np.take, np.where, np.zeros, np.array, np.int32, np.ones_like
+    ns["jax"].checkpoint_policies = types.SimpleNamespace(nothing_saveable=None)
+    ns["jax"].lax.Precision = object
+    ns["jax"].nn.initializers = types.SimpleNamespace(normal=lambda stddev=None: None)
+    record = []
+
+    def ringattention(q, k, v, attn_bias, segment_ids, axis_name=None, float32_logits=None, cache_idx=None, blockwise_kwargs=None):
+        kw = blockwise_kwargs
+        assert axis_name == "sp" and float32_logits is True and cache_idx is None and kw["causal_block_size"] == 1
+        record.append("ringattention")
+        return A.blockwise_ring_attention(q, k, v, ring=1, q_chunk=kw["query_chunk_size"], k_chunk=kw["key_chunk_size"], causal=True,
+                                          segment_ids=segment_ids, key_valid=(attn_bias[:, 0, 0] == 0).astype(np.uint8))
+
+    def ringattention_inference(q, k, v, attn_mask, axis_name=None):
+        record.append("ringattention_inference")
+        return A.ring_inference(q, k, v, attn_mask[:, 0])
+
+    def blockwise_feedforward(module, xx, chunk_size, pre_remat=None):
+        record.append("blockwise_feedforward")
+        return module(xx)
+
+    class Output:                                      # transformers' ModelOutput: fields by name, non-None fields by position
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+        def __getitem__(self, i):
+            return [v for v in self.__dict__.values() if v is not None][i]
+    ns.update(nn=mf.nn, nn_partitioning=types.SimpleNamespace(ScanIn=lambda axis: axis), remat=lambda cls, **kw: cls,
+              Optional=Optional, Union=Union, Any=Any, Dict=Dict, List=List, partial=functools.partial,
+              LLaMAConfig=types.SimpleNamespace(get_jax_mesh=lambda mesh_dim: None), PS=lambda *a: a,
+              with_sharding_constraint=lambda t, spec: t, shard_map=lambda fn, mesh=None, in_specs=None, out_specs=None, check_rep=None: fn,
+              ringattention=ringattention, ringattention_inference=ringattention_inference, blockwise_feedforward=blockwise_feedforward,
+              FlaxBaseModelOutput=Output, FlaxCausalLMOutput=Output)
+    exec(compile(ast.Module(body=nodes, type_ignores=[]), f"{path}:{nodes[0].lineno}", "exec"), ns)      # the reference's definitions
+
+    g = np.random.default_rng(982)
+    Vc, d, H, F, NL, L = 37, 32, 2, 48, 2, 32
+    B, S = 2, 24
+    std = 0.2
+    per = {"attention/wq": (d, d), "attention/wk": (d, d), "attention/wv": (d, d), "attention/wo": (d, d),
+           "feed_forward/w1": (d, F), "feed_forward/w2": (F, d), "feed_forward/w3": (d, F)}
+    layers = [{**{k + "/kernel": (g.standard_normal(shp) * std).astype(np.float32) for k, shp in per.items()},
+               "attention_norm/kernel": (1 + 0.1 * g.standard_normal(d)).astype(np.float32),
+               "ffn_norm/kernel": (1 + 0.1 * g.standard_normal(d)).astype(np.float32)} for _ in range(NL)]
+    top = {"transformer/wte/embedding": g.standard_normal((Vc, d)).astype(np.float32),
+           "transformer/ln_f/kernel": (1 + 0.1 * g.standard_normal(d)).astype(np.float32),
+           "lm_head/kernel": (g.standard_normal((d, Vc)) * std).astype(np.float32)}
+    # the two on-disk layouts of a FlaxLLaMAForCausalLM train state, by the names lwm_amd/weights.py::flax_llama_to_lwm maps
+    flat_layers = dict(top, **{f"transformer/h/{i}/{k}": v for i, lay in enumerate(layers) for k, v in lay.items()})
+    flat_scan = dict(top, **{f"transformer/h/scan_decoder/{k}": np.stack([lay[k] for lay in layers], axis=0) for k in layers[0]})
+
+    def nest(flat):
+        tree = {}
+        for k, v in flat.items():
+            t = tree
+            parts = k.split("/")
+            for p in parts[:-1]:
+                t = t.setdefault(p, {})
+            t[parts[-1]] = v
+        return tree
+    tokens = g.integers(0, Vc, (B, S)).astype(np.int32)
+    am = np.ones((B, S), np.int32)
+    am[0, :3] = 0
+    seg = np.zeros((B, S), np.int32)
+    seg[1, 11:] = 1
+    pos = np.tile(np.arange(S, dtype=np.int32), (B, 1))
+    results = {}
+    for tag, flat, scan_layers, chunk, use_seg in (("layers", flat_layers, False, 1024, True), ("scan", flat_scan, True, 1024, True),
+                                                    ("scan_blockwise", flat_scan, True, 8, False)):
+        cfg = types.SimpleNamespace(vocab_size=Vc, hidden_size=d, intermediate_size=F, num_hidden_layers=NL, num_attention_heads=H,
+                                    max_sequence_length=L, rms_norm_eps=1e-6, initializer_range=0.02, resid_pdrop=0.0, embd_pdrop=0.0,
+                                    attn_pdrop=0.0, tie_word_embeddings=False, scan_attention=True, scan_mlp=True,
+                                    scan_query_chunk_size=chunk, scan_key_chunk_size=chunk, scan_mlp_chunk_size=chunk,
+                                    scan_layers=scan_layers, param_scan_axis=0, mesh_dim="1,1,1,1", theta=10000)
+        tree = nest(flat)
+        mf.read.clear()
+        record.clear()
+        m = ns["FlaxLLaMAForCausalLMModule"](cfg, dtype=np.float32)
+        res = mf.run(tree, lambda: m(tokens, am, seg if use_seg else None, pos))
+        logits = res.logits
+        assert logits.shape == (B, S, Vc) and logits.dtype == np.float32
+        read = {"/".join(p) for p in mf.read}
+        assert read == set(flat), (sorted(set(flat) - read)[:4], sorted(read - set(flat))[:4])       # every leaf read, none missing
+        results[tag] = logits
+        out.update({f"model_{tag}_logits": logits, f"model_{tag}_calls": np.array(sorted(set(record)))})
+    assert np.array_equal(results["layers"], results["scan"])         # the stacked layout is the same model
+    out.update({f"model_flat_layers::{k}": v for k, v in flat_layers.items()})
+    out.update({f"model_flat_scan::{k}": v for k, v in flat_scan.items() if "scan_decoder" in k})
+    out.update({"model_tokens": tokens, "model_am": am, "model_seg": seg, "model_dims": np.array([Vc, d, H, F, NL, L, B, S], np.int32)})
+
+
 def main():
     out = {}
     rope(out)
@@ -701,6 +870,7 @@ def main():
     video(out)
     layer(out)
     network(out)
+    model(out)
     np.savez_compressed(os.path.join(HERE, "ref_run.npz"), **out)
     print("wrote ref_run.npz;", "lines", {k: out[k].tolist() for k in out if k.endswith("_lines")}, "vq margin", float(out["vq_min_margin"]))
 
