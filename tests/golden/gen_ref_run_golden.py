@@ -858,6 +858,39 @@ def model(out):
     out.update({f"model_flat_scan::{k}": v for k, v in flat_scan.items() if "scan_decoder" in k})
     out.update({"model_tokens": tokens, "model_am": am, "model_seg": seg, "model_dims": np.array([Vc, d, H, F, NL, L, B, S], np.int32)})
 
+    # ---- the vision-language model of BASELINE configs[3] (lwm/vision_llama.py:255-443): the same transformer with a second
+    # embedding table and a second head
+    vpath = f"{REF}/vision_llama.py"
+    vsrc = open(vpath).read()
+    vwant = ["FlaxVideoLLaMAModule", "FlaxVideoLLaMAForCausalLMModule"]
+    vnodes = [n for n in ast.parse(vsrc).body if isinstance(n, ast.ClassDef) and n.name in vwant]
+    assert [n.name for n in vnodes] == vwant
+    out["vmodel_lines"] = np.array([[n.lineno, n.end_lineno] for n in vnodes], np.int32)
+    ns.update(VideoLLaMAConfig=object)
+    jnp.zeros_like, jnp.cumsum = np.zeros_like, np.cumsum
+    jnp.clip = lambda a, a_min=None, a_max=None: np.clip(a, a_min, a_max)
+    exec(compile(ast.Module(body=vnodes, type_ignores=[]), f"{vpath}:{vnodes[0].lineno}", "exec"), ns)
+    VV = 19
+    vflat = dict(flat_scan, **{"transformer/vte/embedding": g.standard_normal((VV, d)).astype(np.float32),
+                               "vision_head/kernel": (g.standard_normal((d, VV)) * std).astype(np.float32)})
+    vm = g.random((B, S)) < 0.5
+    vtokens = np.where(vm, g.integers(0, VV, (B, S)), tokens).astype(np.int32)
+    cfg = types.SimpleNamespace(vocab_size=Vc, vision_vocab_size=VV, hidden_size=d, intermediate_size=F, num_hidden_layers=NL,
+                                num_attention_heads=H, max_sequence_length=L, rms_norm_eps=1e-6, initializer_range=0.02, resid_pdrop=0.0,
+                                embd_pdrop=0.0, attn_pdrop=0.0, tie_word_embeddings=False, tie_vision_embeddings=False, sample_mode="all",
+                                scan_attention=True, scan_mlp=True, scan_query_chunk_size=1024, scan_key_chunk_size=1024,
+                                scan_mlp_chunk_size=1024, scan_layers=True, param_scan_axis=0, mesh_dim="1,1,1,1", theta=10000)
+    mf.read.clear()
+    m = ns["FlaxVideoLLaMAForCausalLMModule"](cfg, dtype=np.float32)
+    # attention_mask / segment_ids / position_ids left to the module's own defaults (lwm/vision_llama.py:385-394), as lwm/train.py:186-191 calls it
+    res = mf.run(nest(vflat), lambda: m(vtokens, vm))
+    vlogits, tlogits = res.logits
+    assert vlogits.shape == (B, S, VV) and tlogits.shape == (B, S, Vc)
+    read = {"/".join(p) for p in mf.read}
+    assert read == set(vflat), (sorted(set(vflat) - read)[:4], sorted(read - set(vflat))[:4])
+    out.update({"vmodel_tokens": vtokens, "vmodel_vm": vm, "vmodel_vision_logits": vlogits, "vmodel_text_logits": tlogits,
+                "vmodel_vte": vflat["transformer/vte/embedding"], "vmodel_vision_head": vflat["vision_head/kernel"]})
+
 
 def main():
     out = {}
