@@ -1,6 +1,6 @@
 """`python -m lwm_amd.cli.vision_chat` -- the flag set of lwm/vision_chat.py:22-37
 (scripts/run_vision_chat.sh): frames -> VQGAN codes (HIP tokeniser) -> the prompt of
-lwm/vision_chat.py:110-147 -> sampled continuation through the cached-decode hot path -> text."""
+lwm/vision_chat.py:110-145 -> sampled continuation through the cached-decode hot path -> text."""
 from __future__ import annotations
 
 import math
@@ -19,7 +19,7 @@ GROUPS = ("llama", "jax_distributed")
 
 
 def _process_frame(image, size):
-    """lwm/vision_chat.py:57-75: resize the short side to `size`, centre crop, scale to [-1, 1]."""
+    """lwm/vision_chat.py:59-74: resize the short side to `size`, centre crop, scale to [-1, 1]."""
     w, h = image.size
     if w < h:
         nw, nh = size, int(size * h / w)
@@ -67,13 +67,15 @@ class Sampler:
         cfg = C.build_config(F, vision=True)
         cfg.update(dict(bos_token_id=self.tokenizer.bos_token_id, eos_token_id=self.tokenizer.eos_token_id))
         self.config = cfg
-        self.block_size = int(F.llama.get("block_size", 512)) if isinstance(F.llama, dict) else 512
+        # lwm/vision_chat.py:51-53: the prompt buffer is padded to, and at most this many tokens are generated:
+        # max(scan_query_chunk_size, scan_key_chunk_size) * mesh.shape['sp']
+        self.block_size = max(cfg.scan_query_chunk_size, cfg.scan_key_chunk_size) * int(self.mesh["sp"])
         self.model = C.load_checkpoint(C.build_model(cfg, True, C.torch_dtype(F.dtype), F.seed, self.dev),
                                        F.load_checkpoint)
         self.gen = torch.Generator(device=self.dev).manual_seed(F.seed)
 
     def _read_process_vision(self, path, max_n_frames):
-        """frames -> [256 codes, 8192] per frame, 8193 after the last (lwm/vision_chat.py:91-108)."""
+        """frames -> [256 codes, 8192] per frame, 8193 after the last (lwm/vision_chat.py:76-108)."""
         vision = read_frames(path, max_n_frames)
         _, idx = self.vqgan.encode(torch.from_numpy(vision))             # all frames in one call (independent)
         enc = idx.reshape(len(vision), -1).cpu().numpy().astype(int)

@@ -47,6 +47,11 @@ for the handful of `jax.numpy` / `jax.lax` names they use:
       order, the literal jnp.pad [(0,0),(0,1),(0,1),(0,0)] before the VALID stride-2 conv, GroupNorm -> silu -> conv order --
       and that the parameter tree lwm_amd.vqgan builds (random_params: the layout of the pickles of lwm/vqgan.py:19) is the
       tree this code asks for: every leaf is read, none is missing.
+  THE PROMPT of lwm/vision_chat.py (b5, the caller of the tokeniser): Sampler._process_frame (:59-74), ._read_process_vision
+      (:76-108: 256 codes per frame, 8192 between frames, 8193 after the last) and .construct_input (:110-145: text, <vision>,
+      codes, </vision>, tail; left padding to a multiple of block_size; vision and attention masks) executed with `self` = a
+      plain object holding a recording tokenizer stub, a vqgan stub that returns known codes and block_size; PIL does the image
+      work as in the reference.
     The mask statements are statement RANGES inside larger methods (the rest of the methods builds flax layers and calls ringattention):
     the ranges are located in the syntax tree by what they assign, compiled as they are and executed with the locals the
     method would hold (xq, xk, hidden_states, attention_mask, segment_ids; `self` = a plain object with has_variable /
@@ -892,6 +897,53 @@ def model(out):
                 "vmodel_vte": vflat["transformer/vte/embedding"], "vmodel_vision_head": vflat["vision_head/kernel"]})
 
 
+def chat_prompt(out):
+    import io
+    import math
+    from PIL import Image
+    path = f"{REF}/vision_chat.py"
+    frame, a0, a1 = cut(path, "Sampler", "_process_frame")
+    read, b0, b1 = cut(path, "Sampler", "_read_process_vision")
+    cons, c0, c1 = cut(path, "Sampler", "construct_input")
+    out["chat_lines"] = np.array([[a0, a1], [b0, b1], [c0, c1]], np.int32)
+    g = np.random.default_rng(57)
+    # (1) frames: a wide and a tall picture
+    for tag, (w, h) in (("wide", (97, 64)), ("tall", (50, 83))):
+        img = g.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        y = frame(None, Image.fromarray(img), 32)
+        assert y.shape == (32, 32, 3) and y.dtype == np.float32
+        out.update({f"chat_frame_{tag}_in": img, f"chat_frame_{tag}_out": y})
+    # (2) one picture -> tokens; (3) the whole prompt, two prompts of different length in one batch
+    png = io.BytesIO()
+    Image.fromarray(g.integers(0, 256, (300, 280, 3)).astype(np.uint8)).save(png, format="PNG")
+    out["chat_png"] = np.frombuffer(png.getvalue(), np.uint8)
+    codes = g.integers(0, 8192, (1, 16, 16)).astype(np.int64)
+
+    class Tok:                                            # a tokenizer stub: one id per character, offset so that ids are not codes
+        def encode(self, text):
+            return [9000 + ord(c) for c in text]
+    seen = []
+
+    def encode(v):
+        seen.append(np.array(v))
+        return None, codes[:len(v)]
+    self = types.SimpleNamespace(tokenizer=Tok(), vqgan=types.SimpleNamespace(encode=encode), n_tokens_per_frame=257, min_buffer_size=256,
+                                 block_size=128)
+    self._process_frame = types.MethodType(frame, self)
+    self._read_process_vision = types.MethodType(read, self)
+    glob = read.__globals__
+    glob.update(open_file=lambda p, mode: io.BytesIO(png.getvalue()), Image=Image)
+    glob["jax"].device_get = lambda x: x
+    cons.__globals__.update(math=math, tqdm=lambda x: x)
+    toks = read(self, "picture.png", 4)
+    assert len(toks) == 257 and toks[-1] == 8193 and toks[:256] == codes[0].reshape(-1).tolist()
+    assert seen[0].shape == (1, 256, 256, 3) and abs(float(seen[0].max())) <= 1.0
+    out.update({"chat_codes": codes, "chat_tokens": np.array(toks, np.int64), "chat_pixels": seen[0]})
+    batch = cons(self, [dict(input_path="picture.png", question="What is this?"), dict(input_path="picture.png", question="And what colour is the sky in it?")], 2)
+    out.update({"chat_input_ids": batch["input_ids"].astype(np.int64), "chat_vision_masks": batch["vision_masks"],
+                "chat_attention_mask": batch["attention_mask"].astype(np.int64), "chat_block_size": np.int32(128)})
+
+
 def main():
     out = {}
     rope(out)
@@ -904,6 +956,7 @@ def main():
     layer(out)
     network(out)
     model(out)
+    chat_prompt(out)
     np.savez_compressed(os.path.join(HERE, "ref_run.npz"), **out)
     print("wrote ref_run.npz;", "lines", {k: out[k].tolist() for k in out if k.endswith("_lines")}, "vq margin", float(out["vq_min_margin"]))
 
