@@ -76,10 +76,12 @@ random initialisation (codes U(-1/8192, 1/8192), lwm/vqgan.py:198-200) distances
 depends on the order of additions, under XLA as under anything else.
 
 Writes tests/golden/ref_run.npz.  Needs /root/reference (this container only); the tests read the .npz.
-Re-run:  python tests/golden/gen_ref_run_golden.py
+Re-run:  python tests/golden/gen_ref_run_golden.py [output.npz]   (deterministic: tests/test_golden.py regenerates and compares
+when /root/reference is present)
 """
 import ast
 import os
+import sys
 import types
 from typing import Tuple
 
@@ -957,8 +959,9 @@ def main():
     network(out)
     model(out)
     chat_prompt(out)
-    np.savez_compressed(os.path.join(HERE, "ref_run.npz"), **out)
-    print("wrote ref_run.npz;", "lines", {k: out[k].tolist() for k in out if k.endswith("_lines")}, "vq margin", float(out["vq_min_margin"]))
+    target = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "ref_run.npz")
+    np.savez_compressed(target, **out)
+    print("wrote", os.path.basename(target) + ";", "lines", {k: out[k].tolist() for k in out if k.endswith("_lines")}, "vq margin", float(out["vq_min_margin"]))
 
 
 if __name__ == "__main__":
