@@ -63,15 +63,23 @@ class LLaMAConfig:
 
     def __init__(self, vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32,
                  num_attention_heads=32, max_sequence_length=4096, rms_norm_eps=1e-6, initializer_range=0.02,
-                 scan_attention=True, scan_mlp=True, scan_query_chunk_size=1024, scan_key_chunk_size=1024,
-                 scan_mlp_chunk_size=1024, theta=10000, **kwargs):
+                 use_cache=True, bos_token_id=0, eos_token_id=1, resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0,
+                 tie_word_embeddings=False, scan_attention=True, scan_mlp=True, scan_query_chunk_size=1024,
+                 scan_key_chunk_size=1024, scan_mlp_chunk_size=1024, scan_layers=True, param_scan_axis=0, mesh_dim=None,
+                 theta=10000, **kwargs):
+        # (every keyword and default of the reference's signature -- tests/test_golden.py holds them to the reference's own
+        # __init__; scan_layers / param_scan_axis describe the checkpoint layout, the *_pdrop fields are 0 and unused)
         self.vocab_size, self.hidden_size, self.intermediate_size = vocab_size, hidden_size, intermediate_size
         self.num_hidden_layers, self.num_attention_heads = num_hidden_layers, num_attention_heads
         self.max_sequence_length, self.rms_norm_eps = max_sequence_length, rms_norm_eps
         self.initializer_range = initializer_range
+        self.use_cache, self.bos_token_id, self.eos_token_id = use_cache, bos_token_id, eos_token_id
+        self.resid_pdrop, self.embd_pdrop, self.attn_pdrop = resid_pdrop, embd_pdrop, attn_pdrop
+        self.tie_word_embeddings = tie_word_embeddings
         self.scan_attention, self.scan_mlp = scan_attention, scan_mlp
         self.scan_query_chunk_size, self.scan_key_chunk_size = scan_query_chunk_size, scan_key_chunk_size
         self.scan_mlp_chunk_size, self.theta = scan_mlp_chunk_size, theta
+        self.scan_layers, self.param_scan_axis, self.mesh_dim = scan_layers, param_scan_axis, mesh_dim
         for k, v in kwargs.items():
             setattr(self, k, v)
         self._validate()

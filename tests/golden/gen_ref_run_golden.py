@@ -946,6 +946,44 @@ def chat_prompt(out):
                 "chat_attention_mask": batch["attention_mask"].astype(np.int64), "chat_block_size": np.int32(128)})
 
 
+def flags(out):
+    """The flag DEFINITIONS of the three entry points (b5): the `define_flags_with_default(...)` statement of lwm/train.py,
+    lwm/vision_chat.py and lwm/vision_generation.py executed with a recorder for tux's function; the config groups
+    (`X.get_default_config()`) become the marker "<group>"."""
+    import json
+    rec = {}
+    for mod in ("train", "vision_chat", "vision_generation"):
+        src = open(f"{REF}/{mod}.py").read()
+        node = next(n for n in ast.parse(src).body if isinstance(n, ast.Assign) and "define_flags_with_default" in ast.get_source_segment(src, n))
+
+        class Group:
+            def __getattr__(self, name):
+                return self
+
+            def __call__(self, *a, **kw):
+                return "<group>"
+        ns = dict(define_flags_with_default=lambda **kw: (kw, kw))
+        for name in ("DatasetFactory", "OptimizerFactory", "StreamingCheckpointer", "VideoLLaMAConfig", "JaxDistributedConfig", "tux"):
+            ns[name] = Group()
+        exec(compile(ast.Module(body=[node], type_ignores=[]), f"{REF}/{mod}.py:{node.lineno}", "exec"), ns)
+        rec[mod] = dict(lines=[node.lineno, node.end_lineno], flags=ns["FLAGS"])
+    out["flags_json"] = np.array(json.dumps(rec, sort_keys=True))
+    # ... and the configuration objects those flags fill: the keyword defaults of LLaMAConfig / VideoLLaMAConfig / VQGANConfig
+    # (read off the reference's __init__ signatures) and the size table LLAMA_STANDARD_CONFIGS (a literal)
+    conf = {}
+    for mod, cls in (("llama", "LLaMAConfig"), ("vision_llama", "VideoLLaMAConfig"), ("vqgan", "VQGANConfig")):
+        src = open(f"{REF}/{mod}.py").read()
+        c = next(n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == cls)
+        f = next(n for n in c.body if isinstance(n, ast.FunctionDef) and n.name == "__init__")
+        names = [a.arg for a in f.args.args][1:]
+        conf[cls] = dict(lines=[f.lineno, f.end_lineno],
+                         defaults={n: ast.literal_eval(v) for n, v in zip(names[len(names) - len(f.args.defaults):], f.args.defaults)})
+    src = open(f"{REF}/llama.py").read()
+    node = next(n for n in ast.parse(src).body if isinstance(n, ast.Assign) and getattr(n.targets[0], "id", "") == "LLAMA_STANDARD_CONFIGS")
+    conf["LLAMA_STANDARD_CONFIGS"] = dict(lines=[node.lineno, node.end_lineno], table=ast.literal_eval(node.value))
+    out["configs_json"] = np.array(json.dumps(conf, sort_keys=True))
+
+
 def main():
     out = {}
     rope(out)
@@ -959,6 +997,7 @@ def main():
     network(out)
     model(out)
     chat_prompt(out)
+    flags(out)
     target = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "ref_run.npz")
     np.savez_compressed(target, **out)
     print("wrote", os.path.basename(target) + ";", "lines", {k: out[k].tolist() for k in out if k.endswith("_lines")}, "vq margin", float(out["vq_min_margin"]))
