@@ -117,7 +117,9 @@ def shims():
         idxs = np.broadcast_to(np.arange(x.shape[-1], dtype=np.int32), x.shape)
         return np.greater_equal(idxs[..., None], idxs[..., None, :])[..., None, :, :].astype(dtype)
 
-    return {"np": np, "jnp": jnp, "jax": jax, "lax": lax, "Tuple": Tuple, "combine_masks": combine_masks,
+    from typing import Optional
+    jax.Array = np.ndarray
+    return {"np": np, "jnp": jnp, "jax": jax, "lax": lax, "Tuple": Tuple, "Optional": Optional, "combine_masks": combine_masks,
             "make_causal_mask": make_causal_mask}
 
 
@@ -946,6 +948,39 @@ def chat_prompt(out):
                 "chat_attention_mask": batch["attention_mask"].astype(np.int64), "chat_block_size": np.int32(128)})
 
 
+def generation_inputs(out):
+    """FlaxVideoLLaMAForCausalLM.prepare_inputs_for_generation / update_inputs_for_generation (lwm/vision_llama.py:447-474) and
+    the text model's (lwm/llama.py:1113-1140): the extended key mask over max_length, the positions of a left-padded prompt
+    (cumsum of the mask - 1) and of the following steps."""
+    g = np.random.default_rng(447)
+    B, S, L = 3, 9, 14
+    am = np.ones((B, S), np.int32)
+    am[0, :4] = 0
+    am[2, :1] = 0
+    ids = g.integers(0, 50, (B, S)).astype(np.int32)
+    lines = []
+    for tag, path, cls in (("vision", f"{REF}/vision_llama.py", "FlaxVideoLLaMAForCausalLM"), ("text", f"{REF}/llama.py", "FlaxLLaMAForCausalLM")):
+        prep, a0, a1 = cut(path, cls, "prepare_inputs_for_generation")
+        upd, b0, b1 = cut(path, cls, "update_inputs_for_generation")
+        lines += [[a0, a1], [b0, b1]]
+        prep.__globals__["jnp"].ones, prep.__globals__["jnp"].broadcast_to, prep.__globals__["jnp"].arange = np.ones, np.broadcast_to, np.arange
+
+        def dus(operand, update, start):
+            res = np.array(operand, copy=True)
+            res[tuple(slice(int(s0), int(s0) + u) for s0, u in zip(start, update.shape))] = update
+            return res
+        prep.__globals__["lax"].dynamic_update_slice = dus
+        self = types.SimpleNamespace(init_cache=lambda b, m: ("cache", b, m))
+        for case, mask in (("padded", am), ("nomask", None)):
+            kw = dict(vision_masks="vm") if tag == "vision" else {}
+            r = prep(self, ids, L, attention_mask=mask, **kw)
+            assert r["past_key_values"] == ("cache", B, L)
+            nxt = upd(self, types.SimpleNamespace(past_key_values="pkv"), dict(r))
+            out.update({f"gen_{tag}_{case}_mask": np.asarray(r["attention_mask"]), f"gen_{tag}_{case}_pos": np.asarray(r["position_ids"]),
+                        f"gen_{tag}_{case}_next": np.asarray(nxt["position_ids"])})
+    out.update({"gen_lines": np.array(lines, np.int32), "gen_ids": ids, "gen_am": am, "gen_max_length": np.int32(L)})
+
+
 def flags(out):
     """The flag DEFINITIONS of the three entry points (b5): the `define_flags_with_default(...)` statement of lwm/train.py,
     lwm/vision_chat.py and lwm/vision_generation.py executed with a recorder for tux's function; the config groups
@@ -997,6 +1032,7 @@ def main():
     network(out)
     model(out)
     chat_prompt(out)
+    generation_inputs(out)
     flags(out)
     target = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "ref_run.npz")
     np.savez_compressed(target, **out)
