@@ -1,79 +1,70 @@
-"""Golden vectors produced by the REFERENCE'S OWN SOURCE LINES (not by a restatement).
+"""Golden vectors produced by EXECUTING THE REFERENCE'S OWN SOURCE (not a restatement of it).
 
-Almost everything on the hot path lives in packages that cannot be imported here (jax, flax, ringattention, tux:
-SURVEY.md section 8c), but four pieces of /root/reference are self-contained enough to be EXECUTED with numpy standing in
-for the handful of `jax.numpy` / `jax.lax` names they use:
+The reference as a whole cannot run here: jax, flax, ringattention and tux are not installable.  But
+most of what sits on and around the hot path is plain Python over `jax.numpy` calls, and THAT can run: this script cuts
+functions, methods, statement ranges and whole class hierarchies out of the files under /root/reference with `ast`,
+compiles the text as it is (nothing is copied into the repo; the file name and line of every code object are the
+reference's) and executes it with stand-ins for what is missing.  TEST INFRASTRUCTURE: only tests/test_golden.py reads the
+result.
 
-  precompute_freqs_cis        lwm/llama.py:344-350   module-level function (numpy code in the reference already)
-  apply_rotary_emb            lwm/llama.py:353-375   module-level function
-  RMSNorm._norm / .__call__   lwm/llama.py:334-341   methods of a flax Module; `self` = a plain object holding eps, dtype, weight
-  VectorQuantizer.__call__    lwm/vqgan.py:191-221   method of a flax Module; `self.param(...)` returns the codebook handed in
-  the MASK statements of FlaxLLaMAAttention  (the in-tree specification of SURVEY.md section 8 row a4):
-      setup:     self.causal_mask = make_causal_mask(...)                                   lwm/llama.py:425
-      __call__:  blockwise branch, attention_mask -> additive key-padding bias               lwm/llama.py:526-537
-                 dense branch, causal (with the cache's shift) AND segment AND key mask      lwm/llama.py:573-592
-  FlaxLLaMAAttention._concatenate_to_cache  lwm/llama.py:441-492  the whole method (row a6): first call creates the cache
-      variables, later calls with a block of Q > 1 tokens write it at cache_index (lax.dynamic_update_slice stood in from
-      XLA's documented semantics: the start index is clamped so that the update fits) and advance the index; the one-token
-      branch (:452-483) is shard_map / lax.cond / .at[].set code and is not executed
-  FlaxVideoLLaMAModule.__call__, the embedding choice   lwm/vision_llama.py:308-311 (text ids -> wte, vision ids -> vte, mixed
-      by the vision mask; nn.Embed stood in by a table lookup)
-  train_step.loss_and_accuracy, modality 'vision,text'   lwm/train.py:185-202: which targets and which masks go to which head, and
-      0.5 * (vision_loss + text_loss); model.apply returns the logits handed in, tux's cross_entropy_loss_and_accuracy (absent)
-      is stood in by a function that RECORDS its arguments and returns oracle/llama_ops_ref's restatement
-  VQGANModel.encode / .decode   lwm/vqgan.py:117-141 (row v7): 5-D video folded into the batch and unfolded again, the final
-      clip; the sub-modules (encoder, quant_conv, quantize, post_quant_conv, decoder) are the ORACLE's, so the vectors pin the
-      glue, not the networks
-  ONE WHOLE LAYER (BASELINE configs[0]'s arithmetic around the op): FlaxLLaMABlock.__call__ (lwm/llama.py:705-744),
-      FlaxLLaMAAttention.__call__ (:494-620, both branches), ._split_heads / ._merge_heads (:434-438), FlaxLLaMAMLP.__call__
-      (:658-661) and RMSNorm executed as they are, composed the way the reference composes them.  Stood in: flax's nn.Dense (x @
-      kernel, no bias: use_bias=False), nn.Dropout (identity: deterministic), nn.silu (x * sigmoid(x)), tux's
-      with_sharding_constraint (identity), jax's shard_map (returns the function: one device), and -- the arithmetic that IS
-      NOT the reference's here -- the two ops of the absent `ringattention` package: `ringattention(...)` is the oracle's f32
-      blockwise restatement (after asserting the keyword arguments the call site passes), `ringattention_inference(...)` the
-      oracle's dense-mask restatement, `blockwise_feedforward(module, x, chunk, pre_remat=True)` = module(x) recorded.  What
-      this pins for oracle/llama_model_ref.py: projections on the NORMALISED input, heads split by reshape, RoPE on q and k
-      (not v) at the given positions, which branch runs when (S > max(chunk sizes)), what each branch hands the op (bias vs
-      combined mask), merge, wo, both residual adds, the FFN's structure and when it goes blockwise.
-  THE WHOLE TOKENISER NETWORK (rows v1-v5, v7; the parameter tree of f.4): every class of lwm/vqgan.py from VQGANModel to
-      MidBlock (lines 105-351: VQGANModel, Encoder, Decoder, VectorQuantizer, DownsamplingBlock, ResnetBlock, AttnBlock,
-      Downsample, Upsample, UpsamplingBlock, MidBlock) executed as CLASS DEFINITIONS under a ~60-line emulation of
-      flax.linen.Module (MiniFlax below: dataclass-style fields from the annotations, setup(), @nn.compact, and flax's
-      naming rule -- a submodule made in setup() is named by its attribute, one made inside a compact __call__ gets
-      ClassName_<n>, n counting that class within the parent).  nn.Conv / nn.GroupNorm are the ORACLE's primitives fed the
-      {'kernel','bias'} / {'scale','bias'} leaves the naming rule leads to, nn.silu the oracle's, jnp.pad numpy's,
-      jax.image.resize(method='nearest') an integer repeat.  What this pins: the wiring of the reference's own module code --
-      block order, channel widths, where Downsample / Upsample sit, the shortcut rule and its position in the creation
-      order, the literal jnp.pad [(0,0),(0,1),(0,1),(0,0)] before the VALID stride-2 conv, GroupNorm -> silu -> conv order --
-      and that the parameter tree lwm_amd.vqgan builds (random_params: the layout of the pickles of lwm/vqgan.py:19) is the
-      tree this code asks for: every leaf is read, none is missing.
-  THE PROMPT of lwm/vision_chat.py (b5, the caller of the tokeniser): Sampler._process_frame (:59-74), ._read_process_vision
-      (:76-108: 256 codes per frame, 8192 between frames, 8193 after the last) and .construct_input (:110-145: text, <vision>,
-      codes, </vision>, tail; left padding to a multiple of block_size; vision and attention masks) executed with `self` = a
-      plain object holding a recording tokenizer stub, a vqgan stub that returns known codes and block_size; PIL does the image
-      work as in the reference.
-    The mask statements are statement RANGES inside larger methods (the rest of the methods builds flax layers and calls ringattention):
-    the ranges are located in the syntax tree by what they assign, compiled as they are and executed with the locals the
-    method would hold (xq, xk, hidden_states, attention_mask, segment_ids; `self` = a plain object with has_variable /
-    variables / causal_mask / config / dtype).  Two flax helpers they call are stood in from flax's documented behaviour
-    (flax 0.8.4, pinned in gpu_requirements.txt): combine_masks(*masks) = logical AND of the masks that are not None, cast
-    to float32; make_causal_mask(x, dtype) = (1, 1, L, L) with [q, k] = q >= k.
+What is executed (function below -> reference lines; the committed .npz records the line ranges, the tests pin them):
 
-This script cuts exactly those definitions out of the reference files with `ast` (the text is executed where it lies --
-nothing is copied into the repo; decorators such as @nn.compact are dropped) and runs them.  Stand-ins, all one-to-one:
-jnp.{asarray, reshape, stack, real, imag, square, sum, einsum, argmin, promote_types, float32} = numpy's;
-jax.lax.complex(a, b) = a + 1j*b (complex64); jax.lax.rsqrt(x) = 1 / sqrt(x) in x's dtype; jax.lax.stop_gradient and
-jax.device_put = identity; jax.nn.one_hot = an identity-matrix gather (its result is discarded by the reference).
+  rope()               precompute_freqs_cis, apply_rotary_emb                      lwm/llama.py:344-375
+  rmsnorm()            RMSNorm._norm / __call__ (dtype float32)                    lwm/llama.py:334-341
+  vq()                 VectorQuantizer.__call__ (encode and lookup paths)          lwm/vqgan.py:192-221
+  masks()              FlaxLLaMAAttention: causal_mask (setup), the blockwise branch's bias, the dense branch's mask with and
+                       without a cache -- statement RANGES inside larger methods, located in the syntax tree by what they
+                       assign and executed with the locals the method would hold   lwm/llama.py:425, :527-537, :572-592
+  cache()              FlaxLLaMAAttention._concatenate_to_cache, creation + three prefill blocks (the one-token branch is
+                       shard_map / lax.cond / .at[].set code and is not executed)  lwm/llama.py:441-492
+  vision_text()        the embedding choice of FlaxVideoLLaMAModule.__call__       lwm/vision_llama.py:308-311
+                       the 'vision,text' objective of train_step                   lwm/train.py:185-202
+  video()              VQGANModel.encode / decode over the oracle's networks       lwm/vqgan.py:117-141
+  layer()              FlaxLLaMABlock.__call__, FlaxLLaMAAttention.__call__ (both branches), _split_heads / _merge_heads,
+                       FlaxLLaMAMLP.__call__, RMSNorm, RoPE composed as the reference composes them
+                                                                                   lwm/llama.py:434-438, :494-620, :658-661, :704-744
+  network()            EVERY module class of lwm/vqgan.py (VQGANModel ... MidBlock) as class definitions under MiniFlax
+                                                                                   lwm/vqgan.py:105-351
+  model()              the model classes of lwm/llama.py (RMSNorm, Attention, MLP, Block, BlockCollection in its loop and its
+                       nn.scan form, Module, ForCausalLMModule) and of lwm/vision_llama.py as class definitions under
+                       MiniFlax: a 2-layer model produces logits from a train state in either on-disk layout
+                                                                                   lwm/llama.py:320-1106, lwm/vision_llama.py:255-439
+  chat_prompt()        Sampler._process_frame / _read_process_vision / construct_input   lwm/vision_chat.py:59-145
+  generation_inputs()  prepare_inputs_for_generation / update_inputs_for_generation of both model classes
+                                                                                   lwm/vision_llama.py:447-474, lwm/llama.py:1113-1137
+  flags()              the define_flags_with_default(...) statements of the three entry points (with a recorder), the keyword
+                       defaults of LLaMAConfig / VideoLLaMAConfig / VQGANConfig, the size table LLAMA_STANDARD_CONFIGS
 
-What this PINS for the oracle, the product's host logic and the HIP kernels: the RoPE table formula, frequency dtype, pair
-interleaving, reshape / stack order and position indexing (the call site's jnp.take, lwm/llama.py:515); RMSNorm's order of
-casts and operations at dtype = float32 (the reference's default dtype; numpy has no bfloat16); the quantiser's distance
-formula, first-index argmin, gather and output shapes; the boolean visibility of every (query, key) pair in the training
-and the cached-inference branch and the bias constants the blockwise branch hands to ringattention.  What it does NOT pin: XLA's rounding and summation order (numpy
-performs the arithmetic here) -- which is why the quantiser case is a WELL-CONDITIONED one (codes drawn N(0, 1), inputs near
-codes: top-2 margins far above f32 rounding), where every summation order gives the same indices; with the reference's
-random initialisation (codes U(-1/8192, 1/8192), lwm/vqgan.py:198-200) distances tie at f32 resolution and the index
-depends on the order of additions, under XLA as under anything else.
+Stand-ins, by kind:
+  * numpy for the jax.numpy / jax.lax names the code uses, one to one (shims()): asarray, reshape, stack, real, imag, square,
+    sum, einsum, argmin, take, where, pad, clip, cumsum, ...; lax.complex(a, b) = a + 1j*b in complex64; lax.rsqrt = 1/sqrt in
+    the argument's dtype; lax.select = where; lax.dynamic_update_slice = a copy with the block written at the start index,
+    clamped so that it fits (XLA's documented semantics); stop_gradient / device_put / with_sharding_constraint = identity;
+    shard_map(fn, ...) = fn (one device); jax.image.resize(method='nearest') = an integer repeat.
+  * flax: MiniFlax (below, ~150 lines) emulates the part of flax.linen the classes use -- Module with dataclass-style fields
+    from the annotations, setup(), @nn.compact, the NAMING RULE (a submodule made in setup() is named by its attribute, one
+    made inside a compact __call__ is ClassName_<n> with n counting that class within the parent, name= overrides), param(),
+    nn.scan as lwm/llama.py:927-941 uses it (`length` applications over leaves stacked on the scan axis), remat = identity;
+    nn.Dense = x @ kernel (every Dense on the path has use_bias=False), nn.Embed = a lookup, nn.Dropout = identity
+    (deterministic), nn.silu = x * sigmoid(x); combine_masks = logical AND of the masks that are not None cast to float32,
+    make_causal_mask = (1, 1, L, L) with [q, k] = q >= k (flax 0.8.4's documented behaviour, gpu_requirements.txt).
+  * what is NOT in the reference tree at all and is therefore NOT pinned by these vectors -- the arithmetic of
+      - the `ringattention` package: `ringattention(...)` is the oracle's f32 blockwise restatement (after asserting the
+        keyword arguments the call site passes), `ringattention_inference(...)` the oracle's dense-mask restatement,
+        `blockwise_feedforward(module, x, chunk, pre_remat=True)` = module(x);
+      - XLA's convolution / GroupNorm: nn.Conv / nn.GroupNorm in network() are the oracle's C primitives, fed the leaves the
+        naming rule leads to;
+      - tux.cross_entropy_loss_and_accuracy: a recorder that returns the oracle's restatement.
+    numpy also performs the sums and products that XLA would: rounding and summation order are numpy's.  That is why the
+    quantiser cases are WELL CONDITIONED (codes N(0, 1) or planted on the inputs: top-2 margins far above f32 rounding), where
+    every summation order finds the same index; with the reference's random initialisation (codes U(-1/8192, 1/8192),
+    lwm/vqgan.py:198-200) distances tie at f32 resolution and the index depends on the order of additions, under XLA as
+    under anything else.
+
+What the vectors pin, then, is everything a restatement can get wrong that is not rounding: formulas, operand order, casts,
+pair interleaving, reshape / stack order, position and cache indexing, first-index argmin, mask semantics and bias constants,
+which branch runs when and what it hands the op, residual structure, module wiring, parameter names and layouts, token
+layouts, flag names and defaults.
 
 Writes tests/golden/ref_run.npz.  Needs /root/reference (this container only); the tests read the .npz.
 Re-run:  python tests/golden/gen_ref_run_golden.py [output.npz]   (deterministic: tests/test_golden.py regenerates and compares
