@@ -15,8 +15,9 @@ What is executed (function below -> reference lines; the committed .npz records 
   masks()              FlaxLLaMAAttention: causal_mask (setup), the blockwise branch's bias, the dense branch's mask with and
                        without a cache -- statement RANGES inside larger methods, located in the syntax tree by what they
                        assign and executed with the locals the method would hold   lwm/llama.py:425, :527-537, :572-592
-  cache()              FlaxLLaMAAttention._concatenate_to_cache, creation + three prefill blocks (the one-token branch is
-                       shard_map / lax.cond / .at[].set code and is not executed)  lwm/llama.py:441-492
+  cache()              FlaxLLaMAAttention._concatenate_to_cache, creation + three prefill blocks     lwm/llama.py:441-492
+  cache_decode()       the same method's one-token branch (:452-483) over an emulated 4-device "sp" axis: only the shard that
+                       owns row cache_index writes
   vision_text()        the embedding choice of FlaxVideoLLaMAModule.__call__       lwm/vision_llama.py:308-311
                        the 'vision,text' objective of train_step                   lwm/train.py:185-202
   video()              VQGANModel.encode / decode over the oracle's networks       lwm/vqgan.py:117-141
@@ -40,7 +41,9 @@ Stand-ins, by kind:
     sum, einsum, argmin, take, where, pad, clip, cumsum, ...; lax.complex(a, b) = a + 1j*b in complex64; lax.rsqrt = 1/sqrt in
     the argument's dtype; lax.select = where; lax.dynamic_update_slice = a copy with the block written at the start index,
     clamped so that it fits (XLA's documented semantics); stop_gradient / device_put / with_sharding_constraint = identity;
-    shard_map(fn, ...) = fn (one device); jax.image.resize(method='nearest') = an integer repeat.
+    shard_map(fn, ...) = fn (one device; cache_decode() emulates an n-device "sp" axis: per-device slices by the in_specs,
+    lax.axis_index = the device, outputs concatenated), lax.cond(p, t, f) = t() if p else f(), x.at[i].set(v) = a copy with x[i] = v;
+    jax.image.resize(method='nearest') = an integer repeat.
   * flax: MiniFlax (below, ~150 lines) emulates the part of flax.linen the classes use -- Module with dataclass-style fields
     from the annotations, setup(), @nn.compact, the NAMING RULE (a submodule made in setup() is named by its attribute, one
     made inside a compact __call__ is ClassName_<n> with n counting that class within the parent, name= overrides), param(),
@@ -336,6 +339,93 @@ def cache(out):
         out.update({f"cache_{i}_index": np.int32(idx), f"cache_{i}_key": key, f"cache_{i}_value": value,
                     f"cache_{i}_k": ck, f"cache_{i}_v": cv, f"cache_{i}_next": np.int32(nxt)})
     out["cache_steps"] = np.int32(len(steps))
+
+
+def cache_decode(out):
+    """The one-token branch of _concatenate_to_cache (lwm/llama.py:452-483): the cache is sharded over the "sp" mesh axis and only
+    the shard that owns row cache_index writes.  jax's shard_map is emulated for an n-device "sp" axis -- the function runs once
+    per device on the slices its in_specs give it (dimension 1 split where the spec names 'sp'), jax.lax.axis_index('sp') is that
+    device's index, the outputs are concatenated back along 'sp' -- lax.cond(p, t, f) = t() if p else f(), x.at[i].set(v) = a
+    copy with x[i] = v."""
+    fn, a0, a1 = cut(f"{REF}/llama.py", "FlaxLLaMAAttention", "_concatenate_to_cache")
+    out["cache_decode_lines"] = np.array([[a0, a1]], np.int32)
+    n = 4
+
+    class At(np.ndarray):
+        @property
+        def at(self):
+            arr = self
+
+            class Ix:
+                def __getitem__(self, idx):
+                    class Set:
+                        def set(self, v):
+                            res = arr.copy()
+                            res[idx] = v
+                            return res
+                    return Set()
+            return Ix()
+    state = {"rank": 0}
+
+    def shard_map(f, mesh=None, in_specs=None, out_specs=None, check_rep=None):
+        def run(*args):
+            outs = []
+            for r in range(n):
+                state["rank"] = r
+                loc = []
+                for a, spec in zip(args, in_specs):
+                    if len(spec) > 1 and spec[1] == "sp":
+                        c = a.shape[1] // n
+                        a = a[:, r * c:(r + 1) * c]
+                    loc.append(a)
+                outs.append(f(*loc))
+            return tuple(np.concatenate([o[i] for o in outs], axis=1).view(At) for i in range(len(out_specs)))
+        return run
+
+    def dus(operand, update, start):
+        res = operand.copy()
+        st = [int(np.clip(int(s0), 0, d - u)) for s0, d, u in zip(start, operand.shape, update.shape)]
+        res[tuple(slice(a, a + u) for a, u in zip(st, update.shape))] = update
+        return res
+    glob = fn.__globals__
+    glob["lax"].dynamic_update_slice = dus
+    glob["jnp"].zeros = lambda shape, dtype=None: np.zeros(shape, dtype).view(At)
+    glob["jnp"].array, glob["jnp"].int32, glob["jnp"].logical_and = np.array, np.int32, np.logical_and
+    glob["jax"].lax.axis_index = lambda axis: state["rank"]
+    glob["jax"].lax.cond = lambda p, t, f: t() if bool(p) else f()
+    glob.update(shard_map=shard_map, PS=lambda *a: a, LLaMAConfig=types.SimpleNamespace(
+        get_jax_mesh=lambda mesh_dim: types.SimpleNamespace(shape={"sp": n})))
+
+    class Var:
+        def __init__(self, value):
+            self.value = value
+    store = {}
+    self = types.SimpleNamespace(config=types.SimpleNamespace(mesh_dim="1,1,1,4"))
+    self.has_variable = lambda col, name: (col, name) in store
+
+    def variable(col, name, init, *args):
+        if (col, name) not in store:
+            store[(col, name)] = Var(init(*args))
+        return store[(col, name)]
+    self.variable = variable
+    g = np.random.default_rng(452)
+    B, L, H, D = 2, 16, 2, 4
+    am = np.ones((B, L), np.int32)
+    fn(self, np.ones((B, L, H, D), np.float32), np.ones((B, L, H, D), np.float32), np.zeros((B, L, H, D), np.float32), am)     # creation
+    key, value = (g.standard_normal((B, 6, H, D)).astype(np.float32) for _ in range(2))
+    fn(self, key, value, np.zeros((B, 6, H, D), np.float32), am)                                   # a prefill block: rows 0..5
+    out.update({"cache_decode_prefill_key": key, "cache_decode_prefill_value": value})
+    steps = []
+    for _ in range(5):                                                                            # rows 6..10: shards 1 and 2 of 4
+        key, value = (g.standard_normal((B, 1, H, D)).astype(np.float32) for _ in range(2))
+        idx = int(store[("cache", "cache_index")].value)
+        rk, rv, _ = fn(self, key, value, np.zeros((B, 1, H, D), np.float32), am)
+        assert rk.shape == (B, L, H, D) and np.array_equal(rk[:, idx], key[:, 0])
+        steps.append((idx, key, value, np.asarray(rk).copy(), np.asarray(rv).copy(), int(store[("cache", "cache_index")].value)))
+    for i, (idx, key, value, ck, cv, nxt) in enumerate(steps):
+        out.update({f"cache_decode_{i}_index": np.int32(idx), f"cache_decode_{i}_key": key, f"cache_decode_{i}_value": value,
+                    f"cache_decode_{i}_k": ck, f"cache_decode_{i}_v": cv, f"cache_decode_{i}_next": np.int32(nxt)})
+    out.update({"cache_decode_steps": np.int32(len(steps)), "cache_decode_ranks": np.int32(n)})
 
 
 def vision_text(out):
@@ -1017,6 +1107,7 @@ def main():
     vq(out)
     masks(out)
     cache(out)
+    cache_decode(out)
     vision_text(out)
     video(out)
     layer(out)
