@@ -555,7 +555,7 @@ def layer(out):
     seg[1, 9:] = 1
     seg[1, 17:] = 2
     pos = np.tile(np.arange(S, dtype=np.int32), (B, 1))
-    record = []
+    record, specs = [], []
 
     def ringattention(q, k, v, attn_bias, segment_ids, axis_name=None, float32_logits=None, cache_idx=None, blockwise_kwargs=None):
         kw = blockwise_kwargs
@@ -588,8 +588,11 @@ def layer(out):
         exec(setup_code, dict(ns, self=sa, config=cfg))
         glob = attn.__globals__
         glob.update(ns)
+        def shard_map(fn, mesh=None, in_specs=None, out_specs=None, check_rep=None):
+            specs.append((getattr(fn, "func", fn).__name__, in_specs, out_specs))      # the partitioning contract of the call site
+            return fn
         glob.update(apply_rotary_emb=rot, with_sharding_constraint=lambda t, spec: t, PS=lambda *a: a, partial=functools.partial,
-                    shard_map=lambda fn, mesh=None, in_specs=None, out_specs=None, check_rep=None: fn,
+                    shard_map=shard_map,
                     ringattention=ringattention, ringattention_inference=ringattention_inference,
                     LLaMAConfig=types.SimpleNamespace(get_jax_mesh=lambda mesh_dim: None))
         glob["jax"].checkpoint_policies = types.SimpleNamespace(nothing_saveable=None)
@@ -616,6 +619,8 @@ def layer(out):
         out.update({f"layer_{tag}_out": y, f"layer_{tag}_final": rms(np.ones(d, np.float32))(y),    # ... and ln_f with a unit weight (lwm/llama.py:1034)
                     f"layer_{tag}_calls": np.array([r[0] for r in record]), f"layer_{tag}_theta": np.float64(theta),
                     f"layer_{tag}_chunks": np.array([qc, kc, int(scan_mlp), mlp_chunk, int(use_seg)], np.int32)})
+    import json
+    out["layer_specs_json"] = np.array(json.dumps(sorted({json.dumps(sp) for sp in specs})))      # (lwm/llama.py:557-566, :601-609)
     out.update({f"layer_W_{n}": w for n, w in W.items()})
     out.update({"layer_x": x, "layer_am": am, "layer_seg": seg, "layer_pos": pos, "layer_dims": np.array([B, S, H, D, F, L], np.int32)})
 
