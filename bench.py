@@ -262,22 +262,30 @@ def pmc_traffic(kernel, S):
     passes) WHOSE KERNEL SOURCES ARE THE TREE'S (`kernel_source_stamp`, see attn_kernel_stamp).  bench.py cannot
     collect counters itself; (None, None) when no such profile is committed -- a stale file must not label a
     newer kernel."""
+    return pmc_traffic_any(kernel, S, same_sources=True)
+
+
+def pmc_traffic_any(kernel, S, same_sources):
+    """same_sources=True: only a summary stamped with the tree's kernel sources counts (what `roofline.traffic` quotes);
+    False: the newest stamped summary of OTHER sources -> (bytes, file, its stamp), reported beside a null `traffic` as
+    `traffic_of_earlier_kernel_sources` so that the reader sees what the last counter pass measured and of which code."""
     if S != 32768:
-        return None, None
+        return (None, None) if same_sources else (None, None, None)
     import glob
     stamp = attn_kernel_stamp()
-    best = (None, None)
+    best = (None, None) if same_sources else (None, None, None)
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_attention*.json"))):
         try:
             doc = json.load(open(f))
-            if doc.get("kernel_source_stamp") != stamp:
+            theirs = doc.get("kernel_source_stamp")
+            if (theirs == stamp) != same_sources or theirs is None:
                 continue
             ks = doc["kernels"]
         except Exception:
             continue
         for name, d in ks.items():
             if name.startswith(kernel) and "hbm_traffic_bytes" in d:
-                best = (d["hbm_traffic_bytes"], os.path.relpath(f, ROOT))
+                best = (d["hbm_traffic_bytes"], os.path.relpath(f, ROOT)) + (() if same_sources else (theirs,))
     return best
 
 
@@ -1314,7 +1322,12 @@ def main():
                 "kernel": dom, "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
                 "traffic": pmc_traffic(dom, S)[0], "traffic_profile": pmc_traffic(dom, S)[1],
-                "traffic_source": "committed rocprofv3 --pmc profile of the same command (bench.py cannot collect counters)",
+                "traffic_source": ("committed rocprofv3 --pmc profile of the same command (bench.py cannot collect counters)"
+                                   if pmc_traffic(dom, S)[0] is not None else
+                                   "none: no committed rocprofv3 --pmc summary carries the stamp of the tree's kernel sources "
+                                   f"({attn_kernel_stamp()}); bench.py cannot collect counters"),
+                "traffic_of_earlier_kernel_sources": (None if pmc_traffic(dom, S)[0] is not None or pmc_traffic_any(dom, S, False)[0] is None else
+                                                      dict(zip(("bytes", "profile", "kernel_source_stamp"), pmc_traffic_any(dom, S, False)))),
                 "avg_launch_ms": cand[dom]["avg_ms"],
                 "executed_tflops": exec_units[dom] * unit / avg_s / 1e12,
                 "all_kernels_algorithmic_tflops": {

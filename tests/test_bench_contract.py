@@ -74,6 +74,12 @@ def test_committed_bench_line_follows_the_contract():
     if r["traffic_profile"] is not None:
         prof = json.load(open(os.path.join(ROOT, r["traffic_profile"])))
         assert "kernel_source_stamp" in prof
+    # ... and the tree as it is: a summary of OTHER kernel sources never becomes `traffic`; it is reported beside a null one
+    got, other = bench.pmc_traffic("attn_bwd_dkdv4_kernel", 32768), bench.pmc_traffic_any("attn_bwd_dkdv4_kernel", 32768, False)
+    for byts, prof, *stamp in (got, other):
+        if prof is not None:
+            doc = json.load(open(os.path.join(ROOT, prof)))
+            assert (doc["kernel_source_stamp"] == bench.attn_kernel_stamp()) == (not stamp) and byts > 1e9
     # the ring-8 compute models run the product's launch list (the C driver, gathered form) and carry BASELINE configs[4]
     assert d["ring8_compute_model_32k"]["driver"] == "c" and d["ring8_compute_model_32k"]["form"] == "gathered"
     assert "packed documents" in d["ring8_compute_model_packed_1m"]["workload"]
