@@ -116,7 +116,8 @@ class CRing:
             if box[0][0] is not None:
                 raise RuntimeError(f"lwm_ring_unique_id failed on rank 0 of the group: {box[0][0]}")
             ident = (C.c_char * 128).from_buffer_copy(box[0][1])
-            rc = L.lwm_ring_create_from_id(ident, self.rank, self.size, side_ptr, C.byref(h))
+            with torch.cuda.device(self.device):          # ncclCommInitRank binds the communicator to the CURRENT device
+                rc = L.lwm_ring_create_from_id(ident, self.rank, self.size, side_ptr, C.byref(h))
         _capi.check(L, rc, "lwm_ring_create")
         self._h = h
         self._ws = None
