@@ -30,6 +30,8 @@ What is executed (function below -> reference lines; the committed .npz records 
                        nn.scan form, Module, ForCausalLMModule) and of lwm/vision_llama.py as class definitions under
                        MiniFlax: a 2-layer model produces logits from a train state in either on-disk layout
                                                                                    lwm/llama.py:320-1106, lwm/vision_llama.py:255-439
+  cached_model()       the same model classes in cached inference: init_cache, a prefill, greedy one-token steps through
+                       _concatenate_to_cache and the shifted mask                  lwm/llama.py:440-620, :806-824
   chat_prompt()        Sampler._process_frame / _read_process_vision / construct_input   lwm/vision_chat.py:59-145
   generation_inputs()  prepare_inputs_for_generation / update_inputs_for_generation of both model classes
                                                                                    lwm/vision_llama.py:447-474, lwm/llama.py:1113-1137
@@ -631,6 +633,7 @@ class MiniFlax:
     def __init__(self, conv, groupnorm, silu):
         mf = self
         self.stack, self.read = [], set()          # scopes: [tree, path, per-class counters]; leaves that were read
+        self.vars = {}                             # (module path, collection, name) -> holder with .value ('cache' collection)
 
         class Module:
             _fields = ()
@@ -650,7 +653,6 @@ class MiniFlax:
                     object.__setattr__(self, f, vals[f] if f in vals else getattr(type(self), f))
                 object.__setattr__(self, "_name", name)           # name=...: explicit (lwm/llama.py:953: name=str(i))
                 object.__setattr__(self, "_set_up", False)
-                object.__setattr__(self, "variables", {})          # no 'cache' collection: training / prefill without a cache
                 if name is None and mf.stack and mf.stack[-1][3] == "compact":     # made inside a compact __call__: ClassName_<n>
                     cnt = mf.stack[-1][2]
                     n = cnt.get(type(self).__name__, 0)
@@ -668,7 +670,21 @@ class MiniFlax:
                 return tree[name]
 
             def has_variable(self, collection, name):
-                return False
+                return (mf.stack[-1][1], collection, name) in mf.vars
+
+            def variable(self, collection, name, init, *args):
+                key = (mf.stack[-1][1], collection, name)
+                if key not in mf.vars:
+                    mf.vars[key] = types.SimpleNamespace(value=init(*args))
+                return mf.vars[key]
+
+            @property
+            def variables(self):
+                path, res = mf.stack[-1][1], {}
+                for (p, col, name), var in mf.vars.items():
+                    if p == path:
+                        res.setdefault(col, {})[name] = var.value
+                return res
 
             def is_mutable_collection(self, collection):
                 return False
@@ -987,6 +1003,123 @@ def model(out):
                 "vmodel_vte": vflat["transformer/vte/embedding"], "vmodel_vision_head": vflat["vision_head/kernel"]})
 
 
+def cached_model(out):
+    """f.1: the reference's model classes in CACHED INFERENCE -- init_cache (lwm/llama.py:806-824: one pass over max_length rows with
+    init_cache=True creates the cache variables), a prefill of the prompt, then one token at a time; flax's variable collections are
+    MiniFlax's (`self.variable / has_variable / variables`), the one-token cache write runs through the shard_map emulation of
+    cache_decode() with one device.  Every step's last-position logits are recorded; the test compares them with the oracle model's
+    FULL forward over the sequence so far -- the cache machinery (mask shift, cache write, positions) computes the same function."""
+    import functools
+    from typing import Any, Dict, List, Optional, Union
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import attention_ref as A
+    path = f"{REF}/llama.py"
+    src = open(path).read()
+    want = ["RMSNorm", "precompute_freqs_cis", "apply_rotary_emb", "FlaxLLaMAAttention", "FlaxLLaMAMLP", "FlaxLLaMABlock",
+            "FlaxLLaMABlockCollection", "FlaxLLaMAModule", "FlaxLLaMAForCausalLMModule"]
+    nodes = [n for n in ast.parse(src).body if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name in want]
+    mf = MiniFlax(None, None, lambda t: t * (1.0 / (1.0 + np.exp(-t))).astype(t.dtype))
+    ns = shims()
+    jnp = ns["jnp"]
+
+    class At(np.ndarray):
+        @property
+        def at(self):
+            arr = self
+
+            class Ix:
+                def __getitem__(self, idx):
+                    return types.SimpleNamespace(set=lambda v: (lambda r: (r.__setitem__(idx, v), r)[1])(arr.copy()))
+            return Ix()
+
+    def dus(operand, update, start):
+        res = operand.copy()
+        st = [int(np.clip(int(s0), 0, d - u)) for s0, d, u in zip(start, operand.shape, update.shape)]
+        res[tuple(slice(a, a + u) for a, u in zip(st, update.shape))] = update
+        return res
+    jnp.take, jnp.where, jnp.array, jnp.int32, jnp.ones_like, jnp.logical_and = np.take, np.where, np.array, np.int32, np.ones_like, np.logical_and
+    jnp.zeros = lambda shape, dtype=None: np.zeros(shape, dtype).view(At)
+    ns["lax"].dynamic_update_slice = dus
+    ns["jax"].lax.axis_index = lambda axis: 0
+    ns["jax"].lax.cond = lambda p, t, f: t() if bool(p) else f()
+    ns["jax"].checkpoint_policies = types.SimpleNamespace(nothing_saveable=None)
+    ns["jax"].lax.Precision = object
+    ns["jax"].nn.initializers = types.SimpleNamespace(normal=lambda stddev=None: None)
+    calls = []
+
+    def ringattention_inference(q, k, v, attn_mask, axis_name=None):
+        calls.append((q.shape[1], k.shape[1]))
+        return A.ring_inference(q, k, v, attn_mask[:, 0])
+
+    def no_training_op(*a, **kw):
+        raise AssertionError("the blockwise branch must not run in cached inference with S <= chunk")
+
+    class Output:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+        def __getitem__(self, i):
+            return [v for v in self.__dict__.values() if v is not None][i]
+    ns.update(nn=mf.nn, nn_partitioning=types.SimpleNamespace(ScanIn=lambda axis: axis), remat=lambda cls, **kw: cls,
+              Optional=Optional, Union=Union, Any=Any, Dict=Dict, List=List, partial=functools.partial,
+              LLaMAConfig=types.SimpleNamespace(get_jax_mesh=lambda mesh_dim: types.SimpleNamespace(shape={"sp": 1})), PS=lambda *a: a,
+              with_sharding_constraint=lambda t, spec: t, shard_map=lambda fn, mesh=None, in_specs=None, out_specs=None, check_rep=None: fn,
+              ringattention=no_training_op, ringattention_inference=ringattention_inference, blockwise_feedforward=no_training_op,
+              FlaxBaseModelOutput=Output, FlaxCausalLMOutput=Output)
+    exec(compile(ast.Module(body=nodes, type_ignores=[]), f"{path}:{nodes[0].lineno}", "exec"), ns)
+
+    g = np.random.default_rng(806)
+    Vc, d, H, F, NL, L = 37, 32, 2, 48, 2, 20
+    B, S, NEW = 2, 9, 5
+    std = 0.2
+    flat = {"transformer/wte/embedding": g.standard_normal((Vc, d)).astype(np.float32),
+            "transformer/ln_f/kernel": (1 + 0.1 * g.standard_normal(d)).astype(np.float32),
+            "lm_head/kernel": (g.standard_normal((d, Vc)) * std).astype(np.float32)}
+    for i in range(NL):
+        for k, shp in (("attention/wq", (d, d)), ("attention/wk", (d, d)), ("attention/wv", (d, d)), ("attention/wo", (d, d)),
+                       ("feed_forward/w1", (d, F)), ("feed_forward/w2", (F, d)), ("feed_forward/w3", (d, F))):
+            flat[f"transformer/h/{i}/{k}/kernel"] = (g.standard_normal(shp) * std).astype(np.float32)
+        for k in ("attention_norm", "ffn_norm"):
+            flat[f"transformer/h/{i}/{k}/kernel"] = (1 + 0.1 * g.standard_normal(d)).astype(np.float32)
+    tree = {}
+    for k, v in flat.items():
+        t = tree
+        parts = k.split("/")
+        for p_ in parts[:-1]:
+            t = t.setdefault(p_, {})
+        t[parts[-1]] = v
+    cfg = types.SimpleNamespace(vocab_size=Vc, hidden_size=d, intermediate_size=F, num_hidden_layers=NL, num_attention_heads=H,
+                                max_sequence_length=L, rms_norm_eps=1e-6, initializer_range=0.02, resid_pdrop=0.0, embd_pdrop=0.0,
+                                attn_pdrop=0.0, tie_word_embeddings=False, scan_attention=True, scan_mlp=False,
+                                scan_query_chunk_size=1024, scan_key_chunk_size=1024, scan_mlp_chunk_size=1024,
+                                scan_layers=False, param_scan_axis=0, mesh_dim="1,1,1,1", theta=10000)
+    m = ns["FlaxLLaMAForCausalLMModule"](cfg, dtype=np.float32)
+    ext = np.ones((B, L), np.int32)                                   # the key mask over max_length (prepare_inputs_for_generation)
+    # init_cache (lwm/llama.py:806-824)
+    mf.run(tree, lambda: m(np.ones((B, L), np.int32), np.ones((B, L), np.int32), None, np.tile(np.arange(L, dtype=np.int32), (B, 1)),
+                           init_cache=True))
+    cache_vars = sorted("/".join(p) + ":" + n for (p, col, n) in mf.vars if col == "cache")
+    assert len(cache_vars) == 3 * NL and all(v.value.shape == (B, L, H, d // H) for (p, c_, n), v in mf.vars.items() if n != "cache_index")
+    prompt = g.integers(0, Vc, (B, S)).astype(np.int32)
+    step_logits, tokens = [], prompt
+    pos = np.tile(np.arange(S, dtype=np.int32), (B, 1))
+    res = mf.run(tree, lambda: m(prompt, ext, None, pos))              # prefill
+    for t in range(NEW):
+        logits = res.logits[:, -1]
+        step_logits.append(logits)
+        nxt = logits.argmax(-1).astype(np.int32)[:, None]            # greedy
+        tokens = np.concatenate([tokens, nxt], axis=1)
+        pos = pos[:, -1:] + 1                                        # update_inputs_for_generation
+        if t + 1 < NEW:
+            res = mf.run(tree, lambda: m(nxt, ext, None, pos))       # one token through the cache
+    idx = {int(v.value) for (p, col, n), v in mf.vars.items() if n == "cache_index"}
+    assert idx == {S + NEW - 1}, idx
+    assert calls[-1] == (1, L) and (S, L) in calls                     # attention always runs over the WHOLE cache
+    out.update({"cached_step_logits": np.stack(step_logits, 1), "cached_tokens": tokens, "cached_dims": np.array([Vc, d, H, F, NL, L, B, S, NEW], np.int32),
+                "cached_cache_vars": np.array(cache_vars)})
+    out.update({f"cached_flat::{k}": v for k, v in flat.items()})
+
+
 def chat_prompt(out):
     import io
     import math
@@ -1118,6 +1251,7 @@ def main():
     layer(out)
     network(out)
     model(out)
+    cached_model(out)
     chat_prompt(out)
     generation_inputs(out)
     flags(out)
