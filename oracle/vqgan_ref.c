@@ -4,10 +4,11 @@
  * bench.py's cpu_baseline leg may load this library (oracle/vqgan_ref.py).
  * Nothing under lwm_amd/ does.
  *
- * PARITY UNPINNED: the reference (lwm/vqgan.py) is flax/JAX code; jax and flax
- * cannot be installed here and the reference ships no tests or golden vectors
- * (SURVEY.md section 4, 8c).  This file restates, in plain C with f32
- * arithmetic, what lwm/vqgan.py asks flax to compute:
+ * PARITY: the ARITHMETIC below is unpinned -- the reference (lwm/vqgan.py) is flax/JAX code, jax and flax
+ * cannot be installed here and the reference ships no tests or golden vectors; XLA's
+ * rounding is not reproducible.  How these primitives are WIRED into the tokeniser, and the quantiser as a whole, are
+ * pinned to a run of the reference's own module code (oracle/vqgan_ref.py header; tests/golden/gen_ref_run_golden.py).
+ * This file restates, in plain C with f32 arithmetic, what lwm/vqgan.py asks flax to compute:
  *
  *   ref_conv2d      nn.Conv(features, [k,k]) NHWC, kernel HWIO, bias on,
  *                   padding SAME (lwm/vqgan.py:155,163,172-175,183,253,257,262,
