@@ -969,6 +969,41 @@ def model(out):
     out.update({f"model_flat_scan::{k}": v for k, v in flat_scan.items() if "scan_decoder" in k})
     out.update({"model_tokens": tokens, "model_am": am, "model_seg": seg, "model_dims": np.array([Vc, d, H, F, NL, L, B, S], np.int32)})
 
+    # ---- the reference's own 'debug' size (LLAMA_STANDARD_CONFIGS['debug']: hidden 256, 2 heads -> head_dim 128, the one the HIP
+    # kernels are written for), bf16-representable weights: what the product path, kernel sources included, is run against on the
+    # host (tests/test_golden.py::test_product_path_with_emulated_kernels_reproduces_the_reference_model)
+    gd = np.random.default_rng(2560)
+    dV, dd, dH, dF, dNL, dL, dB, dS = 64, 256, 2, 256, 2, 128, 2, 64
+
+    def bf(a):
+        b = np.asarray(a, np.float32).view(np.uint32).astype(np.uint64)
+        return ((b + 0x7FFF + ((b >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32)
+    dper = {"attention/wq": (dd, dd), "attention/wk": (dd, dd), "attention/wv": (dd, dd), "attention/wo": (dd, dd),
+            "feed_forward/w1": (dd, dF), "feed_forward/w2": (dF, dd), "feed_forward/w3": (dd, dF)}
+    dlayers = [{**{k + "/kernel": bf(gd.standard_normal(shp) * 0.06) for k, shp in dper.items()},
+                "attention_norm/kernel": bf(1 + 0.1 * gd.standard_normal(dd)), "ffn_norm/kernel": bf(1 + 0.1 * gd.standard_normal(dd))}
+               for _ in range(dNL)]
+    dflat = {"transformer/wte/embedding": bf(gd.standard_normal((dV, dd))), "transformer/ln_f/kernel": bf(1 + 0.1 * gd.standard_normal(dd)),
+             "lm_head/kernel": bf(gd.standard_normal((dd, dV)) * 0.06)}
+    dflat.update({f"transformer/h/scan_decoder/{k}": np.stack([lay[k] for lay in dlayers], axis=0) for k in dlayers[0]})
+    dtokens = gd.integers(0, dV, (dB, dS)).astype(np.int32)
+    dam = np.ones((dB, dS), np.int32)
+    dam[0, :5] = 0
+    dseg = np.zeros((dB, dS), np.int32)
+    dseg[1, 23:] = 1
+    dcfg = types.SimpleNamespace(vocab_size=dV, hidden_size=dd, intermediate_size=dF, num_hidden_layers=dNL, num_attention_heads=dH,
+                                 max_sequence_length=dL, rms_norm_eps=1e-6, initializer_range=0.02, resid_pdrop=0.0, embd_pdrop=0.0,
+                                 attn_pdrop=0.0, tie_word_embeddings=False, scan_attention=True, scan_mlp=True,
+                                 scan_query_chunk_size=1024, scan_key_chunk_size=1024, scan_mlp_chunk_size=1024,
+                                 scan_layers=True, param_scan_axis=0, mesh_dim="1,1,1,1", theta=10000)
+    mf.read.clear()
+    md = ns["FlaxLLaMAForCausalLMModule"](dcfg, dtype=np.float32)
+    dres = mf.run(nest(dflat), lambda: md(dtokens, dam, dseg, np.tile(np.arange(dS, dtype=np.int32), (dB, 1))))
+    assert dres.logits.shape == (dB, dS, dV) and {"/".join(p_) for p_ in mf.read} == set(dflat)
+    out.update({f"model_debug_flat_bf16::{k}": (v.view(np.uint32) >> 16).astype(np.uint16) for k, v in dflat.items()})    # (bf16 bits)
+    out.update({"model_debug_logits": dres.logits, "model_debug_tokens": dtokens, "model_debug_am": dam, "model_debug_seg": dseg,
+                "model_debug_dims": np.array([dV, dd, dH, dF, dNL, dL, dB, dS], np.int32)})
+
     # ---- the vision-language model of BASELINE configs[3] (lwm/vision_llama.py:255-443): the same transformer with a second
     # embedding table and a second head
     vpath = f"{REF}/vision_llama.py"
