@@ -837,14 +837,23 @@ def network(out):
     code = compile(ast.Module(body=classes, type_ignores=[]), f"{REF}/vqgan.py:{classes[0].lineno}", "exec")
     exec(code, ns)                                                  # the reference's class definitions, as they are
 
-    cfgo = VQGANConfig.get_default_config(dict(resolution=32, channel_mult=(1, 2, 4), num_embeddings=1024))
+    # two sizes: 32 x 32 with three levels, and 8 x 8 with two -- small enough for the kernel SOURCES to run it on the host
+    # (tests/test_golden.py::test_product_tokeniser_with_emulated_kernels_reproduces_the_reference_run)
+    for tag, updates, seed in (("network", dict(resolution=32, channel_mult=(1, 2, 4), num_embeddings=1024), 105),
+                               ("network8", dict(resolution=8, channel_mult=(1, 2), num_embeddings=256), 108)):
+        _network_case(out, ns, mf, V, VQGANConfig, random_params, tag, updates, seed)
+
+
+def _network_case(out, ns, mf, V, VQGANConfig, random_params, tag, updates, seed):
+    cfgo = VQGANConfig.get_default_config(updates)
     cfg = cfgo.as_dict()
-    params = random_params(cfgo, seed=105)
+    params = random_params(cfgo, seed=seed)
     conf = types.SimpleNamespace(**cfg)
     conf.num_resolutions = len(cfg["channel_mult"])                # VQGANConfig.get_default_config, lwm/vqgan.py:97
     conf.dropout = 0.0
-    g = np.random.default_rng(105)
-    px = g.uniform(-1, 1, (2, 32, 32, 3)).astype(np.float32)
+    g = np.random.default_rng(seed)
+    res = cfg["resolution"]
+    px = g.uniform(-1, 1, (2, res, res, 3)).astype(np.float32)
     # codes placed ON the encoder's outputs (plus far-away ones): every summation order finds the same index
     z = V._conv(params["quant_conv"], V.encoder(params["encoder"], px, cfg))
     zf = z.reshape(-1, z.shape[-1])
@@ -853,13 +862,14 @@ def network(out):
     cb[slots] = zf
     params["quantize"]["embeddings"] = cb
     model = ns["VQGANModel"](conf)
+    mf.read.clear()
     zq, idx = mf.run(params, lambda: model.encode(px))
     assert np.array_equal(idx.reshape(-1), slots)
     rec = mf.run(params, lambda: model.decode(idx))
     want = set(leaves(params))
     assert mf.read == want, (sorted(want - mf.read)[:5], sorted(mf.read - want)[:5])      # every leaf read, none missing
-    out.update({"network_px": px, "network_idx": idx.astype(np.int32), "network_zq": np.asarray(zq, np.float32), "network_rec": rec,
-                "network_seed": np.int32(105), "network_codebook": cb, "network_leaves": np.int32(len(want))})
+    out.update({f"{tag}_px": px, f"{tag}_idx": idx.astype(np.int32), f"{tag}_zq": np.asarray(zq, np.float32), f"{tag}_rec": rec,
+                f"{tag}_seed": np.int32(seed), f"{tag}_codebook": cb, f"{tag}_leaves": np.int32(len(want))})
 
 
 def model(out):
