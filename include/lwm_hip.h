@@ -343,12 +343,31 @@ int lwm_rmsnorm_fwd_bf16(const void* x, const void* w, void* y, float* rstd, int
 int64_t lwm_rmsnorm_bwd_workspace_bytes(int64_t rows, int32_t C);
 int lwm_rmsnorm_bwd_bf16(const void* x, const void* w, const void* g, const float* rstd, void* dx,
                          void* dw, void* workspace, int64_t rows, int32_t C, void* stream);
+/* The same with the gradient of the residual branch that by-passes the norm folded in (FlaxLLaMABlock,
+ * lwm/llama.py:704-744: `x` feeds the norm AND the residual add behind it): dx = bf16(bf16(dx_norm) + res) -- the
+ * roundings of a separate bf16 add, one pass less over (rows, C).  res == NULL: lwm_rmsnorm_bwd_bf16. */
+int lwm_rmsnorm_bwd_res_bf16(const void* x, const void* w, const void* g, const float* rstd, const void* res,
+                             void* dx, void* dw, void* workspace, int64_t rows, int32_t C, void* stream);
 
 /* The SwiGLU gate of FlaxLLaMAMLP (lwm/llama.py:659): y = silu(a) * b and its backward
  * (da, db from g = dL/dy); bf16, n % 8 == 0, all pointers 16-byte aligned. */
 int lwm_swiglu_fwd_bf16(const void* a, const void* b, void* y, int64_t n, void* stream);
 int lwm_swiglu_bwd_bf16(const void* a, const void* b, const void* g, void* da, void* db, int64_t n,
                         void* stream);
+/* The same on (rows, cols) windows of wider buffers (leading dimensions in elements, multiples of 8): gate and up as the
+ * two halves of ONE (rows, 2F) GEMM output -- w1 | w3 run as one library GEMM (lwm/llama.py:631-655 share their input) --
+ * and d gate | d up written into the halves of the one buffer the fused dgrad / wgrad GEMMs read. */
+int lwm_swiglu_fwd_ld_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int64_t ldy, int64_t rows,
+                           int64_t cols, void* stream);
+int lwm_swiglu_bwd_ld_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, const void* g, int64_t ldg, void* da,
+                           int64_t ldda, void* db, int64_t lddb, int64_t rows, int64_t cols, void* stream);
+
+/* dst[c][r] = src[r][c], bf16, rows and cols multiples of 64 (leading dimensions in elements).  Serves the library GEMMs
+ * around the hot path: flax Dense kernels are (in, out) (lwm/llama.py:390-421, :631-655); hipBLASLt runs fastest with the
+ * reduction dimension contiguous in both operands, so the harness re-lays each kernel as (out, in) once per step and
+ * transposes the narrow operand of each weight gradient.  HBM-bound (2 x rows x cols x 2 bytes). */
+int lwm_transpose_bf16(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int64_t cols,
+                       void* stream);
 
 /* y[r, :] = x[r, :] . W for rows <= 4 -- the projections of a cached-decode step (one token per batch row
  * against the [K, N] bf16 kernels wq/wk/wv/wo, w1/w2/w3, lm_head; x @ kernel as flax nn.Dense computes it,

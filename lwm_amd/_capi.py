@@ -142,6 +142,10 @@ PROTOTYPES = {
                                       C.c_float, C.c_void_p]),
     "lwm_rmsnorm_bwd_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
     "lwm_rmsnorm_bwd_bf16": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_void_p]),
+    "lwm_rmsnorm_bwd_res_bf16": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_void_p]),
+    "lwm_swiglu_fwd_ld_bf16": (C.c_int, [C.c_void_p, C.c_int64] * 3 + [C.c_int64, C.c_int64, C.c_void_p]),
+    "lwm_swiglu_bwd_ld_bf16": (C.c_int, [C.c_void_p, C.c_int64] * 5 + [C.c_int64, C.c_int64, C.c_void_p]),
+    "lwm_transpose_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     "lwm_swiglu_fwd_bf16": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_void_p]),
     "lwm_swiglu_bwd_bf16": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_void_p]),
     "lwm_softmax_ce_bf16": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.c_void_p]),

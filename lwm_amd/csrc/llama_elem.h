@@ -64,6 +64,7 @@ struct RmsParams {
     const bf16_t* x;
     const bf16_t* w;      // [C]
     const bf16_t* g;      // upstream gradient (bwd)
+    const bf16_t* res;    // bwd: gradient of the residual branch that by-passes the norm (or null): dx += res, one pass
     bf16_t* y;            // fwd output / dx
     float* rstd;          // [rows]: saved by fwd (may be null), read by bwd
     float* dw_part;       // [gridDim][C] f32 partial weight gradients (bwd)
@@ -186,9 +187,21 @@ LWM_KERNEL(256) void rmsnorm_bwd_kernel(RmsParams p) {
             const int v = tid + 256 * k;
             if (v < nv) {
                 u32x4 o;
-                for (int j = 0; j < 4; ++j)
-                    o[j] = pack_bf16x2(r * (dy[k][2 * j] - xh[k][2 * j] * mean),
-                                       r * (dy[k][2 * j + 1] - xh[k][2 * j + 1] * mean));
+                if (p.res) {
+                    // the block's residual branch: x feeds the norm AND the add behind it, so its gradient is
+                    // bf16(dx_norm) + res, rounded as autograd's separate bf16 add would round it
+                    u32x4 rr = global_load_b128(p.res + row * p.C + v * 8);
+                    for (int j = 0; j < 4; ++j) {
+                        const float d0 = (float)(bf16_t)(r * (dy[k][2 * j] - xh[k][2 * j] * mean));
+                        const float d1 = (float)(bf16_t)(r * (dy[k][2 * j + 1] - xh[k][2 * j + 1] * mean));
+                        o[j] = pack_bf16x2(d0 + __builtin_bit_cast(float, rr[j] << 16),
+                                           d1 + __builtin_bit_cast(float, rr[j] & 0xffff0000u));
+                    }
+                } else {
+                    for (int j = 0; j < 4; ++j)
+                        o[j] = pack_bf16x2(r * (dy[k][2 * j] - xh[k][2 * j] * mean),
+                                           r * (dy[k][2 * j + 1] - xh[k][2 * j + 1] * mean));
+                }
                 global_store_b128(p.y + row * p.C + v * 8, o);
             }
         }
@@ -205,13 +218,32 @@ LWM_KERNEL(256) void rmsnorm_bwd_kernel(RmsParams p) {
     }
 }
 
-// dw[c] = bf16(sum_blocks dw_part[block][c]) in block order.
+// dw[c] = bf16(sum_blocks dw_part[block][c]), a fixed tree: one workgroup = 32 columns x 8 row groups (row group j sums the
+// blocks j, j + 8, ... in order -- four independent chains per thread keep loads in flight), then the 8 group sums in
+// group order.  (Round 5's kernel walked all blocks of a column in ONE thread: 2048 dependent loads, 0.61 ms per call
+// -- 40 ms of the 32-layer LWM-7B step, profiles/r06_model_full.md.)
 LWM_KERNEL(256) void rmsnorm_dw_reduce_kernel(const float* part, bf16_t* dw, int nblk, int C) {
-    const int c = block_idx_x() * 256 + thread_idx();
-    if (c >= C) return;
-    float s = 0.0f;
-    for (int i = 0; i < nblk; ++i) s += part[(int64_t)i * C + c];
-    dw[c] = (bf16_t)s;
+    const lds_t lds = dyn_lds();          // 8 x 32 floats
+    const int tid = thread_idx();
+    const int col = block_idx_x() * 32 + (tid & 31), grp = tid >> 5;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    if (col < C) {
+        int i = grp;
+        for (; i + 24 < nblk; i += 32) {
+            s0 += part[(int64_t)i * C + col];
+            s1 += part[(int64_t)(i + 8) * C + col];
+            s2 += part[(int64_t)(i + 16) * C + col];
+            s3 += part[(int64_t)(i + 24) * C + col];
+        }
+        for (; i < nblk; i += 8) s0 += part[(int64_t)i * C + col];
+    }
+    lds_write_f32(lds + tid * 4, (s0 + s1) + (s2 + s3));
+    block_sync();
+    if (tid < 32 && col < C) {
+        float t = 0.0f;
+        for (int g2 = 0; g2 < 8; ++g2) t += lds_read_f32(lds + (g2 * 32 + tid) * 4);
+        dw[col] = (bf16_t)t;
+    }
 }
 
 // ---------------------------------------------------------------- softmax cross-entropy
@@ -363,6 +395,116 @@ LWM_KERNEL(256) void swiglu_bwd_kernel(const bf16_t* a, const bf16_t* b, const b
         }
         global_store_b128(da + i * 8, oa);
         global_store_b128(db + i * 8, ob);
+    }
+}
+
+// The same two kernels on ROWS of a wider buffer: gate and up are the two halves of ONE (rows, 2F) GEMM output (w1 | w3 as
+// one library GEMM, lwm_amd/llama_ops.py), and the backward writes d gate | d up into the halves of one (rows, 2F) buffer
+// that the fused dgrad / wgrad GEMMs read -- no concatenation pass on either side.  cols % 8 == 0, every ld % 8 == 0.
+struct SwigluLdParams {
+    const bf16_t* a; const bf16_t* b; const bf16_t* g;
+    bf16_t* y; bf16_t* da; bf16_t* db;
+    int64_t lda, ldb, ldg, ldy, ldda, lddb, rows;
+    int32_t cols;
+};
+
+LWM_KERNEL(256) void swiglu_fwd_ld_kernel(SwigluLdParams p) {
+    const int cv = p.cols >> 3;
+    const int64_t nvec = p.rows * cv;
+    for (int64_t i = (int64_t)block_idx_x() * 256 + thread_idx(); i < nvec; i += (int64_t)grid_dim_x() * 256) {
+        const int64_t row = i / cv;
+        const int c = (int)(i - row * cv) * 8;
+        u32x4 ra = global_load_b128(p.a + row * p.lda + c), rb = global_load_b128(p.b + row * p.ldb + c), o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a0 = __builtin_bit_cast(float, ra[j] << 16), a1 = __builtin_bit_cast(float, ra[j] & 0xffff0000u);
+            const float b0 = __builtin_bit_cast(float, rb[j] << 16), b1 = __builtin_bit_cast(float, rb[j] & 0xffff0000u);
+            o[j] = pack_bf16x2(a0 * sigmoid_fast(a0) * b0, a1 * sigmoid_fast(a1) * b1);
+        }
+        global_store_b128(p.y + row * p.ldy + c, o);
+    }
+}
+
+LWM_KERNEL(256) void swiglu_bwd_ld_kernel(SwigluLdParams p) {
+    const int cv = p.cols >> 3;
+    const int64_t nvec = p.rows * cv;
+    for (int64_t i = (int64_t)block_idx_x() * 256 + thread_idx(); i < nvec; i += (int64_t)grid_dim_x() * 256) {
+        const int64_t row = i / cv;
+        const int c = (int)(i - row * cv) * 8;
+        u32x4 ra = global_load_b128(p.a + row * p.lda + c), rb = global_load_b128(p.b + row * p.ldb + c),
+              rg = global_load_b128(p.g + row * p.ldg + c);
+        u32x4 oa, ob;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float av[2] = {__builtin_bit_cast(float, ra[j] << 16), __builtin_bit_cast(float, ra[j] & 0xffff0000u)};
+            float bv[2] = {__builtin_bit_cast(float, rb[j] << 16), __builtin_bit_cast(float, rb[j] & 0xffff0000u)};
+            float gv[2] = {__builtin_bit_cast(float, rg[j] << 16), __builtin_bit_cast(float, rg[j] & 0xffff0000u)};
+            float dav[2], dbv[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float sg = sigmoid_fast(av[e]);
+                dbv[e] = gv[e] * av[e] * sg;
+                dav[e] = gv[e] * bv[e] * sg * (1.0f + av[e] * (1.0f - sg));
+            }
+            oa[j] = pack_bf16x2(dav[0], dav[1]);
+            ob[j] = pack_bf16x2(dbv[0], dbv[1]);
+        }
+        global_store_b128(p.da + row * p.ldda + c, oa);
+        global_store_b128(p.db + row * p.lddb + c, ob);
+    }
+}
+
+// ---------------------------------------------------------------- 2-D transpose (bf16)
+// dst[c][r] = src[r][c] over 64 x 64 tiles: 16-byte global loads along the source rows, the tile parked in LDS at a pitch
+// of 33 words (column walks hit 32 different banks, two lanes per word), 16-byte global stores along the destination rows.
+// What it is for: hipBLASLt runs a GEMM fastest when BOTH operands have the reduction dimension contiguous
+// (profiles/r06_model_full.md: 1.36-1.58 PF/s against 0.90-1.05 for the weight-gradient layout x^T g).  The (in, out)
+// flax kernels (lwm/llama.py:390-421) are re-laid as (out, in) once per step for the forward GEMMs, and the narrow
+// operand of every weight gradient is transposed so that S is contiguous.  HBM-bound: 2 x rows x cols x 2 B.
+struct TransposeParams {
+    const bf16_t* src; bf16_t* dst;
+    int64_t ld_src, ld_dst;
+    int32_t tiles_r, tiles_c;     // rows / 64, cols / 64
+};
+
+constexpr int kTrPitchWords = 33;
+LWM_KERNEL(256) void transpose_bf16_kernel(TransposeParams p) {
+    const lds_t lds = dyn_lds();          // 64 x 33 words
+    const int tid = thread_idx();
+    const int64_t ntiles = (int64_t)p.tiles_r * p.tiles_c;
+    for (int64_t t = block_idx_x(); t < ntiles; t += grid_dim_x()) {
+        // consecutive workgroups walk down the source ROWS of one column band: their stores fill whole destination rows
+        const int tc = (int)(t / p.tiles_r), tr = (int)(t - (int64_t)tc * p.tiles_r);
+        {
+            const int r = tid >> 2, seg = tid & 3;
+            const bf16_t* s = p.src + ((int64_t)tr * 64 + r) * p.ld_src + (int64_t)tc * 64 + seg * 16;
+            u32x4 v0 = global_load_b128(s), v1 = global_load_b128(s + 8);
+            const lds_t w = lds + (r * kTrPitchWords + seg * 8) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                lds_write_i32(w + j * 4, (int32_t)v0[j]);
+                lds_write_i32(w + (4 + j) * 4, (int32_t)v1[j]);
+            }
+        }
+        block_sync();
+        {
+            const int c = tid >> 2, rseg = tid & 3;
+            const int sh = (c & 1) * 16;
+            u32x4 o0, o1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t a0 = (uint32_t)lds_read_i32(lds + ((rseg * 16 + 2 * j) * kTrPitchWords + (c >> 1)) * 4);
+                const uint32_t a1 = (uint32_t)lds_read_i32(lds + ((rseg * 16 + 2 * j + 1) * kTrPitchWords + (c >> 1)) * 4);
+                const uint32_t b0 = (uint32_t)lds_read_i32(lds + ((rseg * 16 + 8 + 2 * j) * kTrPitchWords + (c >> 1)) * 4);
+                const uint32_t b1 = (uint32_t)lds_read_i32(lds + ((rseg * 16 + 8 + 2 * j + 1) * kTrPitchWords + (c >> 1)) * 4);
+                o0[j] = ((a0 >> sh) & 0xffffu) | (((a1 >> sh) & 0xffffu) << 16);
+                o1[j] = ((b0 >> sh) & 0xffffu) | (((b1 >> sh) & 0xffffu) << 16);
+            }
+            bf16_t* d = p.dst + ((int64_t)tc * 64 + c) * p.ld_dst + (int64_t)tr * 64 + rseg * 16;
+            global_store_b128(d, o0);
+            global_store_b128(d + 8, o1);
+        }
+        block_sync();
     }
 }
 

@@ -17,10 +17,10 @@ import os
 import torch
 
 from . import ops as _ops
-from .llama_ops import (LLaMAMLP, RMSNorm, apply_rotary_emb, chunked_lm_head_loss, dense, dense_multi,
-                        precompute_freqs_cis, swiglu)
+from .llama_ops import (LLaMAMLP, RMSNorm, apply_rotary_emb, chunked_lm_head_loss, dense, dense_fused, dense_multi,
+                        fused_dense_ok, precompute_freqs_cis, qkv_rope, rmsnorm_residual, swiglu)
 from .ringattention import (blockwise_feedforward, concatenate_to_cache, ringattention,
-                            ringattention_inference, sp_positions, sp_size_rank)
+                            ringattention_inference, sp_layout_is_explicit, sp_positions, sp_size_rank)
 
 # The model sizes of lwm/llama.py:33-130:
 # name: (hidden, intermediate, layers, heads, max_sequence_length, rms_norm_eps)
@@ -171,13 +171,28 @@ class LLaMAAttention(torch.nn.Module):
         self.num_heads, self.head_dim = cfg.num_attention_heads, d // cfg.num_attention_heads
         self.wq, self.wk, self.wv, self.wo = (_dense(d, d, cfg.initializer_range, dtype) for _ in range(4))
 
-    def forward(self, x, freqs_cis, attention_mask=None, segment_ids=None, position_ids=None, cache=None):
+    def forward(self, x, freqs_cis, attention_mask=None, segment_ids=None, position_ids=None, cache=None, layout=None,
+                residual=None):
+        """layout (extension): which global positions this rank's rows are -- None = the rule bound to the "sp" axis
+        (lwm_amd.ringattention.set_sp_group), "contiguous" | "zigzag", or a lwm_amd.ring.SeqLayout (a packed batch's
+        balanced ownership table, lwm_amd.ring.balanced_layout).
+        residual (extension): the block's `x`, added to the result (lwm/llama.py:726) -- in the wo GEMM's epilogue."""
         B, S, d = x.shape
         split = lambda t: t.reshape(B, S, self.num_heads, self.head_dim)      # reshape, no transpose (:434-438)
-        xq, xk, xv = (split(t) for t in dense_multi(x, (self.wq, self.wk, self.wv)))
-        xq, xk = apply_rotary_emb(xq, xk, freqs_cis, position_ids)
+        fused = cache is None and freqs_cis.is_cuda and fused_dense_ok(x, (self.wq, self.wk, self.wv, self.wo))
+        if fused:
+            # wq | wk | wv as ONE library GEMM into a (B,S,3,H,D) buffer, RoPE on its q | k part in one launch; the
+            # attention kernels take the three strided views as they are
+            xq, xk, xv = qkv_rope(x, self.wq, self.wk, self.wv, freqs_cis, position_ids, self.num_heads)
+            if _multi_rank():
+                xq, xk, xv = xq.contiguous(), xk.contiguous(), xv.contiguous()      # (the exchange sends whole blocks)
+        else:
+            xq, xk, xv = (split(t) for t in dense_multi(x, (self.wq, self.wk, self.wv)))
+            xq, xk = apply_rotary_emb(xq, xk, freqs_cis, position_ids)
+            xv = xv.contiguous()
         if cache is not None:
-            return dense(self._cached(xq, xk, xv.contiguous(), attention_mask, cache).reshape(B, S, d), self.wo)
+            out = dense(self._cached(xq, xk, xv, attention_mask, cache).reshape(B, S, d), self.wo)
+            return out if residual is None else residual + out
         bias = None
         if attention_mask is not None:                                        # (:527-537)
             # the bias is NOT sharded over "sp" (lwm/llama.py:563): it covers the global sequence
@@ -186,12 +201,16 @@ class LLaMAAttention(torch.nn.Module):
                 raise ValueError(f"attention_mask covers {attention_mask.shape[-1]} positions; the sequence ring "
                                  f"needs the global length {S * n_sp} (= local {S} x sp {n_sp}) on every rank")
             bias = key_padding_bias(attention_mask.reshape(B, S * n_sp))
-        out = ringattention(xq, xk, xv.contiguous(), bias, segment_ids, axis_name="sp", float32_logits=True,
+        out = ringattention(xq, xk, xv, bias, segment_ids, axis_name="sp", float32_logits=True,
                             cache_idx=None,
                             blockwise_kwargs=dict(causal_block_size=1, deterministic=True, attn_pdrop=0.0,
                                                   query_chunk_size=self.cfg.scan_query_chunk_size,
-                                                  key_chunk_size=self.cfg.scan_key_chunk_size))
-        return out.reshape(B, S, d) @ self.wo
+                                                  key_chunk_size=self.cfg.scan_key_chunk_size),
+                            layout=layout)
+        if fused:
+            return dense_fused(out.reshape(B, S, d), (self.wo,), residual)
+        out = out.reshape(B, S, d) @ self.wo
+        return out if residual is None else residual + out
 
     def _cached(self, xq, xk, xv, attention_mask, cache):
         """The inference branch (lwm/llama.py:571-614): mask = key j visible to query i iff
@@ -237,8 +256,17 @@ class LLaMABlock(torch.nn.Module):
         self.ffn_norm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, dtype)
         self.feed_forward = LLaMAMLP(cfg.hidden_size, cfg.intermediate_size, dtype, cfg.initializer_range)
 
-    def forward(self, x, freqs_cis, attention_mask=None, segment_ids=None, position_ids=None, cache=None):
-        x = x + self.attention(self.attention_norm(x), freqs_cis, attention_mask, segment_ids, position_ids, cache)
+    def forward(self, x, freqs_cis, attention_mask=None, segment_ids=None, position_ids=None, cache=None, layout=None):
+        if cache is None and x.is_cuda and x.dtype == torch.bfloat16:
+            # training / uncached branch: `x` goes through each norm as (norm(x), x) so that the residual branch's gradient
+            # is added inside the RMSNorm backward kernel, and each residual add rides in the epilogue of the GEMM before it
+            h, x = rmsnorm_residual(self.attention_norm, x)
+            x = self.attention(h, freqs_cis, attention_mask, segment_ids, position_ids, None, layout, residual=x)
+            h, x = rmsnorm_residual(self.ffn_norm, x)
+            if self.cfg.scan_mlp and h.shape[1] >= self.cfg.scan_mlp_chunk_size:      # (:728-734)
+                return x + blockwise_feedforward(self.feed_forward, h, self.cfg.scan_mlp_chunk_size)
+            return self.feed_forward(h, residual=x)
+        x = x + self.attention(self.attention_norm(x), freqs_cis, attention_mask, segment_ids, position_ids, cache, layout)
         h = self.ffn_norm(x)
         if self.cfg.scan_mlp and h.shape[1] >= self.cfg.scan_mlp_chunk_size:      # (:728-734)
             ff = blockwise_feedforward(self.feed_forward, h, self.cfg.scan_mlp_chunk_size)
@@ -266,27 +294,39 @@ class LLaMAForCausalLM(torch.nn.Module):
         return self._freqs
 
     @staticmethod
-    def _ring_position_ids(input_ids, position_ids, cache):
+    def _ring_position_ids(input_ids, position_ids, cache, layout=None):
         """position_ids of a sequence-sharded training batch: the GLOBAL positions of this rank's rows under the
         ownership rule bound to the "sp" axis (lwm_amd.ringattention.set_sp_group: zigzag by default, or the
-        reference's contiguous blocks, lwm/llama.py:560-562) -- the rows were cut with `sp_shard`, so RoPE and the
-        causal mask both see where each token really sits."""
+        reference's contiguous blocks, lwm/llama.py:560-562) or under `layout` -- the rows were cut with `sp_shard`,
+        so RoPE and the causal mask both see where each token really sits.
+
+        A caller that brings its OWN position_ids to a sharded training batch cut the rows itself; the masks are
+        evaluated at the positions the ownership rule gives those rows, so the rule has to be NAMED then -- `layout=`
+        here, set_sp_group(group, layout=...) or LWM_SP_LAYOUT.  With the defaulted rule (zigzag) a batch sharded the
+        reference's way would get RoPE at contiguous positions and causal masks at zigzag ones, without an error
+        anywhere: refused instead."""
         n_sp = sp_size_rank("sp")[0]
         if n_sp > 1 and position_ids is None and cache is None:
             B, S = input_ids.shape
-            position_ids = sp_positions(S, "sp", input_ids.device).to(torch.int32)[None].expand(B, S).contiguous()
+            position_ids = sp_positions(S, "sp", input_ids.device, layout).to(torch.int32)[None].expand(B, S).contiguous()
+        elif n_sp > 1 and cache is None and layout is None and not sp_layout_is_explicit("sp"):
+            raise ValueError(
+                "position_ids were given for a sequence-sharded batch, but nobody said which global positions this "
+                "rank's rows ARE: pass layout= ('contiguous' = the reference's blocks, lwm/llama.py:560-562; 'zigzag' = "
+                "what sp_shard cuts by default; or a SeqLayout), or name the rule once with "
+                "set_sp_group(group, layout=...) / LWM_SP_LAYOUT")
         if n_sp > 1 and position_ids is None:
             raise ValueError("cached inference over a sequence ring needs explicit global position_ids")
         return n_sp, position_ids
 
-    def hidden_states(self, input_ids, attention_mask=None, segment_ids=None, position_ids=None, cache=None):
-        n_sp, position_ids = self._ring_position_ids(input_ids, position_ids, cache)
+    def hidden_states(self, input_ids, attention_mask=None, segment_ids=None, position_ids=None, cache=None, layout=None):
+        n_sp, position_ids = self._ring_position_ids(input_ids, position_ids, cache, layout)
         x = torch.nn.functional.embedding(input_ids.long(), self.wte)
         fc = self._table(x.device)
         if cache is not None and self._fused_decode_ok(x, n_sp):
             return self.ln_f(self._decode_layers_fused(x, fc, attention_mask, position_ids, cache))
         for i, blk in enumerate(self.h):
-            x = blk(x, fc, attention_mask, segment_ids, position_ids, None if cache is None else cache[i])
+            x = blk(x, fc, attention_mask, segment_ids, position_ids, None if cache is None else cache[i], layout)
         return self.ln_f(x)
 
     def _fused_decode_ok(self, x, n_sp):
@@ -423,9 +463,14 @@ class LLaMAForCausalLM(torch.nn.Module):
         return (out, torch.stack(logits_out, 1)) if return_logits else out
 
     def loss(self, input_tokens, target_tokens, loss_masks=None, attention_mask=None, segment_ids=None,
-             position_ids=None, chunk=8192):
-        h = self.hidden_states(input_tokens, attention_mask, segment_ids, position_ids)
-        return chunked_lm_head_loss(h, self.lm_head, target_tokens, loss_masks, chunk)
+             position_ids=None, chunk=8192, layout=None, sp_sharded=True):
+        """lwm/train.py:171-181.  Over a sequence ring (more than one rank on the "sp" axis) the arguments are this
+        rank's ROWS of the batch (sp_shard) and the result is this rank's SHARE of the reference's per-sequence mean:
+        the count of valid targets is all-reduced over "sp" (every sp rank must enter the call), and the shares add up
+        to the reference's loss.  sp_sharded=False says the tokens are REPLICATED on the sp ranks (evaluation /
+        scoring of a short batch on every rank): no collective, each rank gets the whole loss."""
+        h = self.hidden_states(input_tokens, attention_mask, segment_ids, position_ids, layout=layout)
+        return chunked_lm_head_loss(h, self.lm_head, target_tokens, loss_masks, chunk, sp_sharded=sp_sharded)
 
 def hf_rotary_to_interleaved(w_out_in, num_heads):
     """HF-PyTorch LLaMA checkpoints (README.md:74, scripts/sample_pyt.py:8) store wq/wk for the

@@ -134,24 +134,29 @@ def _softmax_ce(logits2d, target, weight, want_grad):
     return nll, correct, dl
 
 
-def _row_weights(valid, B, S, device):
+def _row_weights(valid, B, S, device, sp_sharded=True):
     """valid (B,S) or None -> (valid f32, per-row gradient weight valid / (max(sum_s valid, 1e-10) * B)).
     Over a sequence ring S is this rank's SHARD of each sequence: the count of valid targets is summed over the "sp"
     axis, so that each rank's loss is its share of the reference's per-sequence mean (tux.cross_entropy_loss_and_accuracy,
-    lwm/train.py:177-181) and the shares ADD UP to it -- whatever the masks do to the counts per rank."""
+    lwm/train.py:177-181) and the shares ADD UP to it -- whatever the masks do to the counts per rank.
+    CONTRACT of that sum (sp_sharded=True, the default): every rank of the "sp" group enters the call (it is a
+    collective), and the rows are this rank's shard.  A loss on tokens that are REPLICATED on the sp ranks (evaluation,
+    scoring) must say sp_sharded=False: no collective, the count is the local one -- with the default the count would
+    come out n times too large and the loss n times too small, without any error."""
     v = torch.ones(B, S, dtype=torch.float32, device=device) if valid is None else valid.to(torch.float32)
     count = v.sum(dim=-1, keepdim=True)
-    from .ringattention import sp_all_reduce_sum
-    sp_all_reduce_sum(count, "sp")
+    if sp_sharded:
+        from .ringattention import sp_all_reduce_sum
+        sp_all_reduce_sum(count, "sp")
     denom = count.clamp_min(1e-10) * B
     return v, (v / denom).contiguous()
 
 
 class _CrossEntropy(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, tokens, valid):
+    def forward(ctx, logits, tokens, valid, sp_sharded=True):
         B, S, V = logits.shape
-        v, w = _row_weights(valid, B, S, logits.device)
+        v, w = _row_weights(valid, B, S, logits.device, sp_sharded)
         nll, correct, dl = _softmax_ce(logits.reshape(B * S, V), tokens.reshape(-1).to(torch.int32).contiguous(),
                                        w.reshape(-1), logits.requires_grad)
         loss = (nll.reshape(B, S) * w).sum()
@@ -164,14 +169,16 @@ class _CrossEntropy(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_acc):
         (dl,) = ctx.saved_tensors
-        return (dl.reshape(ctx.shape) * g_loss.to(dl.dtype)), None, None
+        return (dl.reshape(ctx.shape) * g_loss.to(dl.dtype)), None, None, None
 
 
-def cross_entropy_loss_and_accuracy(logits, tokens, valid=None):
+def cross_entropy_loss_and_accuracy(logits, tokens, valid=None, sp_sharded=True):
     """tux.cross_entropy_loss_and_accuracy (call sites lwm/train.py:177-181, :192-201):
     loss = -mean_b( sum_s valid*log p(token) / max(sum_s valid, 1e-10) ), accuracy likewise
-    with argmax == token.  logits (B,S,V) bf16 (upcast to f32 in the kernel), tokens (B,S) int."""
-    return _CrossEntropy.apply(logits, tokens, valid)
+    with argmax == token.  logits (B,S,V) bf16 (upcast to f32 in the kernel), tokens (B,S) int.
+    Over a sequence ring: this rank's share of that mean, a collective over "sp" -- see _row_weights for the contract
+    and for sp_sharded=False (replicated tokens)."""
+    return _CrossEntropy.apply(logits, tokens, valid, sp_sharded)
 
 
 class _ChunkedHeadLoss(torch.autograd.Function):
@@ -180,10 +187,10 @@ class _ChunkedHeadLoss(torch.autograd.Function):
     (hipBLASLt through torch.matmul: a plain library GEMM) and the fused loss/gradient kernel."""
 
     @staticmethod
-    def forward(ctx, hidden, kernel, tokens, valid, chunk):
+    def forward(ctx, hidden, kernel, tokens, valid, chunk, sp_sharded=True):
         B, S, Dm = hidden.shape
         V = kernel.shape[1]
-        v, w = _row_weights(valid, B, S, hidden.device)
+        v, w = _row_weights(valid, B, S, hidden.device, sp_sharded)
         tok = tokens.to(torch.int32)
         need = hidden.requires_grad or kernel.requires_grad
         loss = torch.zeros((), dtype=torch.float32, device=hidden.device)
@@ -211,13 +218,14 @@ class _ChunkedHeadLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_acc):
         dh, dk = ctx.saved_tensors
-        return dh * g_loss.to(dh.dtype), (dk * g_loss).to(ctx.kdtype), None, None, None
+        return dh * g_loss.to(dh.dtype), (dk * g_loss).to(ctx.kdtype), None, None, None, None
 
 
-def chunked_lm_head_loss(hidden, lm_head_kernel, tokens, valid=None, chunk=8192):
+def chunked_lm_head_loss(hidden, lm_head_kernel, tokens, valid=None, chunk=8192, sp_sharded=True):
     """logits = hidden @ kernel (lwm/llama.py:1101, flax Dense kernel (d_model, vocab)) followed by
-    cross_entropy_loss_and_accuracy, chunked over the sequence.  Returns (loss, accuracy)."""
-    return _ChunkedHeadLoss.apply(hidden, lm_head_kernel, tokens, valid, int(chunk))
+    cross_entropy_loss_and_accuracy, chunked over the sequence.  Returns (loss, accuracy).  Over a sequence ring the
+    call is a collective over "sp" and returns this rank's share (sp_sharded, see _row_weights)."""
+    return _ChunkedHeadLoss.apply(hidden, lm_head_kernel, tokens, valid, int(chunk), bool(sp_sharded))
 
 
 def vision_text_loss(vision_logits, text_logits, target_tokens, loss_masks, target_vision_masks):
@@ -383,6 +391,253 @@ def _as_dtype(k, dtype):
     return hit[1]
 
 
+# ---------------------------------------------------------------- library GEMMs of the TRAINING path, laid out for hipBLASLt
+# The projections stay plain library GEMMs (SURVEY.md section 8f allows it); what this section decides is HOW they are
+# handed to the library (profiles/r06_model_full.md: 46 % of the LWM-7B step at S = 32768 is these GEMMs):
+#   * projections that share their input run as ONE GEMM (wq | wk | wv -> N = 3d, w1 | w3 -> N = 2F): dgrad becomes one
+#     GEMM over K = sum N instead of a sum of GEMM results, wgrad one GEMM instead of three;
+#   * hipBLASLt is fastest when both operands have the REDUCTION dimension contiguous (1.36-1.58 PF/s against 1.04-1.34
+#     forward and 0.90-1.05 wgrad in the flax (in, out) layout): the kernels are re-laid as (out, in) -- lwm_transpose_bf16,
+#     cached per parameter version -- for the forward, used as they are for dgrad, and the NARROW operand of each weight
+#     gradient is transposed so that S is contiguous;
+#   * the residual add rides in the GEMM epilogue (beta = 1) forward, and in the RMSNorm backward kernel backward.
+# Parameters keep the reference's names and (in, out) shapes (lwm/llama.py:390-421, :631-655).
+import os as _os
+
+_RELAYOUT_EPOCH = [0]
+
+
+def weights_changed():
+    """Tell the re-layout cache that kernels were written through a path that does not bump tensor versions (a load
+    into .data, an optimizer that swaps storage) -- or, in a benchmark without an optimizer step, that the next step
+    must pay for its re-layouts as a training step would."""
+    _RELAYOUT_EPOCH[0] += 1
+
+
+def transpose2d(src, out=None):
+    """(R, C) bf16 with contiguous rows (any row stride) -> (C, R): lwm_transpose_bf16 for multiples of 64, else torch."""
+    R, Cc = src.shape
+    if out is None:
+        out = torch.empty(Cc, R, dtype=src.dtype, device=src.device)
+    if (src.is_cuda and src.dtype == torch.bfloat16 and src.stride(1) == 1 and out.stride(1) == 1 and R % 64 == 0 and
+            Cc % 64 == 0 and src.stride(0) % 8 == 0 and out.stride(0) % 8 == 0 and src.data_ptr() % 16 == 0 and
+            out.data_ptr() % 16 == 0):
+        L = lib()
+        _capi.check(L, L.lwm_transpose_bf16(src.data_ptr(), src.stride(0), out.data_ptr(), out.stride(0), R, Cc,
+                                            _stream_ptr()), "lwm_transpose_bf16")
+    else:
+        out.copy_(src.t())
+    return out
+
+
+def _relayout(kernels):
+    """[(K, N_i)] flax kernels -> (wt (sum N_i, K) for the forward, wcat (K, sum N_i) for dgrad), kept on the first kernel
+    while none of them changes (tensor versions + weights_changed())."""
+    k0 = kernels[0]
+    key = (_RELAYOUT_EPOCH[0],) + tuple((k._version, k.data_ptr()) for k in kernels)
+    hit = getattr(k0, "_lwm_relayout", None)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    K = k0.shape[0]
+    Ns = [int(k.shape[1]) for k in kernels]
+    with torch.no_grad():
+        wt = torch.empty(sum(Ns), K, dtype=k0.dtype, device=k0.device)
+        off = 0
+        for k, n in zip(kernels, Ns):
+            transpose2d(k.detach(), wt[off:off + n])
+            off += n
+        wcat = k0.detach() if len(kernels) == 1 else torch.cat([k.detach() for k in kernels], dim=1)
+    k0._lwm_relayout = (key, wt, wcat)
+    return wt, wcat
+
+
+def fused_dense_ok(x, kernels):
+    """The fused / re-laid path serves bf16 GEMMs on the device with more rows than a decode step has."""
+    return (_os.environ.get("LWM_DENSE_FUSED", "1") == "1" and x.is_cuda and x.dtype == torch.bfloat16 and
+            x.numel() // x.shape[-1] > 4 and
+            all(k.is_cuda and k.dtype == torch.bfloat16 and k.is_contiguous() and k.dim() == 2 and
+                k.shape[0] == x.shape[-1] for k in kernels))
+
+
+def _dense_fwd(x2, kernels, residual2=None, out=None):
+    wt, _ = _relayout(kernels)
+    if residual2 is None:
+        return torch.matmul(x2, wt.t(), out=out) if out is not None else x2 @ wt.t()
+    return torch.addmm(residual2, x2, wt.t(), out=out) if out is not None else torch.addmm(residual2, x2, wt.t())
+
+
+def _dense_bwd(x2, kernels, g2, need_dx=True, need_dw=True):
+    """-> (dx2 (M, K) or None, [dW_i (K, N_i)] or None) from g2 (M, sum N_i)"""
+    _, wcat = _relayout(kernels)
+    dx2 = g2 @ wcat.t() if need_dx else None
+    if not need_dw:
+        return dx2, None
+    K, Nt = wcat.shape
+    if K <= Nt:
+        dw = transpose2d(x2) @ g2                       # x transposed: S contiguous in the A operand
+    else:
+        dw = x2.t() @ transpose2d(g2).t()               # g transposed: S contiguous in the B operand
+    if len(kernels) == 1:
+        return dx2, [dw]
+    return dx2, list(dw.split([int(k.shape[1]) for k in kernels], dim=1))
+
+
+class _DenseFused(torch.autograd.Function):
+    """y = x @ [k_0 | k_1 | ...] (+ residual): one library GEMM for projections that share their input."""
+
+    @staticmethod
+    def forward(ctx, x, residual, *kernels):
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        Nt = sum(int(k.shape[1]) for k in kernels)
+        r2 = None if residual is None else residual.reshape(-1, Nt)
+        y = _dense_fwd(x2, kernels, r2)
+        ctx.save_for_backward(x2, *kernels)
+        ctx.xshape, ctx.has_res = x.shape, residual is not None
+        return y.reshape(*x.shape[:-1], Nt)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, *kernels = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        dx2, dws = _dense_bwd(x2, kernels, g2, ctx.needs_input_grad[0], any(ctx.needs_input_grad[2:]))
+        dws = dws or [None] * len(kernels)
+        return (None if dx2 is None else dx2.reshape(ctx.xshape), g if ctx.has_res else None, *dws)
+
+
+def dense_fused(x, kernels, residual=None):
+    """x @ concat(kernels, axis=1) (+ residual), the kernels flax Dense kernels (in, out_i) that share their input
+    (lwm/llama.py:427-432 wq / wk / wv, :659 w1 / w3) or a single one (wo, w2); the residual add (lwm/llama.py:726, :743)
+    is the GEMM's epilogue."""
+    return _DenseFused.apply(x, residual, *kernels)
+
+
+class _QKVRope(torch.autograd.Function):
+    """(x, wq, wk, wv) -> (xq, xk, xv) as (B,S,H,D) views of ONE (B,S,3,H,D) buffer, RoPE applied to xq and xk in place in
+    ONE launch (they are neighbours: a (B,S,2H,D) tensor).  lwm/llama.py:494-520.  Backward: the conjugate rotation writes
+    dq / dk straight into the (B,S,3,H,D) gradient buffer the fused dgrad / wgrad GEMMs read."""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv, table, pos, H):
+        B, S, d = x.shape
+        D = wq.shape[1] // H
+        x2 = x.reshape(-1, d)
+        qkv = torch.empty(B, S, 3, H, D, dtype=x.dtype, device=x.device)
+        _dense_fwd(x2, (wq, wk, wv), out=qkv.view(B * S, 3 * H * D))
+        qk = qkv[:, :, 0:2].reshape(B, S, 2 * H, D)          # (a view: q and k heads are neighbours)
+        assert qk.data_ptr() == qkv.data_ptr()
+        L = lib()
+        _capi.check(L, L.lwm_rope_bf16(_t4(qk, "qk"), _t4(qk, "qk"), table.data_ptr(), pos.data_ptr(), B, S, 2 * H, D,
+                                       table.shape[0], 0, _stream_ptr()), "lwm_rope_bf16")
+        ctx.save_for_backward(x2, wq, wk, wv, table, pos)
+        ctx.dims = (B, S, d, H, D)
+        return qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+
+    @staticmethod
+    def backward(ctx, gq, gk, gv):
+        x2, wq, wk, wv, table, pos = ctx.saved_tensors
+        B, S, d, H, D = ctx.dims
+        g = torch.empty(B, S, 3, H, D, dtype=x2.dtype, device=x2.device)
+        L = lib()
+        for i, t in ((0, gq), (1, gk)):
+            t = t if t.stride(3) == 1 else t.contiguous()
+            _capi.check(L, L.lwm_rope_bf16(_t4(t, "g"), _t4(g[:, :, i], "g"), table.data_ptr(), pos.data_ptr(), B, S, H, D,
+                                           table.shape[0], 1, _stream_ptr()), "lwm_rope_bf16")
+        g[:, :, 2].copy_(gv)
+        dx2, dws = _dense_bwd(x2, (wq, wk, wv), g.view(B * S, 3 * H * D), ctx.needs_input_grad[0],
+                              any(ctx.needs_input_grad[1:4]))
+        dws = dws or [None] * 3
+        return (None if dx2 is None else dx2.reshape(B, S, d), *dws, None, None, None)
+
+
+def qkv_rope(x, wq, wk, wv, freqs_cis, position_ids, num_heads):
+    """FlaxLLaMAAttention's projections + head split + apply_rotary_emb (lwm/llama.py:494-520) as one operator."""
+    B, S = x.shape[:2]
+    if position_ids is None:
+        position_ids = torch.arange(S, device=x.device, dtype=torch.int32)[None].expand(B, S)
+    pos = position_ids.to(torch.int32).contiguous()
+    if not freqs_cis.is_cuda or freqs_cis.dtype != torch.float32 or not freqs_cis.is_contiguous():
+        raise ValueError("qkv_rope: freqs_cis must be the contiguous f32 device table of precompute_freqs_cis")
+    return _QKVRope.apply(x, wq, wk, wv, freqs_cis, pos, int(num_heads))
+
+
+class _RmsNormRes(torch.autograd.Function):
+    """(x) -> (RMSNorm(x), x): the block's `x` feeds the norm AND the residual add behind it (lwm/llama.py:704-744); handing
+    it through here lets the backward add the residual branch's gradient inside the RMSNorm backward kernel
+    (lwm_rmsnorm_bwd_res_bf16) instead of in a separate pass over (rows, C)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, eps):
+        y = _RmsNorm.forward(ctx, x, weight, eps)
+        ctx.set_materialize_grads(False)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g, g_pass):
+        x, w, rstd = ctx.saved_tensors
+        if g is None:
+            return g_pass, None, None
+        Cc = x.shape[-1]
+        rows = x.numel() // Cc
+        g = g.contiguous()
+        res = None if g_pass is None else g_pass.contiguous()
+        dx = torch.empty_like(x)
+        dw = torch.empty(Cc, dtype=torch.bfloat16, device=x.device)
+        L = lib()
+        ws = torch.empty(max(L.lwm_rmsnorm_bwd_workspace_bytes(rows, Cc), 16) // 4, dtype=torch.float32, device=x.device)
+        _capi.check(L, L.lwm_rmsnorm_bwd_res_bf16(x.data_ptr(), w.data_ptr(), g.data_ptr(), rstd.data_ptr(),
+                                                  None if res is None else res.data_ptr(), dx.data_ptr(), dw.data_ptr(),
+                                                  ws.data_ptr(), rows, Cc, _stream_ptr()), "lwm_rmsnorm_bwd_res_bf16")
+        return dx, dw.to(ctx.wdtype), None
+
+
+def rmsnorm_residual(norm, x):
+    """-> (norm(x), x) with the residual branch's gradient folded into the norm's backward kernel."""
+    return _RmsNormRes.apply(x.to(norm.dtype), norm.kernel, norm.eps)
+
+
+class _SwiGLUHalves(torch.autograd.Function):
+    """silu(y[..., :F]) * y[..., F:] on the two halves of one (rows, 2F) GEMM output; d gate | d up land in the halves of
+    one (rows, 2F) buffer (lwm_swiglu_*_ld_bf16)."""
+
+    @staticmethod
+    def forward(ctx, y13):
+        F2 = y13.shape[-1]
+        F = F2 // 2
+        y2 = y13.reshape(-1, F2)
+        if not y2.is_cuda or y2.dtype != torch.bfloat16 or y2.stride(1) != 1 or F % 8:
+            raise ValueError("swiglu_halves: expected a bf16 ROCm tensor (..., 2F) with F % 8 == 0")
+        rows = y2.shape[0]
+        out = torch.empty(rows, F, dtype=y2.dtype, device=y2.device)
+        L = lib()
+        _capi.check(L, L.lwm_swiglu_fwd_ld_bf16(y2.data_ptr(), y2.stride(0), y2.data_ptr() + 2 * F, y2.stride(0),
+                                                out.data_ptr(), F, rows, F, _stream_ptr()), "lwm_swiglu_fwd_ld_bf16")
+        ctx.save_for_backward(y2)
+        ctx.shape = y13.shape
+        return out.reshape(*y13.shape[:-1], F)
+
+    @staticmethod
+    def backward(ctx, g):
+        (y2,) = ctx.saved_tensors
+        rows, F2 = y2.shape
+        F = F2 // 2
+        g2 = g.reshape(rows, F)
+        if g2.stride(1) != 1 or g2.stride(0) % 8 or g2.data_ptr() % 16:
+            g2 = g2.contiguous()
+        d13 = torch.empty(rows, F2, dtype=y2.dtype, device=y2.device)
+        L = lib()
+        _capi.check(L, L.lwm_swiglu_bwd_ld_bf16(y2.data_ptr(), y2.stride(0), y2.data_ptr() + 2 * F, y2.stride(0),
+                                                g2.data_ptr(), g2.stride(0), d13.data_ptr(), F2, d13.data_ptr() + 2 * F, F2,
+                                                rows, F, _stream_ptr()), "lwm_swiglu_bwd_ld_bf16")
+        return d13.reshape(ctx.shape)
+
+
+def swiglu_halves(y13):
+    return _SwiGLUHalves.apply(y13)
+
+
 class LLaMAMLP(torch.nn.Module):
     """FlaxLLaMAMLP (lwm/llama.py:623-661): w2(silu(w1 x) * w3 x), flax Dense kernels
     (in, out), no bias.  The three GEMMs are library GEMMs (hipBLASLt via torch.matmul); in a cached-decode
@@ -394,6 +649,13 @@ class LLaMAMLP(torch.nn.Module):
         self.w1, self.w2, self.w3 = mk(hidden_size, intermediate_size), mk(intermediate_size, hidden_size), \
             mk(hidden_size, intermediate_size)
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """residual (extension): added to the result (the block's `x + ff`, lwm/llama.py:743) -- in the w2 GEMM's epilogue
+        on the fused path."""
+        if fused_dense_ok(x, (self.w1, self.w3)) and self.w2.dtype == torch.bfloat16 and self.w2.is_contiguous() and \
+                self.w1.shape[1] % 8 == 0:
+            # w1 | w3 as one GEMM, the gate on the halves of its output, w2 with the residual as its epilogue
+            return dense_fused(swiglu_halves(dense_fused(x, (self.w1, self.w3))), (self.w2,), residual)
         gate, up = dense_multi(x, (self.w1, self.w3))
-        return dense(swiglu(gate.contiguous(), up.contiguous()), self.w2)
+        out = dense(swiglu(gate.contiguous(), up.contiguous()), self.w2)
+        return out if residual is None else residual + out

@@ -95,7 +95,9 @@ def balanced_layout(n, seq_len, doc_lengths=None, chunks_per_rank=4, align=256):
     (every rank gets chunks_per_rank chunks).  Zigzag is the two-chunk answer for ONE document; for BASELINE configs[4]'s
     packing (1,048,576 tokens in 15 documents, n = 8) it leaves the slowest rank at 1.9x the mean, this at ~1.03 with four
     chunks.  The loader knows the document lengths (lwm/data.py packs them); all ranks must build the same table.
-    -> SeqLayout("table"); falls back to fewer chunks per rank while a chunk would not be a multiple of `align` rows."""
+    -> SeqLayout("table"); falls back to fewer chunks per rank while a chunk would not be a multiple of `align` rows.
+    More than 8 chunks per rank (LWM_MAX_PIECES of the kernels' piecewise position maps) is accepted: ring_attention then
+    runs the table through this module's pair-form driver instead of the C driver's gathered form."""
     import numpy as np
     P = int(chunks_per_rank)
     while P > 1 and seq_len % (n * P * align):
@@ -544,8 +546,10 @@ def ring_forward(block, comm, q, k, v, *, layout, causal=True, segment_ids=None,
             acc_o[qi] = block.empty((B, ln, H, D), torch.float32, q)
             acc_l[qi] = block.empty((B, H, ln), torch.float32, q)
 
-    k_cur = k if k.is_contiguous() else k.contiguous()
-    v_cur = v if v.is_contiguous() else v.contiguous()
+    # (one rank: nothing travels, and the kernels take strided views as they are -- the harness hands over views of its
+    #  fused (B,S,3,H,D) projection buffer; a copy here would be a pass over K and V per layer for nothing)
+    k_cur = k if (n == 1 or k.is_contiguous()) else k.contiguous()
+    v_cur = v if (n == 1 or v.is_contiguous()) else v.contiguous()
     mesh = _MeshBlocks(comm, layout, [k_cur, v_cur], causal, block=block, tag="fwd") if _is_mesh(comm) else None
     keep = []
     idx = 0
@@ -615,8 +619,8 @@ def ring_backward(block, comm, q, k, v, out, lses, dout, *, layout, causal=True,
     dv_acc = [block.empty((B, ln, H, D), torch.float32, q) for _, ln, _ in ksegs0]
     nks = len(ksegs0)
 
-    k_cur = k if k.is_contiguous() else k.contiguous()
-    v_cur = v if v.is_contiguous() else v.contiguous()
+    k_cur = k if (n == 1 or k.is_contiguous()) else k.contiguous()
+    v_cur = v if (n == 1 or v.is_contiguous()) else v.contiguous()
     keep = []
     dkv_handle = None
     for t in range(n):
@@ -805,6 +809,7 @@ def _torch_comm(group):
 
 
 _C_RINGS = {}
+_C_RINGS_PARKED = []        # rings replaced by a larger one: kept alive for graphs that still refer to them
 _C_RING_REFUSED = set()     # groups whose first contact with the C driver failed on some rank: they stay on this module's driver
 
 
@@ -852,8 +857,11 @@ def _c_ring_for(group, layout_kind, schedule, transport, slot_bytes, slots=8):
     key = (group, layout_kind, schedule, transport, torch.cuda.current_device())      # (the group object itself: an id() can be recycled)
     ring = _C_RINGS.get(key)
     if ring is not None and transport == "ipc" and (ring.ipc_slot_bytes < slot_bytes or ring._ipc_slots < slots):
-        ring.close()          # a larger shard than the mailboxes were cut for: every rank sees the same shapes, so
-        ring = None           # every rank comes through here together
+        # a larger shard than the mailboxes were cut for: every rank sees the same shapes, so every rank comes through
+        # here together.  The old ring is PARKED, not closed: an autograd graph of an earlier forward may still hold it
+        # (ctx.cfg) and would run its backward on a destroyed handle.
+        _C_RINGS_PARKED.append(ring)
+        ring = None
     if ring is None:
         err = None
         try:
@@ -862,8 +870,11 @@ def _c_ring_for(group, layout_kind, schedule, transport, slot_bytes, slots=8):
             err = e
         if _vote(group, err is None):
             try:
-                ring = CRing(group, layout=layout_kind, schedule=schedule, transport=transport,
-                             ipc_slot_bytes=slot_bytes if transport == "ipc" else None, ipc_slots=slots)
+                # (ncclCommInitRank / the IPC handle exchange: under the first-contact watchdog, lwm_amd/ring_c.py)
+                from .ring_c import first_contact
+                with first_contact(f"set-up of the C ring driver over {transport}"):
+                    ring = CRing(group, layout=layout_kind, schedule=schedule, transport=transport,
+                                 ipc_slot_bytes=slot_bytes if transport == "ipc" else None, ipc_slots=slots)
             except Exception as e:       # noqa: BLE001
                 err = e
             if not _vote(group, err is None):
@@ -927,8 +938,14 @@ def ring_attention(q, k, v, *, group=None, causal=True, segment_ids=None, key_va
                 # (an ownership table travels with the call: one ring object serves every table; it posts up to
                 #  2 x chunks-per-rank messages per pair and group)
                 table = layout if kind == "table" else None
+                # an ownership table runs in the C driver's GATHERED form only (lwm_ring_attn_*: B = 1, causal, at most
+                # LWM_MAX_PIECES = 8 chunks per rank, the direct schedule = at most 16 ranks); any other table call is
+                # this module's driver's, whose pair form has none of those limits
+                c_ok = table is None or (q.shape[0] == 1 and causal and dist.get_world_size(group) <= 16 and
+                                         len(layout.owner) // layout.n <= 8 and sched in ("mesh", "direct"))
                 slots = max(8, 4 * q.shape[0], 2 * (len(layout.owner) // layout.n) if table is not None else 0)
-                c_ring = _c_ring_for(group, "zigzag" if table is not None else kind, sched, transport, q.numel() * 4, slots)
+                c_ring = _c_ring_for(group, "zigzag" if table is not None else kind, sched, transport, q.numel() * 4,
+                                     slots) if c_ok else None
                 if c_ring is not None:
                     return ring_attention_c(q, k, v, c_ring, causal=causal, segment_ids=segment_ids,
                                             key_valid=key_valid, scale=scale, layout=table)

@@ -22,6 +22,42 @@ from ._lib import lib
 from .ops import _t4
 
 
+import contextlib
+import os
+import sys
+import threading
+
+
+@contextlib.contextmanager
+def first_contact(what, seconds=None):
+    """A watchdog around the FIRST time this process does `what` with its peers (the communicator set-up, the first
+    forward exchange, the first backward exchange of a ring).  The RCCL path of the C driver has run on one GPU and over
+    real processes sharing a GPU, never across GPUs; a peer that never arrives would leave every rank inside
+    ncclCommInitRank or a stream wait where no exception can reach it -- the default training path would deadlock
+    silently.  If the guarded region is still running after LWM_RING_FIRST_CONTACT_S seconds (default 300,
+    0 = no watchdog) the process says what hung and how to take the other driver, and exits with code 75: the launcher
+    ends the job instead of a hang."""
+    limit = float(os.environ.get("LWM_RING_FIRST_CONTACT_S", "300")) if seconds is None else float(seconds)
+    if limit <= 0:
+        yield
+        return
+
+    def fire():
+        print(f"[lwm_amd.ring] rank {os.environ.get('RANK', '?')}: {what} did not finish within {limit:.0f} s -- a peer never "
+              "arrived or the transport is stuck.  LWM_RING_DRIVER=python takes the torch.distributed ring driver, "
+              "LWM_RING_TRANSPORT=ipc the library's own IPC transport, LWM_RING_FIRST_CONTACT_S the limit.  Exiting (75).",
+              file=sys.stderr, flush=True)
+        os._exit(75)
+
+    t = threading.Timer(limit, fire)
+    t.daemon = True
+    t.start()
+    try:
+        yield
+    finally:
+        t.cancel()
+
+
 class CRing:
     """One ring object per (process group, device).  transport: None / "rccl" = RCCL (a communicator is created
     from an ncclUniqueId broadcast over `group`); "ipc" = the library's CU-free transport (peer mailboxes mapped through
@@ -122,6 +158,10 @@ class CRing:
         self._h = h
         self._ws = None
         self._parked = []
+        # first-contact watchdog state: a real transport's first forward and first backward are run to completion under
+        # first_contact(); test transports (callbacks) and one-rank rings have no peer to wait for
+        self._unproven = {"forward", "backward"} if (self.size > 1 and (transport in (None, "rccl", "ipc"))) else set()
+        self._kept_bytes = 0
         # layout: "contiguous" | "zigzag" | a lwm_amd.ring.SeqLayout (kind "table": the ownership table travels with every
         # call); forward / backward take another one per call (a packed batch has its own balanced ownership)
         self.layout, self._owner = self._layout_code(layout)
@@ -220,13 +260,16 @@ class CRing:
         """A buffer for the gathered K/V of one layer (lwm_ring_kv_keep_bytes) when keeping it between the forward and the
         backward is within the budget -- LWM_RING_KEEP_KV_MB per layer, default 1024 (0 = never): the backward then fetches
         no K/V again, a quarter of the layer's xGMI bytes.  A function of the geometry only, so every rank decides alike."""
-        import os
-        if self.size < 2:
-            return None
+        if self.size < 2 or self.schedule != _capi.RING_SCHEDULE["direct"]:
+            return None          # (the neighbour ring never gathers: nothing to keep)
         B, c, H, D = q.shape
         need = int(lib().lwm_ring_kv_keep_bytes(B, c, H, D, self.size))
         cap = float(os.environ.get("LWM_RING_KEEP_KV_MB", "1024")) * (1 << 20)
-        if need <= 0 or need > cap:
+        # ... and over the whole model: the buffers of all layers are alive between the forward and the backward of a step
+        # (LWM_RING_KEEP_KV_TOTAL_MB, default 32768; 32 layers at S = 32768 over 8 ranks hold 15 GB).  The count goes up
+        # in the forward and down in the backward of each layer -- the same sequence on every rank.
+        total = float(os.environ.get("LWM_RING_KEEP_KV_TOTAL_MB", "32768")) * (1 << 20)
+        if need <= 0 or need > cap or self._kept_bytes + need > total:
             return None
         buf = torch.empty(need + 256, dtype=torch.uint8, device=q.device)
         off = (-buf.data_ptr()) % 256
@@ -243,9 +286,23 @@ class CRing:
         if kv_keep is not None:
             a.kv_keep = kv_keep.data_ptr()
         L = lib()
-        _capi.check(L, L.lwm_ring_attn_fwd(self._h, C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
-                    "lwm_ring_attn_fwd")
+        with self._guard("forward"):
+            _capi.check(L, L.lwm_ring_attn_fwd(self._h, C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                        "lwm_ring_attn_fwd")
         return out, lse
+
+    @contextlib.contextmanager
+    def _guard(self, which):
+        """the first forward / backward of a ring over a real transport: run to completion under the watchdog"""
+        if which not in self._unproven:
+            yield
+            return
+        with first_contact(f"the first ring-attention {which} exchange ({self.size} ranks)"):
+            yield
+            torch.cuda.current_stream().synchronize()
+            if self.side is not None:
+                self.side.synchronize()
+        self._unproven.discard(which)
 
     def backward(self, q, k, v, out, lse, dout, *, causal=True, segment_ids=None, key_valid=None, scale=None, layout=None,
                  kv_keep=None):
@@ -257,15 +314,18 @@ class CRing:
             a.kv_keep, a.kv_kept = kv_keep.data_ptr(), 1
         a.dout, a.dq, a.dk, a.dv = _t4(dout, "dout"), _t4(dq, "dq"), _t4(dk, "dk"), _t4(dv, "dv")
         L = lib()
-        _capi.check(L, L.lwm_ring_attn_bwd(self._h, C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
-                    "lwm_ring_attn_bwd")
+        with self._guard("backward"):
+            _capi.check(L, L.lwm_ring_attn_bwd(self._h, C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                        "lwm_ring_attn_bwd")
         return dq, dk, dv
 
 
 class _RingAttentionC(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, ring, causal, segment_ids, key_valid, scale, layout):
-        keep = ring.kv_keep_buffer(q)       # (None beyond the budget: the backward fetches again)
+        # (None beyond the budget -- the backward fetches again -- and when nothing asks for a gradient: a no_grad / eval
+        #  forward has no backward to keep the K/V for.  ctx.needs_input_grad is the same on every rank of a model.)
+        keep = ring.kv_keep_buffer(q) if any(ctx.needs_input_grad[:3]) else None
         out, lse = ring.forward(q, k, v, causal=causal, segment_ids=segment_ids, key_valid=key_valid, scale=scale, layout=layout,
                                 kv_keep=keep)
         ctx.save_for_backward(q, k, v, out, lse)
@@ -273,6 +333,8 @@ class _RingAttentionC(torch.autograd.Function):
         # the gathered K/V of this layer, kept for its backward -- only when the call took the gathered form (else the
         # buffer was not written)
         ctx.kv_keep = keep if (keep is not None and ring.last_form == 1) else None
+        if ctx.kv_keep is not None:
+            ring._kept_bytes += ctx.kv_keep.numel()
         return out
 
     @staticmethod
@@ -281,6 +343,8 @@ class _RingAttentionC(torch.autograd.Function):
         ring, causal, segment_ids, key_valid, scale, layout = ctx.cfg
         dq, dk, dv = ring.backward(q, k, v, out, lse, dout, causal=causal, segment_ids=segment_ids,
                                    key_valid=key_valid, scale=scale, layout=layout, kv_keep=ctx.kv_keep)
+        if ctx.kv_keep is not None:
+            ring._kept_bytes = max(0, ring._kept_bytes - ctx.kv_keep.numel())
         ctx.kv_keep = None
         return dq, dk, dv, None, None, None, None, None, None
 

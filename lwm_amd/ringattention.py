@@ -14,7 +14,7 @@ import torch
 from .ring import (HipBlockOps, SeqLayout, SingleComm, TorchRingComm, cache_update, ring_attention,
                    ring_inference)
 
-_SP_GROUP = {"group": None, "bound": False, "layout": None}
+_SP_GROUP = {"group": None, "bound": False, "layout": None, "explicit": False}
 
 
 def set_sp_group(group, layout=None):
@@ -39,6 +39,19 @@ def set_sp_group(group, layout=None):
     if layout not in (None, "zigzag", "contiguous"):
         raise ValueError(f"unknown sp layout {layout!r} (zigzag | contiguous)")
     _SP_GROUP["layout"] = layout if group is not None else None
+    # (the caller -- or LWM_SP_LAYOUT -- NAMED the rule: what sp_layout_is_explicit() reports, see
+    # LLaMAForCausalLM._ring_position_ids)
+    _SP_GROUP["explicit"] = layout is not None and group is not None
+
+
+def sp_layout_is_explicit(axis_name="sp"):
+    """True when the ownership rule along the axis was NAMED (set_sp_group(layout=...) / LWM_SP_LAYOUT) rather than
+    defaulted.  A caller that brings its own position_ids to a sequence-sharded batch has sharded the rows itself: with
+    a defaulted rule nobody has said which positions those rows ARE (the reference's contiguous blocks,
+    lwm/llama.py:560-562, or sp_shard's zigzag half-chunks), and a wrong guess is a silently wrong causal mask."""
+    if axis_name is None or isinstance(axis_name, str) or axis_name is _SP_GROUP["group"]:
+        return bool(_SP_GROUP["explicit"])
+    return False
 
 
 def _resolve_axis(axis_name):
@@ -69,12 +82,18 @@ def sp_size_rank(axis_name="sp"):
 
 
 def sp_layout(axis_name="sp", local_len=None):
-    """The ownership rule in force along the "sp" axis: "contiguous" for one rank; else what set_sp_group was given,
-    else "zigzag" (when `local_len` is given and odd -- zigzag needs two half-chunks -- "contiguous")."""
+    """The ownership rule in force along the "sp" axis: "contiguous" for one rank; else what set_sp_group was given
+    (also when the axis is handed over as the bound ProcessGroup object itself), else "zigzag" (when `local_len` is given
+    and odd -- zigzag needs two half-chunks -- "contiguous").  A ProcessGroup that was never bound with set_sp_group
+    has no rule of its own: it gets the reference's contiguous blocks (lwm/llama.py:560-562), as the low-level
+    lwm_amd.ring.ring_attention does -- pass `layout=` to ringattention / sp_shard / sp_positions for anything else."""
     n, _ = sp_size_rank(axis_name)
     if n == 1:
         return "contiguous"
-    kind = _SP_GROUP["layout"] if (axis_name is None or isinstance(axis_name, str)) else None
+    named = axis_name is None or isinstance(axis_name, str)
+    if not named and axis_name is not _SP_GROUP["group"]:
+        return "contiguous"
+    kind = _SP_GROUP["layout"]
     if kind is None:
         kind = "zigzag" if (local_len is None or local_len % 2 == 0) else "contiguous"
     return kind

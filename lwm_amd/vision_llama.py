@@ -45,29 +45,29 @@ class VideoLLaMAForCausalLM(LLaMAForCausalLM):
         return torch.where(vm[..., None], vis, text)
 
     def hidden_states(self, input_ids, vision_masks, attention_mask=None, segment_ids=None, position_ids=None,
-                      cache=None):
-        _, position_ids = self._ring_position_ids(input_ids, position_ids, cache)
+                      cache=None, layout=None):
+        _, position_ids = self._ring_position_ids(input_ids, position_ids, cache, layout)
         x = self._embed(input_ids, vision_masks)
         fc = self._table(x.device)
         for i, blk in enumerate(self.h):
-            x = blk(x, fc, attention_mask, segment_ids, position_ids, None if cache is None else cache[i])
+            x = blk(x, fc, attention_mask, segment_ids, position_ids, None if cache is None else cache[i], layout)
         return self.ln_f(x)
 
     def _vision_kernel(self):
         return self.vte.t() if self.cfg.tie_vision_embeddings else self.vision_head
 
     def loss(self, input_tokens, input_vision_masks, target_tokens, target_vision_masks, loss_masks=None,
-             attention_mask=None, segment_ids=None, position_ids=None, chunk=8192):
+             attention_mask=None, segment_ids=None, position_ids=None, chunk=8192, layout=None, sp_sharded=True):
         """modality 'vision,text' of lwm/train.py:183-209 -> (loss, metrics); both heads go through the
         chunked head+loss operator so that no (S, vocab) logits tensor exists at 256K-1M tokens."""
-        h = self.hidden_states(input_tokens, input_vision_masks, attention_mask, segment_ids, position_ids)
+        h = self.hidden_states(input_tokens, input_vision_masks, attention_mask, segment_ids, position_ids, layout=layout)
         tvm = target_vision_masks.to(torch.bool)
         lm = torch.ones_like(target_tokens, dtype=torch.float32) if loss_masks is None else loss_masks.float()
         zero = torch.zeros_like(target_tokens)
         v_loss, v_acc = chunked_lm_head_loss(h, self._vision_kernel().contiguous(), torch.where(tvm, target_tokens, zero),
-                                             lm * tvm.float(), chunk)
+                                             lm * tvm.float(), chunk, sp_sharded=sp_sharded)
         t_loss, t_acc = chunked_lm_head_loss(h, self.lm_head, torch.where(tvm, zero, target_tokens),
-                                             lm * (~tvm).float(), chunk)
+                                             lm * (~tvm).float(), chunk, sp_sharded=sp_sharded)
         return 0.5 * (v_loss + t_loss), dict(vision_loss=v_loss, vision_acc=v_acc, text_loss=t_loss, text_acc=t_acc)
 
     # ---- generation (lwm/vision_llama.py:447-745).  Eager, through the KV cache of lwm_amd/llama.py.

@@ -205,8 +205,17 @@ def _chunk_bias(vis):
 
 def blockwise_ring_attention(q, k, v, *, ring=1, q_chunk=1024, k_chunk=1024, causal=True,
                              segment_ids=None, key_valid=None, scale=None,
-                             return_stats=False):
+                             return_stats=False, additive_bias=False):
     """Forward of the ring/blockwise algorithm, simulated for `ring` devices.
+
+    additive_bias=True: the masks act ONLY as the reference applies them -- additive float32 biases, key padding
+    (lwm/llama.py:533-537: 0 / finfo.min) + segment + causal terms, summed in float32 (two
+    violated conditions overflow to -inf) -- with no special case for rows that never see a key.  For every row with at
+    least one visible key the result is the default mode's (exp(finfo.min - max) underflows to 0); a row with NONE -- a
+    left-padded query, lwm/vision_chat.py:136-140 -- comes out as the UNIFORM AVERAGE of V over the keys of the processed
+    chunks that violate exactly one condition (all their logits equal finfo.min: |q.k| is far below its ulp), where the
+    default mode -- and the product -- define out = 0, lse = -inf.  This is the one place where the product's output is
+    knowingly not the reference's; tests/test_oracle_ring.py and tests/test_gpu_attention.py state both values.
 
     q,k,v are the GLOBAL (B,S,H,D) arrays; rank r owns rows [r*c,(r+1)*c)
     (contiguous sharding, lwm/llama.py:560-562).  For ring step t, rank r holds
@@ -253,9 +262,28 @@ def blockwise_ring_attention(q, k, v, *, ring=1, q_chunk=1024, k_chunk=1024, cau
                         seg_k=None if segment_ids is None else np.asarray(segment_ids)[:, k0:k0 + kc],
                         key_valid=None if key_valid is None else np.asarray(key_valid)[:, k0:k0 + kc],
                         B=B)[:, None]
-                    s = s + _chunk_bias(vis)
                     sl = slice(qi * qc, qi * qc + qc)
                     m_old = mx[:, :, sl]
+                    if additive_bias:
+                        terms = [visible_mask(qc, kc, causal=causal, q_start=q0, k_start=k0, B=B)[:, None]]
+                        if segment_ids is not None:
+                            sg = np.asarray(segment_ids)
+                            terms.append((sg[:, q0:q0 + qc, None] == sg[:, None, k0:k0 + kc])[:, None])
+                        if key_valid is not None:
+                            terms.append((np.asarray(key_valid)[:, None, k0:k0 + kc] != 0)[:, None])
+                        with np.errstate(over="ignore"):
+                            for tm in terms:
+                                s = s + _chunk_bias(tm)
+                        m_new = np.maximum(m_old, s.max(axis=-1))
+                        with np.errstate(invalid="ignore"):
+                            p = np.where(np.isfinite(m_new)[..., None], np.exp(s - m_new[..., None]), np.float32(0.0))
+                            corr = np.where(np.isfinite(m_old), np.exp(m_old - m_new), np.float32(0.0))
+                        num[:, sl] = num[:, sl] * np.transpose(corr, (0, 2, 1))[..., None] + \
+                            np.einsum("bhqk,bkhd->bqhd", p, vs)
+                        den[:, :, sl] = den[:, :, sl] * corr + p.sum(axis=-1)
+                        mx[:, :, sl] = m_new
+                        continue
+                    s = s + _chunk_bias(vis)
                     m_new = np.maximum(m_old, s.max(axis=-1))
                     p = np.exp(s - m_new[..., None])
                     # a chunk whose every entry carries the finfo.min bias must not

@@ -67,3 +67,38 @@ def blockwise_fwd_bwd(q, k, v, dout, *, q_chunk=1024, k_chunk=1024, causal=True)
             dk[:, :, k0:k0 + kc] += torch.matmul(ds.transpose(-1, -2), qs)
     back = lambda t: t.permute(0, 2, 1, 3).contiguous()
     return back(out), back(dq), back(dk), back(dv)
+
+
+# ---- every host thread at once: heads are independent, so a many-core host runs them side by side (bench.py cpu_baseline)
+def _heads_worker(idx, S, heads, threads, barrier, out_q):
+    import time
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(100 + idx)
+    mk = lambda s: [torch.randn(1, s, 1, 128, generator=g) for _ in range(4)]
+    blockwise_fwd_bwd(*mk(1024))                      # warm this process's BLAS threads
+    data = mk(S)
+    barrier.wait()
+    t0 = time.time()
+    for _ in range(heads):
+        blockwise_fwd_bwd(*data)
+    out_q.put((idx, t0, time.time()))
+
+
+def heads_in_parallel(S, workers, heads_per_worker, threads_per_worker=8, timeout=900):
+    """`workers` processes x `threads_per_worker` BLAS threads, each running `heads_per_worker` passes of blockwise_fwd_bwd
+    (1 head, S tokens) after a common barrier.  -> (wall seconds from the first start to the last end, heads done)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    barrier, out_q = ctx.Barrier(workers), ctx.Queue()
+    procs = [ctx.Process(target=_heads_worker, args=(i, S, heads_per_worker, threads_per_worker, barrier, out_q))
+             for i in range(workers)]
+    for p in procs:
+        p.start()
+    try:
+        spans = [out_q.get(timeout=timeout) for _ in range(workers)]
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    return max(e for _, _, e in spans) - min(s for _, s, _ in spans), workers * heads_per_worker

@@ -148,3 +148,71 @@ def test_gemv_validation():
     assert L.lwm_gemv_bf16(p, 64, p, p, 60, None, p, 1, 64, 60, None) == -2       # N % 8
     assert L.lwm_gemv_bf16(p, 64, p, None, 64, None, p, 1, 64, 64, None) == -1    # no output
     assert L.lwm_gemv_workspace_bytes(2, 4096, 11008) == 32 * 2 * 11008 * 4
+
+
+# ---- round 6: the entry points the re-laid training GEMMs lean on (lwm_amd/llama_ops.py, "library GEMMs of the TRAINING path")
+@pytest.mark.parametrize("R_,C_,pad_s,pad_d", [(64, 64, 0, 0), (128, 192, 8, 16), (256, 64, 24, 0)])
+def test_transpose_is_exact(R_, C_, pad_s, pad_d):
+    from oracle.attention_ref import to_bf16_bits
+    L = _emu.lib()
+    src = _emu.aligned((R_, C_ + pad_s), np.uint16)
+    src[...] = to_bf16_bits(_rnd((R_, C_ + pad_s), 11))
+    dst = _emu.aligned((C_, R_ + pad_d), np.uint16)
+    dst[...] = 0x7fc0                                                   # (what the kernel must not leave / must not touch)
+    assert L.lwm_transpose_bf16(src.ctypes.data, C_ + pad_s, dst.ctypes.data, R_ + pad_d, R_, C_, None) == 0
+    assert np.array_equal(dst[:, :R_], src[:, :C_].T)
+    assert np.all(dst[:, R_:] == 0x7fc0)                                # the padding of the destination rows stays
+    from lwm_amd import _capi
+    assert L.lwm_transpose_bf16(src.ctypes.data, C_ + pad_s, dst.ctypes.data, R_ + pad_d, R_ - 1, C_, None) == _capi.LWM_EUNSUPPORTED
+    assert L.lwm_transpose_bf16(src.ctypes.data, C_ - 8, dst.ctypes.data, R_ + pad_d, R_, C_, None) == _capi.LWM_EINVAL
+
+
+@pytest.mark.parametrize("rows,F", [(16, 64), (5, 11008 // 8), (1, 8)])
+def test_swiglu_on_halves_equals_the_flat_kernels(rows, F):
+    """gate | up as the halves of one (rows, 2F) buffer, d gate | d up into the halves of another: bit for bit the flat
+    kernels on contiguous copies (lwm/llama.py:659)."""
+    from oracle.attention_ref import to_bf16_bits
+    L = _emu.lib()
+    y13 = _emu.aligned((rows, 2 * F), np.uint16)
+    y13[...] = to_bf16_bits(_rnd((rows, 2 * F), 12, 2.0))
+    g = _emu.aligned((rows, F), np.uint16)
+    g[...] = to_bf16_bits(_rnd((rows, F), 13))
+    a, b = _emu.aligned((rows, F), np.uint16), _emu.aligned((rows, F), np.uint16)
+    a[...], b[...] = y13[:, :F], y13[:, F:]
+    y0, y1, da0, db0 = (_emu.aligned((rows, F), np.uint16) for _ in range(4))
+    d13 = _emu.aligned((rows, 2 * F), np.uint16)
+    assert L.lwm_swiglu_fwd_bf16(a.ctypes.data, b.ctypes.data, y0.ctypes.data, rows * F, None) == 0
+    assert L.lwm_swiglu_fwd_ld_bf16(y13.ctypes.data, 2 * F, y13.ctypes.data + 2 * F, 2 * F, y1.ctypes.data, F, rows, F, None) == 0
+    assert np.array_equal(y0, y1)
+    assert L.lwm_swiglu_bwd_bf16(a.ctypes.data, b.ctypes.data, g.ctypes.data, da0.ctypes.data, db0.ctypes.data, rows * F, None) == 0
+    assert L.lwm_swiglu_bwd_ld_bf16(y13.ctypes.data, 2 * F, y13.ctypes.data + 2 * F, 2 * F, g.ctypes.data, F, d13.ctypes.data, 2 * F,
+                                    d13.ctypes.data + 2 * F, 2 * F, rows, F, None) == 0
+    assert np.array_equal(d13[:, :F], da0) and np.array_equal(d13[:, F:], db0)
+    # against the oracle's SwiGLU as well
+    from oracle.attention_ref import from_bf16_bits
+    ref = R.swiglu(from_bf16_bits(a), from_bf16_bits(b)) if hasattr(R, "swiglu") else None
+    if ref is not None:
+        assert np.abs(from_bf16_bits(y1) - ref).max() <= 2 ** -6 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("rows,C", [(300, 256), (2049, 64), (5, 4096)])
+def test_rmsnorm_bwd_with_the_residual_gradient_folded_in(rows, C):
+    """dx = bf16(bf16(dx_norm) + res): the roundings of autograd's separate add (FlaxLLaMABlock's `x` feeds the norm and the
+    residual add, lwm/llama.py:704-744); dw unchanged; and the re-worked dW reduction against a float64 sum."""
+    from oracle.attention_ref import from_bf16_bits, to_bf16_bits
+    L = _emu.lib()
+    x, g, res = _rnd((rows, C), 21, 2.0), _rnd((rows, C), 22), _rnd((rows, C), 23)
+    w = round_bf16((1 + 0.1 * np.random.default_rng(24).standard_normal(C)).astype(np.float32))
+    _, rstd = _emu.rmsnorm_fwd(x, w)
+    dx0, dw0 = _emu.rmsnorm_bwd(x, w, g, rstd)
+    xb, wb, gb, rb = (_emu.bf16_array(t) for t in (x, w, g, res))
+    dx1, dw1 = _emu.aligned((rows, C), np.uint16), _emu.aligned((C,), np.uint16)
+    ws = _emu.aligned((max(L.lwm_rmsnorm_bwd_workspace_bytes(rows, C), 16) // 4,), np.float32)
+    r = _emu.aligned((rows,), np.float32)
+    r[...] = rstd
+    assert L.lwm_rmsnorm_bwd_res_bf16(xb.ctypes.data, wb.ctypes.data, gb.ctypes.data, r.ctypes.data, rb.ctypes.data, dx1.ctypes.data,
+                                      dw1.ctypes.data, ws.ctypes.data, rows, C, None) == 0
+    assert np.array_equal(dx1, to_bf16_bits(dx0 + res))
+    assert np.array_equal(from_bf16_bits(dw1), dw0)
+    dwr = (g.astype(np.float64) * x.astype(np.float64) * rstd[:, None].astype(np.float64)).sum(0)
+    assert np.abs(dw0 - dwr).max() <= 6e-3 * np.abs(dwr).max()          # (one bf16 rounding of the result)

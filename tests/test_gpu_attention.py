@@ -261,6 +261,49 @@ def test_autograd_ring1_matches_oracle():
     _check("dv", _np(vd.grad), rv)
 
 
+def test_left_padded_queries_the_one_known_divergence_from_the_reference():
+    """The product on a LEFT-PADDED batch through the reference's own call surface (attn_bias built as lwm/llama.py:527-537
+    builds it, prompts padded as lwm/vision_chat.py:136-140 pads them).  Rows that see a key: the oracle's values.  Rows that
+    see none (the padding queries): the product returns out = 0 and propagates NO gradient through them, where the reference's
+    additive finfo.min bias yields the uniform average of V over the once-masked keys of the processed chunks
+    (oracle: blockwise_ring_attention(additive_bias=True)).  Both values are stated here; INTEGRATION.md
+    section 7 says why no downstream result changes (tests/test_oracle.py::test_the_reference_additive_bias_... shows it)."""
+    import torch
+    from lwm_amd.llama import key_padding_bias
+    from lwm_amd.ringattention import ringattention
+    B, S, H, pad = 2, 768, 2, 37
+    q, k, v, do = (_rand((B, S, H, 128), s) for s in (61, 62, 63, 64))
+    am = np.ones((B, S), np.int32)
+    am[0, :pad] = 0                                        # row 0 of the batch is left-padded, row 1 is not
+    bias = key_padding_bias(torch.from_numpy(am).cuda())
+    assert float(bias.min()) == float(np.finfo(np.float32).min) and float(bias.max()) == 0.0
+    qd, kd, vd = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    out = ringattention(qd, kd, vd, bias, None, axis_name="sp",
+                        blockwise_kwargs=dict(causal_block_size=1, query_chunk_size=256, key_chunk_size=256))
+    out.backward(do.cuda())
+    o = _np(out)
+    kvd = (am > 0).astype(np.uint8)
+    ro, _ = R.dense_attention(_np(q), _np(k), _np(v), causal=True, key_valid=kvd)
+    # the product's value on the rows that see no key, and the oracle's definition of it
+    assert np.all(o[0, :pad] == 0) and np.all(ro[0, :pad] == 0)
+    # the reference's value there: NOT zero -- the mean of V over the keys masked exactly once (q chunk 0 sees k chunk 0 only)
+    ref_add = R.blockwise_ring_attention(_np(q), _np(k), _np(v), ring=1, q_chunk=256, k_chunk=256, key_valid=kvd, additive_bias=True)
+    for i in (0, pad - 1):
+        once = np.r_[0:i + 1, pad:256]
+        assert np.allclose(ref_add[0, i], _np(v)[0, once].mean(axis=0), rtol=1e-5, atol=1e-6)
+    assert np.abs(ref_add[0, :pad]).max() > 1e-2
+    # everywhere else the product, the oracle and the reference's additive arithmetic agree
+    _check("out", o[:, pad:], ro[:, pad:])
+    _check("out vs additive-bias restatement", o[:, pad:], ref_add[:, pad:])
+    _check("out (unpadded batch row)", o[1], ref_add[1])
+    # gradients: nothing flows through the padding queries (dq = 0 there), and padded KEYS receive none
+    rq, rk, rv, rqx = R.dense_attention_bwd(_np(q), _np(k), _np(v), _np(do), causal=True, key_valid=kvd, out_saved=o)
+    assert np.all(_np(qd.grad)[0, :pad] == 0) and np.all(_np(kd.grad)[0, :pad] == 0) and np.all(_np(vd.grad)[0, :pad] == 0)
+    _check_dq("dq", _np(qd.grad), rq, rqx)
+    _check("dk", _np(kd.grad), rk)
+    _check("dv", _np(vd.grad), rv)
+
+
 def test_errors_are_loud():
     import torch
     from lwm_amd import ops, _capi

@@ -213,3 +213,87 @@ def test_dense_routes_decode_rows_through_gemv():
     big = torch.randn(2, 8, 4096, generator=g, device="cuda").to(torch.bfloat16)
     with torch.no_grad():
         assert torch.equal(dense(big, w), big @ w)
+
+
+# ---- round 6: the library GEMMs of the training path, re-laid for hipBLASLt (lwm_amd/llama_ops.py)
+@pytest.mark.parametrize("R_,C_", [(4096, 4096), (256, 11008), (22016, 4096), (100, 36)])
+def test_transpose2d_is_exact(R_, C_):
+    import torch
+    from lwm_amd.llama_ops import transpose2d
+    x = torch.randn(R_, C_ + 8, device="cuda").to(torch.bfloat16)[:, :C_]          # (a row stride that is not the width)
+    out = torch.full((C_, R_ + 16), float("nan"), device="cuda", dtype=torch.bfloat16)
+    transpose2d(x, out[:, :R_])
+    assert torch.equal(out[:, :R_], x.t())
+    assert bool(torch.isnan(out[:, R_:]).all())
+
+
+def test_fused_operators_against_separate_ones():
+    """qkv_rope / dense_fused / swiglu_halves / rmsnorm_residual -- the training path's operators -- against the separate
+    operators they replace (dense_multi + apply_rotary_emb, x @ k, swiglu, RMSNorm + add), forward and every gradient:
+    same math, another grouping of the library GEMMs (results agree to bf16 GEMM noise; the elementwise kernels are the same
+    instructions)."""
+    import torch
+    from lwm_amd import llama_ops as LO
+    bf = torch.bfloat16
+    torch.manual_seed(0)
+    B, S, H, D, F = 1, 640, 4, 128, 1408
+    d = H * D
+    mk = lambda *s, sc=1.0: (torch.randn(*s, device="cuda") * sc).to(bf)
+    x0 = mk(B, S, d)
+    ws = {n: mk(d, d, sc=0.03) for n in ("wq", "wk", "wv", "wo")}
+    w1, w3, w2 = mk(d, F, sc=0.03), mk(d, F, sc=0.03), mk(F, d, sc=0.03)
+    nw = (1 + 0.1 * torch.randn(d, device="cuda")).float()
+    tab = LO.precompute_freqs_cis(D, 2048, 10000.0, device="cuda")
+    pos = torch.arange(S, device="cuda", dtype=torch.int32)[None]
+    gout = mk(B, S, d)
+
+    def run(fused):
+        leaves = {n: t.clone().requires_grad_(True) for n, t in dict(ws, w1=w1, w3=w3, w2=w2, x=x0, nw=nw).items()}
+        L = leaves
+        norm = LO.RMSNorm(d).cuda()
+        norm.kernel = torch.nn.Parameter(L["nw"].detach().clone())
+        if fused:
+            h, xr = LO.rmsnorm_residual(norm, L["x"])
+            q, k, v = LO.qkv_rope(h, L["wq"], L["wk"], L["wv"], tab, pos, H)
+            a = (q.float() * torch.tanh(k.float()) + v.float()).to(bf).reshape(B, S, d)       # (a stand-in for attention)
+            x2 = LO.dense_fused(a, (L["wo"],), xr)
+            h2, x2r = LO.rmsnorm_residual(norm, x2)
+            out = LO.dense_fused(LO.swiglu_halves(LO.dense_fused(h2, (L["w1"], L["w3"]))), (L["w2"],), x2r)
+        else:
+            h = norm(L["x"])
+            q, k, v = (t.reshape(B, S, H, D) for t in (h @ L["wq"], h @ L["wk"], h @ L["wv"]))
+            q, k = LO.apply_rotary_emb(q, k, tab, pos)
+            a = (q.float() * torch.tanh(k.float()) + v.float()).to(bf).reshape(B, S, d)
+            x2 = L["x"] + a @ L["wo"]
+            h2 = norm(x2)
+            out = x2 + LO.swiglu((h2 @ L["w1"]).contiguous(), (h2 @ L["w3"]).contiguous()) @ L["w2"]
+        out.backward(gout)
+        grads = {n: t.grad.float() for n, t in leaves.items() if n != "nw"}
+        grads["nw"] = norm.kernel.grad.float()
+        return out.float(), grads
+
+    o1, g1 = run(True)
+    o0, g0 = run(False)
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+    assert rel(o1, o0) <= 1e-2, rel(o1, o0)
+    for n in g0:
+        assert rel(g1[n], g0[n]) <= 2e-2, (n, rel(g1[n], g0[n]))
+        assert g1[n].shape == g0[n].shape
+
+
+def test_relayout_cache_follows_the_weights():
+    """the (out, in) copy of a kernel is rebuilt when the kernel changes in place, and on weights_changed()"""
+    import torch
+    from lwm_amd import llama_ops as LO
+    w = (torch.randn(256, 512, device="cuda") * 0.05).to(torch.bfloat16)
+    x = torch.randn(64, 256, device="cuda").to(torch.bfloat16)
+    y0 = LO.dense_fused(x, (w,))
+    assert torch.allclose(y0.float(), (x @ w).float(), rtol=2e-2, atol=2e-2)
+    wt0 = w._lwm_relayout[1]
+    assert LO._relayout((w,))[0] is wt0                               # cached
+    w.mul_(2.0)
+    y1 = LO.dense_fused(x, (w,))
+    assert torch.allclose(y1.float(), 2 * y0.float(), rtol=2e-2, atol=2e-2)
+    wt1 = w._lwm_relayout[1]
+    LO.weights_changed()
+    assert LO._relayout((w,))[0] is not wt1

@@ -183,3 +183,38 @@ def test_dense_oracle_matches_torch_sdpa(case):
     for got, t in ((dq, tq), (dk, tk), (dv, tv)):
         g = np.nan_to_num(t.grad.numpy().transpose(0, 2, 1, 3))
         assert np.abs(got - g).max() < 1e-11, case
+
+
+def test_the_reference_additive_bias_and_the_one_known_divergence():
+    """SURVEY.md Appendix A.1 applies the masks as additive float32 biases (key padding: lwm/llama.py:533-537, 0 / finfo.min).
+    (1) For every query row that sees at least one key this gives what the oracle's where-masking gives.  (2) A row that
+    sees NONE -- the left-padded queries of lwm/vision_chat.py:136-140 -- comes out of the reference's arithmetic as the
+    uniform average of V over the once-masked keys of the processed chunks, where the oracle (and the product) define
+    out = 0, lse = -inf: the one place the outputs knowingly differ.  (3) Nothing downstream sees it: those rows are
+    masked KEYS in every later layer, so a second attention layer over either version of the first layer's output is
+    identical on every valid row."""
+    rng = np.random.default_rng(5)
+    B, S, H, D, pad, qc = 2, 96, 2, 16, 13, 32
+    q, k, v = (R.round_bf16(rng.standard_normal((B, S, H, D)).astype(np.float32)) for _ in range(3))
+    key_valid = np.ones((B, S), np.uint8)
+    key_valid[:, :pad] = 0                                           # left padding
+    o_where, lse_where = R.blockwise_ring_attention(q, k, v, ring=1, q_chunk=qc, k_chunk=qc, key_valid=key_valid, return_stats=True)
+    o_add, _ = R.blockwise_ring_attention(q, k, v, ring=1, q_chunk=qc, k_chunk=qc, key_valid=key_valid, return_stats=True,
+                                          additive_bias=True)
+    assert np.array_equal(o_add[:, pad:], o_where[:, pad:])          # (1) rows with a visible key: the same, bit for bit
+    assert np.all(o_where[:, :pad] == 0) and np.all(np.isneginf(lse_where[:, :, :pad]))
+    # (2) row i < pad, one q chunk [0, qc): the chunk pairs not wholly above the diagonal are k chunk 0 only; in it the keys
+    # j <= i violate padding alone, the keys pad <= j < qc violate causality alone (logit finfo.min each), the keys
+    # i < j < pad violate both (-inf): the reference's value is the mean of V over the first kind and the second
+    for i in (0, 5, pad - 1):
+        once = np.r_[0:i + 1, pad:qc]
+        assert np.allclose(o_add[:, i], v[:, once].mean(axis=1), rtol=1e-5, atol=1e-6)
+        assert np.abs(o_add[:, i]).max() > 0
+    # (3) a second layer (q = k = v = layer-1 output) under the same masks: identical on the valid rows
+    h_ref, h_ours = R.round_bf16(o_add), R.round_bf16(o_where)
+    o2_ref = R.blockwise_ring_attention(h_ref, h_ref, h_ref, ring=1, q_chunk=qc, k_chunk=qc, key_valid=key_valid, additive_bias=True)
+    o2_ours = R.blockwise_ring_attention(h_ours, h_ours, h_ours, ring=1, q_chunk=qc, k_chunk=qc, key_valid=key_valid)
+    assert np.array_equal(o2_ref[:, pad:], o2_ours[:, pad:])
+    # the ring (2 ranks) agrees with one rank in both modes on the valid rows
+    o_add2 = R.blockwise_ring_attention(q, k, v, ring=2, q_chunk=16, k_chunk=16, key_valid=key_valid, additive_bias=True)
+    assert np.allclose(o_add2[:, pad:], o_where[:, pad:], rtol=2e-6, atol=2e-6)
