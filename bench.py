@@ -83,6 +83,9 @@ def cpu_config1():
             "kind": "port", "cores": _cpu_threads(), "sample": "oracle/llama_model_ref.forward_loss + backward, 1 pass"}
 
 
+CPU_BASELINE_CONVENTION_R05 = ("value = S / (seconds of ONE timed pass at the workload's own S: 1 head, 1 layer, fwd+bwd) / 32 heads / 32 layers; "
+                               "the pass is timed at 8 and at 32 threads and the faster one counts (thread sweep at S=4096 x 8 heads over "
+                               "{8, 32, all} kept as context)")       # (the lines of round 5 carry this text)
 CPU_BASELINE_CONVENTION = ("value = S / (wall seconds of ONE LAYER's 32 heads at the workload's own S, fwd+bwd, the heads run side by side "
                            "as floor(host threads / 8) processes of 8 BLAS threads each) / 32 layers; cores = the host's thread count. "
                            "(Rounds 1-5 timed ONE head on 8 or 32 threads and multiplied by 32 heads, leaving most of a many-core host "
@@ -645,6 +648,80 @@ def ring_model_leg(torch, n=8, S=131072, schedule="mesh", driver="c", packed=Fal
             "imbalance_max_over_mean": worst / (sum(per_rank) / n),
             "compute_bound_tokens_per_s": S / (worst * 1e-3 * N_LAYERS),
             "compute_bound_tflops_per_gpu": flops_layer / n / (worst * 1e-3) / 1e12}
+
+
+XGMI_LINK_GBPS = 153.0          # one xGMI link, one direction (MI355X_MICROARCH.md); 7 links per GPU, point to point
+XGMI_LINK_EFFICIENCY = 0.75     # what a large send/recv is assumed to reach of that -- an ASSUMPTION, stated in the line
+
+
+def predicted_scaling_leg(torch, known=None):
+    """A MODEL of the 1 -> 8 curve from what ONE GPU can measure -- labelled as such, never a measured scaling number:
+      compute: every rank's launch list of the product path (C driver, zigzag ownership, direct schedule = the N > 1
+               default) run on this GPU with a transport that moves nothing (ring_model_leg); the slowest rank counts;
+               N = 1 is one directly timed layer (fwd+bwd) at the same S;
+      link:    the bytes the slowest-sending rank posts per layer (lwm_ring_planned_bytes, fwd + bwd; the backward's K/V
+               re-fetch is dropped when the gathered K/V is kept, LWM_RING_KEEP_KV_MB), spread over min(N - 1, 7) xGMI
+               links at XGMI_LINK_GBPS x XGMI_LINK_EFFICIENCY;
+      predicted tokens/s = S / (32 layers x max(compute, link))  [exchange fully hidden]  and  S / (32 x (compute + link))
+               [nothing hidden]; efficiency = that / (N x the N = 1 figure): strong scaling at fixed S, BASELINE's metric.
+    S = 32768 is what `--gpus N` times (configs[1] at every N), S = 131072 is configs[2]."""
+    from lwm_amd import _capi
+    from lwm_amd._lib import lib
+    from lwm_amd.ring import HipBlockOps, SeqLayout, SingleComm, ring_backward, ring_forward
+    L = lib()
+    known = known or {}
+    out = {"kind": "model, not measured", "link_GBps_assumed": XGMI_LINK_GBPS * XGMI_LINK_EFFICIENCY,
+           "link_note": f"{XGMI_LINK_GBPS:.0f} GB/s per xGMI link and direction x {XGMI_LINK_EFFICIENCY} assumed efficiency, "
+                        "min(N-1, 7) links per rank", "by_S": {}}
+    for S in (32768, 131072):
+        g = torch.Generator(device="cuda").manual_seed(99)
+        mk = lambda: torch.randn(1, S, N_HEADS, HEAD_DIM, generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+        q, k, v, do = mk(), mk(), mk(), mk()
+        lay, comm = SeqLayout("contiguous", 1, S), SingleComm()
+
+        def layer():
+            o, lses = ring_forward(HipBlockOps, comm, q, k, v, layout=lay, causal=True)
+            ring_backward(HipBlockOps, comm, q, k, v, o, lses, do, layout=lay, causal=True)
+
+        layer()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 3 if S <= 32768 else 2
+        e0.record()
+        for _ in range(reps):
+            layer()
+        e1.record()
+        torch.cuda.synchronize()
+        ms1 = e0.elapsed_time(e1) / reps
+        del q, k, v, do
+        torch.cuda.empty_cache()
+        base = S / (ms1 * 1e-3 * N_LAYERS)
+        rows = {"1": {"compute_ms_per_layer": round(ms1, 3), "source": "one layer fwd+bwd timed directly on this GPU",
+                      "link_ms_per_layer": 0.0, "bytes_sent_per_rank_per_layer": 0, "predicted_tokens_per_s": base,
+                      "predicted_tokens_per_s_nothing_hidden": base, "efficiency": 1.0,
+                      "tflops_per_gpu": 7.0 * gemm_unit_flops(S) / (ms1 * 1e-3) / 1e12}}
+        for n in (2, 4, 8):
+            m = known.get((n, S)) or ring_model_leg(torch, n=n, S=S, reps=3 if S <= 32768 else 2)
+            comp = max(m["per_rank_ms_per_layer"])
+            c = S // n
+            lay_code, sched = _capi.RING_LAYOUT["zigzag"], _capi.RING_SCHEDULE["direct"]
+            sent = [int(L.lwm_ring_planned_bytes(lay_code, sched, n, r, 1, c, N_HEADS, HEAD_DIM, 1, 0)) +
+                    int(L.lwm_ring_planned_bytes(lay_code, sched, n, r, 1, c, N_HEADS, HEAD_DIM, 1, 1)) for r in range(n)]
+            kv_again = [int(L.lwm_ring_planned_bytes(lay_code, sched, n, r, 1, c, N_HEADS, HEAD_DIM, 1, 0)) for r in range(n)]
+            keep_ok = int(L.lwm_ring_kv_keep_bytes(1, c, N_HEADS, HEAD_DIM, n)) <= float(os.environ.get("LWM_RING_KEEP_KV_MB", "1024")) * (1 << 20)
+            if keep_ok:          # the backward reads the kept K/V instead of fetching it again
+                sent = [a - b for a, b in zip(sent, kv_again)]
+            link = max(sent) / (min(n - 1, 7) * XGMI_LINK_GBPS * 1e9 * XGMI_LINK_EFFICIENCY) * 1e3
+            hid, exposed = S / (max(comp, link) * 1e-3 * N_LAYERS), S / ((comp + link) * 1e-3 * N_LAYERS)
+            rows[str(n)] = {"compute_ms_per_layer": round(comp, 3), "imbalance_max_over_mean": round(m["imbalance_max_over_mean"], 4),
+                            "source": "slowest rank of the product's launch list, all ranks run on this GPU, no exchange",
+                            "bytes_sent_per_rank_per_layer": max(sent), "kv_kept_for_backward": bool(keep_ok),
+                            "link_ms_per_layer": round(link, 3), "bound": "compute" if comp >= link else "link",
+                            "predicted_tokens_per_s": hid, "predicted_tokens_per_s_nothing_hidden": exposed,
+                            "efficiency": hid / (n * base), "efficiency_nothing_hidden": exposed / (n * base),
+                            "tflops_per_gpu": 7.0 * gemm_unit_flops(S) / n / (comp * 1e-3) / 1e12}
+        out["by_S"][str(S)] = rows
+    return out
 
 
 def elementwise_leg(torch, S=32768):
@@ -1427,6 +1504,13 @@ def main():
                     # ... no (max / mean 1.9): an ownership table from the document lengths, 4 chunks per rank by visible pairs
                     res["ring8_compute_model_packed_1m"] = leg(ring_model_leg, torch, S=1 << 20, packed=True, layout="balanced", reps=1)
                 res["elementwise"] = leg(elementwise_leg, torch)
+                # the 1 -> 8 curve as a MODEL (compute per rank measured here, link time from planned bytes): what the first
+                # real 8-GPU run is to be held against
+                known = {}
+                for key_, n_, S_ in (("ring8_compute_model", 8, 131072), ("ring8_compute_model_32k", 8, 32768)):
+                    if isinstance(res.get(key_), dict) and "per_rank_ms_per_layer" in res[key_]:
+                        known[(n_, S_)] = res[key_]
+                res["predicted_scaling"] = leg(predicted_scaling_leg, torch, known)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -64,12 +64,37 @@ def test_committed_bench_line_follows_the_contract():
     # pass), multiplied out over 32 heads x 32 layers; nothing is scaled in S
     sys.path.insert(0, ROOT)
     import bench
-    assert c["convention"] == bench.CPU_BASELINE_CONVENTION
     m = c["measured_at"]
-    assert (m["S"], m["heads"], m["layers"]) == (32768, 1, 1) and "extrapolated" not in c["sample"]
-    assert abs(c["value"] - 32768 / (m["seconds"] * 32 * 32)) < 1e-6 * c["value"]
-    assert abs(c["gflops"] - 7.0 * 32768 ** 2 * 128 / m["seconds"] / 1e9) < 1e-6 * c["gflops"]
-    assert c["cores"] in (8, 32) or c["cores"] == c["config1"]["cores"]
+    if c["convention"] == bench.CPU_BASELINE_CONVENTION_R05:       # a line of round 5: one head on 8 or 32 threads, multiplied out
+        assert (m["S"], m["heads"], m["layers"]) == (32768, 1, 1) and "extrapolated" not in c["sample"]
+        assert abs(c["value"] - 32768 / (m["seconds"] * 32 * 32)) < 1e-6 * c["value"]
+        assert abs(c["gflops"] - 7.0 * 32768 ** 2 * 128 / m["seconds"] / 1e9) < 1e-6 * c["gflops"]
+        assert c["cores"] in (8, 32) or c["cores"] == c["config1"]["cores"]
+    else:
+        # round 6, frozen: one layer's 32 heads side by side on EVERY host thread (floor(threads / 8) processes x 8 threads)
+        assert c["convention"] == bench.CPU_BASELINE_CONVENTION
+        assert c["cores"] == c["config1"]["cores"] and m["processes"] * m["threads_per_process"] <= c["cores"]
+        assert (m["S"], m["layers"]) == (32768, 1) and 1 <= m["heads_timed"] <= 32 and "extrapolated" not in c["sample"]
+        assert abs(m["layer_seconds"] - m["wall_seconds"] * 32 / m["heads_timed"]) < 1e-9 * m["layer_seconds"]
+        assert abs(c["value"] - 32768 / (m["layer_seconds"] * 32)) < 1e-6 * c["value"]
+        assert abs(c["gflops"] - 7.0 * 32768 ** 2 * 4096 / m["layer_seconds"] / 1e9) < 1e-6 * c["gflops"]
+        one = c["measured_at_one_head"]                            # the earlier convention's figure stays beside it
+        assert abs(c["value_one_head_convention"] - 32768 / (one["seconds"] * 32 * 32)) < 1e-6 * c["value_one_head_convention"]
+        # round 6: the full-model leg carries its own roofline object; the 1 -> 8 curve rides as a labelled MODEL
+        mf = d["model_full"]["roofline"]
+        assert mf["bound"] == "mfma" and mf["peak"] == 2500.0 and abs(mf["frac"] - mf["achieved"] / mf["peak"]) < 1e-9
+        assert abs(mf["achieved"] - d["model_full"]["model_tflops"]) < 1e-9 and "time_shares" in mf
+        if "share" in mf["time_shares"]:
+            assert abs(sum(mf["time_shares"]["share"].values()) - 1.0) < 1e-3
+            assert {"attention_hip", "library_gemm"} <= set(mf["time_shares"]["share"])
+        ps = d["predicted_scaling"]
+        assert ps["kind"] == "model, not measured" and set(ps["by_S"]) == {"32768", "131072"}
+        for S_, rows in ps["by_S"].items():
+            assert set(rows) == {"1", "2", "4", "8"} and rows["1"]["efficiency"] == 1.0
+            for n_ in ("2", "4", "8"):
+                r_ = rows[n_]
+                assert r_["bytes_sent_per_rank_per_layer"] > 0 and r_["link_ms_per_layer"] > 0 and r_["bound"] in ("compute", "link")
+                assert 0.0 < r_["efficiency_nothing_hidden"] <= r_["efficiency"] <= 1.05
     # roofline.traffic comes from a PMC summary stamped with the kernel sources of the tree (bench.attn_kernel_stamp)
     if r["traffic_profile"] is not None:
         prof = json.load(open(os.path.join(ROOT, r["traffic_profile"])))
@@ -83,6 +108,31 @@ def test_committed_bench_line_follows_the_contract():
     # the ring-8 compute models run the product's launch list (the C driver, gathered form) and carry BASELINE configs[4]
     assert d["ring8_compute_model_32k"]["driver"] == "c" and d["ring8_compute_model_32k"]["form"] == "gathered"
     assert "packed documents" in d["ring8_compute_model_packed_1m"]["workload"]
+
+
+def test_counter_evidence_is_of_the_kernel_sources_that_ship():
+    """the NEWEST committed PMC summary of the attention kernels (profiles/r*_pmc_attention_1layer.json)
+    must be stamped with the sha256 of the kernel sources of THIS tree (bench.attn_kernel_stamp) -- a change under
+    lwm_amd/csrc/attn_* without a fresh counter pass (scripts/gpu_pmc_attention.sh + summarise_pmc.py) fails here, instead
+    of surfacing as `roofline.traffic: null` in the driver's line."""
+    import re
+    sys.path.insert(0, ROOT)
+    import bench
+    files = []
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_attention_1layer.json")):
+        m = re.fullmatch(r"r(\d+)([a-z]*)_pmc_attention_1layer\.json", os.path.basename(f))
+        if m:
+            files.append(((int(m.group(1)), m.group(2) == "", m.group(2)), f))
+    assert files
+    newest = max(files)[1]
+    doc = json.load(open(newest))
+    assert doc["kernel_source_stamp"] == bench.attn_kernel_stamp(), \
+        f"{os.path.basename(newest)} is of other kernel sources: re-run scripts/gpu_pmc_attention.sh + summarise_pmc.py"
+    byts, prof = bench.pmc_traffic("attn_bwd_dkdv4_kernel", 32768)
+    assert prof is not None and byts > 1e9
+    for kname in ("attn_fwd64_kernel", "attn_bwd_dkdv4_kernel", "attn_bwd_dq4_kernel"):
+        kk = doc["kernels"][kname]
+        assert 0.3 < kk["mfma_util"] < 1.0 and kk["hbm_traffic_bytes"] > 1e9
 
 
 def test_bench_cli_contract_without_a_gpu():
