@@ -968,6 +968,8 @@ def main():
     ap.add_argument("--force-configs34", action="store_true",
                     help="(functional check) run the configs3 / configs4 legs even when the ranks share a GPU (--backend gloo "
                          "--transport ipc): the IPC mailboxes are then sized for c = 1048576 / N")
+    ap.add_argument("--no-transport-trials", action="store_true",
+                    help="N > 1: skip the last secondary leg (a few layers under every transport / schedule pair of the C driver)")
     ap.add_argument("--no-configs34", action="store_true",
                     help="N > 1: skip the S = 262144 (BASELINE configs[3]) and packed S = 1048576 (configs[4]) legs of the line")
     args = ap.parse_args()
@@ -1005,6 +1007,10 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     rccl_ranks_seen = ranks_seen = None
+    if world > 1 and int(os.environ.get("LWM_RING_RESERVE_CUS", "0") or 0) > 0:
+        # the attention kernels on a stream that leaves k CUs alone (for RCCL's send/recv kernels): priced in this line
+        from lwm_amd.ring_c import reserved_cu_stream
+        torch.cuda.set_stream(reserved_cu_stream(int(os.environ["LWM_RING_RESERVE_CUS"]), dev))
     if world > 1:
         import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -1140,14 +1146,14 @@ def main():
             out, lses = ring_forward(TimedOps, comm, q_, k_, v_, layout=lay, causal=True, segment_ids=seg)
             ring_backward(TimedOps, comm, q_, k_, v_, out, lses, do_, layout=lay, causal=True, segment_ids=seg)
 
-    def null_ring():
+    def null_ring(schedule=None):
         """the same C driver with a transport that moves nothing (buffers left as allocated): what the step costs when
         every transfer is free"""
         from lwm_amd import _capi
         from lwm_amd.ring_c import CRing
         ok = lambda *a: 0
         t = _capi.LwmRingTransport(None, _capi.RING_GROUP_FN(ok), _capi.RING_SEND_FN(ok), _capi.RING_SEND_FN(ok), _capi.RING_GROUP_FN(ok))
-        return CRing(rank=rank, size=world, transport=t, layout=args.layout, schedule=sched_c)
+        return CRing(rank=rank, size=world, transport=t, layout=args.layout, schedule=schedule or sched_c)
 
     def barrier():
         torch.cuda.synchronize()
@@ -1185,7 +1191,7 @@ def main():
     elapsed = max_over_ranks(time.perf_counter() - t0)
     dog.disarm()
     sent_timed = (c_ring.bytes_sent - sent_before) if c_ring is not None else 0
-    exchange = configs2 = configs3 = configs4 = None
+    exchange = configs2 = configs3 = configs4 = transport_trials = None
 
     def main_line():
         """the line as far as it is known: the timed region is over when this is first called; the secondary
@@ -1218,6 +1224,7 @@ def main():
             },
             "tokens_per_s_per_gpu": tokens_per_s / world,
             "exchange": exchange,
+            "transport_trials": transport_trials,
             "configs2": configs2,
             "configs3": configs3,
             "configs4": configs4,
@@ -1441,6 +1448,71 @@ def main():
         configs3 = other_config("configs[3] sequence (262144 tokens; its VQGAN tokenisation is the `vqgan` leg of the N = 1 line)", 262144, 2, False)
         torch.cuda.empty_cache()
         configs4 = other_config("configs[4]", 1 << 20, 2, True)
+
+    if world > 1 and c_ring is not None and not args.no_transport_trials and not args.packed:
+        # LAST of the secondary legs (a hang here costs only this object: the late watchdog prints the line as it stands):
+        # the same few layers under EVERY (transport, schedule) pair the C driver has -- RCCL send/recv kernels or the CU-free
+        # IPC transport, the direct schedule or the neighbour ring -- against the same launches with a transport that moves
+        # nothing: four exposed_ms_per_step figures in one line, and which pair a real run should take.
+        try:
+            from lwm_amd.ring_c import CRing
+            lt = 4
+            gq = torch.Generator(device=dev).manual_seed(777 + rank)
+            tq = [torch.randn(1, c, N_HEADS, HEAD_DIM, generator=gq, device=dev, dtype=torch.float32).to(torch.bfloat16)
+                  for _ in range(4)]
+
+            def run_layers(ring):
+                step(ring, ten=tq, lay=layout, layers=1)
+                barrier()
+                t0_ = time.perf_counter()
+                step(ring, ten=tq, lay=layout, layers=lt)
+                barrier()
+                return max_over_ranks(time.perf_counter() - t0_) / lt
+
+            compute = {}
+            for sc in ("direct", "ring"):
+                nr = null_ring(sc)
+                compute[sc] = run_layers(nr)
+                nr.close()
+            pairs = {}
+            for tr in (("ipc",) if shared else ("rccl", "ipc")):
+                for sc in ("direct", "ring"):
+                    ok, why, ring, mine = 1, "", None, (tr, sc) == (args.transport, sched_c)
+                    try:
+                        CRing.probe(tr)
+                    except Exception as e:      # noqa: BLE001
+                        ok, why = 0, repr(e)[:300]
+                    if all_ranks_ok(ok):
+                        try:
+                            ring = c_ring if mine else CRing(dist.group.WORLD, transport=tr, layout=args.layout, schedule=sc,
+                                                             ipc_slot_bytes=c * N_HEADS * HEAD_DIM * 4, ipc_slots=8)
+                        except Exception as e:      # noqa: BLE001
+                            ok, why = 0, repr(e)[:300]
+                        if all_ranks_ok(ok):
+                            try:
+                                per_layer = run_layers(ring)
+                                pairs[f"{tr}/{sc}"] = {
+                                    "ms_per_layer": per_layer * 1e3, "compute_only_ms_per_layer": compute[sc] * 1e3,
+                                    "exposed_ms_per_step": (per_layer - compute[sc]) * 1e3 * args.layers,
+                                    "tokens_per_s": S / (per_layer * args.layers), "timed_the_value": mine}
+                            except Exception as e:      # noqa: BLE001
+                                pairs[f"{tr}/{sc}"] = {"error": repr(e)[:300]}
+                        else:
+                            pairs[f"{tr}/{sc}"] = {"error": why or "the set-up failed on another rank"}
+                        if ring is not None and not mine:
+                            ring.close()
+                    else:
+                        pairs[f"{tr}/{sc}"] = {"error": why or "the transport is not available on another rank"}
+            good = {k_: v_ for k_, v_ in pairs.items() if "tokens_per_s" in v_}
+            transport_trials = {"layers_timed": lt, "pairs": pairs,
+                                "fastest": max(good, key=lambda k_: good[k_]["tokens_per_s"]) if good else None,
+                                "value_was_timed_on": f"{args.transport}/{sched_c}",
+                                "reserved_cus": int(os.environ.get("LWM_RING_RESERVE_CUS", "0") or 0),
+                                "note": "a few layers per pair AFTER the timed region; rerun with --transport / --schedule set to "
+                                        "`fastest` when it differs from value_was_timed_on"}
+            del tq
+        except Exception as e:      # noqa: BLE001 -- a secondary leg must not cost the line
+            transport_trials = {"error": repr(e)[:500]}
 
     dog.disarm()
     if rank == 0:

@@ -58,6 +58,35 @@ def first_contact(what, seconds=None):
         t.cancel()
 
 
+def reserved_cu_stream(reserve, device=None):
+    """A HIP stream whose kernels may use all but `reserve` compute units (hipExtStreamCreateWithCUMask), as a
+    torch.cuda.ExternalStream: make it the current stream (torch.cuda.set_stream) and the attention launches -- grids of
+    whole-CU workgroups, 128-131 KiB of LDS each -- leave those CUs to whatever else wants them, e.g. RCCL's send/recv
+    kernels on the ring driver's side stream.  Whether the exchange is served faster from reserved CUs than from CUs that
+    free up between workgroups is a question for a multi-GPU run (bench.py: LWM_RING_RESERVE_CUS prices it in the N > 1
+    line); the mask's top `reserve` bits are cleared, which CUs those are is the driver's enumeration."""
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    n_cu = int(torch.cuda.get_device_properties(dev).multi_processor_count)
+    reserve = int(reserve)
+    if not 0 < reserve < n_cu:
+        raise ValueError(f"reserve must be in 1..{n_cu - 1}")
+    words = (n_cu + 31) // 32
+    mask = [0xFFFFFFFF] * words
+    if n_cu % 32:
+        mask[-1] = (1 << (n_cu % 32)) - 1
+    for cu in range(n_cu - reserve, n_cu):
+        mask[cu // 32] &= ~(1 << (cu % 32))
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipExtStreamCreateWithCUMask.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]
+    hip.hipExtStreamCreateWithCUMask.restype = C.c_int
+    st = C.c_void_p()
+    with torch.cuda.device(dev):
+        rc = hip.hipExtStreamCreateWithCUMask(C.byref(st), words, (C.c_uint32 * words)(*mask))
+    if rc != 0 or not st.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+    return torch.cuda.ExternalStream(st.value, device=dev)
+
+
 class CRing:
     """One ring object per (process group, device).  transport: None / "rccl" = RCCL (a communicator is created
     from an ncclUniqueId broadcast over `group`); "ipc" = the library's CU-free transport (peer mailboxes mapped through

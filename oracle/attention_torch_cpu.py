@@ -70,8 +70,16 @@ def blockwise_fwd_bwd(q, k, v, dout, *, q_chunk=1024, k_chunk=1024, causal=True)
 
 
 # ---- every host thread at once: heads are independent, so a many-core host runs them side by side (bench.py cpu_baseline)
-def _heads_worker(idx, S, heads, threads, barrier, out_q):
+def _heads_worker(idx, S, heads, threads, cpus, barrier, out_q):
+    import os
     import time
+    if cpus:
+        # this process's BLAS / OpenMP threads on ITS OWN logical CPUs: without the mask every process's pool lands on the
+        # same few cores (measured on a 128-thread host: 16 processes x 8 threads took 20x the time of one)
+        try:
+            os.sched_setaffinity(0, cpus)
+        except OSError:
+            pass
     torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(100 + idx)
     mk = lambda s: [torch.randn(1, s, 1, 128, generator=g) for _ in range(4)]
@@ -84,21 +92,47 @@ def _heads_worker(idx, S, heads, threads, barrier, out_q):
     out_q.put((idx, t0, time.time()))
 
 
-def heads_in_parallel(S, workers, heads_per_worker, threads_per_worker=8, timeout=900):
-    """`workers` processes x `threads_per_worker` BLAS threads, each running `heads_per_worker` passes of blockwise_fwd_bwd
-    (1 head, S tokens) after a common barrier.  -> (wall seconds from the first start to the last end, heads done)."""
+def heads_in_parallel(S, workers, heads_per_worker, threads_per_worker=8, timeout=600):
+    """`workers` processes x `threads_per_worker` BLAS threads -- each pinned to its own slice of the logical CPUs this
+    process may use -- each running `heads_per_worker` passes of blockwise_fwd_bwd (1 head, S tokens) after a common
+    barrier.  -> (wall seconds from the first start to the last end, heads done).  A worker that dies ends the call
+    with an error instead of a wait for `timeout`."""
     import multiprocessing as mp
+    import os
+    import queue
+    import time
     ctx = mp.get_context("spawn")
     barrier, out_q = ctx.Barrier(workers), ctx.Queue()
-    procs = [ctx.Process(target=_heads_worker, args=(i, S, heads_per_worker, threads_per_worker, barrier, out_q))
-             for i in range(workers)]
-    for p in procs:
-        p.start()
     try:
-        spans = [out_q.get(timeout=timeout) for _ in range(workers)]
-    finally:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = []
+    masks = [cpus[i * threads_per_worker:(i + 1) * threads_per_worker] if len(cpus) >= workers * threads_per_worker else []
+             for i in range(workers)]
+    keep = {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "GOMP_CPU_AFFINITY", "KMP_AFFINITY")}
+    os.environ["OMP_PROC_BIND"] = "false"            # (inherited by the workers: the mask above decides, not the runtime)
+    os.environ.pop("GOMP_CPU_AFFINITY", None)
+    os.environ.pop("KMP_AFFINITY", None)
+    procs = [ctx.Process(target=_heads_worker, args=(i, S, heads_per_worker, threads_per_worker, masks[i], barrier, out_q))
+             for i in range(workers)]
+    try:
         for p in procs:
-            p.join(timeout=30)
+            p.start()
+        spans, t_end = [], time.time() + timeout
+        while len(spans) < workers:
+            try:
+                spans.append(out_q.get(timeout=2.0))
+            except queue.Empty:
+                dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+                if dead:
+                    raise RuntimeError(f"a CPU-baseline worker ended with exit code {dead[0]}")
+                if time.time() > t_end:
+                    raise TimeoutError(f"CPU-baseline workers did not finish within {timeout} s")
+    finally:
+        for k, v in keep.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        for p in procs:
+            p.join(timeout=5)
             if p.is_alive():
                 p.kill()
     return max(e for _, _, e in spans) - min(s for _, s, _ in spans), workers * heads_per_worker

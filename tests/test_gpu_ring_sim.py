@@ -351,3 +351,32 @@ def test_sharded_cache_and_decode_on_gpu(n):
     ro, _ = R.dense_attention(q_dec.float().cpu().numpy(), ck.numpy(), cv.numpy(), causal=False, dense_mask=rmask)
     for r in res:
         _check("out sharded decode", r[3].numpy(), ro)
+
+
+def test_reserved_cu_stream_runs_the_attention_kernels_bit_for_bit():
+    """lwm_amd.ring_c.reserved_cu_stream (hipExtStreamCreateWithCUMask): the attention forward + backward on a stream that
+    leaves 16 CUs alone give the bits of the default stream (the knob bench.py prices as LWM_RING_RESERVE_CUS)."""
+    import torch
+    from lwm_amd.ring import ring_attention
+    from lwm_amd.ring_c import reserved_cu_stream
+    g = torch.Generator().manual_seed(5)
+    q, k, v, do = (torch.randn(1, 2048, 4, 128, generator=g).to(torch.bfloat16).cuda() for _ in range(4))
+
+    def run():
+        qd, kd, vd = (t.clone().requires_grad_(True) for t in (q, k, v))
+        out = ring_attention(qd, kd, vd, causal=True)
+        out.backward(do)
+        return out.detach(), qd.grad, kd.grad, vd.grad
+
+    ref = run()
+    torch.cuda.synchronize()
+    st = reserved_cu_stream(16)
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        got = run()
+    st.synchronize()
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    import pytest as _pytest
+    with _pytest.raises(ValueError):
+        reserved_cu_stream(0)
