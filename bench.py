@@ -391,7 +391,8 @@ def model_full_leg(torch, S=32768, layers=N_LAYERS, mlp_chunk=8192, scan_mlp=Fal
     n_params = sum(p.numel() for p in model.parameters())
     tok = torch.randint(0, cfg.vocab_size, (1, S + 1), device="cuda")
 
-    from lwm_amd.llama_ops import weights_changed
+    from lwm_amd.llama_ops import use_tuned_gemms, weights_changed
+    tuned = use_tuned_gemms()
 
     def step():
         model.zero_grad(set_to_none=True)
@@ -411,7 +412,7 @@ def model_full_leg(torch, S=32768, layers=N_LAYERS, mlp_chunk=8192, scan_mlp=Fal
     attn = 7.0 * gemm_unit_flops(S) * layers
     out = {"workload": f"LWM-7B, all {layers} layers + embedding + lm_head ({n_params / 1e9:.2f} B parameters), B=1, S={S}, "
                        f"bf16, forward+backward, one GPU, scan_mlp={scan_mlp}",
-           "scan_mlp": scan_mlp, "scan_mlp_chunk_size": mlp_chunk,
+           "scan_mlp": scan_mlp, "scan_mlp_chunk_size": mlp_chunk, "tuned_gemm_solutions": tuned,
            "ms_per_step": dt * 1e3, "tokens_per_s": S / dt, "loss": float(loss.detach()),
            "model_tflops": (dense + attn) / dt / 1e12, "attention_share_of_flops": attn / (dense + attn),
            "peak_hbm_gib": peak0 / 2 ** 30}

@@ -63,6 +63,9 @@ def main(argv=None):
     cfg = C.build_config(F, vision)
     dtype = C.torch_dtype(F.dtype)
     model = C.load_checkpoint(C.build_model(cfg, vision, dtype, F.seed, dev), F.load_checkpoint)
+    from ..llama_ops import use_tuned_gemms
+    if use_tuned_gemms():
+        C.note("library GEMMs: tuned solutions of lwm_amd/gemm_tuning_gfx950.csv where a shape is listed (LWM_GEMM_TUNING=0: off)")
     for g in ("eval_dataset", "checkpointer", "logger", "jax_distributed"):
         if F[g]:
             C.note(f"--{g}.* accepted, unused here: {sorted(F[g])}")

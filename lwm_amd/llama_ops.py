@@ -414,6 +414,33 @@ def weights_changed():
     _RELAYOUT_EPOCH[0] += 1
 
 
+def use_tuned_gemms(path=None):
+    """Hand hipBLASLt / rocBLAS the solution a tuning run picked for each GEMM of the LWM-7B step at S = 32768
+    (lwm_amd/gemm_tuning_gfx950.csv: PyTorch TunableOp results of scripts/gpu_tune_gemms.py over the call forms of this
+    module; +9 % on the wqkv and w2 weight gradients, level elsewhere -- profiles/r06_gemm_tuning_log.txt).  Tuning itself
+    stays OFF: shapes that are not in the file take the library's default, and a file of another ROCm / hipBLASLt version is
+    ignored by its validators.  Process-wide (TunableOp is a global switch), hence a call the entry points make
+    (bench.py's model legs, lwm_amd.cli.train), not an import side effect.  LWM_GEMM_TUNING=0 opts out.  -> bool."""
+    if _os.environ.get("LWM_GEMM_TUNING", "1") == "0" or not torch.cuda.is_available():
+        return False
+    path = path or _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "gemm_tuning_gfx950.csv")
+    if not _os.path.exists(path):
+        return False
+    try:
+        import shutil
+        import tempfile
+        import torch.cuda.tunable as T
+        # (TunableOp rewrites its file when the process ends: it gets a private copy, never the tracked one)
+        tmp = _os.path.join(tempfile.mkdtemp(prefix="lwm_gemm_tuning_"), "results.csv")
+        shutil.copyfile(path, tmp)
+        T.enable(True)
+        T.tuning_enable(False)
+        T.set_filename(tmp)
+        return bool(T.read_file(tmp))
+    except Exception:       # noqa: BLE001 -- an optimisation hint: the default solutions are always there
+        return False
+
+
 def transpose2d(src, out=None):
     """(R, C) bf16 with contiguous rows (any row stride) -> (C, R): lwm_transpose_bf16 for multiples of 64, else torch."""
     R, Cc = src.shape
