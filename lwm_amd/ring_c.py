@@ -116,6 +116,10 @@ class CRing:
         ring = cls(rank=rank, size=size, transport=_capi.LwmRingTransport(None, *fns), layout=layout, schedule=schedule,
                    device=device)
         ring._keep = fns
+        # what the kernels read as "received" K/V must toggle like real data: on all-zero or stale low-entropy memory the
+        # MFMA kernels draw less power and run up to 25 % faster (profiles/r04_backward.md section 3) -- a freshly allocated
+        # workspace flattered this model by 2-5 % (profiles/r06_null_transport_fill.txt): it is filled with N(0,1) bf16
+        ring._null = True
         return ring
 
     def __init__(self, group=None, *, rank=None, size=None, transport=None, device=None, layout="contiguous",
@@ -249,6 +253,9 @@ class CRing:
             if self._ws is not None:
                 self._parked.append(self._ws)
             self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+            if getattr(self, "_null", False):        # (CRing.null: nothing will ever be received into it)
+                n = self._ws.numel() // 2 * 2
+                self._ws[:n].view(torch.bfloat16).normal_()
         off = (-self._ws.data_ptr()) % 256
         return self._ws.data_ptr() + off
 
