@@ -58,62 +58,6 @@ LWM_KERNEL(256) void rope_kernel(RopeParams p) {
     }
 }
 
-// The same arithmetic for LONG sequences: one thread = one (b, s, 8-element column group); its (cos, sin) row is loaded
-// ONCE and applied to all H heads of the position (the per-head kernel above fetches 32 table bytes per 16 bytes of x and
-// pays three 64-bit divisions per thread: 5.0 TB/s at S = 32768).  The heads' rows of a position are x_sh elements apart;
-// a wave covers four positions.  Short calls (a decode step: a handful of positions) keep the per-head kernel -- there the
-// heads ARE the parallelism.
-LWM_KERNEL(256) void rope_rows_kernel(RopeParams p) {
-    const int vec = p.D >> 3;                         // threads per (b,s) position
-    const int64_t total = (int64_t)p.B * p.S * vec;
-    for (int64_t i = (int64_t)block_idx_x() * 256 + thread_idx(); i < total;
-         i += (int64_t)grid_dim_x() * 256) {
-        const int c = (int)(i % vec);
-        const int64_t r = i / vec;
-        const int s = (int)(r % p.S);
-        const int b = (int)(r / p.S);
-        int ps = p.pos[(int64_t)b * p.S + s];
-        ps = ps < 0 ? 0 : (ps >= p.max_pos ? p.max_pos - 1 : ps);
-        const float* t = p.table + ((int64_t)ps * (p.D >> 1) + c * 4) * 2;
-        const f32x4 t0 = global_load_f32x4(t), t1 = global_load_f32x4(t + 4);   // (c,s,c,s) x 2
-        float cs[4], sn[4];
-        for (int j = 0; j < 4; ++j) {
-            cs[j] = j < 2 ? t0[2 * j] : t1[2 * j - 4];
-            const float sj = j < 2 ? t0[2 * j + 1] : t1[2 * j - 3];
-            sn[j] = p.conj ? -sj : sj;
-        }
-        const bf16_t* xr = p.x + (int64_t)b * p.x_sb + (int64_t)s * p.x_ss + c * 8;
-        bf16_t* yr = p.y + (int64_t)b * p.y_sb + (int64_t)s * p.y_ss + c * 8;
-        int h = 0;
-        for (; h + 4 <= p.H; h += 4) {                // four independent loads in flight per thread
-            u32x4 raw[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) raw[u] = global_load_b128(xr + (int64_t)(h + u) * p.x_sh);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                u32x4 o;
-                for (int j = 0; j < 4; ++j) {
-                    const float x0 = __builtin_bit_cast(float, raw[u][j] << 16);
-                    const float x1 = __builtin_bit_cast(float, raw[u][j] & 0xffff0000u);
-                    // complex multiply as jnp does: re = x0*c - x1*s, im = x0*s + x1*c
-                    o[j] = pack_bf16x2(x0 * cs[j] - x1 * sn[j], x0 * sn[j] + x1 * cs[j]);
-                }
-                global_store_b128(yr + (int64_t)(h + u) * p.y_sh, o);
-            }
-        }
-        for (; h < p.H; ++h) {
-            const u32x4 raw = global_load_b128(xr + (int64_t)h * p.x_sh);
-            u32x4 o;
-            for (int j = 0; j < 4; ++j) {
-                const float x0 = __builtin_bit_cast(float, raw[j] << 16);
-                const float x1 = __builtin_bit_cast(float, raw[j] & 0xffff0000u);
-                o[j] = pack_bf16x2(x0 * cs[j] - x1 * sn[j], x0 * sn[j] + x1 * cs[j]);
-            }
-            global_store_b128(yr + (int64_t)h * p.y_sh, o);
-        }
-    }
-}
-
 // ---------------------------------------------------------------- RMSNorm
 // rows of C bf16 (C % 8 == 0, C <= 8192), one workgroup (256 threads) per row.
 struct RmsParams {

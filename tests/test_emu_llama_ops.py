@@ -216,26 +216,3 @@ def test_rmsnorm_bwd_with_the_residual_gradient_folded_in(rows, C):
     assert np.array_equal(from_bf16_bits(dw1), dw0)
     dwr = (g.astype(np.float64) * x.astype(np.float64) * rstd[:, None].astype(np.float64)).sum(0)
     assert np.abs(dw0 - dwr).max() <= 6e-3 * np.abs(dwr).max()          # (one bf16 rounding of the result)
-
-
-@pytest.mark.parametrize("H", [3, 5, 8])
-def test_rope_long_sequence_kernel_equals_the_per_head_kernel(H):
-    """lwm_rope_bf16 takes `rope_rows_kernel` from 4096 positions on (one thread walks the heads of a position with its table row
-    in registers) and `rope_kernel` below: the same arithmetic -- bit for bit, forward and conjugate, also in place."""
-    from oracle.attention_ref import to_bf16_bits
-    B, S, D, max_pos = 1, 4096, 128, 8192
-    x = _rnd((B, S, H, D), 31)
-    pos = np.random.default_rng(32).integers(0, max_pos, (B, S)).astype(np.int32)
-    tab = precompute_freqs_cis(D, max_pos, 1e7).numpy()
-    for conj in (False, True):
-        long_ = _emu.rope(x, tab, pos, conj=conj)                                   # 4096 positions: the rows kernel
-        short = np.concatenate([_emu.rope(x[:, a:a + 2048], tab, pos[:, a:a + 2048], conj=conj) for a in (0, 2048)], axis=1)
-        assert np.array_equal(to_bf16_bits(long_), to_bf16_bits(short))
-    # in place (y aliases x), as the fused QKV path runs it
-    L = _emu.lib()
-    xb = _emu.bf16_array(x)
-    tb = _emu.aligned(tab.shape, np.float32)
-    tb[...] = tab
-    t4 = _emu._t4(xb)
-    assert L.lwm_rope_bf16(t4, t4, tb.ctypes.data, pos.ctypes.data, B, S, H, D, max_pos, 0, None) == 0
-    assert np.array_equal(xb, to_bf16_bits(_emu.rope(x, tab, pos)))

@@ -297,28 +297,3 @@ def test_relayout_cache_follows_the_weights():
     wt1 = w._lwm_relayout[1]
     LO.weights_changed()
     assert LO._relayout((w,))[0] is not wt1
-
-
-def test_rope_long_sequence_kernel_equals_the_per_head_kernel_on_gpu():
-    """from 4096 positions on lwm_rope_bf16 runs `rope_rows_kernel` (table row held in registers across the heads); below it the
-    per-head kernel: same bits, on strided views (the q | k part of the fused projection buffer) and in place"""
-    import torch
-    from lwm_amd.llama_ops import _rope, precompute_freqs_cis
-    B, S, H, D = 1, 8192, 32, 128
-    buf = torch.randn(B, S, 3, H, D, device="cuda").to(torch.bfloat16)
-    qk = buf[:, :, 0:2].reshape(B, S, 2 * H, D)                       # strided view: rows 3 * H * D apart
-    assert qk.data_ptr() == buf.data_ptr()
-    tab = precompute_freqs_cis(D, 1 << 20, 5e7, device="cuda")
-    pos = torch.randint(0, 1 << 20, (B, S), device="cuda", dtype=torch.int32)
-    for conj in (0, 1):
-        long_ = _rope(qk, tab, pos, conj)
-        short = torch.cat([_rope(qk[:, a:a + 2048], tab, pos[:, a:a + 2048].contiguous(), conj) for a in range(0, S, 2048)], dim=1)
-        assert torch.equal(long_, short)
-    from lwm_amd import _capi
-    from lwm_amd._lib import lib
-    from lwm_amd.ops import _stream_ptr, _t4
-    want = _rope(qk, tab, pos, 0)
-    L = lib()
-    _capi.check(L, L.lwm_rope_bf16(_t4(qk, "qk"), _t4(qk, "qk"), tab.data_ptr(), pos.data_ptr(), B, S, 2 * H, D, tab.shape[0], 0,
-                                   _stream_ptr()), "lwm_rope_bf16")
-    assert torch.equal(qk, want)
