@@ -369,6 +369,17 @@ int lwm_swiglu_bwd_ld_bf16(const void* a, int64_t lda, const void* b, int64_t ld
 int lwm_transpose_bf16(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int64_t cols,
                        void* stream);
 
+/* The weight gradient of a flax Dense kernel (lwm/llama.py:390-421, :631-655: y = x @ W with W (in, out)):
+ * dw[K][N] = sum over s of x[s][K] * g[s][N], bf16 operands with the feature dimension contiguous (leading dimensions in
+ * elements), f32 accumulation in a fixed order, bf16 result.  S % 32 == 0, K % 256 == 0, N % 256 == 0.  Both operands are
+ * read where they lie (no transposed copies): LDS-DMA tiles, transposed MFMA fragments.  Tiles beyond the last whole round
+ * of one tile per CU are cut along S (stream-K) and summed from f32 partials in `workspace`
+ * (lwm_wgrad_workspace_bytes(S, K, N), 16-byte aligned; may be null when that is 0).
+ * FLOPs 2 S K N; HBM bytes 2 (S K + S N + K N) algorithmic. */
+int64_t lwm_wgrad_workspace_bytes(int64_t S, int64_t K, int64_t N);
+int lwm_wgrad_bf16(const void* x, int64_t ldx, const void* g, int64_t ldg, void* dw, int64_t lddw, int64_t S, int64_t K,
+                   int64_t N, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* y[r, :] = x[r, :] . W for rows <= 4 -- the projections of a cached-decode step (one token per batch row
  * against the [K, N] bf16 kernels wq/wk/wv/wo, w1/w2/w3, lm_head; x @ kernel as flax nn.Dense computes it,
  * lwm/llama.py:427-432, :659, :1075-1106).  HBM-bound: W is read once (2*K*N bytes), f32 accumulation in a fixed

@@ -145,6 +145,9 @@ PROTOTYPES = {
     "lwm_rmsnorm_bwd_res_bf16": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_void_p]),
     "lwm_swiglu_fwd_ld_bf16": (C.c_int, [C.c_void_p, C.c_int64] * 3 + [C.c_int64, C.c_int64, C.c_void_p]),
     "lwm_swiglu_bwd_ld_bf16": (C.c_int, [C.c_void_p, C.c_int64] * 5 + [C.c_int64, C.c_int64, C.c_void_p]),
+    "lwm_wgrad_workspace_bytes": (C.c_int64, [C.c_int64] * 3),
+    "lwm_wgrad_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int64] * 4 +
+                       [C.c_void_p, C.c_int64, C.c_void_p]),
     "lwm_transpose_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     "lwm_swiglu_fwd_bf16": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_void_p]),
     "lwm_swiglu_bwd_bf16": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_void_p]),

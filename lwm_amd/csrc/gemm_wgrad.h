@@ -1,0 +1,305 @@
+// gemm_wgrad.h -- the weight gradient of a flax Dense kernel (lwm/llama.py:390-421, :631-655: y = x @ W, W (in, out)):
+//
+//     dW[K][N] = sum_s x[s][K] * g[s][N]          x, g bf16 with the FEATURE dimension contiguous, f32 accumulation
+//
+// -- the one GEMM of the LWM-7B step whose reduction dimension (S) is contiguous in NEITHER operand.  hipBLASLt runs it at
+// 0.90-1.05 PF/s in this layout (1.1-1.2 once the narrow operand is transposed first, profiles/r06_model_full.md); here
+// both operands stay where they are: their tiles arrive in LDS by LDS-DMA in the natural layout and BOTH MFMA operands are
+// read as TRANSPOSED fragments (ds_read_b64_tr_b16) -- the read the dK/dV attention kernel uses for Q^T and dO^T
+// (attn_common.h: frag_tr_addr; the k order inside a fragment is the C/D row order, the same permutation on both operands).
+// Requires wave_ops.h, attn_common.h (tile geometry: 128-column tiles, XOR swizzle), attn_fwd64.h (f4_dma1, f4_mfma_o),
+// attn_bwd64.h (d4_settle_acc4).
+//
+// Workgroup = 8 waves (two per SIMD) = a 256 x 256 tile of dW; wave (wm, wn) owns 64 x 128 of it: 2 x 4 accumulator tuples
+// (128 AGPRs).  A stage = 32 rows of S: [x cols 0..127 | x cols 128..255 | g cols 0..127 | g cols 128..255], 8 KiB each;
+// FOUR stages are in LDS (128 KiB) and the one barrier of a stage stands in its MIDDLE:
+//
+//     step 0 of stage i   8 MFMAs; the fragments of step 1 are requested behind them
+//     middle              wait for this wave's pieces of stage i + 1 (those of stage i + 2 stay in flight), barrier
+//     step 1 of stage i   8 MFMAs; the first fragments of stage i + 1 are requested behind them, and the wave's four
+//                         pieces of stage i + 3, one per second MFMA gap, into the slot stage i - 1 used (every wave has
+//                         left stage i - 1; four requests back to back hold an in-order wave for 250-700 cycles)
+//
+// so no wave ever meets the barrier with an empty matrix pipe behind it, and a piece has 1.5 stages (>= 1500 cycles) to
+// land.  Skeleton timings on wqkv (profiles/r06_wgrad.md): 2.78 ms as is; without the waits 2.73, without the barrier 2.69,
+// without the fragment reads 2.38, without the requests 2.27, MFMAs alone 1.87 (1.76 PF/s: the clock under this load).
+//
+// Work split: tiles are numbered in bands of 8 tile columns, row-major inside a band, so that the 32 workgroups an XCD runs
+// at a time form a 4 x 8 block of tiles (12 operand streams for 32 tiles share that XCD's L2).  The first
+// floor(tiles / CUs) * CUs tiles take one workgroup each; the REST (a last, partly filled round: 5.4 rounds for w1|w3, 2.7
+// for w2 at 256 CUs) is cut along S into equal stage ranges, one per CU (stream-K): a workgroup whose range is not a whole
+// tile leaves its f32 partial in the workspace and wgrad_fixup_kernel adds the partials of a tile in a fixed order
+// (deterministic; 66 MB of traffic for w1|w3).
+#pragma once
+
+namespace lwm {
+
+constexpr int kWgBM = 256, kWgBN = 256, kWgBK = 32;
+constexpr int kWgThreads = 512;
+constexpr int kWgSubBytes = kWgBK * kRowBytes;       // 8 KiB: a [32 s][128 columns] tile
+constexpr int kWgSlotBytes = 4 * kWgSubBytes;        // x lo | x hi | g lo | g hi
+constexpr int kWgSlots = 4;
+constexpr int kWgLdsBytes = kWgSlots * kWgSlotBytes; // 128 KiB
+constexpr int kWgTileFloats = kWgBM * kWgBN;         // one f32 partial
+
+struct WgradParams {
+    const bf16_t* x;
+    const bf16_t* g;
+    bf16_t* dw;
+    float* ws;                  // stream-K partials: [2 * sk_blocks][256 * 256] f32 (null when sk_blocks == 0)
+    int64_t ldx, ldg, lddw;     // elements
+    int32_t S, K, N;
+    int32_t tiles_m, tiles_n;   // K / 256, N / 256
+    int32_t nst;                // stages per tile = S / 32
+    int32_t direct_tiles;       // tiles [0, direct_tiles): one workgroup each (blocks [0, direct_tiles))
+    int32_t sk_blocks;          // blocks [direct_tiles, direct_tiles + sk_blocks): stream-K over the remaining tiles
+    int32_t sk_q;               // stages per stream-K block
+};
+
+// tile number -> tile coordinates: bands of 8 tile columns (the last one narrower), row-major inside a band
+LWM_DEVICE void wg_tile_coords(const WgradParams& p, int t, int& tm, int& tn) {
+    const int band_tiles = p.tiles_m * 8;
+    const int band = t / band_tiles, r = t - band * band_tiles;
+    const int rest = p.tiles_n - 8 * band;
+    const int w = rest < 8 ? rest : 8;
+    tm = r / w;
+    tn = 8 * band + r % w;
+}
+
+// where thread `tid` keeps element (a, b, r) of its accumulators in an f32 partial: float4 granules, consecutive threads
+// consecutive granules (1 KiB per wave instruction)
+LWM_DEVICE int wg_partial_index(int tid, int a, int b, int r4) { return ((((a * 4 + b) * 4 + r4) * kWgThreads) + tid) * 4; }
+
+// the (a, b, r) element's place in the tile: row 64 wm + 32 a + cd_row(r, hi), column 128 wn + 32 b + l31.  A lane holds ONE
+// column of each 32 x 32 block: stored from registers that is 2 bytes per lane and row (288 MB written for a 100 MB wqkv
+// gradient, PMC WRITE_SIZE), so the wave's 64 x 128 part goes through its own 16 KiB of LDS (row-major, free once every
+// wave has left the loop) and out as 16 bytes per lane: 4 rows x 256 B per instruction.
+LWM_DEVICE void wg_store_tile(const WgradParams& p, lds_t lds, int tid, int tm, int tn, const f32x16 (&acc)[2][4]) {
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const lds_t mine = lds + (uint32_t)wave * (64 * 256);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                lds_write_bf16(mine + (uint32_t)((32 * a + cd_row(r, hi)) * 256 + (32 * b + l31) * 2), (bf16_t)acc[a][b][r]);
+    wave_lds_fence();
+    bf16_t* out = p.dw + ((int64_t)tm * kWgBM + 64 * wm) * p.lddw + (int64_t)tn * kWgBN + 128 * wn;
+    const bool wide = ((p.lddw & 7) == 0) && (((uintptr_t)p.dw & 15) == 0);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int row = 4 * q + (lane >> 4), c8 = (lane & 15) * 8;
+        const u32x4 v = lds_read_u32x4(mine + (uint32_t)(row * 256 + c8 * 2));
+        bf16_t* dst = out + (int64_t)row * p.lddw + c8;
+        if (wide) {
+            global_store_b128(dst, v);
+        } else {
+            union { u32x4 v; bf16_t h[8]; } u;
+            u.v = v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dst[e] = u.h[e];
+        }
+    }
+}
+
+// stages [s0, s1) of tile (tm, tn); `partial` null: the bf16 tile is written, else the f32 partial
+LWM_DEVICE void wg_segment(const WgradParams& p, lds_t lds, int tid, int tm, int tn, int s0, int s1, float* partial) {
+    const int wave = wave_uniform(tid >> 6), lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t m0 = (int64_t)tm * kWgBM, n0 = (int64_t)tn * kWgBN;
+
+    // ---- LDS-DMA: 32 pieces of 1 KiB (4 rows x 256 B) per stage, wave w moves piece w of each of the four sub-tiles; lane l
+    // writes physical slot l & 15 of row 4 w + (l >> 4) and therefore fetches logical slot (l & 15) ^ swz(row)
+    uint32_t voff[4];
+    {
+        const int row = 4 * wave + (lane >> 4);
+        const int c16 = ((lane & 15) ^ swz(row)) << 3;
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            const int64_t ld = sub < 2 ? p.ldx : p.ldg;
+            voff[sub] = (uint32_t)(((int64_t)row * ld + ((sub & 1) << 7) + c16) * 2);
+        }
+    }
+    const int64_t xstep = (int64_t)kWgBK * p.ldx * 2, gstep = (int64_t)kWgBK * p.ldg * 2;
+    const char* xsrc = (const char*)(p.x + m0) + (int64_t)s0 * xstep;
+    const char* gsrc = (const char*)(p.g + n0) + (int64_t)s0 * gstep;
+    // piece `sub` (x lo, x hi, g lo, g hi) of local stage i -> slot i & 3
+    auto piece = [&](int sub, int i) {
+        const lds_t dst = lds + (uint32_t)(i & 3) * kWgSlotBytes + (uint32_t)wave * 1024 + (uint32_t)sub * kWgSubBytes;
+        f4_dma1(voff[sub], (sub < 2 ? xsrc + (int64_t)i * xstep : gsrc + (int64_t)i * gstep), dst);
+    };
+    auto issue = [&](int i) {
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) piece(sub, i);
+    };
+    // ---- fragment addresses (relative to a slot): x sub-tile (wm >> 1), column blocks 2 (wm & 1) + {0, 1}; g sub-tile wn,
+    // blocks 0..3 (frag_tr_addr's arithmetic written out: no register array is indexed by a run-time value)
+    uint32_t xlo[2], xup[2], glo[4], gup[4];
+    {
+        const int gq = lane >> 4, i15 = lane & 15, h2 = gq >> 1;
+        const int row = 4 * h2 + (i15 >> 2);
+        const lds_t xb = lds + (uint32_t)(wm >> 1) * kWgSubBytes, gb = lds + (uint32_t)(2 + wn) * kWgSubBytes;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int dcol = 32 * (2 * (wm & 1) + a) + 16 * (gq & 1) + 4 * (i15 & 3);
+            xlo[a] = xb + tile_off(row, dcol >> 3) + (dcol & 7) * 2;
+            xup[a] = xb + tile_off(row + 8, dcol >> 3) + (dcol & 7) * 2;
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int dcol = 32 * b + 16 * (gq & 1) + 4 * (i15 & 3);
+            glo[b] = gb + tile_off(row, dcol >> 3) + (dcol & 7) * 2;
+            gup[b] = gb + tile_off(row + 8, dcol >> 3) + (dcol & 7) * 2;
+        }
+    }
+    auto frag = [&](uint32_t lo_a, uint32_t up_a, uint32_t off) {
+        const bf16x4 lo = lds_read_tr16(lo_a + off), up = lds_read_tr16(up_a + off);
+        bf16x8 o;
+        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+        o[4] = up[0]; o[5] = up[1]; o[6] = up[2]; o[7] = up[3];
+        return o;
+    };
+    // fragment f of a 16-row step: 0, 1 = x blocks, 2..5 = g blocks
+    auto req = [&](int f, uint32_t off) { return f < 2 ? frag(xlo[f], xup[f], off) : frag(glo[f - 2], gup[f - 2], off); };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = zero_f32x16();
+    d4_settle_acc4(acc[0]);       // (compiler-written zeros: two wait states before an asm MFMA reads them)
+    d4_settle_acc4(acc[1]);
+
+    const int n = s1 - s0;
+    block_sync_lds();             // (a second segment: every wave has left the slots of the first)
+    issue(0);
+    if (n > 1) issue(1);
+    if (n > 2) issue(2);
+    if (n > 2) wait_vmem_le<8>();
+    else if (n > 1) wait_vmem_le<4>();
+    else wait_vmem_le<0>();
+    block_sync_lds();
+
+    // MFMA m of a step (0..7) = (g block m >> 1, x block m & 1); fr[set][f]: the step's six fragments, requested one per gap
+    // behind the first six MFMAs of the step before (program order is kept: the MFMAs are asm statements, sched_fence() pins
+    // what stands between them)
+    bf16x8 fr[2][6];
+#pragma unroll
+    for (int f = 0; f < 6; ++f) fr[0][f] = req(f, 0);
+    for (int i = 0; i < n; ++i) {
+        const uint32_t cur = (uint32_t)(i & 3) * kWgSlotBytes;
+        const uint32_t nxt = (uint32_t)((i + 1) & 3) * kWgSlotBytes;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            sched_fence();
+            f4_mfma_o(acc[m & 1][m >> 1], fr[0][m & 1], fr[0][2 + (m >> 1)]);
+            if (m < 6) fr[1][m] = req(m, cur + (uint32_t)(16 * kRowBytes));
+            sched_fence();
+        }
+        // (the last stage keeps the shape of the others: its barrier is one too many and the fragments it requests from the
+        // next slot are never used -- a branch around them would put the accumulators through a control-flow join, and hipcc
+        // then moves them between register files inside the loop)
+        if (i + 2 < n) wait_vmem_le<4>();
+        else wait_vmem_le<0>();
+        block_sync_lds();
+
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            sched_fence();
+            f4_mfma_o(acc[m & 1][m >> 1], fr[1][m & 1], fr[1][2 + (m >> 1)]);
+            if (m < 6) fr[0][m] = req(m, nxt);
+            if ((m & 1) && i + 3 < n) piece(m >> 1, i + 3);
+            sched_fence();
+        }
+    }
+    d4_settle_acc4(acc[0]);
+    d4_settle_acc4(acc[1]);
+
+    if (!partial) {
+        block_sync_lds();         // every wave has left the slots
+        wg_store_tile(p, lds, tid, tm, tn, acc);
+    } else {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    f32x4 v;
+                    v[0] = acc[a][b][4 * r4]; v[1] = acc[a][b][4 * r4 + 1]; v[2] = acc[a][b][4 * r4 + 2]; v[3] = acc[a][b][4 * r4 + 3];
+                    global_store_f32x4(partial + wg_partial_index(tid, a, b, r4), v);
+                }
+    }
+}
+
+LWM_KERNEL(kWgThreads) void wgrad_bf16_kernel(WgradParams p) {
+    const lds_t lds = dyn_lds();
+    const int tid = thread_idx();
+    const int lin = block_idx_x();
+    // this block's stages [a, b) of the tiles [base, ...) laid end to end -- a whole tile for the first direct_tiles blocks,
+    // stages [w q, (w + 1) q) of the remaining tiles for stream-K block w (q <= nst: at most two tiles)
+    int base, w = 0;
+    int64_t a, b;
+    if (lin < p.direct_tiles) {
+        // XCD x runs blocks x, x + 8, ...: 32 consecutive ones of an XCD take 32 consecutive tiles (a 4 x 8 block)
+        base = lin;
+        if ((p.direct_tiles & 255) == 0) {
+            const int xcd = lin & 7, i = lin >> 3;
+            base = (((i >> 5) * 8 + xcd) << 5) + (i & 31);
+        }
+        a = 0;
+        b = p.nst;
+    } else {
+        w = lin - p.direct_tiles;
+        base = p.direct_tiles;
+        const int64_t total = (int64_t)(p.tiles_m * p.tiles_n - p.direct_tiles) * p.nst;
+        a = (int64_t)w * p.sk_q;
+        b = a + p.sk_q;
+        if (b > total) b = total;
+    }
+    for (int seg = 0; seg < 2 && a < b; ++seg) {
+        const int j = (int)(a / p.nst), s0 = (int)(a - (int64_t)j * p.nst);
+        const int64_t tile_end = (int64_t)(j + 1) * p.nst;
+        const int64_t e = b < tile_end ? b : tile_end;
+        const int s1 = (int)(e - (int64_t)j * p.nst);
+        int tm, tn;
+        wg_tile_coords(p, base + j, tm, tn);
+        const bool whole = s0 == 0 && s1 == p.nst;
+        wg_segment(p, lds, tid, tm, tn, s0, s1, whole ? nullptr : p.ws + (int64_t)(2 * w + seg) * kWgTileFloats);
+        a = e;
+    }
+}
+
+// one workgroup per stream-K tile: the partials of the blocks that cut it, added in block order
+LWM_KERNEL(kWgThreads) void wgrad_fixup_kernel(WgradParams p) {
+    const int tid = thread_idx();
+    const int j = block_idx_x();
+    const int64_t t0 = (int64_t)j * p.nst, t1 = t0 + p.nst;
+    const int w_first = (int)(t0 / p.sk_q), w_last = (int)((t1 - 1) / p.sk_q);
+    if (w_first == w_last) return;      // no block boundary inside the tile: one block wrote it whole
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = zero_f32x16();
+    for (int w = w_first; w <= w_last; ++w) {
+        const int seg = ((int64_t)w * p.sk_q) / p.nst == j ? 0 : 1;      // the block's first tile, or its second
+        const float* part = p.ws + (int64_t)(2 * w + seg) * kWgTileFloats;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const f32x4 v = global_load_f32x4(part + wg_partial_index(tid, a, b, r4));
+                    acc[a][b][4 * r4] += v[0]; acc[a][b][4 * r4 + 1] += v[1]; acc[a][b][4 * r4 + 2] += v[2]; acc[a][b][4 * r4 + 3] += v[3];
+                }
+    }
+    int tm, tn;
+    wg_tile_coords(p, p.direct_tiles + j, tm, tn);
+    wg_store_tile(p, dyn_lds(), tid, tm, tn, acc);
+}
+
+}  // namespace lwm

@@ -209,7 +209,7 @@ class _ChunkedHeadLoss(torch.autograd.Function):
             acc += (correct.to(torch.float32) * wc).sum()
             if need:
                 dh[:, s0:s1] = (dl @ kb.t()).reshape(B, s1 - s0, Dm)
-                dk += (h.t() @ dl).to(torch.float32)
+                dk += wgrad(h, dl).to(torch.float32)
         ctx.save_for_backward(dh, dk)
         ctx.kdtype = kernel.dtype
         ctx.mark_non_differentiable(acc)
@@ -457,6 +457,40 @@ def transpose2d(src, out=None):
     return out
 
 
+_WGRAD_WS = {}
+
+
+def wgrad(x2, g2):
+    """dW (K, N) = x2^T g2 for x2 (M, K), g2 (M, N): the weight gradient of a flax Dense kernel (lwm/llama.py:390-421,
+    :631-655).  bf16 on the device with M % 32 == 0, K % 256 == 0, N % 256 == 0 -> lwm_wgrad_bf16 (hand-written: both
+    operands read where they lie, csrc/gemm_wgrad.h; 1.1-1.2 PF/s against the library's 0.9-1.05 in this layout and
+    1.1-1.17 behind a transposed copy of the narrow operand -- profiles/r06_wgrad.md); anything else -> the narrow operand
+    transposed by lwm_transpose_bf16 and a library GEMM.  LWM_WGRAD_HIP=0: the library form throughout."""
+    M, K = x2.shape
+    N = g2.shape[1]
+    if (_os.environ.get("LWM_WGRAD_HIP", "1") == "1" and x2.is_cuda and x2.dtype == torch.bfloat16 and g2.dtype == torch.bfloat16
+            and M % 32 == 0 and K % 256 == 0 and N % 256 == 0 and x2.stride(1) == 1 and g2.stride(1) == 1
+            and x2.stride(0) % 8 == 0 and g2.stride(0) % 8 == 0 and x2.data_ptr() % 16 == 0 and g2.data_ptr() % 16 == 0
+            and 64 * max(x2.stride(0), g2.stride(0)) < 2 ** 31):
+        L = lib()
+        dw = torch.empty(K, N, dtype=torch.bfloat16, device=x2.device)
+        nws = int(L.lwm_wgrad_workspace_bytes(M, K, N))
+        ws = None
+        if nws:
+            # one workspace per device and stream: launches on a stream are ordered, the partials of one call are consumed
+            # by its own second launch
+            key = (x2.device.index, _stream_ptr().value)
+            ws = _WGRAD_WS.get(key)
+            if ws is None or ws.numel() < nws:
+                ws = _WGRAD_WS[key] = torch.empty(nws, dtype=torch.uint8, device=x2.device)
+        _capi.check(L, L.lwm_wgrad_bf16(x2.data_ptr(), x2.stride(0), g2.data_ptr(), g2.stride(0), dw.data_ptr(), N, M, K, N,
+                                        ws.data_ptr() if ws is not None else None, nws, _stream_ptr()), "lwm_wgrad_bf16")
+        return dw
+    if K <= N:
+        return transpose2d(x2) @ g2                     # x transposed: S contiguous in the A operand
+    return x2.t() @ transpose2d(g2).t()                 # g transposed: S contiguous in the B operand
+
+
 def _relayout(kernels):
     """[(K, N_i)] flax kernels -> (wt (sum N_i, K) for the forward, wcat (K, sum N_i) for dgrad), kept on the first kernel
     while none of them changes (tensor versions + weights_changed())."""
@@ -499,11 +533,7 @@ def _dense_bwd(x2, kernels, g2, need_dx=True, need_dw=True):
     dx2 = g2 @ wcat.t() if need_dx else None
     if not need_dw:
         return dx2, None
-    K, Nt = wcat.shape
-    if K <= Nt:
-        dw = transpose2d(x2) @ g2                       # x transposed: S contiguous in the A operand
-    else:
-        dw = x2.t() @ transpose2d(g2).t()               # g transposed: S contiguous in the B operand
+    dw = wgrad(x2, g2)
     if len(kernels) == 1:
         return dx2, [dw]
     return dx2, list(dw.split([int(k.shape[1]) for k in kernels], dim=1))

@@ -18,7 +18,12 @@ inline int zero_device(void* p, size_t bytes, void* stream) {
     memset(p, 0, bytes);
     return 0;
 }
-inline long device_cu_count() { return 24; }   // a few "XCDs" worth of persistent workgroups
+// a few "XCDs" worth of persistent workgroups; LWM_EMU_CUS: a test of a split that depends on the device's size
+inline long device_cu_count() {
+    const char* e = getenv("LWM_EMU_CUS");
+    const long n = e ? atol(e) : 0;
+    return n > 0 ? n : 24;
+}
 
 template <class... KArgs, class... Args>
 inline int launch(const char* name, void (*kernel)(KArgs...), long grid, int threads,

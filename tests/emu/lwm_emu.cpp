@@ -16,6 +16,7 @@
 #include "misc_kernels.h"
 #include "llama_elem.h"
 #include "gemv.h"
+#include "gemm_wgrad.h"
 #include "api.inc"
 #include "vqgan_conv.h"
 #include "vqgan_misc.h"

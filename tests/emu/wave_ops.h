@@ -273,6 +273,7 @@ LWM_DEVICE void lds_write_b128(lds_t a, u32x4 v) { memcpy(emu::lds_ptr(a, 16, 16
 LWM_DEVICE void lds_write_b64(lds_t a, u32x2 v) { memcpy(emu::lds_ptr(a, 8, 8), &v, 8); }
 LWM_DEVICE void lds_write_f32x4(lds_t a, f32x4 v) { memcpy(emu::lds_ptr(a, 16, 16), &v, 16); }
 LWM_DEVICE void lds_write_i32(lds_t a, int32_t v) { memcpy(emu::lds_ptr(a, 4, 4), &v, 4); }
+LWM_DEVICE void lds_write_bf16(lds_t a, bf16_t v) { memcpy(emu::lds_ptr(a, 2, 2), &v, 2); }
 LWM_DEVICE void lds_write_f32(lds_t a, float v) { memcpy(emu::lds_ptr(a, 4, 4), &v, 4); }
 LWM_DEVICE float lds_read_f32(lds_t a) { float v; memcpy(&v, emu::lds_ptr(a, 4, 4), 4); return v; }
 LWM_DEVICE int32_t lds_read_i32(lds_t a) { int32_t v; memcpy(&v, emu::lds_ptr(a, 4, 4), 4); return v; }

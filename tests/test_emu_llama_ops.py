@@ -216,3 +216,62 @@ def test_rmsnorm_bwd_with_the_residual_gradient_folded_in(rows, C):
     assert np.array_equal(from_bf16_bits(dw1), dw0)
     dwr = (g.astype(np.float64) * x.astype(np.float64) * rstd[:, None].astype(np.float64)).sum(0)
     assert np.abs(dw0 - dwr).max() <= 6e-3 * np.abs(dwr).max()          # (one bf16 rounding of the result)
+
+
+# ---- round 6: the hand-written weight-gradient GEMM (lwm_amd/csrc/gemm_wgrad.h)
+def _wgrad_emu(x, g, K, N, S, pad_x=0, pad_g=0, pad_w=0):
+    from oracle.attention_ref import from_bf16_bits, to_bf16_bits
+    L = _emu.lib()
+    xb = _emu.aligned((S, K + pad_x), np.uint16)
+    gb = _emu.aligned((S, N + pad_g), np.uint16)
+    xb[...] = 0x7fc0
+    gb[...] = 0x7fc0                                                      # (padding columns must never be read into a sum)
+    xb[:, :K], gb[:, :N] = to_bf16_bits(x), to_bf16_bits(g)
+    dw = _emu.aligned((K, N + pad_w), np.uint16)
+    dw[...] = 0x7fc0
+    nbytes = L.lwm_wgrad_workspace_bytes(S, K, N)
+    ws = _emu.aligned((max(nbytes, 16) // 4,), np.float32)
+    ws[...] = np.nan                                                      # (a partial nobody wrote must not be summed)
+    rc = L.lwm_wgrad_bf16(xb.ctypes.data, K + pad_x, gb.ctypes.data, N + pad_g, dw.ctypes.data, N + pad_w, S, K, N,
+                          ws.ctypes.data if nbytes else None, nbytes, None)
+    assert rc == 0, _emu.last_error() if hasattr(_emu, "last_error") else rc
+    assert np.all(dw[:, N:] == 0x7fc0)
+    return from_bf16_bits(dw[:, :N]), nbytes
+
+
+@pytest.mark.parametrize("S,K,N,cus,pads", [
+    (160, 256, 256, 24, (0, 0, 0)),        # one tile cut into five one-stage ranges: five partials summed
+    (32, 256, 512, 24, (8, 16, 24)),       # a single stage per tile (prologue only), padded leading dimensions
+    (224, 1024, 2816, 24, (0, 0, 0)),      # 44 tiles on 24 "CUs": 24 whole, 20 stream-K with ranges that span two tiles; a ragged band
+    (96, 512, 3328, 24, (0, 8, 0)),        # 26 tiles: two left over, cut into 1-stage ranges
+    (64, 4096, 4096, 256, (0, 0, 0)),      # 256 tiles on 256 CUs: the XCD-blocked tile numbering, no stream-K
+])
+def test_wgrad_gemm(S, K, N, cus, pads, monkeypatch):
+    """dW = x^T g with f32 accumulation (the flax Dense kernel's gradient, lwm/llama.py:390-421): products of bf16 values are
+    exact in f32, so only the ORDER of the f32 sums differs from the oracle -- bound = bf16 rounding of the result plus f32
+    summation noise."""
+    monkeypatch.setenv("LWM_EMU_CUS", str(cus))
+    x, g = _rnd((S, K), 21), _rnd((S, N), 22)
+    got, nbytes = _wgrad_emu(x, g, K, N, S, *pads)
+    tiles = (K // 256) * (N // 256)
+    assert (nbytes > 0) == (tiles % cus != 0) and nbytes in (0, 2 * cus * 256 * 256 * 4)
+    ref = x.astype(np.float64).T @ g.astype(np.float64)
+    assert np.abs(got - ref).max() <= 2 ** -8 * np.abs(ref).max() + 1e-3
+    assert np.mean(got != round_bf16(ref.astype(np.float32))) < 2e-3      # (a rounding tie now and then)
+
+
+def test_wgrad_validation():
+    from lwm_amd import _capi
+    L = _emu.lib()
+    a = _emu.aligned((64, 256), np.uint16)
+    d = _emu.aligned((256, 256), np.uint16)
+    ws = _emu.aligned((2 * 24 * 65536,), np.float32)
+    args = lambda **kw: [kw.get("x", a.ctypes.data), kw.get("ldx", 256), a.ctypes.data, 256, d.ctypes.data, 256,
+                         kw.get("S", 64), kw.get("K", 256), kw.get("N", 256), kw.get("ws", ws.ctypes.data), kw.get("wsb", ws.nbytes), None]
+    assert L.lwm_wgrad_bf16(*args()) == 0
+    assert L.lwm_wgrad_bf16(*args(S=48)) == _capi.LWM_EUNSUPPORTED
+    assert L.lwm_wgrad_bf16(*args(K=128)) == _capi.LWM_EUNSUPPORTED
+    assert L.lwm_wgrad_bf16(*args(ldx=248)) == _capi.LWM_EINVAL
+    assert L.lwm_wgrad_bf16(*args(ws=None)) == _capi.LWM_EINVAL
+    assert L.lwm_wgrad_bf16(*args(wsb=1024)) == _capi.LWM_EINVAL
+    assert L.lwm_wgrad_workspace_bytes(64, 256, 100) == 0

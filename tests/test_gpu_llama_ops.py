@@ -297,3 +297,54 @@ def test_relayout_cache_follows_the_weights():
     wt1 = w._lwm_relayout[1]
     LO.weights_changed()
     assert LO._relayout((w,))[0] is not wt1
+
+
+# ---- round 6: the hand-written weight-gradient GEMM (csrc/gemm_wgrad.h) behind llama_ops.wgrad
+@pytest.mark.parametrize("M,K,N", [
+    (4096, 4096, 12288),      # wq|wk|wv: 768 tiles = 3 whole rounds on 256 CUs
+    (2048, 4096, 22016),      # w1|w3: 1376 tiles = 5 rounds + 96 stream-K tiles
+    (2048, 11008, 4096),      # w2: 2 rounds + 176 stream-K tiles, ranges that span two tiles
+    (4096, 256, 512),         # 2 tiles: stream-K alone, 128 stages over 256 blocks (empty blocks too)
+    (8192, 4096, 32000),      # lm_head chunk
+    (96, 512, 768),           # a ragged call: three stages
+])
+def test_wgrad_gemm_against_fp32(M, K, N):
+    """dW = x^T g (the flax Dense kernel's gradient, lwm/llama.py:390-421) with f32 accumulation: products of bf16 values are
+    exact in f32, so against an f32 torch GEMM of the same operands only the ORDER of the sums differs -- bound: the bf16
+    rounding of the result (2^-8 relative) plus f32 summation noise; and the kernel is deterministic."""
+    import torch
+    from lwm_amd import llama_ops as ops
+    gen = torch.Generator(device="cuda").manual_seed(M + K + N)
+    x = torch.randn(M, K, device="cuda", generator=gen).to(torch.bfloat16)
+    g = torch.randn(M, N, device="cuda", generator=gen).to(torch.bfloat16)
+    dw = ops.wgrad(x, g)
+    assert dw.shape == (K, N) and dw.dtype == torch.bfloat16
+    assert torch.equal(dw, ops.wgrad(x, g))
+    worst, big = 0.0, 0.0
+    for c0 in range(0, N, 4096):
+        ref = x.float().t() @ g[:, c0:c0 + 4096].float()
+        worst = max(worst, float((dw[:, c0:c0 + 4096].float() - ref).abs().max()))
+        big = max(big, float(ref.abs().max()))
+    assert worst <= 2 ** -8 * big + 1e-3 * M ** 0.5
+
+
+def test_wgrad_on_strided_views_and_the_library_fallback(monkeypatch):
+    """The operands the training path hands over are views: a column block of the fused (S, 3d) gradient buffer, rows with a
+    padded leading dimension.  Shapes the kernel does not take go to the library; both forms agree to bf16 rounding."""
+    import torch
+    from lwm_amd import llama_ops as ops
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    M, K, N = 1024, 512, 768
+    xb = torch.randn(M, K + 64, device="cuda", generator=gen).to(torch.bfloat16)
+    gb = torch.randn(M, 3 * N, device="cuda", generator=gen).to(torch.bfloat16)
+    x, g = xb[:, :K], gb[:, N:2 * N]
+    dw = ops.wgrad(x, g)
+    ref = x.float().t() @ g.float()
+    assert float((dw.float() - ref).abs().max()) <= 2 ** -8 * float(ref.abs().max()) + 0.05
+    monkeypatch.setenv("LWM_WGRAD_HIP", "0")
+    lib_form = ops.wgrad(x.contiguous(), g.contiguous())
+    assert float((dw.float() - lib_form.float()).abs().max()) <= 2 ** -7 * float(ref.abs().max())
+    monkeypatch.delenv("LWM_WGRAD_HIP")
+    odd = ops.wgrad(xb[:1000, :K], gb[:1000, :N])          # 1000 rows: not a multiple of 32 -> the library form
+    ref = xb[:1000, :K].float().t() @ gb[:1000, :N].float()
+    assert float((odd.float() - ref).abs().max()) <= 2 ** -7 * float(ref.abs().max())
