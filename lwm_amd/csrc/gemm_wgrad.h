@@ -34,8 +34,13 @@
 
 namespace lwm {
 
+#ifndef LWM_EMU
+// (the host build brings its own)
+LWM_DEVICE void lds_write_bf16(lds_t a, bf16_t v) { *LWM_LDS(bf16_t, a) = v; }
+#endif
+
 constexpr int kWgBM = 256, kWgBN = 256, kWgBK = 32;
-constexpr int kWgThreads = 512;
+constexpr int kWgThreads = 512;                     // (the 8-wave form; the 4-wave form runs 256)
 constexpr int kWgSubBytes = kWgBK * kRowBytes;       // 8 KiB: a [32 s][128 columns] tile
 constexpr int kWgSlotBytes = 4 * kWgSubBytes;        // x lo | x hi | g lo | g hi
 constexpr int kWgSlots = 4;
@@ -68,28 +73,31 @@ LWM_DEVICE void wg_tile_coords(const WgradParams& p, int t, int& tm, int& tn) {
 
 // where thread `tid` keeps element (a, b, r) of its accumulators in an f32 partial: float4 granules, consecutive threads
 // consecutive granules (1 KiB per wave instruction)
-LWM_DEVICE int wg_partial_index(int tid, int a, int b, int r4) { return ((((a * 4 + b) * 4 + r4) * kWgThreads) + tid) * 4; }
+template <int NW>
+LWM_DEVICE int wg_partial_index(int tid, int a, int b, int r4) { return ((((a * 4 + b) * 4 + r4) * (64 * NW)) + tid) * 4; }
 
 // the (a, b, r) element's place in the tile: row 64 wm + 32 a + cd_row(r, hi), column 128 wn + 32 b + l31.  A lane holds ONE
 // column of each 32 x 32 block: stored from registers that is 2 bytes per lane and row (288 MB written for a 100 MB wqkv
 // gradient, PMC WRITE_SIZE), so the wave's 64 x 128 part goes through its own 16 KiB of LDS (row-major, free once every
 // wave has left the loop) and out as 16 bytes per lane: 4 rows x 256 B per instruction.
-LWM_DEVICE void wg_store_tile(const WgradParams& p, lds_t lds, int tid, int tm, int tn, const f32x16 (&acc)[2][4]) {
+template <int NW>
+LWM_DEVICE void wg_store_tile(const WgradParams& p, lds_t lds, int tid, int tm, int tn, const f32x16 (&acc)[16 / NW][4]) {
+    constexpr int AM = 16 / NW, RM = 32 * AM;      // a wave's part: RM rows x 128 columns
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const lds_t mine = lds + (uint32_t)wave * (64 * 256);
+    const lds_t mine = lds + (uint32_t)wave * (RM * 256);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < AM; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 lds_write_bf16(mine + (uint32_t)((32 * a + cd_row(r, hi)) * 256 + (32 * b + l31) * 2), (bf16_t)acc[a][b][r]);
     wave_lds_fence();
-    bf16_t* out = p.dw + ((int64_t)tm * kWgBM + 64 * wm) * p.lddw + (int64_t)tn * kWgBN + 128 * wn;
+    bf16_t* out = p.dw + ((int64_t)tm * kWgBM + RM * wm) * p.lddw + (int64_t)tn * kWgBN + 128 * wn;
     const bool wide = ((p.lddw & 7) == 0) && (((uintptr_t)p.dw & 15) == 0);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < RM / 4; ++q) {
         const int row = 4 * q + (lane >> 4), c8 = (lane & 15) * 8;
         const u32x4 v = lds_read_u32x4(mine + (uint32_t)(row * 256 + c8 * 2));
         bf16_t* dst = out + (int64_t)row * p.lddw + c8;
@@ -105,13 +113,16 @@ LWM_DEVICE void wg_store_tile(const WgradParams& p, lds_t lds, int tid, int tm, 
 }
 
 // stages [s0, s1) of tile (tm, tn); `partial` null: the bf16 tile is written, else the f32 partial
+template <int NW>
 LWM_DEVICE void wg_segment(const WgradParams& p, lds_t lds, int tid, int tm, int tn, int s0, int s1, float* partial) {
+    constexpr int AM = 16 / NW, RM = 32 * AM, NF = AM + 4, NP = 32 / NW;      // x blocks, rows, fragments per step, pieces per stage
     const int wave = wave_uniform(tid >> 6), lane = tid & 63;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 1, wn = wave & 1;      // rows RM wm.., columns 128 wn..
     const int64_t m0 = (int64_t)tm * kWgBM, n0 = (int64_t)tn * kWgBN;
 
-    // ---- LDS-DMA: 32 pieces of 1 KiB (4 rows x 256 B) per stage, wave w moves piece w of each of the four sub-tiles; lane l
-    // writes physical slot l & 15 of row 4 w + (l >> 4) and therefore fetches logical slot (l & 15) ^ swz(row)
+    // ---- LDS-DMA: 32 pieces of 1 KiB (4 rows x 256 B) per stage, 8 per sub-tile; wave w moves pieces w (, w + NW) of each of the
+    // four sub-tiles; lane l writes physical slot l & 15 of row 4 w + (l >> 4) (+ 16: the same swizzle) and therefore fetches
+    // logical slot (l & 15) ^ swz(row)
     uint32_t voff[4];
     {
         const int row = 4 * wave + (lane >> 4);
@@ -125,25 +136,27 @@ LWM_DEVICE void wg_segment(const WgradParams& p, lds_t lds, int tid, int tm, int
     const int64_t xstep = (int64_t)kWgBK * p.ldx * 2, gstep = (int64_t)kWgBK * p.ldg * 2;
     const char* xsrc = (const char*)(p.x + m0) + (int64_t)s0 * xstep;
     const char* gsrc = (const char*)(p.g + n0) + (int64_t)s0 * gstep;
-    // piece `sub` (x lo, x hi, g lo, g hi) of local stage i -> slot i & 3
-    auto piece = [&](int sub, int i) {
-        const lds_t dst = lds + (uint32_t)(i & 3) * kWgSlotBytes + (uint32_t)wave * 1024 + (uint32_t)sub * kWgSubBytes;
-        f4_dma1(voff[sub], (sub < 2 ? xsrc + (int64_t)i * xstep : gsrc + (int64_t)i * gstep), dst);
+    // piece q of this wave (sub-tile q & 3: x lo, x hi, g lo, g hi; rows + 16 (q >> 2)) of local stage i -> slot i & 3
+    auto piece = [&](int q, int i) {
+        const int sub = q & 3, half = q >> 2;
+        const lds_t dst = lds + (uint32_t)(i & 3) * kWgSlotBytes + (uint32_t)wave * 1024 + (uint32_t)sub * kWgSubBytes + (uint32_t)half * 4096;
+        const char* src = sub < 2 ? xsrc + (int64_t)i * xstep + (int64_t)half * (xstep >> 1) : gsrc + (int64_t)i * gstep + (int64_t)half * (gstep >> 1);
+        f4_dma1(voff[sub], src, dst);
     };
     auto issue = [&](int i) {
 #pragma unroll
-        for (int sub = 0; sub < 4; ++sub) piece(sub, i);
+        for (int q = 0; q < NP; ++q) piece(q, i);
     };
-    // ---- fragment addresses (relative to a slot): x sub-tile (wm >> 1), column blocks 2 (wm & 1) + {0, 1}; g sub-tile wn,
-    // blocks 0..3 (frag_tr_addr's arithmetic written out: no register array is indexed by a run-time value)
-    uint32_t xlo[2], xup[2], glo[4], gup[4];
+    // ---- fragment addresses (relative to a slot): x sub-tile (RM wm) >> 7, column blocks ((RM wm) & 127) / 32 + a; g sub-tile
+    // wn, blocks 0..3 (frag_tr_addr's arithmetic written out: no register array is indexed by a run-time value)
+    uint32_t xlo[AM], xup[AM], glo[4], gup[4];
     {
         const int gq = lane >> 4, i15 = lane & 15, h2 = gq >> 1;
         const int row = 4 * h2 + (i15 >> 2);
-        const lds_t xb = lds + (uint32_t)(wm >> 1) * kWgSubBytes, gb = lds + (uint32_t)(2 + wn) * kWgSubBytes;
+        const lds_t xb = lds + (uint32_t)((RM * wm) >> 7) * kWgSubBytes, gb = lds + (uint32_t)(2 + wn) * kWgSubBytes;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int dcol = 32 * (2 * (wm & 1) + a) + 16 * (gq & 1) + 4 * (i15 & 3);
+        for (int a = 0; a < AM; ++a) {
+            const int dcol = 32 * ((((RM * wm) & 127) >> 5) + a) + 16 * (gq & 1) + 4 * (i15 & 3);
             xlo[a] = xb + tile_off(row, dcol >> 3) + (dcol & 7) * 2;
             xup[a] = xb + tile_off(row + 8, dcol >> 3) + (dcol & 7) * 2;
         }
@@ -161,80 +174,83 @@ LWM_DEVICE void wg_segment(const WgradParams& p, lds_t lds, int tid, int tm, int
         o[4] = up[0]; o[5] = up[1]; o[6] = up[2]; o[7] = up[3];
         return o;
     };
-    // fragment f of a 16-row step: 0, 1 = x blocks, 2..5 = g blocks
-    auto req = [&](int f, uint32_t off) { return f < 2 ? frag(xlo[f], xup[f], off) : frag(glo[f - 2], gup[f - 2], off); };
+    // fragment f of a 16-row step: 0..AM-1 = x blocks, AM..AM+3 = g blocks
+    auto req = [&](int f, uint32_t off) { return f < AM ? frag(xlo[f], xup[f], off) : frag(glo[f - AM], gup[f - AM], off); };
+    // the k-th request of a step, in the order the MFMAs need them: x0, g0, x1 .. x(AM-1), g1, g2, g3
+    auto nth = [](int k) { return k == 0 ? 0 : k == 1 ? AM : k <= AM ? k - 1 : k; };
 
-    f32x16 acc[2][4];
+    f32x16 acc[AM][4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < AM; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = zero_f32x16();
-    d4_settle_acc4(acc[0]);       // (compiler-written zeros: two wait states before an asm MFMA reads them)
-    d4_settle_acc4(acc[1]);
+#pragma unroll
+    for (int a = 0; a < AM; ++a) d4_settle_acc4(acc[a]);       // (compiler-written zeros: two wait states before an asm MFMA reads them)
 
     const int n = s1 - s0;
     block_sync_lds();             // (a second segment: every wave has left the slots of the first)
     issue(0);
     if (n > 1) issue(1);
     if (n > 2) issue(2);
-    if (n > 2) wait_vmem_le<8>();
-    else if (n > 1) wait_vmem_le<4>();
+    if (n > 2) wait_vmem_le<2 * NP>();
+    else if (n > 1) wait_vmem_le<NP>();
     else wait_vmem_le<0>();
     block_sync_lds();
 
-    // MFMA m of a step (0..7) = (g block m >> 1, x block m & 1); fr[set][f]: the step's six fragments, requested one per gap
-    // behind the first six MFMAs of the step before (program order is kept: the MFMAs are asm statements, sched_fence() pins
-    // what stands between them)
-    bf16x8 fr[2][6];
+    // MFMA m of a step (0..4 AM - 1) = (g block m / AM, x block m % AM); fr[set][f]: the step's fragments, requested one per
+    // gap behind the first NF MFMAs of the step before (program order is kept: the MFMAs are asm statements, sched_fence()
+    // pins what stands between them)
+    bf16x8 fr[2][NF];
 #pragma unroll
-    for (int f = 0; f < 6; ++f) fr[0][f] = req(f, 0);
+    for (int k = 0; k < NF; ++k) fr[0][nth(k)] = req(nth(k), 0);
     for (int i = 0; i < n; ++i) {
         const uint32_t cur = (uint32_t)(i & 3) * kWgSlotBytes;
         const uint32_t nxt = (uint32_t)((i + 1) & 3) * kWgSlotBytes;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
+        for (int m = 0; m < 4 * AM; ++m) {
             sched_fence();
-            f4_mfma_o(acc[m & 1][m >> 1], fr[0][m & 1], fr[0][2 + (m >> 1)]);
-            if (m < 6) fr[1][m] = req(m, cur + (uint32_t)(16 * kRowBytes));
+            f4_mfma_o(acc[m % AM][m / AM], fr[0][m % AM], fr[0][AM + m / AM]);
+            if (m < NF) fr[1][nth(m)] = req(nth(m), cur + (uint32_t)(16 * kRowBytes));
             sched_fence();
         }
         // (the last stage keeps the shape of the others: its barrier is one too many and the fragments it requests from the
         // next slot are never used -- a branch around them would put the accumulators through a control-flow join, and hipcc
         // then moves them between register files inside the loop)
-        if (i + 2 < n) wait_vmem_le<4>();
+        if (i + 2 < n) wait_vmem_le<NP>();
         else wait_vmem_le<0>();
         block_sync_lds();
 
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
+        for (int m = 0; m < 4 * AM; ++m) {
             sched_fence();
-            f4_mfma_o(acc[m & 1][m >> 1], fr[1][m & 1], fr[1][2 + (m >> 1)]);
-            if (m < 6) fr[0][m] = req(m, nxt);
+            f4_mfma_o(acc[m % AM][m / AM], fr[1][m % AM], fr[1][AM + m / AM]);
+            if (m < NF) fr[0][nth(m)] = req(nth(m), nxt);
             if ((m & 1) && i + 3 < n) piece(m >> 1, i + 3);
             sched_fence();
         }
     }
-    d4_settle_acc4(acc[0]);
-    d4_settle_acc4(acc[1]);
+#pragma unroll
+    for (int a = 0; a < AM; ++a) d4_settle_acc4(acc[a]);
 
     if (!partial) {
         block_sync_lds();         // every wave has left the slots
-        wg_store_tile(p, lds, tid, tm, tn, acc);
+        wg_store_tile<NW>(p, lds, tid, tm, tn, acc);
     } else {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < AM; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     f32x4 v;
                     v[0] = acc[a][b][4 * r4]; v[1] = acc[a][b][4 * r4 + 1]; v[2] = acc[a][b][4 * r4 + 2]; v[3] = acc[a][b][4 * r4 + 3];
-                    global_store_f32x4(partial + wg_partial_index(tid, a, b, r4), v);
+                    global_store_f32x4(partial + wg_partial_index<NW>(tid, a, b, r4), v);
                 }
     }
 }
 
-LWM_KERNEL(kWgThreads) void wgrad_bf16_kernel(WgradParams p) {
+template <int NW>
+LWM_KERNEL(64 * NW) void wgrad_bf16_kernel(WgradParams p) {
     const lds_t lds = dyn_lds();
     const int tid = thread_idx();
     const int lin = block_idx_x();
@@ -267,39 +283,41 @@ LWM_KERNEL(kWgThreads) void wgrad_bf16_kernel(WgradParams p) {
         int tm, tn;
         wg_tile_coords(p, base + j, tm, tn);
         const bool whole = s0 == 0 && s1 == p.nst;
-        wg_segment(p, lds, tid, tm, tn, s0, s1, whole ? nullptr : p.ws + (int64_t)(2 * w + seg) * kWgTileFloats);
+        wg_segment<NW>(p, lds, tid, tm, tn, s0, s1, whole ? nullptr : p.ws + (int64_t)(2 * w + seg) * kWgTileFloats);
         a = e;
     }
 }
 
 // one workgroup per stream-K tile: the partials of the blocks that cut it, added in block order
-LWM_KERNEL(kWgThreads) void wgrad_fixup_kernel(WgradParams p) {
+template <int NW>
+LWM_KERNEL(64 * NW) void wgrad_fixup_kernel(WgradParams p) {
+    constexpr int AM = 16 / NW;
     const int tid = thread_idx();
     const int j = block_idx_x();
     const int64_t t0 = (int64_t)j * p.nst, t1 = t0 + p.nst;
     const int w_first = (int)(t0 / p.sk_q), w_last = (int)((t1 - 1) / p.sk_q);
     if (w_first == w_last) return;      // no block boundary inside the tile: one block wrote it whole
-    f32x16 acc[2][4];
+    f32x16 acc[AM][4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < AM; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = zero_f32x16();
     for (int w = w_first; w <= w_last; ++w) {
         const int seg = ((int64_t)w * p.sk_q) / p.nst == j ? 0 : 1;      // the block's first tile, or its second
         const float* part = p.ws + (int64_t)(2 * w + seg) * kWgTileFloats;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < AM; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
-                    const f32x4 v = global_load_f32x4(part + wg_partial_index(tid, a, b, r4));
+                    const f32x4 v = global_load_f32x4(part + wg_partial_index<NW>(tid, a, b, r4));
                     acc[a][b][4 * r4] += v[0]; acc[a][b][4 * r4 + 1] += v[1]; acc[a][b][4 * r4 + 2] += v[2]; acc[a][b][4 * r4 + 3] += v[3];
                 }
     }
     int tm, tn;
     wg_tile_coords(p, p.direct_tiles + j, tm, tn);
-    wg_store_tile(p, dyn_lds(), tid, tm, tn, acc);
+    wg_store_tile<NW>(p, dyn_lds(), tid, tm, tn, acc);
 }
 
 }  // namespace lwm

@@ -102,7 +102,6 @@ LWM_DEVICE void lds_write_b128(lds_t a, u32x4 v) { *LWM_LDS(u32x4, a) = v; }
 LWM_DEVICE void lds_write_b64(lds_t a, u32x2 v) { *LWM_LDS(u32x2, a) = v; }
 LWM_DEVICE void lds_write_f32x4(lds_t a, f32x4 v) { *LWM_LDS(f32x4, a) = v; }
 LWM_DEVICE void lds_write_i32(lds_t a, int32_t v) { *LWM_LDS(int32_t, a) = v; }
-LWM_DEVICE void lds_write_bf16(lds_t a, bf16_t v) { *LWM_LDS(bf16_t, a) = v; }
 LWM_DEVICE void lds_write_f32(lds_t a, float v) { *LWM_LDS(float, a) = v; }
 LWM_DEVICE float lds_read_f32(lds_t a) { return *LWM_LDS(const float, a); }
 LWM_DEVICE int32_t lds_read_i32(lds_t a) { return *LWM_LDS(const int32_t, a); }
