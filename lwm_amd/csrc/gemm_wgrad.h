@@ -83,22 +83,26 @@ LWM_DEVICE int wg_partial_index(int tid, int a, int b, int r4) { return ((((a * 
 template <int NW>
 LWM_DEVICE void wg_store_tile(const WgradParams& p, lds_t lds, int tid, int tm, int tn, const f32x16 (&acc)[16 / NW][4]) {
     constexpr int AM = 16 / NW, RM = 32 * AM;      // a wave's part: RM rows x 128 columns
-    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    // (opaque: the addresses below are not loop invariants hipcc may compute before the main loop and spill)
+    const int wave = tid >> 6, lane = (int)opaque((uint32_t)(tid & 63)), l31 = lane & 31, hi = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const lds_t mine = lds + (uint32_t)wave * (RM * 256);
 #pragma unroll
     for (int a = 0; a < AM; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < 4; ++b) {
+            sched_fence();        // (one tuple at a time: hipcc otherwise copies every accumulator out first and spills)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 lds_write_bf16(mine + (uint32_t)((32 * a + cd_row(r, hi)) * 256 + (32 * b + l31) * 2), (bf16_t)acc[a][b][r]);
+        }
     wave_lds_fence();
     bf16_t* out = p.dw + ((int64_t)tm * kWgBM + RM * wm) * p.lddw + (int64_t)tn * kWgBN + 128 * wn;
     const bool wide = ((p.lddw & 7) == 0) && (((uintptr_t)p.dw & 15) == 0);
+    const int ln = lane;
 #pragma unroll
     for (int q = 0; q < RM / 4; ++q) {
-        const int row = 4 * q + (lane >> 4), c8 = (lane & 15) * 8;
+        const int row = 4 * q + (ln >> 4), c8 = (ln & 15) * 8;
         const u32x4 v = lds_read_u32x4(mine + (uint32_t)(row * 256 + c8 * 2));
         bf16_t* dst = out + (int64_t)row * p.lddw + c8;
         if (wide) {
@@ -136,17 +140,18 @@ LWM_DEVICE void wg_segment(const WgradParams& p, lds_t lds, int tid, int tm, int
     const int64_t xstep = (int64_t)kWgBK * p.ldx * 2, gstep = (int64_t)kWgBK * p.ldg * 2;
     const char* xsrc = (const char*)(p.x + m0) + (int64_t)s0 * xstep;
     const char* gsrc = (const char*)(p.g + n0) + (int64_t)s0 * gstep;
-    // piece q of this wave (sub-tile q & 3: x lo, x hi, g lo, g hi; rows + 16 (q >> 2)) of local stage i -> slot i & 3
-    auto piece = [&](int q, int i) {
+    // piece q of this wave (sub-tile q & 3: x lo, x hi, g lo, g hi; rows + 16 (q >> 2)) of local stage i -> slot `slot` & 3
+    auto piece = [&](int q, int i, int slot) {
         const int sub = q & 3, half = q >> 2;
-        const lds_t dst = lds + (uint32_t)(i & 3) * kWgSlotBytes + (uint32_t)wave * 1024 + (uint32_t)sub * kWgSubBytes + (uint32_t)half * 4096;
+        const lds_t dst = lds + (uint32_t)(slot & 3) * kWgSlotBytes + (uint32_t)wave * 1024 + (uint32_t)sub * kWgSubBytes + (uint32_t)half * 4096;
         const char* src = sub < 2 ? xsrc + (int64_t)i * xstep + (int64_t)half * (xstep >> 1) : gsrc + (int64_t)i * gstep + (int64_t)half * (gstep >> 1);
         f4_dma1(voff[sub], src, dst);
     };
-    auto issue = [&](int i) {
+    auto piece_set = [&](int i, int slot) {
 #pragma unroll
-        for (int q = 0; q < NP; ++q) piece(q, i);
+        for (int q = 0; q < NP; ++q) piece(q, i, slot);
     };
+    auto issue = [&](int i) { piece_set(i, i); };
     // ---- fragment addresses (relative to a slot): x sub-tile (RM wm) >> 7, column blocks ((RM wm) & 127) / 32 + a; g sub-tile
     // wn, blocks 0..3 (frag_tr_addr's arithmetic written out: no register array is indexed by a run-time value)
     uint32_t xlo[AM], xup[AM], glo[4], gup[4];
@@ -187,14 +192,14 @@ LWM_DEVICE void wg_segment(const WgradParams& p, lds_t lds, int tid, int tm, int
 #pragma unroll
     for (int a = 0; a < AM; ++a) d4_settle_acc4(acc[a]);       // (compiler-written zeros: two wait states before an asm MFMA reads them)
 
-    const int n = s1 - s0;
+    // Every stage requests its pieces whether or not a stage i + 3 exists (past the end: the last stage once more, into a
+    // slot nobody reads again): no branch stands in the MFMA stream and the counted wait is the same in every stage.
+    const int n = s1 - s0, last = n - 1;
     block_sync_lds();             // (a second segment: every wave has left the slots of the first)
     issue(0);
-    if (n > 1) issue(1);
-    if (n > 2) issue(2);
-    if (n > 2) wait_vmem_le<2 * NP>();
-    else if (n > 1) wait_vmem_le<NP>();
-    else wait_vmem_le<0>();
+    piece_set(1 < last ? 1 : last, 1);
+    piece_set(2 < last ? 2 : last, 2);
+    wait_vmem_le<2 * NP>();
     block_sync_lds();
 
     // MFMA m of a step (0..4 AM - 1) = (g block m / AM, x block m % AM); fr[set][f]: the step's fragments, requested one per
@@ -216,26 +221,28 @@ LWM_DEVICE void wg_segment(const WgradParams& p, lds_t lds, int tid, int tm, int
         // (the last stage keeps the shape of the others: its barrier is one too many and the fragments it requests from the
         // next slot are never used -- a branch around them would put the accumulators through a control-flow join, and hipcc
         // then moves them between register files inside the loop)
-        if (i + 2 < n) wait_vmem_le<NP>();
-        else wait_vmem_le<0>();
+        wait_vmem_le<NP>();
         block_sync_lds();
+        const int ahead = i + 3 < last ? i + 3 : last;
 
 #pragma unroll
         for (int m = 0; m < 4 * AM; ++m) {
             sched_fence();
             f4_mfma_o(acc[m % AM][m / AM], fr[1][m % AM], fr[1][AM + m / AM]);
             if (m < NF) fr[0][nth(m)] = req(nth(m), nxt);
-            if ((m & 1) && i + 3 < n) piece(m >> 1, i + 3);
+            if (m & 1) piece(m >> 1, ahead, i + 3);
             sched_fence();
         }
     }
 #pragma unroll
     for (int a = 0; a < AM; ++a) d4_settle_acc4(acc[a]);
 
+    wait_vmem_le<0>();            // (the requests past the end)
     if (!partial) {
-        block_sync_lds();         // every wave has left the slots
+        block_sync_lds();         // every wave has left the slots, every piece has landed
         wg_store_tile<NW>(p, lds, tid, tm, tn, acc);
     } else {
+        const int otid = (int)opaque((uint32_t)tid);
 #pragma unroll
         for (int a = 0; a < AM; ++a)
 #pragma unroll
@@ -244,7 +251,7 @@ LWM_DEVICE void wg_segment(const WgradParams& p, lds_t lds, int tid, int tm, int
                 for (int r4 = 0; r4 < 4; ++r4) {
                     f32x4 v;
                     v[0] = acc[a][b][4 * r4]; v[1] = acc[a][b][4 * r4 + 1]; v[2] = acc[a][b][4 * r4 + 2]; v[3] = acc[a][b][4 * r4 + 3];
-                    global_store_f32x4(partial + wg_partial_index<NW>(tid, a, b, r4), v);
+                    global_store_f32x4(partial + wg_partial_index<NW>(otid, a, b, r4), v);
                 }
     }
 }

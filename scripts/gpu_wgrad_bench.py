@@ -60,14 +60,15 @@ def main():
         line = f"{tag:5s} K={K:6d} N={N:6d}  hipBLASLt x.t()@g {t_lib:7.3f} ms {fl / t_lib / 1e9:7.1f} TF/s | narrow transpose + hipBLASLt {t_tr:7.3f} ms {fl / t_tr / 1e9:7.1f}"
         if ok:
             t_me = timed(mine)
-            err, big = 0.0, 0.0
-            for c0 in range(0, N, 4096):          # (f32 reference in column chunks: an (S, N) f32 copy of g would be 2.9 GB)
+            # element-wise: a correctly rounded bf16 result is within 2^-8 of the f32 sum (relative; elements near zero are
+            # measured against 1 % of the largest instead) -- the f32 reference in column chunks (an (S, N) f32 g is 2.9 GB)
+            big = max(float(torch.matmul(x.t().float(), g[:, c0:c0 + 4096].float()).abs().max()) for c0 in range(0, N, 4096))
+            err = 0.0
+            for c0 in range(0, N, 4096):
                 ref = torch.matmul(x.t().float(), g[:, c0:c0 + 4096].float())
-                err = max(err, float((dw[:, c0:c0 + 4096].float() - ref).abs().max()))
-                big = max(big, float(ref.abs().max()))
+                err = max(err, float(((dw[:, c0:c0 + 4096].float() - ref).abs() / ref.abs().clamp_min(0.01 * big)).max()))
                 del ref
-            err /= big
-            line += f" | lwm_wgrad_bf16 {t_me:7.3f} ms {fl / t_me / 1e9:7.1f} TF/s  max rel err {err:.2e}"
+            line += f" | lwm_wgrad_bf16 {t_me:7.3f} ms {fl / t_me / 1e9:7.1f} TF/s  max rel err {err:.2e} (half a bf16 ulp: <= 2^-8 = 3.91e-03)"
         else:
             line += " | lwm_wgrad_bf16: shape not a multiple of 256"
         print(line, flush=True)

@@ -310,8 +310,8 @@ def test_relayout_cache_follows_the_weights():
 ])
 def test_wgrad_gemm_against_fp32(M, K, N):
     """dW = x^T g (the flax Dense kernel's gradient, lwm/llama.py:390-421) with f32 accumulation: products of bf16 values are
-    exact in f32, so against an f32 torch GEMM of the same operands only the ORDER of the sums differs -- bound: the bf16
-    rounding of the result (2^-8 relative) plus f32 summation noise; and the kernel is deterministic."""
+    exact in f32, so against an f32 torch GEMM of the same operands only the ORDER of the sums differs -- bound, per element: the bf16
+    rounding of the result (half an ulp: 2^-8 relative at most) plus f32 summation noise; and the kernel is deterministic."""
     import torch
     from lwm_amd import llama_ops as ops
     gen = torch.Generator(device="cuda").manual_seed(M + K + N)
@@ -320,12 +320,11 @@ def test_wgrad_gemm_against_fp32(M, K, N):
     dw = ops.wgrad(x, g)
     assert dw.shape == (K, N) and dw.dtype == torch.bfloat16
     assert torch.equal(dw, ops.wgrad(x, g))
-    worst, big = 0.0, 0.0
+    big = max(float((x.float().t() @ g[:, c0:c0 + 4096].float()).abs().max()) for c0 in range(0, N, 4096))
     for c0 in range(0, N, 4096):
         ref = x.float().t() @ g[:, c0:c0 + 4096].float()
-        worst = max(worst, float((dw[:, c0:c0 + 4096].float() - ref).abs().max()))
-        big = max(big, float(ref.abs().max()))
-    assert worst <= 2 ** -8 * big + 1e-3 * M ** 0.5
+        rel = (dw[:, c0:c0 + 4096].float() - ref).abs() / ref.abs().clamp_min(0.01 * big)
+        assert float(rel.max()) <= 2 ** -8 * 1.05          # every element: the bf16 rounding of the f32 sum, nothing more
 
 
 def test_wgrad_on_strided_views_and_the_library_fallback(monkeypatch):
