@@ -441,6 +441,8 @@ def kernel_class(name):
         return "attention_hip"
     if name.startswith(("Cijk_", "Custom_Cijk_")):
         return "library_gemm"
+    if "lwm::wgrad_" in name:
+        return "wgrad_gemm_hip"          # the weight gradients: lwm_wgrad_bf16 (csrc/gemm_wgrad.h)
     if "lwm::" in name:
         return "elementwise_hip"
     return "torch_elementwise_copy"

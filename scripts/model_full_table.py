@@ -20,7 +20,7 @@ INIT = ("distribution_elementwise", "randint", "random_", "normal_")
 
 def short(n):
     n = n.split("(")[0]
-    n = n.replace("void at::native::", "at::").replace("lwm::", "")
+    n = n.replace("void at::native::", "at::").replace("void lwm::", "").replace("lwm::", "")
     if n.startswith(("Cijk", "Custom_Cijk")):
         m = re.search(r"(Cijk_A[a-z]+_B[a-z]+)", n)
         mt = re.search(r"MT(\d+x\d+x\d+)", n)
@@ -34,6 +34,8 @@ def klass(n):
         return "attention (hand-written HIP)"
     if n.startswith("gemm "):
         return "library GEMM (hipBLASLt)"
+    if n.startswith("wgrad_"):
+        return "weight-gradient GEMM (hand-written HIP)"
     if n.startswith("at::"):
         return "torch elementwise / copy"
     return "elementwise (hand-written HIP)"
