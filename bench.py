@@ -430,6 +430,16 @@ def model_full_leg(torch, S=32768, layers=N_LAYERS, mlp_chunk=8192, scan_mlp=Fal
     out["roofline"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": 2500.0, "achieved": out["model_tflops"],
                        "frac": out["model_tflops"] / 2500.0, "flops_per_step": dense + attn,
                        "time_shares": model_time_shares(torch, step)}
+    # the hand-written weight-gradient GEMM inside the step (lwm_wgrad_bf16: dW = x^T g for every Dense kernel, lm_head
+    # included): 2 S K N FLOPs per kernel over the kernel time the profiler saw for it in that extra step
+    dense_kernel_params = sum(p.numel() for n, p in model.named_parameters() if p.dim() == 2 and not n.endswith("wte"))
+    wg_ms = (out["roofline"]["time_shares"].get("kernel_ms") or {}).get("wgrad_gemm_hip")
+    out["wgrad_gemm"] = {"kernel": "lwm::wgrad_bf16_kernel (+ wgrad_fixup_kernel)", "flops_per_step": 2.0 * S * dense_kernel_params,
+                         "kernel_ms_per_step": wg_ms, "bound": "mfma", "peak": 2500.0, "unit": "TFLOP/s",
+                         "achieved": None if not wg_ms else 2.0 * S * dense_kernel_params / (wg_ms * 1e-3) / 1e12,
+                         "frac": None if not wg_ms else 2.0 * S * dense_kernel_params / (wg_ms * 1e-3) / 1e12 / 2500.0,
+                         "algorithmic_bytes_per_call": "2 (S K + S N + K N): MFMA-bound at every shape of the step",
+                         "enabled": os.environ.get("LWM_WGRAD_HIP", "1") == "1", "profile": "profiles/r06_wgrad.md"}
     del model
     torch.cuda.empty_cache()
     return out

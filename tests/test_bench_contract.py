@@ -87,6 +87,11 @@ def test_committed_bench_line_follows_the_contract():
         if "share" in mf["time_shares"]:
             assert abs(sum(mf["time_shares"]["share"].values()) - 1.0) < 1e-3
             assert {"attention_hip", "library_gemm"} <= set(mf["time_shares"]["share"])
+        wg = d["model_full"].get("wgrad_gemm")         # round 6, second half: the hand-written weight-gradient GEMM inside the step
+        if wg is not None and wg["kernel_ms_per_step"]:
+            assert wg["bound"] == "mfma" and abs(wg["achieved"] - wg["flops_per_step"] / (wg["kernel_ms_per_step"] * 1e-3) / 1e12) < 1e-6
+            assert abs(wg["frac"] - wg["achieved"] / 2500.0) < 1e-9 and wg["achieved"] < 2500.0
+            assert "wgrad_gemm_hip" in mf["time_shares"]["share"]
         ps = d["predicted_scaling"]
         assert ps["kind"] == "model, not measured" and set(ps["by_S"]) == {"32768", "131072"}
         for S_, rows in ps["by_S"].items():
