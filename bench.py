@@ -1148,7 +1148,11 @@ def main():
                 fail_line(args, "C ring driver, first layer", RuntimeError(why or "another rank failed"), {"transport": args.transport})
                 os._exit(5)
             driver_fallback = {"from": f"C driver ({args.transport}, {sched_c})", "to": "lwm_amd/ring.py over torch.distributed",
-                               "first_error_on_this_rank": why or None}
+                               "first_error_on_this_rank": why or None,
+                               "consequence": "the per-pair Python driver launches one kernel per segment pair instead of the C driver's "
+                                              "gathered form: 709 against 824-849 TF/s per GPU on the compute side of 8 ranks at "
+                                              "S = 32768 (ring8_compute_model_32k_per_pair / ring8_compute_model_32k in the N = 1 line, "
+                                              "profiles/r05_ring_shards.md) -- this line's value is NOT the product's default path"}
             if c_ring is not None:
                 c_ring.close()
             c_ring = None
