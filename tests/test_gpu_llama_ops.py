@@ -327,6 +327,19 @@ def test_wgrad_gemm_against_fp32(M, K, N):
         assert float(rel.max()) <= 2 ** -8 * 1.05          # every element: the bf16 rounding of the f32 sum, nothing more
 
 
+def test_wgrad_one_wave_per_simd_form_agrees(monkeypatch):
+    """LWM_WGRAD_WAVES=4 (128 x 128 per wave, one wave per SIMD; kept as a switch, profiles/r06_wgrad.md): the same sums in the
+    same order per element -- bit-identical to the default form, stream-K tail included."""
+    import torch
+    from lwm_amd import llama_ops as ops
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(2048, 4096, device="cuda", generator=gen).to(torch.bfloat16)
+    g = torch.randn(2048, 22016, device="cuda", generator=gen).to(torch.bfloat16)
+    base = ops.wgrad(x, g)
+    monkeypatch.setenv("LWM_WGRAD_WAVES", "4")
+    assert torch.equal(ops.wgrad(x, g), base)
+
+
 def test_wgrad_on_strided_views_and_the_library_fallback(monkeypatch):
     """The operands the training path hands over are views: a column block of the fused (S, 3d) gradient buffer, rows with a
     padded leading dimension.  Shapes the kernel does not take go to the library; both forms agree to bf16 rounding."""
