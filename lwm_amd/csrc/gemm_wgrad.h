@@ -10,8 +10,8 @@
 // Requires wave_ops.h, attn_common.h (tile geometry: 128-column tiles, XOR swizzle), attn_fwd64.h (f4_dma1, f4_mfma_o),
 // attn_bwd64.h (d4_settle_acc4).
 //
-// Workgroup = 8 waves (two per SIMD) = a 256 x 256 tile of dW; wave (wm, wn) owns 64 x 128 of it: 2 x 4 accumulator tuples
-// (128 AGPRs).  A stage = 32 rows of S: [x cols 0..127 | x cols 128..255 | g cols 0..127 | g cols 128..255], 8 KiB each;
+// Workgroup = 8 waves (two per SIMD, NW = 8) = a 256 x 256 tile of dW; wave (wm, wn) owns 64 x 128 of it: 2 x 4 accumulator
+// tuples (128 AGPRs).  A stage = 32 rows of S: [x cols 0..127 | x cols 128..255 | g cols 0..127 | g cols 128..255], 8 KiB each;
 // FOUR stages are in LDS (128 KiB) and the one barrier of a stage stands in its MIDDLE:
 //
 //     step 0 of stage i   8 MFMAs; the fragments of step 1 are requested behind them
@@ -21,8 +21,14 @@
 //                         left stage i - 1; four requests back to back hold an in-order wave for 250-700 cycles)
 //
 // so no wave ever meets the barrier with an empty matrix pipe behind it, and a piece has 1.5 stages (>= 1500 cycles) to
-// land.  Skeleton timings on wqkv (profiles/r06_wgrad.md): 2.78 ms as is; without the waits 2.73, without the barrier 2.69,
-// without the fragment reads 2.38, without the requests 2.27, MFMAs alone 1.87 (1.76 PF/s: the clock under this load).
+// land.  The request stream has no branch: past the end of its range a stage re-requests the LAST stage into a slot nobody
+// reads again, so every stage issues the same instructions and waits on the same count (a uniform branch around each
+// request and wait cost 5 %).  The same body serves one wave per SIMD (NW = 4: 128 x 128 per wave, 256 AGPRs, a third
+// fewer fragment reads per MFMA -- 3 % behind: every stall of the only wave is the matrix pipe's; LWM_WGRAD_WAVES=4).
+// Measured (profiles/r06_wgrad.md): 1.22-1.37 PF/s on the step's four shapes against 0.91-1.21 for the library on the same
+// box, mfma_util 0.84, no LDS bank conflicts.  Skeletons of an earlier version on wqkv: 2.78 ms as it was; without the
+// waits 2.73, without the barrier 2.69, without the fragment reads 2.38, without the requests 2.27, MFMAs alone 1.87
+// (1.76 PF/s: what the clock allows under this load).
 //
 // Work split: tiles are numbered in bands of 8 tile columns, row-major inside a band, so that the 32 workgroups an XCD runs
 // at a time form a 4 x 8 block of tiles (12 operand streams for 32 tiles share that XCD's L2).  The first
