@@ -246,11 +246,13 @@ def _wgrad_emu(x, g, K, N, S, pad_x=0, pad_g=0, pad_w=0):
     (96, 512, 3328, 24, (0, 8, 0)),        # 26 tiles: two left over, cut into 1-stage ranges
     (64, 4096, 4096, 256, (0, 0, 0)),      # 256 tiles on 256 CUs: the XCD-blocked tile numbering, no stream-K
 ])
-def test_wgrad_gemm(S, K, N, cus, pads, monkeypatch):
+@pytest.mark.parametrize("waves", [8, 4])
+def test_wgrad_gemm(S, K, N, cus, pads, waves, monkeypatch):
     """dW = x^T g with f32 accumulation (the flax Dense kernel's gradient, lwm/llama.py:390-421): products of bf16 values are
     exact in f32, so only the ORDER of the f32 sums differs from the oracle -- bound = bf16 rounding of the result plus f32
     summation noise."""
     monkeypatch.setenv("LWM_EMU_CUS", str(cus))
+    monkeypatch.setenv("LWM_WGRAD_WAVES", str(waves))          # 8: two waves per SIMD (default); 4: one wave per SIMD, 128 x 128 each
     x, g = _rnd((S, K), 21), _rnd((S, N), 22)
     got, nbytes = _wgrad_emu(x, g, K, N, S, *pads)
     tiles = (K // 256) * (N // 256)
