@@ -132,6 +132,21 @@ int lwm_attn_bwd_dkdv(const LwmAttnArgs* args, void* stream);
 /* Bytes of the backward's row statistics (LwmAttnArgs::delta) for a [B, Sq, H, D] query block. */
 int64_t lwm_attn_bwd_delta_bytes(int32_t B, int32_t H, int32_t Sq);
 
+/* ------------------------------------------------------------------ the float32 flavour of the training op
+ * The reference computes in `--dtype`, and its own default is fp32 (lwm/train.py:36; the launch scripts of
+ * scripts/run_train_*.sh pass --dtype='fp32'; BASELINE configs[0] is the fp32 model).  These four entry points are
+ * lwm_attn_fwd / lwm_attn_bwd_delta / _dq / _dkdv with FLOAT32 tensors behind every LwmTensor4 of LwmAttnArgs
+ * (q, k, v, out, dout, dq, dk, dv: f32, D contiguous, strides in elements and multiples of 4; lse, the carries and the
+ * row statistics are what they are in the bf16 flavour, and the statistics buffer has the same size).  Same mask
+ * semantics, same carries (carry_in / final_out), same "rows with no visible key give 0 / -inf"; every contraction runs
+ * on the exact-f32 matrix instruction (v_mfma_f32_32x32x2_f32), no operand is rounded to bf16.  Not taken:
+ * piecewise position maps (q_pieces / k_pieces > 1), dense_mask, k_splits -> LWM_EUNSUPPORTED; the block-sparsity
+ * hints are accepted and not read.  Kernels: lwm_amd/csrc/attn_f32.h. */
+int lwm_attn_fwd_f32(const LwmAttnArgs* args, void* stream);
+int lwm_attn_bwd_delta_f32(const LwmAttnArgs* args, void* stream);
+int lwm_attn_bwd_dq_f32(const LwmAttnArgs* args, void* stream);
+int lwm_attn_bwd_dkdv_f32(const LwmAttnArgs* args, void* stream);
+
 /* ------------------------------------------------------------------ the sequence ring
  * The exchange that lax.ppermute performs under ringattention (lwm/llama.py:539-569, SURVEY.md Appendix
  * A.1), driven from C: for ring step t rank r holds the K/V block of rank (r - t) mod n, runs the local

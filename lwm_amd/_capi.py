@@ -108,6 +108,10 @@ PROTOTYPES = {
     "lwm_attn_bwd_dq": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
     "lwm_attn_bwd_dkdv": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
     "lwm_attn_bwd_delta_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "lwm_attn_fwd_f32": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
+    "lwm_attn_bwd_delta_f32": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
+    "lwm_attn_bwd_dq_f32": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
+    "lwm_attn_bwd_dkdv_f32": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
     "lwm_ring_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "lwm_ring_unique_id": (C.c_int, [C.c_void_p]),
     "lwm_ring_create_from_id": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -17,6 +17,8 @@
 #include "llama_elem.h"
 #include "gemv.h"
 #include "gemm_wgrad.h"
+#include "attn_f32.h"
 #include "api.inc"
+#include "api_f32.inc"
 #include "ring_driver.inc"
 #include "ring_ipc.inc"

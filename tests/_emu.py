@@ -173,6 +173,100 @@ def attn_bwd(q, k, v, out, lse, dout, *, causal=True, q_start=0, k_start=0, seg_
     return dq_acc, dk_acc, dv_acc
 
 
+# ---------------------------------------------------------------- the float32 flavour (lwm_attn_*_f32)
+def _t4f(arr):
+    """numpy float32 array (B,S,H,D) -> LwmTensor4."""
+    assert arr.dtype == np.float32 and arr.ndim == 4 and arr.strides[-1] == 4
+    sb, ss, sh, _ = (s // 4 for s in arr.strides)
+    return _capi.LwmTensor4(arr.ctypes.data, sb, ss, sh)
+
+
+def f32_array(x):
+    a = aligned(np.shape(x), np.float32)
+    a[...] = x
+    return a
+
+
+def _base_args_f32(qa, ka, va, *, causal, q_start, k_start, seg_q, seg_k, key_valid, scale):
+    B, Sq, H, D = qa.shape
+    Sk = ka.shape[1]
+    a = _capi.LwmAttnArgs()
+    a.q, a.k, a.v = _t4f(qa), _t4f(ka), _t4f(va)
+    a.B, a.H, a.Sq, a.Sk, a.D = B, H, Sq, Sk, D
+    a.q_start, a.k_start = q_start, k_start
+    a.scale = scale if scale is not None else 1.0 / np.sqrt(D)
+    a.causal = int(causal)
+    keep = []
+    if seg_q is not None:
+        sq = np.ascontiguousarray(seg_q, dtype=np.int32)
+        sk = np.ascontiguousarray(seg_k, dtype=np.int32)
+        a.segment_ids_q, a.segment_ids_k = sq.ctypes.data, sk.ctypes.data
+        keep += [sq, sk]
+    if key_valid is not None:
+        kv = np.ascontiguousarray(key_valid, dtype=np.uint8)
+        a.key_valid = kv.ctypes.data
+        keep.append(kv)
+    return a, keep
+
+
+def attn_fwd_f32(q, k, v, *, causal=True, q_start=0, k_start=0, seg_q=None, seg_k=None, key_valid=None, scale=None,
+                 carry=None, final=True):
+    """float32 operands, nothing rounded.  Returns (out, lse) or the updated carry (out_acc, lse_acc) when final=False."""
+    L = lib()
+    qa, ka, va = f32_array(q), f32_array(k), f32_array(v)
+    B, Sq, H, D = qa.shape
+    a, keep = _base_args_f32(qa, ka, va, causal=causal, q_start=q_start, k_start=k_start, seg_q=seg_q, seg_k=seg_k,
+                             key_valid=key_valid, scale=scale)
+    out = aligned((B, Sq, H, D), np.float32)
+    out[...] = np.nan
+    lse = aligned((B, H, Sq), np.float32)
+    lse[...] = np.nan
+    if carry is not None:
+        out_acc, lse_acc = carry
+        a.carry_in = 1
+    else:
+        out_acc, lse_acc = aligned((B, Sq, H, D), np.float32), aligned((B, H, Sq), np.float32)
+    a.out = _t4f(out)
+    a.lse = lse.ctypes.data
+    a.out_acc, a.lse_acc = out_acc.ctypes.data, lse_acc.ctypes.data
+    a.final_out = int(final)
+    _capi.check(L, L.lwm_attn_fwd_f32(C.byref(a), None), "lwm_attn_fwd_f32")
+    return (out, lse) if final else (out_acc, lse_acc)
+
+
+def attn_bwd_f32(q, k, v, out, lse, dout, *, causal=True, q_start=0, k_start=0, seg_q=None, seg_k=None, key_valid=None,
+                 scale=None, carry=None, final=True):
+    """(dq, dk, dv) f32: lwm_attn_bwd_delta_f32 + lwm_attn_bwd_dkdv_f32 + lwm_attn_bwd_dq_f32."""
+    L = lib()
+    qa, ka, va, oa, doa = (f32_array(t) for t in (q, k, v, out, dout))
+    B, Sq, H, D = qa.shape
+    Sk = ka.shape[1]
+    a, keep = _base_args_f32(qa, ka, va, causal=causal, q_start=q_start, k_start=k_start, seg_q=seg_q, seg_k=seg_k,
+                             key_valid=key_valid, scale=scale)
+    lse_a = f32_array(lse)
+    delta = aligned((L.lwm_attn_bwd_delta_bytes(B, H, Sq) // 4,), np.float32)
+    delta[...] = np.nan
+    dq, dk, dv = (aligned((B, Sq, H, D), np.float32), aligned((B, Sk, H, D), np.float32), aligned((B, Sk, H, D), np.float32))
+    for t in (dq, dk, dv):
+        t[...] = np.nan
+    if carry is not None:
+        dq_acc, dk_acc, dv_acc = carry
+        a.carry_in = 1
+    else:
+        dq_acc, dk_acc, dv_acc = (aligned((B, Sq, H, D), np.float32), aligned((B, Sk, H, D), np.float32),
+                                  aligned((B, Sk, H, D), np.float32))
+    a.out, a.dout = _t4f(oa), _t4f(doa)
+    a.dq, a.dk, a.dv = _t4f(dq), _t4f(dk), _t4f(dv)
+    a.lse, a.delta = lse_a.ctypes.data, delta.ctypes.data
+    a.delta_bytes = delta.nbytes
+    a.dq_acc, a.dk_acc, a.dv_acc = dq_acc.ctypes.data, dk_acc.ctypes.data, dv_acc.ctypes.data
+    a.final_out = int(final)
+    _capi.check(L, L.lwm_attn_bwd_delta_f32(C.byref(a), None), "lwm_attn_bwd_delta_f32")
+    _capi.check(L, L.lwm_attn_bwd_dkdv_f32(C.byref(a), None), "lwm_attn_bwd_dkdv_f32")
+    _capi.check(L, L.lwm_attn_bwd_dq_f32(C.byref(a), None), "lwm_attn_bwd_dq_f32")
+    return (dq, dk, dv) if final else (dq_acc, dk_acc, dv_acc)
+
+
 # ---------------------------------------------------------------- VQGAN primitives
 def _af32(x):
     a = aligned(np.shape(x), np.float32)

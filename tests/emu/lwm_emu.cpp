@@ -17,7 +17,9 @@
 #include "llama_elem.h"
 #include "gemv.h"
 #include "gemm_wgrad.h"
+#include "attn_f32.h"
 #include "api.inc"
+#include "api_f32.inc"
 #include "vqgan_conv.h"
 #include "vqgan_misc.h"
 #include "vqgan_api.inc"
