@@ -146,6 +146,23 @@ int lwm_attn_fwd_f32(const LwmAttnArgs* args, void* stream);
 int lwm_attn_bwd_delta_f32(const LwmAttnArgs* args, void* stream);
 int lwm_attn_bwd_dq_f32(const LwmAttnArgs* args, void* stream);
 int lwm_attn_bwd_dkdv_f32(const LwmAttnArgs* args, void* stream);
+/* The steps either side of the op at dtype = fp32 (lwm_amd/csrc/elem_f32.h): lwm_rope_bf16 / lwm_rmsnorm_{fwd,bwd}_bf16 /
+ * lwm_swiglu_{fwd,bwd}_bf16 / lwm_softmax_ce_bf16 with float tensors (rows of C % 4 == 0, V % 4 == 0, n % 4 == 0, 16-byte
+ * aligned), same arithmetic minus the roundings to bf16 (at dtype = f32 the reference's casts are identities,
+ * lwm/llama.py:339-341); lwm_rmsnorm_bwd_f32 takes lwm_rmsnorm_bwd_workspace_bytes(rows, C) bytes of workspace.
+ * lwm_sum_f32: dst = ((srcs[0] + srcs[1]) + ...) in argument order -- lwm_sum_f32_to_bf16 with a float result (the
+ * owner-side reduction of returned dK / dV partials when the operands are f32). */
+int lwm_rope_f32(LwmTensor4 x, LwmTensor4 y, const float* table, const int32_t* pos, int32_t B, int32_t S, int32_t H,
+                 int32_t D, int32_t max_pos, int32_t conj, void* stream);
+int lwm_rmsnorm_fwd_f32(const float* x, const float* w, float* y, float* rstd, int64_t rows, int32_t C, float eps,
+                        void* stream);
+int lwm_rmsnorm_bwd_f32(const float* x, const float* w, const float* g, const float* rstd, float* dx, float* dw,
+                        void* workspace, int64_t rows, int32_t C, void* stream);
+int lwm_swiglu_fwd_f32(const float* a, const float* b, float* y, int64_t n, void* stream);
+int lwm_swiglu_bwd_f32(const float* a, const float* b, const float* g, float* da, float* db, int64_t n, void* stream);
+int lwm_softmax_ce_f32(const float* logits, const int32_t* target, const float* weight, float* nll, int32_t* correct,
+                       float* dlogits, int64_t rows, int32_t V, void* stream);
+int lwm_sum_f32(const float* const* srcs, int32_t n_src, float* dst, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------ the sequence ring
  * The exchange that lax.ppermute performs under ringattention (lwm/llama.py:539-569, SURVEY.md Appendix

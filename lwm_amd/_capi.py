@@ -112,6 +112,13 @@ PROTOTYPES = {
     "lwm_attn_bwd_delta_f32": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
     "lwm_attn_bwd_dq_f32": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
     "lwm_attn_bwd_dkdv_f32": (C.c_int, [C.POINTER(LwmAttnArgs), C.c_void_p]),
+    "lwm_rope_f32": (C.c_int, [LwmTensor4, LwmTensor4, C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]),
+    "lwm_rmsnorm_fwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
+    "lwm_rmsnorm_bwd_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_void_p]),
+    "lwm_swiglu_fwd_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_void_p]),
+    "lwm_swiglu_bwd_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_void_p]),
+    "lwm_softmax_ce_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.c_void_p]),
+    "lwm_sum_f32": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "lwm_ring_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "lwm_ring_unique_id": (C.c_int, [C.c_void_p]),
     "lwm_ring_create_from_id": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -73,19 +73,28 @@ def build_config(flags, vision: bool):
     return cfg
 
 
-def torch_dtype(name: str):
+def torch_dtype(name: str, inference: bool = False):
     """--dtype (fp32 | bf16 | fp16, tux.get_float_dtype_by_name; the reference's default and every launcher's value
-    is fp32, lwm/train.py:36, scripts/run_train_text.sh:21).  The MI355X hot path exists for bf16 operands only
-    (f32 logits / softmax / accumulation, i.e. the reference's bf16 run with float32_logits=True, BASELINE configs
-    2-5).  The entry points here therefore DEFAULT to bf16 (a documented divergence from the reference's default:
-    README.md), and an explicit --dtype=fp32 / fp16 is REFUSED rather than silently
-    computed in a different precision than the command line says."""
+    is fp32, lwm/train.py:36, scripts/run_train_text.sh:21).
+
+    bf16 is the headline dtype (bf16 operands, f32 logits / softmax / accumulation = the reference's bf16 run with
+    float32_logits=True, BASELINE configs 2-5) and the DEFAULT of the entry points here (a documented divergence from
+    the reference's default: README.md).  fp32 is what the command line says it is in
+    TRAINING: float32 parameters, activations and attention operands through the f32 flavour of every kernel
+    (csrc/attn_f32.h on the exact-f32 matrix instruction, csrc/elem_f32.h; library GEMMs in f32) -- the reference's
+    shipped launch lines run as they are.  The cached-inference entry points (`inference=True`: vision_chat,
+    vision_generation) keep REFUSING fp32: the KV-cache, decode and dense-mask kernels take bf16 operands, and a run
+    is never silently computed in another precision than its command line says.  fp16 has no path."""
     if name not in ("fp32", "bf16", "fp16", "float32", "bfloat16", "float16"):
         raise SystemExit(f"unknown --dtype {name!r}")
+    if name in ("fp32", "float32") and not inference:
+        return torch.float32
     if name not in ("bf16", "bfloat16"):
-        raise SystemExit(f"--dtype={name}: not supported -- the MI355X attention kernels take bf16 operands (f32 logits, "
-                         f"softmax and accumulation).  The reference's launch scripts pass --dtype='fp32' "
-                         f"(scripts/run_train_text.sh:21, run_eval_needle.sh:17, lwm/train.py:36): replace that ONE flag by\n"
+        what = ("the KV-cache, decode and dense-mask attention kernels of the inference entry points take bf16 operands"
+                if name in ("fp32", "float32") else "there is no fp16 path")
+        raise SystemExit(f"--dtype={name}: not supported -- {what} (f32 logits, softmax and accumulation).  The reference's "
+                         f"launch scripts pass --dtype='fp32' (scripts/run_train_text.sh:21, run_eval_needle.sh:17, "
+                         f"lwm/train.py:36): python -m lwm_amd.cli.train takes that flag as it is; here replace that ONE flag by\n"
                          f"    --dtype='bf16'\n"
                          f"and keep the rest of the command line; the run is then the reference's bf16 configuration "
                          f"(BASELINE configs 2-5: bf16 operands, float32_logits=True), not its fp32 default.")

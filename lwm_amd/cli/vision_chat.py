@@ -70,7 +70,7 @@ class Sampler:
         # lwm/vision_chat.py:51-53: the prompt buffer is padded to, and at most this many tokens are generated:
         # max(scan_query_chunk_size, scan_key_chunk_size) * mesh.shape['sp']
         self.block_size = max(cfg.scan_query_chunk_size, cfg.scan_key_chunk_size) * int(self.mesh["sp"])
-        self.model = C.load_checkpoint(C.build_model(cfg, True, C.torch_dtype(F.dtype), F.seed, self.dev),
+        self.model = C.load_checkpoint(C.build_model(cfg, True, C.torch_dtype(F.dtype, inference=True), F.seed, self.dev),
                                        F.load_checkpoint)
         self.gen = torch.Generator(device=self.dev).manual_seed(F.seed)
 

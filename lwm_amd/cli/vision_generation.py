@@ -48,7 +48,7 @@ def main(argv=None):
     tok = C.load_tokenizer(F.tokenizer)
     cfg = C.build_config(F, vision=True)
     cfg.update(dict(bos_token_id=tok.bos_token_id, eos_token_id=tok.eos_token_id))
-    model = C.load_checkpoint(C.build_model(cfg, True, C.torch_dtype(F.dtype), F.seed, dev), F.load_checkpoint)
+    model = C.load_checkpoint(C.build_model(cfg, True, C.torch_dtype(F.dtype, inference=True), F.seed, dev), F.load_checkpoint)
     gen = torch.Generator(device=dev).manual_seed(F.seed)
 
     def sample(prompts, images, n_tokens, cfg_scale, top_k, temperature, max_input_length):

@@ -18,6 +18,7 @@
 #include "gemv.h"
 #include "gemm_wgrad.h"
 #include "attn_f32.h"
+#include "elem_f32.h"
 #include "api.inc"
 #include "api_f32.inc"
 #include "ring_driver.inc"

@@ -6,7 +6,9 @@ lwm_amd/csrc/llama_elem.h, differentiable (torch.autograd).
     xq, xk = apply_rotary_emb(xq, xk, freqs_cis, position_ids)       # lwm/llama.py:353-375
     y = RMSNorm(dim, eps)(x)                                         # lwm/llama.py:320-341
 
-No CPU path: tensors must be bf16 on the ROCm device.
+No CPU path: tensors must be on the ROCm device -- bf16 (the headline dtype), or float32: the reference's `--dtype=fp32`
+(lwm/train.py:36 default; BASELINE configs[0]), served by the f32 flavour of every kernel here (csrc/elem_f32.h: the same
+arithmetic minus the roundings to bf16) and of the attention op (csrc/attn_f32.h).
 """
 from __future__ import annotations
 
@@ -18,6 +20,13 @@ import torch
 from . import _capi
 from ._lib import lib
 from .ops import _stream_ptr, _t4
+
+_DTYPES = (torch.bfloat16, torch.float32)
+
+
+def _fn(L, name, dtype):
+    """lwm_<name>_bf16 or lwm_<name>_f32"""
+    return getattr(L, f"lwm_{name}_{'f32' if dtype == torch.float32 else 'bf16'}")
 
 
 def precompute_freqs_cis(dim: int, max_position_embedding: int, theta: float = 10000.0,
@@ -35,17 +44,17 @@ def precompute_freqs_cis(dim: int, max_position_embedding: int, theta: float = 1
 
 def _rope(x, table, pos, conj):
     B, S, H, D = x.shape
-    if not x.is_cuda or x.dtype != torch.bfloat16 or x.stride(3) != 1:
-        raise ValueError("rope: expected a bf16 (B,S,H,D) ROCm tensor with contiguous D")
+    if not x.is_cuda or x.dtype not in _DTYPES or x.stride(3) != 1:
+        raise ValueError("rope: expected a bf16 / f32 (B,S,H,D) ROCm tensor with contiguous D")
     if not table.is_cuda or table.dtype != torch.float32 or not table.is_contiguous() or \
             tuple(table.shape[1:]) != (D // 2, 2):
         raise ValueError(f"rope: table must be a contiguous f32 (max_pos, {D // 2}, 2) device tensor")
     if pos.dtype != torch.int32 or not pos.is_contiguous() or tuple(pos.shape) != (B, S) or not pos.is_cuda:
         raise ValueError(f"rope: position_ids must be contiguous int32 {(B, S)} on the device")
-    y = torch.empty((B, S, H, D), dtype=torch.bfloat16, device=x.device)
+    y = torch.empty((B, S, H, D), dtype=x.dtype, device=x.device)
     L = lib()
-    _capi.check(L, L.lwm_rope_bf16(_t4(x, "x"), _t4(y, "y"), table.data_ptr(), pos.data_ptr(), B, S, H, D,
-                                   table.shape[0], int(conj), _stream_ptr()), "lwm_rope_bf16")
+    _capi.check(L, _fn(L, "rope", x.dtype)(_t4(x, "x"), _t4(y, "y"), table.data_ptr(), pos.data_ptr(), B, S, H, D,
+                                           table.shape[0], int(conj), _stream_ptr()), "lwm_rope")
     return y
 
 
@@ -75,16 +84,16 @@ def apply_rotary_emb(xq, xk, freqs_cis, position_ids=None, dtype=None):
 class _RmsNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, eps):
-        if not x.is_cuda or x.dtype != torch.bfloat16 or not x.is_contiguous():
-            raise ValueError("RMSNorm: expected a contiguous bf16 ROCm tensor")
+        if not x.is_cuda or x.dtype not in _DTYPES or not x.is_contiguous():
+            raise ValueError("RMSNorm: expected a contiguous bf16 / f32 ROCm tensor")
         Cc = x.shape[-1]
         rows = x.numel() // Cc
-        w = weight.to(torch.bfloat16).contiguous()
+        w = weight.to(x.dtype).contiguous()
         y = torch.empty_like(x)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         L = lib()
-        _capi.check(L, L.lwm_rmsnorm_fwd_bf16(x.data_ptr(), w.data_ptr(), y.data_ptr(), rstd.data_ptr(), rows,
-                                              Cc, float(eps), _stream_ptr()), "lwm_rmsnorm_fwd_bf16")
+        _capi.check(L, _fn(L, "rmsnorm_fwd", x.dtype)(x.data_ptr(), w.data_ptr(), y.data_ptr(), rstd.data_ptr(), rows,
+                                                      Cc, float(eps), _stream_ptr()), "lwm_rmsnorm_fwd")
         ctx.save_for_backward(x, w, rstd)
         ctx.wdtype = weight.dtype
         return y
@@ -96,13 +105,13 @@ class _RmsNorm(torch.autograd.Function):
         rows = x.numel() // Cc
         g = g.contiguous()
         dx = torch.empty_like(x)
-        dw = torch.empty(Cc, dtype=torch.bfloat16, device=x.device)
+        dw = torch.empty(Cc, dtype=x.dtype, device=x.device)
         L = lib()
         ws = torch.empty(max(L.lwm_rmsnorm_bwd_workspace_bytes(rows, Cc), 16) // 4, dtype=torch.float32,
                          device=x.device)
-        _capi.check(L, L.lwm_rmsnorm_bwd_bf16(x.data_ptr(), w.data_ptr(), g.data_ptr(), rstd.data_ptr(),
-                                              dx.data_ptr(), dw.data_ptr(), ws.data_ptr(), rows, Cc,
-                                              _stream_ptr()), "lwm_rmsnorm_bwd_bf16")
+        _capi.check(L, _fn(L, "rmsnorm_bwd", x.dtype)(x.data_ptr(), w.data_ptr(), g.data_ptr(), rstd.data_ptr(),
+                                                      dx.data_ptr(), dw.data_ptr(), ws.data_ptr(), rows, Cc,
+                                                      _stream_ptr()), "lwm_rmsnorm_bwd")
         return dx, dw.to(ctx.wdtype), None
 
 
@@ -121,16 +130,16 @@ class RMSNorm(torch.nn.Module):
 # ---------------------------------------------------------------- loss (lwm/train.py:177-202)
 def _softmax_ce(logits2d, target, weight, want_grad):
     rows, V = logits2d.shape
-    if not logits2d.is_cuda or logits2d.dtype != torch.bfloat16 or not logits2d.is_contiguous():
-        raise ValueError("cross entropy: expected contiguous bf16 ROCm logits")
+    if not logits2d.is_cuda or logits2d.dtype not in _DTYPES or not logits2d.is_contiguous():
+        raise ValueError("cross entropy: expected contiguous bf16 / f32 ROCm logits")
     nll = torch.empty(rows, dtype=torch.float32, device=logits2d.device)
     correct = torch.empty(rows, dtype=torch.int32, device=logits2d.device)
     dl = torch.empty_like(logits2d) if want_grad else None
     L = lib()
-    _capi.check(L, L.lwm_softmax_ce_bf16(logits2d.data_ptr(), target.data_ptr(),
-                                         None if weight is None else weight.data_ptr(), nll.data_ptr(),
-                                         correct.data_ptr(), None if dl is None else dl.data_ptr(), rows, V,
-                                         _stream_ptr()), "lwm_softmax_ce_bf16")
+    _capi.check(L, _fn(L, "softmax_ce", logits2d.dtype)(logits2d.data_ptr(), target.data_ptr(),
+                                                        None if weight is None else weight.data_ptr(), nll.data_ptr(),
+                                                        correct.data_ptr(), None if dl is None else dl.data_ptr(), rows, V,
+                                                        _stream_ptr()), "lwm_softmax_ce")
     return nll, correct, dl
 
 
@@ -197,7 +206,7 @@ class _ChunkedHeadLoss(torch.autograd.Function):
         acc = torch.zeros((), dtype=torch.float32, device=hidden.device)
         dh = torch.empty_like(hidden) if need else None
         dk = torch.zeros(kernel.shape, dtype=torch.float32, device=hidden.device) if need else None
-        kb = kernel.to(torch.bfloat16)
+        kb = kernel.to(hidden.dtype if hidden.dtype == torch.float32 else torch.bfloat16)
         for s0 in range(0, S, chunk):
             s1 = min(S, s0 + chunk)
             h = hidden[:, s0:s1].reshape(-1, Dm)
@@ -245,12 +254,12 @@ class _SwiGLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
         for t in (a, b):
-            if not t.is_cuda or t.dtype != torch.bfloat16 or not t.is_contiguous():
-                raise ValueError("swiglu: expected contiguous bf16 ROCm tensors")
+            if not t.is_cuda or t.dtype not in _DTYPES or t.dtype != a.dtype or not t.is_contiguous():
+                raise ValueError("swiglu: expected contiguous bf16 / f32 ROCm tensors of one dtype")
         y = torch.empty_like(a)
         L = lib()
-        _capi.check(L, L.lwm_swiglu_fwd_bf16(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream_ptr()),
-                    "lwm_swiglu_fwd_bf16")
+        _capi.check(L, _fn(L, "swiglu_fwd", a.dtype)(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream_ptr()),
+                    "lwm_swiglu_fwd")
         ctx.save_for_backward(a, b)
         return y
 
@@ -260,8 +269,8 @@ class _SwiGLU(torch.autograd.Function):
         g = g.contiguous()
         da, db = torch.empty_like(a), torch.empty_like(b)
         L = lib()
-        _capi.check(L, L.lwm_swiglu_bwd_bf16(a.data_ptr(), b.data_ptr(), g.data_ptr(), da.data_ptr(), db.data_ptr(),
-                                             a.numel(), _stream_ptr()), "lwm_swiglu_bwd_bf16")
+        _capi.check(L, _fn(L, "swiglu_bwd", a.dtype)(a.data_ptr(), b.data_ptr(), g.data_ptr(), da.data_ptr(), db.data_ptr(),
+                                                     a.numel(), _stream_ptr()), "lwm_swiglu_bwd")
         return da, db
 
 
@@ -468,6 +477,8 @@ def wgrad(x2, g2):
     transposed by lwm_transpose_bf16 and a library GEMM.  LWM_WGRAD_HIP=0: the library form throughout."""
     M, K = x2.shape
     N = g2.shape[1]
+    if x2.dtype == torch.float32:
+        return x2.t() @ g2                              # the fp32 flavour: a plain library GEMM
     if (_os.environ.get("LWM_WGRAD_HIP", "1") == "1" and x2.is_cuda and x2.dtype == torch.bfloat16 and g2.dtype == torch.bfloat16
             and M % 32 == 0 and K % 256 == 0 and N % 256 == 0 and x2.stride(1) == 1 and g2.stride(1) == 1
             and x2.stride(0) % 8 == 0 and g2.stride(0) % 8 == 0 and x2.data_ptr() % 16 == 0 and g2.data_ptr() % 16 == 0

@@ -27,15 +27,22 @@ def _stream_ptr(stream=None):
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _t4(t, name):
+def _t4(t, name, dtype=None):
+    """(B,S,H,D) bf16 -- or f32, the fp32 flavour of the op -- device tensor -> LwmTensor4; `dtype`: the one it must have"""
     if t is None:
         return _capi.LwmTensor4(None, 0, 0, 0)
     if not t.is_cuda:
         raise ValueError(f"{name}: expected a ROCm device tensor (lwm_amd has no CPU path)")
-    if t.dtype != torch.bfloat16 or t.dim() != 4 or t.stride(3) != 1:
-        raise ValueError(f"{name}: expected bf16 (B,S,H,D) with contiguous D, got "
+    if t.dtype not in ((torch.bfloat16, torch.float32) if dtype is None else (dtype,)) or t.dim() != 4 or t.stride(3) != 1:
+        raise ValueError(f"{name}: expected {'bf16 / f32' if dtype is None else dtype} (B,S,H,D) with contiguous D, got "
                          f"{t.dtype} {tuple(t.shape)} strides {t.stride()}")
     return _capi.LwmTensor4(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2))
+
+
+def _entry(L, name, dtype):
+    """The C entry point of an attention launch for operands of `dtype`: bf16 = the headline kernels, f32 = the
+    `--dtype=fp32` flavour on the exact-f32 matrix instruction (lwm_attn_*_f32, csrc/attn_f32.h)."""
+    return getattr(L, name + "_f32") if dtype == torch.float32 else getattr(L, name)
 
 
 def _f32(t, name, shape=None):
@@ -55,7 +62,7 @@ def _base(q, k, v, *, q_start, k_start, causal, seg_q, seg_k, key_valid, scale, 
     B, Sq, H, D = q.shape
     Sk = k.shape[1]
     a = _capi.LwmAttnArgs()
-    a.q, a.k, a.v = _t4(q, "q"), _t4(k, "k"), _t4(v, "v")
+    a.q, a.k, a.v = _t4(q, "q"), _t4(k, "k", q.dtype), _t4(v, "v", q.dtype)
     a.B, a.H, a.Sq, a.Sk, a.D = B, H, Sq, Sk, D
     a.q_start, a.k_start = int(q_start), int(k_start)
     cuts = lambda c: [c] if isinstance(c, tuple) else list(c)
@@ -77,8 +84,8 @@ def _base(q, k, v, *, q_start, k_start, causal, seg_q, seg_k, key_valid, scale, 
                 tuple(key_valid.shape) != (B, Sk) or not key_valid.is_cuda:
             raise ValueError(f"key_valid: expected contiguous uint8 device tensor of shape {(B, Sk)}")
         a.key_valid = key_valid.data_ptr()
-    if seg_q is not None and SEGMENT_SKIP:
-        # block-sparsity hints: whole documents of a packed batch are skipped in-kernel
+    if seg_q is not None and SEGMENT_SKIP and q.dtype == torch.bfloat16:
+        # block-sparsity hints: whole documents of a packed batch are skipped in-kernel (the f32 kernels do not read them)
         bq, bk = _cached_segment_blocks(seg_q, None), _cached_segment_blocks(seg_k, key_valid)
         a.seg_blocks_q, a.seg_blocks_k = bq.data_ptr(), bk.data_ptr()
         a._keep = (bq, bk)
@@ -123,10 +130,10 @@ def attn_fwd_block(q, k, v, *, q_start=0, k_start=0, causal=True, seg_q=None, se
     _set_dense_mask(a, dense_mask, B, Sq, k.shape[1])
     if final:
         if out is None:
-            out = torch.empty((B, Sq, H, D), dtype=torch.bfloat16, device=q.device)
+            out = torch.empty((B, Sq, H, D), dtype=q.dtype, device=q.device)
         if lse is None:
             lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
-        a.out = _t4(out, "out")
+        a.out = _t4(out, "out", q.dtype)
         a.lse = _f32(lse, "lse", (B, H, Sq))
     else:
         if out_acc is None:
@@ -138,7 +145,7 @@ def attn_fwd_block(q, k, v, *, q_start=0, k_start=0, causal=True, seg_q=None, se
     a.carry_in = int(bool(carry_in))
     a.final_out = int(bool(final))
     L = lib()
-    _capi.check(L, L.lwm_attn_fwd(C.byref(a), _stream_ptr()), "lwm_attn_fwd")
+    _capi.check(L, _entry(L, "lwm_attn_fwd", q.dtype)(C.byref(a), _stream_ptr()), "lwm_attn_fwd")
     return (out, lse) if final else (out_acc, lse_acc)
 
 
@@ -157,6 +164,8 @@ def attn_fwd_splitk(q, k, v, *, k_splits, q_start=0, k_start=0, causal=False, se
     (o_parts f32 [k_splits,B,Sq,H,D], lse_parts f32 [k_splits,B,H,Sq]) -- merge with
     attn_combine."""
     B, Sq, H, D = q.shape
+    if q.dtype != torch.bfloat16:
+        raise ValueError("attn_fwd_splitk: the inference kernels take bf16 operands (the f32 flavour serves the training op)")
     a = _base(q, k, v, q_start=q_start, k_start=k_start, causal=causal, seg_q=seg_q, seg_k=seg_k,
               key_valid=key_valid, scale=scale)
     _set_dense_mask(a, dense_mask, B, Sq, k.shape[1])
@@ -181,7 +190,7 @@ def attn_combine(o_parts, lse_parts, *, out=None, out_f32=None, lse=None, want_b
         out_f32 = torch.empty((B, Sq, H, D), dtype=torch.float32, device=o_parts.device)
     L = lib()
     _capi.check(L, L.lwm_attn_combine(_f32(o_parts, "o_parts"), _f32(lse_parts, "lse_parts", (P, B, H, Sq)), P,
-                                      _t4(out, "out") if want_bf16 else _capi.LwmTensor4(None, 0, 0, 0),
+                                      _t4(out, "out", torch.bfloat16) if want_bf16 else _capi.LwmTensor4(None, 0, 0, 0),
                                       None if want_bf16 else _f32(out_f32, "out_f32"),
                                       _f32(lse, "lse", (B, H, Sq)), B, Sq, H, D, _stream_ptr()),
                 "lwm_attn_combine")
@@ -238,20 +247,20 @@ def attn_bwd_delta(out, dout, lse, delta=None):
     if delta is None:
         delta = torch.empty(bwd_stats_shape(B, H, Sq), dtype=torch.float32, device=out.device)
     a = _capi.LwmAttnArgs()
-    a.out, a.dout = _t4(out, "out"), _t4(dout, "dout")
+    a.out, a.dout = _t4(out, "out"), _t4(dout, "dout", out.dtype)
     a.B, a.H, a.Sq, a.Sk, a.D = B, H, Sq, 0, D
     a.lse = _f32(lse, "lse", (B, H, Sq))
     a.delta = _f32(delta, "delta", bwd_stats_shape(B, H, Sq))
     a.delta_bytes = delta.numel() * 4
     L = lib()
-    _capi.check(L, L.lwm_attn_bwd_delta(C.byref(a), _stream_ptr()), "lwm_attn_bwd_delta")
+    _capi.check(L, _entry(L, "lwm_attn_bwd_delta", out.dtype)(C.byref(a), _stream_ptr()), "lwm_attn_bwd_delta")
     return delta
 
 
 def _bwd_base(q, k, v, dout, lse, delta, kw):
     B, Sq, H, D = q.shape
     a = _base(q, k, v, **kw)
-    a.dout = _t4(dout, "dout")
+    a.dout = _t4(dout, "dout", q.dtype)
     a.lse = _f32(lse, "lse", (B, H, Sq))
     a.delta = _f32(delta, "delta", bwd_stats_shape(B, H, Sq))
     a.delta_bytes = delta.numel() * 4
@@ -272,8 +281,8 @@ def attn_bwd_dq_block(q, k, v, dout, lse, delta, *, q_start=0, k_start=0, causal
                        key_valid=key_valid, scale=scale, q_piece2=q_piece2, k_piece2=k_piece2))
     if final:
         if dq is None:
-            dq = torch.empty((B, Sq, H, D), dtype=torch.bfloat16, device=q.device)
-        a.dq = _t4(dq, "dq")
+            dq = torch.empty((B, Sq, H, D), dtype=q.dtype, device=q.device)
+        a.dq = _t4(dq, "dq", q.dtype)
     elif dq_acc is None:
         dq_acc = torch.empty(_acc_shape(B, Sq, H, D, acc_head_major), dtype=torch.float32, device=q.device)
     a.dq_acc = _f32(dq_acc, "dq_acc", _acc_shape(B, Sq, H, D, acc_head_major))
@@ -281,7 +290,7 @@ def attn_bwd_dq_block(q, k, v, dout, lse, delta, *, q_start=0, k_start=0, causal
     a.carry_in = int(bool(carry_in))
     a.final_out = int(bool(final))
     L = lib()
-    _capi.check(L, L.lwm_attn_bwd_dq(C.byref(a), _stream_ptr()), "lwm_attn_bwd_dq")
+    _capi.check(L, _entry(L, "lwm_attn_bwd_dq", q.dtype)(C.byref(a), _stream_ptr()), "lwm_attn_bwd_dq")
     return dq if final else dq_acc
 
 
@@ -294,10 +303,10 @@ def attn_bwd_dkdv_block(q, k, v, dout, lse, delta, *, q_start=0, k_start=0, caus
                        key_valid=key_valid, scale=scale, q_piece2=q_piece2, k_piece2=k_piece2))
     if final:
         if dk is None:
-            dk = torch.empty((B, Sk, H, D), dtype=torch.bfloat16, device=q.device)
+            dk = torch.empty((B, Sk, H, D), dtype=q.dtype, device=q.device)
         if dv is None:
-            dv = torch.empty((B, Sk, H, D), dtype=torch.bfloat16, device=q.device)
-        a.dk, a.dv = _t4(dk, "dk"), _t4(dv, "dv")
+            dv = torch.empty((B, Sk, H, D), dtype=q.dtype, device=q.device)
+        a.dk, a.dv = _t4(dk, "dk", q.dtype), _t4(dv, "dv", q.dtype)
     else:
         if dk_acc is None:
             dk_acc = torch.empty((B, Sk, H, D), dtype=torch.float32, device=q.device)
@@ -308,7 +317,7 @@ def attn_bwd_dkdv_block(q, k, v, dout, lse, delta, *, q_start=0, k_start=0, caus
     a.carry_in = int(bool(carry_in))
     a.final_out = int(bool(final))
     L = lib()
-    _capi.check(L, L.lwm_attn_bwd_dkdv(C.byref(a), _stream_ptr()), "lwm_attn_bwd_dkdv")
+    _capi.check(L, _entry(L, "lwm_attn_bwd_dkdv", q.dtype)(C.byref(a), _stream_ptr()), "lwm_attn_bwd_dkdv")
     return (dk, dv) if final else (dk_acc, dv_acc)
 
 
@@ -331,10 +340,13 @@ def sum_f32_to_bf16(srcs, dst=None):
             raise ValueError("sum_f32_to_bf16: expected same-shaped contiguous f32 device tensors")
     if dst is None:
         dst = torch.empty(srcs[0].shape, dtype=torch.bfloat16, device=srcs[0].device)
-    elif not dst.is_contiguous() or dst.dtype != torch.bfloat16 or dst.numel() != srcs[0].numel():
-        raise ValueError("sum_f32_to_bf16: dst must be a contiguous bf16 tensor of the same size")
+    elif not dst.is_contiguous() or dst.dtype not in (torch.bfloat16, torch.float32) or dst.numel() != srcs[0].numel():
+        raise ValueError("sum_f32_to_bf16: dst must be a contiguous bf16 (or, the fp32 flavour, f32) tensor of the same size")
     ptrs = (C.c_void_p * len(srcs))(*[s.data_ptr() for s in srcs])
     L = lib()
+    if dst.dtype == torch.float32:      # f32 operands: the same ordered sum, nothing rounded (lwm_sum_f32)
+        _capi.check(L, L.lwm_sum_f32(ptrs, len(srcs), dst.data_ptr(), srcs[0].numel(), _stream_ptr()), "lwm_sum_f32")
+        return dst
     _capi.check(L, L.lwm_sum_f32_to_bf16(ptrs, len(srcs), dst.data_ptr(), srcs[0].numel(), _stream_ptr()),
                 "lwm_sum_f32_to_bf16")
     return dst

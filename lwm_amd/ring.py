@@ -293,6 +293,17 @@ def _rows(t, seg):
     return t[:, off:off + ln]
 
 
+def _from_acc(block, acc, dtype, dst=None):
+    """an f32 carry -> the operands' dtype: the cast kernel for bf16 operands, the carry itself (a copy into `dst`) when
+    the operands ARE f32 -- the fp32 flavour of the op (the reference's --dtype=fp32) rounds nothing on the way out"""
+    if dtype == torch.float32:
+        if dst is None:
+            return acc
+        dst.copy_(acc.reshape(dst.shape))
+        return dst
+    return block.cast(acc) if dst is None else block.cast(acc, dst)
+
+
 def _xbuf(comm, block, tag, shape, dtype, like):
     """An exchange buffer: from the communicator's pool when it has one (TorchRingComm), else fresh."""
     pooled = getattr(comm, "pooled", None)
@@ -408,6 +419,8 @@ class _Gathered:
     def applies(block, comm, layout, q, causal):
         if not (_is_mesh(comm) and causal and q.shape[0] == 1 and getattr(block, "piece_align", 0)):
             return False
+        if q.dtype == torch.float32 and q.is_cuda:
+            return False        # (piecewise position maps are the bf16 kernels'; the f32 flavour runs the pair form)
         if os.environ.get("LWM_RING_FORM") == "pairs":
             return False
         n = comm.size
@@ -661,14 +674,14 @@ def ring_backward(block, comm, q, k, v, out, lses, dout, *, layout, causal=True,
     dk = block.empty((B, c, H, D), q.dtype, q)
     dv = block.empty((B, c, H, D), q.dtype, q)
     if len(qsegs) == 1:
-        block.cast(dq_acc[0], dq)
-        block.cast(dk_acc[0], dk)
-        block.cast(dv_acc[0], dv)
+        _from_acc(block, dq_acc[0], q.dtype, dq)
+        _from_acc(block, dk_acc[0], q.dtype, dk)
+        _from_acc(block, dv_acc[0], q.dtype, dv)
     else:
         for i, (off, ln, _) in enumerate(qsegs):
-            dq[:, off:off + ln].copy_(block.cast(dq_acc[i]))
-            dk[:, off:off + ln].copy_(block.cast(dk_acc[i]))
-            dv[:, off:off + ln].copy_(block.cast(dv_acc[i]))
+            dq[:, off:off + ln].copy_(_from_acc(block, dq_acc[i], q.dtype))
+            dk[:, off:off + ln].copy_(_from_acc(block, dk_acc[i], q.dtype))
+            dv[:, off:off + ln].copy_(_from_acc(block, dv_acc[i], q.dtype))
     return dq, dk, dv
 
 
@@ -768,6 +781,8 @@ def _mesh_backward(block, comm, q, k, v, lses, dout, deltas, *, layout, causal, 
                 dst[:, off:off + ln].zero_()
             elif len(own) == 1 or B == 1:
                 block.sum_cast(srcs, dst[:, off:off + ln] if len(own) > 1 else dst)
+            elif dst.dtype == torch.float32:
+                dst[:, off:off + ln].copy_(block.sum_cast(srcs, block.empty(srcs[0].shape, torch.float32, q)))
             else:
                 dst[:, off:off + ln].copy_(block.sum_cast(srcs))
     return dq, dk, dv
@@ -822,6 +837,8 @@ def _c_driver_transport(group, block_ops, q):
     want = os.environ.get("LWM_RING_DRIVER") or "auto"
     if block_ops is not None or want == "python" or group in _C_RING_REFUSED or not q.is_cuda:
         return None
+    if q.dtype != torch.bfloat16:
+        return None          # (the C driver moves bf16 blocks: the fp32 flavour of the op rides this module's driver)
     try:
         backend, size = dist.get_backend(group), dist.get_world_size(group)
     except Exception:

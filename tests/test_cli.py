@@ -148,22 +148,25 @@ def test_one_step_of_each_entry_point_on_the_debug_model(tmp_path):
 
 
 def test_dtype_flag_refuses_what_the_kernels_do_not_compute():
-    """The reference's launchers pass --dtype=fp32 (scripts/run_train_text.sh:21, lwm/train.py:36).  The MI355X
-    kernels compute on bf16 operands only: anything else is refused, loudly, instead of being run as bf16."""
+    """The reference's launchers pass --dtype=fp32 (scripts/run_train_text.sh:21, lwm/train.py:36).  Training takes it
+    as it is (the f32 flavour of every kernel: csrc/attn_f32.h, csrc/elem_f32.h); the cached-inference entry points, whose
+    KV-cache / decode kernels take bf16 operands, refuse it loudly instead of running it as bf16; fp16 has no path."""
     from lwm_amd.cli._common import torch_dtype
     import torch
     assert torch_dtype("bf16") is torch.bfloat16 and torch_dtype("bfloat16") is torch.bfloat16
-    for name in ("fp32", "float32", "fp16"):
+    assert torch_dtype("fp32") is torch.float32 and torch_dtype("float32") is torch.float32
+    assert torch_dtype("bf16", inference=True) is torch.bfloat16
+    for name, kw in (("fp32", dict(inference=True)), ("float32", dict(inference=True)), ("fp16", {}), ("fp16", dict(inference=True))):
         with pytest.raises(SystemExit) as e:
-            torch_dtype(name)
+            torch_dtype(name, **kw)
         # the message names the replacement for the one flag of the reference's launchers that cannot be kept
         assert "--dtype='bf16'" in str(e.value) and "run_train_text.sh:21" in str(e.value)
     with pytest.raises(SystemExit):
         torch_dtype("int8")
-    # ... and an invocation WITHOUT --dtype must run: the entry points default to what the kernels compute
+    # ... and an invocation WITHOUT --dtype must run: the entry points default to the headline dtype
     from lwm_amd.cli import train, vision_chat, vision_generation
     for mod in (train, vision_chat, vision_generation):
-        assert torch_dtype(mod.DEFAULTS["dtype"]) is torch.bfloat16, mod.__name__
+        assert torch_dtype(mod.DEFAULTS["dtype"], inference=mod is not train) is torch.bfloat16, mod.__name__
 
 
 def test_vision_checkpoint_round_trip_through_load_checkpoint(tmp_path):
