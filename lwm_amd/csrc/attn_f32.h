@@ -38,6 +38,24 @@ constexpr int kX32MetaBytes = 3 * kX32BT * 4;
 constexpr int kX32LdsBytes = 4 * kEpiTileBytes > kX32OffMeta + kX32MetaBytes ? 4 * kEpiTileBytes : kX32OffMeta + kX32MetaBytes;
 static_assert(kEpiRowBytes == kX32RowBytes, "the epilogue staging of attn_common.h uses the same padded row");
 
+// the value must EXIST here (its LDS read issued, not sunk below the MFMAs that follow): an empty statement hipcc cannot move
+#ifdef LWM_EMU
+LWM_DEVICE void x32_pin(f32x4&) {}
+#else
+LWM_DEVICE void x32_pin(f32x4& v) { asm volatile("" : "+v"(v)); }
+#endif
+
+// Workgroup -> (tile, head, batch row), TILE-major: under a causal mask a workgroup's walk grows with its query tile
+// (shrinks with its key block) from a few steps to S / 32, and the heaviest workgroup alone is a quarter of a launch at
+// S = 8192 -- handed out head by head, the last head's long walks start when most of the chip has run dry (measured:
+// 63 % of the wave slots filled on average).  All heads' longest walks go first, the short ones fill the tail.
+LWM_DEVICE void x32_block_to_tile(int bid, int n_tiles, int H, int B, bool descending, int& tile, int& h, int& b) {
+    const int nbh = H * B, order = bid / nbh, bh = bid % nbh;
+    tile = descending ? n_tiles - 1 - order : order;
+    h = bh % H;
+    b = bh / H;
+}
+
 struct X32Frag { float v[64]; };       // B-operand form of 32 rows x 128: v[4 j + c] = row (lane & 31), column 8 j + 4 hi + c
 
 // rows [row0, row0 + 32) of a [.., S, .., 128] f32 tensor as a wave's B-operand fragments (rows >= S: zeros)
@@ -78,29 +96,45 @@ LWM_DEVICE void x32_commit(const X32Pre& pre, lds_t lds, int tid) {
     }
 }
 
-// acc(32 x 32) += tile rows (A operand, from LDS: row = lane & 31, 4 consecutive columns per read) x the wave's fragments
+// acc(32 x 32) += tile rows (A operand, from LDS: row = lane & 31, 4 consecutive columns per read) x the wave's fragments.
+// The read of step j + 1 is issued before the four MFMAs of step j (left to itself hipcc puts each ds_read directly in
+// front of its first MFMA with a full wait in between: the LDS latency, once per 128 cycles of matrix pipe).
 LWM_DEVICE f32x16 x32_rows_times_frag(lds_t tile, const X32Frag& f, f32x16 acc, int l31, int hi) {
     const lds_t a0 = tile + (uint32_t)(l31 * kX32RowBytes + hi * 16);
+    f32x4 t = lds_read_f32x4(a0), n1 = lds_read_f32x4(a0 + 32u);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const f32x4 t = lds_read_f32x4(a0 + (uint32_t)(j * 32));
+        f32x4 n2 = n1;
+        if (j + 2 < 16) n2 = lds_read_f32x4(a0 + (uint32_t)((j + 2) * 32));
         acc = mfma_32x32x2_f32(t[0], f.v[4 * j + 0], acc);
         acc = mfma_32x32x2_f32(t[1], f.v[4 * j + 1], acc);
         acc = mfma_32x32x2_f32(t[2], f.v[4 * j + 2], acc);
         acc = mfma_32x32x2_f32(t[3], f.v[4 * j + 3], acc);
+        x32_pin(n1);
+        t = n1;
+        n1 = n2;
     }
     return acc;
 }
 
 // out^T(128 x 32) += tile^T x w, w a C/D fragment over (tile row, owned row): register i of w multiplies tile row
-// cd_row(i, hi); the A operand is column 32 db + (lane & 31) of that tile row (32 consecutive floats per half wave)
+// cd_row(i, hi); the A operand is column 32 db + (lane & 31) of that tile row (32 consecutive floats per half wave).
+// Reads run two steps ahead of the MFMAs, as above.
+LWM_DEVICE f32x4 x32_col4(lds_t ar) {
+    return f32x4{lds_read_f32(ar), lds_read_f32(ar + 128u), lds_read_f32(ar + 256u), lds_read_f32(ar + 384u)};
+}
 LWM_DEVICE void x32_tileT_times_cd(lds_t tile, const f32x16& w, f32x16 (&out)[4], int l31, int hi) {
     const lds_t a0 = tile + (uint32_t)(4 * hi * kX32RowBytes + l31 * 4);
+    f32x4 t = x32_col4(a0), n1 = x32_col4(a0 + (uint32_t)kX32RowBytes);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const lds_t ar = a0 + (uint32_t)(((i & 3) + 8 * (i >> 2)) * kX32RowBytes);
+        f32x4 n2 = n1;
+        if (i + 2 < 16) n2 = x32_col4(a0 + (uint32_t)((((i + 2) & 3) + 8 * ((i + 2) >> 2)) * kX32RowBytes));
 #pragma unroll
-        for (int db = 0; db < 4; ++db) out[db] = mfma_32x32x2_f32(lds_read_f32(ar + (uint32_t)(db * 128)), w[i], out[db]);
+        for (int db = 0; db < 4; ++db) out[db] = mfma_32x32x2_f32(t[db], w[i], out[db]);
+        x32_pin(n1);
+        t = n1;
+        n1 = n2;
     }
 }
 
@@ -151,8 +185,8 @@ LWM_KERNEL(kX32Threads) void attn_fwd_f32_kernel(AttnParams p) {
     const lds_t lds = dyn_lds();
     const int tid = thread_idx(), wave = wave_uniform(tid >> 6), lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int nqt = (p.Sq + kX32Own - 1) / kX32Own;
-    const int bid = block_idx_x();
-    const int qt = bid % nqt, h = (bid / nqt) % p.H, b = bid / (nqt * p.H);
+    int qt, h, b;
+    x32_block_to_tile(block_idx_x(), nqt, p.H, p.B, p.causal != 0, qt, h, b);     // the longest walks (last queries) first
     const int q0 = qt * kX32Own + wave * 32, row = q0 + l31;
     const bool row_ok = row < p.Sq;
     const float* Q = (const float*)p.q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
@@ -298,8 +332,8 @@ LWM_KERNEL(kX32Threads) void attn_bwd_dq_f32_kernel(AttnParams p) {
     const lds_t lds = dyn_lds();
     const int tid = thread_idx(), wave = wave_uniform(tid >> 6), lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int nqt = (p.Sq + kX32Own - 1) / kX32Own;
-    const int bid = block_idx_x();
-    const int qt = bid % nqt, h = (bid / nqt) % p.H, b = bid / (nqt * p.H);
+    int qt, h, b;
+    x32_block_to_tile(block_idx_x(), nqt, p.H, p.B, p.causal != 0, qt, h, b);     // the longest walks (last queries) first
     const int q0 = qt * kX32Own + wave * 32, row = q0 + l31;
     const float* Q = (const float*)p.q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
     const float* K = (const float*)p.k + (int64_t)b * p.k_sb + (int64_t)h * p.k_sh;
@@ -378,8 +412,8 @@ LWM_KERNEL(kX32Threads) void attn_bwd_dkdv_f32_kernel(AttnParams p) {
     const lds_t lds = dyn_lds();
     const int tid = thread_idx(), wave = wave_uniform(tid >> 6), lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int nkt = (p.Sk + kX32Own - 1) / kX32Own;
-    const int bid = block_idx_x();
-    const int kb = bid % nkt, h = (bid / nkt) % p.H, b = bid / (nkt * p.H);
+    int kb, h, b;
+    x32_block_to_tile(block_idx_x(), nkt, p.H, p.B, false, kb, h, b);             // the longest walks (first keys) first
     const int k0 = kb * kX32Own + wave * 32, row = k0 + l31;
     const float* Q = (const float*)p.q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
     const float* K = (const float*)p.k + (int64_t)b * p.k_sb + (int64_t)h * p.k_sh;
