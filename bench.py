@@ -23,7 +23,7 @@ else (RANK / WORLD_SIZE set) it just takes its rank.
 
 Prints ONE JSON line (rank 0).  `value` = whole-job tokens/s = S*steps/time.
 At N=1 the line also carries `roofline`, `cpu_baseline` and secondary legs that are never
-part of `value`: vqgan, packed, model_slice, decode, generate, ring8_compute_model, elementwise.
+part of `value`: vqgan, packed, model_slice, config0_fp32, decode, generate, ring8_compute_model, elementwise.
 """
 import argparse
 import json
@@ -376,6 +376,67 @@ def model_slice_leg(torch, S=32768):
     dt = time.perf_counter() - t0
     return {"workload": f"LWM-7B 2-layer slice + lm_head, B=1, S={S}, bf16, fwd+bwd", "ms": dt * 1e3,
             "tokens_per_s": S / dt, "loss": float(loss.detach())}
+
+
+def config0_fp32_leg(torch, S=4096):
+    """Secondary leg: BASELINE configs[0] -- LWM-7B, 2-layer slice, seq = 4096, bs = 1, FLOAT32 (the reference's default
+    --dtype, lwm/train.py:36) -- loss forward + backward on the MI355X through the f32 flavour of the path (csrc/attn_f32.h
+    on the exact-f32 matrix instruction, csrc/elem_f32.h, library GEMMs in f32): the SAME workload, dtype and FLOP count as
+    `cpu_baseline.config1` (the reference-shaped CPU model on the host cores), so the two figures of one line compare like
+    with like.  Also the f32 attention op alone at that S, 32 heads, against the f32 MFMA peak (157.3 TF/s dense)."""
+    from lwm_amd import ops
+    from lwm_amd.llama import LLaMAConfig, LLaMAForCausalLM
+    cfg = LLaMAConfig.load_config("7b", num_hidden_layers=2, max_sequence_length=S)
+    torch.manual_seed(0)
+    with torch.device("cuda"):
+        model = LLaMAForCausalLM(cfg, torch.float32)
+    tok = torch.randint(0, cfg.vocab_size, (1, S + 1), device="cuda")
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        loss, _ = model.loss(tok[:, :-1], tok[:, 1:], chunk=4096)
+        loss.backward()
+        return loss
+
+    step()
+    torch.cuda.synchronize()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    d, F, V, L = D_MODEL, 11008, cfg.vocab_size, 2
+    flops = 6.0 * (L * (4 * d * d + 3 * d * F) + d * V) * S + 7.0 * S * S * d * L
+    del model
+    g = torch.Generator(device="cuda").manual_seed(1)
+    q, k, v, do = (torch.randn(1, S, N_HEADS, HEAD_DIM, device="cuda", generator=g) for _ in range(4))
+    o, lse = ops.attn_fwd_block(q, k, v, causal=True)
+    delta = ops.attn_bwd_delta(o, do, lse)
+
+    def attn():
+        ops.attn_fwd_block(q, k, v, causal=True)
+        ops.attn_bwd_delta(o, do, lse, delta)
+        ops.attn_bwd_dq_block(q, k, v, do, lse, delta, causal=True)
+        ops.attn_bwd_dkdv_block(q, k, v, do, lse, delta, causal=True)
+
+    attn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        attn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    a_tf = 7.0 * S * S * D_MODEL / (ms * 1e-3) / 1e12
+    return {"workload": f"LWM-7B 2-layer slice + lm_head, B=1, S={S}, fp32 (--dtype=fp32), loss fwd+bwd on one MI355X [BASELINE configs[0]]",
+            "ms": dt * 1e3, "tokens_per_s": S / dt, "gflops": flops / dt / 1e9, "loss": float(loss.detach()), "dtype": "f32",
+            "attention_f32": {"workload": f"attention fwd+bwd, f32 operands, S={S}, 32 heads x 128, causal, one layer",
+                              "ms_per_layer": ms,
+                              "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": 157.3, "achieved": a_tf, "frac": a_tf / 157.3,
+                                           "kernel": "attn_fwd_f32_kernel + attn_bwd_dq_f32_kernel + attn_bwd_dkdv_f32_kernel",
+                                           "note": "algorithmic 7 units over the three launches (9 executed); f32 MFMA dense peak"}}}
 
 
 def model_full_leg(torch, S=32768, layers=N_LAYERS, mlp_chunk=8192, scan_mlp=False):
@@ -1587,6 +1648,7 @@ def main():
                 res["vqgan"] = leg(vqgan_leg, torch)
                 res["packed"] = leg(packed_leg, torch)
                 res["model_slice"] = leg(model_slice_leg, torch)
+                res["config0_fp32"] = leg(config0_fp32_leg, torch)      # BASELINE configs[0] in its own dtype, beside cpu_baseline.config1
                 if not args.no_full_model:
                     res["model_full"] = leg(model_full_leg, torch)
                 if not args.no_packed_1m:
