@@ -79,25 +79,26 @@ def torch_dtype(name: str, inference: bool = False):
 
     bf16 is the headline dtype (bf16 operands, f32 logits / softmax / accumulation = the reference's bf16 run with
     float32_logits=True, BASELINE configs 2-5) and the DEFAULT of the entry points here (a documented divergence from
-    the reference's default: README.md).  fp32 is what the command line says it is in
-    TRAINING: float32 parameters, activations and attention operands through the f32 flavour of every kernel
-    (csrc/attn_f32.h on the exact-f32 matrix instruction, csrc/elem_f32.h; library GEMMs in f32) -- the reference's
-    shipped launch lines run as they are.  The cached-inference entry points (`inference=True`: vision_chat,
-    vision_generation) keep REFUSING fp32: the KV-cache, decode and dense-mask kernels take bf16 operands, and a run
-    is never silently computed in another precision than its command line says.  fp16 has no path."""
+    the reference's default: README.md).  fp32 is what the command line says it is: float32
+    parameters, activations and attention operands through the f32 flavour of every kernel (csrc/attn_f32.h on the
+    exact-f32 matrix instruction, csrc/elem_f32.h; library GEMMs in f32) -- the reference's shipped launch lines run
+    as they are.  `inference=True` (vision_chat, vision_generation) only changes the note: cached decoding in fp32 runs
+    on ONE rank (prefill and decode steps through the f32 training-op kernel with the mask handed over as its
+    structure; the sharded decode / dense-mask kernels take bf16 and lwm_amd.llama refuses an sp axis > 1 in fp32).
+    fp16 has no path, and a run is never silently computed in another precision than its command line says."""
     if name not in ("fp32", "bf16", "fp16", "float32", "bfloat16", "float16"):
         raise SystemExit(f"unknown --dtype {name!r}")
-    if name in ("fp32", "float32") and not inference:
+    if name in ("fp32", "float32"):
+        if inference:
+            note("--dtype=fp32: cached decoding runs through the float32 flavour of the attention op, one rank, eager steps "
+                 "(the bf16 path has the streaming decode kernel and the hipGraph step)")
         return torch.float32
     if name not in ("bf16", "bfloat16"):
-        what = ("the KV-cache, decode and dense-mask attention kernels of the inference entry points take bf16 operands"
-                if name in ("fp32", "float32") else "there is no fp16 path")
-        raise SystemExit(f"--dtype={name}: not supported -- {what} (f32 logits, softmax and accumulation).  The reference's "
-                         f"launch scripts pass --dtype='fp32' (scripts/run_train_text.sh:21, run_eval_needle.sh:17, "
-                         f"lwm/train.py:36): python -m lwm_amd.cli.train takes that flag as it is; here replace that ONE flag by\n"
-                         f"    --dtype='bf16'\n"
-                         f"and keep the rest of the command line; the run is then the reference's bf16 configuration "
-                         f"(BASELINE configs 2-5: bf16 operands, float32_logits=True), not its fp32 default.")
+        raise SystemExit(f"--dtype={name}: not supported -- there is no fp16 path (the kernels take bf16 operands with f32 "
+                         f"logits, softmax and accumulation, or float32 throughout).  The reference's launch scripts pass "
+                         f"--dtype='fp32' (scripts/run_train_text.sh:21, run_eval_needle.sh:17, lwm/train.py:36), which runs "
+                         f"as it is; for the headline path replace that ONE flag by\n    --dtype='bf16'\n"
+                         f"and keep the rest of the command line (BASELINE configs 2-5: bf16 operands, float32_logits=True).")
     return torch.bfloat16
 
 

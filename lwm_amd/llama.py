@@ -230,7 +230,12 @@ class LLaMAAttention(torch.nn.Module):
         n_sp, r_sp = sp_size_rank("sp")
         # the cache is sharded over "sp" (lwm/llama.py:454-467): every rank holds max_length/sp rows
         max_len, idx = ck.shape[1] * n_sp, int(cache["cache_index"])
-        if Q > 1 and n_sp == 1:
+        if xq.dtype == torch.float32 and n_sp > 1:
+            raise NotImplementedError("cached inference in float32 runs on one rank (the sharded decode / dense-mask kernels "
+                                      "take bf16 operands): --dtype=bf16, or mesh_dim without an sp axis")
+        # (float32 -- the reference's --dtype=fp32 -- takes the structured form for decode steps too: the f32 flavour of the
+        #  op evaluates `key <= cache_index + query AND attention_mask[key]` itself, there is no f32 dense-mask kernel)
+        if (Q > 1 or xq.dtype == torch.float32) and n_sp == 1:
             # prefill into the cache: the same mask, handed over as its structure (see
             # ringattention_inference) -- key tiles past cache_index + Q are never read
             cache["cache_index"] = concatenate_to_cache(ck, cv, xk.contiguous(), xv, idx, axis_name="sp")
@@ -401,6 +406,9 @@ class LLaMAForCausalLM(torch.nn.Module):
         B, S = input_ids.shape
         max_length = max_length or (S + max_new_tokens)
         dev = input_ids.device
+        if graph and self.dtype == torch.float32:
+            raise NotImplementedError("generate(graph=True) captures the bf16 decode kernels; a float32 model decodes eagerly "
+                                      "(graph=False) through the f32 flavour of the attention op")
         cache = self.init_cache(B, max_length, dev)
         ext = torch.ones(B, max_length, dtype=torch.int32, device=dev)
         if attention_mask is not None:

@@ -198,19 +198,22 @@ def attn_combine(o_parts, lse_parts, *, out=None, out_f32=None, lse=None, want_b
 
 
 def kv_cache_write(cache, src, *, dst_row0, src_row0=0, nrows=None):
-    """cache[:, dst_row0:dst_row0+nrows] = src[:, src_row0:src_row0+nrows] for (B,S,H,D) bf16
-    tensors whose (S,H,D) block is contiguous (lwm_kv_cache_write)."""
+    """cache[:, dst_row0:dst_row0+nrows] = src[:, src_row0:src_row0+nrows] for (B,S,H,D) bf16 -- or f32: the copy moves
+    bytes, a float row is two bf16-sized elements per value -- tensors whose (S,H,D) block is contiguous
+    (lwm_kv_cache_write)."""
     for n, t in (("cache", cache), ("src", src)):
-        if not t.is_cuda or t.dtype != torch.bfloat16 or t.dim() != 4 or not t[0].is_contiguous():
-            raise ValueError(f"{n}: expected bf16 (B,S,H,D) device tensor with contiguous (S,H,D)")
+        if not t.is_cuda or t.dtype not in (torch.bfloat16, torch.float32) or t.dtype != cache.dtype or t.dim() != 4 or \
+                not t[0].is_contiguous():
+            raise ValueError(f"{n}: expected bf16 / f32 (B,S,H,D) device tensors of one dtype with contiguous (S,H,D)")
     B, _, H, D = cache.shape
     if nrows is None:
         nrows = src.shape[1] - src_row0
     if dst_row0 < 0 or dst_row0 + nrows > cache.shape[1] or src_row0 + nrows > src.shape[1]:
         raise ValueError("kv_cache_write: row range out of bounds")
+    w = cache.element_size() // 2            # bf16-sized units per element
     L = lib()
-    _capi.check(L, L.lwm_kv_cache_write(cache.data_ptr(), src.data_ptr(), B, cache.stride(0), src.stride(0),
-                                        dst_row0, src_row0, nrows, H * D, _stream_ptr()),
+    _capi.check(L, L.lwm_kv_cache_write(cache.data_ptr(), src.data_ptr(), B, cache.stride(0) * w, src.stride(0) * w,
+                                        dst_row0, src_row0, nrows, H * D * w, _stream_ptr()),
                 "lwm_kv_cache_write")
     return cache
 

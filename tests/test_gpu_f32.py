@@ -244,3 +244,78 @@ def test_f32_cli_train_takes_the_reference_launchers_dtype():
                        "--train_dataset.json_dataset.seq_length=1024", "--train_dataset.json_dataset.batch_size=2",
                        "--optimizer.adamw_optimizer.lr=1e-3", "--optimizer.adamw_optimizer.lr_warmup_steps=1"])
     assert len(hist) == 3 and all(np.isfinite(h["loss"]) for h in hist) and 8.0 < hist[0]["loss"] < 13.0
+
+
+def test_f32_cached_generation_equals_the_uncached_model_and_the_cpu_reference():
+    """Cached inference in float32 on one rank (the inference launchers' --dtype='fp32', scripts/run_eval_needle.sh:17):
+    prefill into the KV cache and the one-token steps both run through the f32 training-op kernel with the mask handed over
+    as its structure (key <= cache_index + query AND attention_mask[key], lwm/llama.py:577-592), the cache is written by
+    lwm_kv_cache_write as bytes.  Every step's logits equal the CPU f32 reference model's logits at that position of the
+    final sequence (teacher forcing) to 1e-4 of their maximum; the greedy tokens are the reference's argmax; a left-padded
+    prompt works; generate(graph=True) says that it captures bf16 kernels."""
+    import torch
+    from lwm_amd.llama import LLaMAConfig, LLaMAForCausalLM
+    from oracle import llama_model_ref as M
+    cfg = LLaMAConfig(vocab_size=1024, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                      max_sequence_length=512)
+    torch.manual_seed(11)
+    model = LLaMAForCausalLM(cfg, torch.float32).cuda()
+    g = torch.Generator().manual_seed(12)
+    B, S, new = 2, 45, 6
+    prompt = torch.randint(3, cfg.vocab_size, (B, S), generator=g)
+    am = torch.ones(B, S, dtype=torch.int32)
+    am[1, :7] = 0                                        # row 1 is left-padded (lwm/vision_chat.py:136-140)
+    with torch.no_grad():
+        out, logits = model.generate(prompt.cuda(), am.cuda(), max_new_tokens=new, max_length=64, return_logits=True)
+    assert logits.dtype == torch.float32 and out.shape == (B, S + new)
+    st = {n_: p.detach().float().cpu() for n_, p in model.named_parameters()}
+    full_am = torch.cat([am, torch.ones(B, new, dtype=torch.int32)], 1)
+    with torch.no_grad():
+        ref = M.forward_logits(st, cfg, out.cpu(), full_am)          # positions are the mask's cumulative sum there too
+    for j in range(new):
+        r = ref[:, S - 1 + j]
+        assert (logits[:, j].cpu() - r).abs().max().item() <= 1e-4 * r.abs().max().item(), j
+        assert torch.equal(out[:, S + j].cpu(), r.argmax(-1)), j
+    with pytest.raises(NotImplementedError, match="bf16"):
+        model.generate(prompt.cuda(), am.cuda(), max_new_tokens=3, graph=True)
+
+
+def test_f32_vision_text_slice_matches_cpu_oracle():
+    """The vision-language harness (lwm/vision_llama.py: vte / wte choice, two heads, 0.5 * (vision CE + text CE),
+    lwm/train.py:183-202) in float32 against the CPU f32 oracle model: the bf16 test's case (tests/test_gpu_vision_llama.py)
+    at the f32 bound."""
+    import torch
+    from lwm_amd.vision_llama import VideoLLaMAConfig, VideoLLaMAForCausalLM
+    from oracle import llama_model_ref as M
+    from tests.test_gpu_vision_llama import _tokens_from_frames
+    cfg = VideoLLaMAConfig(vocab_size=2048, hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=4,
+                           max_sequence_length=4096, theta=1e7, scan_mlp=False)
+    toks, vmask, per = _tokens_from_frames(5, cfg.vocab_size, 3)
+    S = toks.shape[1] - 1
+    inp, tgt, ivm, tvm = toks[:, :-1], toks[:, 1:], vmask[:, :-1], vmask[:, 1:]
+    lm = (torch.rand(1, S, generator=torch.Generator().manual_seed(9)) > 0.1).float()
+    torch.manual_seed(0)
+    model = VideoLLaMAForCausalLM(cfg, torch.float32).cuda()
+    loss, met = model.loss(inp.cuda(), ivm.cuda(), tgt.cuda(), tvm.cuda(), lm.cuda(), chunk=512)
+    loss.backward()
+    st = {n_: p.detach().float().cpu().clone().requires_grad_(True) for n_, p in model.named_parameters()}
+    rl, rmet = M.vision_text_loss(st, cfg, inp, ivm, tgt, tvm, lm)
+    rl.backward()
+    assert abs(loss.item() - rl.item()) <= 2e-5 * abs(rl.item()), (loss.item(), rl.item())
+    for k in ("vision_loss", "text_loss"):
+        assert abs(met[k].item() - rmet[k].item()) <= 2e-5 * abs(rmet[k].item()), k
+    for n_, p in model.named_parameters():
+        a, b = p.grad.cpu().flatten().double(), st[n_].grad.flatten().double()
+        cos = float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-30))
+        assert cos >= 1 - 1e-5, (n_, cos)
+
+
+def test_f32_inference_entry_points_take_the_reference_launchers_dtype():
+    """python -m lwm_amd.cli.vision_chat / vision_generation --dtype=fp32 on the debug model: a few sampled tokens / one
+    frame of codes decoded, in float32 throughout."""
+    from lwm_amd.cli import vision_chat, vision_generation
+    small = ["--load_llama_config=debug", "--mesh_dim=1,-1,1,1", "--dtype=fp32", "--tokenizer=synthetic"]
+    ans = vision_chat.main(small + ["--prompt=What is the video about?", "--input_file=synthetic:2", "--max_n_frames=2",
+                                    "--update_llama_config=dict(sample_mode='text',max_sequence_length=2048,vocab_size=32000)"],
+                           max_new_tokens=4)
+    assert isinstance(ans, str)
