@@ -319,3 +319,46 @@ def test_f32_inference_entry_points_take_the_reference_launchers_dtype():
                                     "--update_llama_config=dict(sample_mode='text',max_sequence_length=2048,vocab_size=32000)"],
                            max_new_tokens=4)
     assert isinstance(ans, str)
+
+
+def test_every_row_of_the_headline_workload_bf16_against_the_f32_flavour():
+    """BASELINE configs[1] at FULL size -- S = 32768, 32 heads, causal -- where the fp64 oracle can only visit windows
+    (tests/test_gpu_attention.py): EVERY element of out, dq, dk, dv of the bf16 kernels is held to the float32 flavour of
+    the op on the same (bf16-valued) inputs -- another kernel, another matrix instruction, another data layout, itself
+    pinned to 1e-5 of the fp64 oracle above -- at the bf16 path's stated bounds (tests/_parity.py: 8e-3 of the tensor's
+    maximum, 2.5e-2 per row of its own scale, cosine 0.9999).  dq per row against the f32 gradient for the SAVED bf16
+    output (the residual the bf16 backward really has), as tests/_parity.py::check_dq does."""
+    import torch
+    from lwm_amd import ops
+    from tests._parity import COS, ROW_FLOOR, ROW_TOL, STATS, TOL
+    S, H = 32768, 32
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    q, k, v, do = (torch.randn(1, S, H, 128, device="cuda", generator=g).to(torch.bfloat16) for _ in range(4))
+    out, lse = ops.attn_fwd_block(q, k, v, causal=True)
+    delta = ops.attn_bwd_delta(out, do, lse)
+    dk, dv = ops.attn_bwd_dkdv_block(q, k, v, do, lse, delta, causal=True)
+    dq = ops.attn_bwd_dq_block(q, k, v, do, lse, delta, causal=True)
+    qf, kf, vf, dof = (t.float() for t in (q, k, v, do))
+    ro, rl = ops.attn_fwd_block(qf, kf, vf, causal=True)
+    assert (lse - rl).abs().max().item() <= 2e-3
+    rdelta = ops.attn_bwd_delta(ro, dof, rl)
+    rk, rv = ops.attn_bwd_dkdv_block(qf, kf, vf, dof, rl, rdelta, causal=True)
+    sdelta = ops.attn_bwd_delta(out.float(), dof, lse)          # the residual the bf16 backward has: its own saved output
+    rq_saved = ops.attn_bwd_dq_block(qf, kf, vf, dof, lse, sdelta, causal=True)
+    torch.cuda.synchronize()
+
+    def held(name, got, ref, row_tol=ROW_TOL, floor=ROW_FLOOR):
+        got = got.float()
+        gmax = ref.abs().max().clamp_min(1e-9)
+        diff = (got - ref).abs()
+        err = (diff.max() / gmax).item()
+        row = (diff.amax(-1) / torch.maximum(ref.abs().amax(-1), floor * gmax)).max().item()
+        cos = ((got.double() * ref.double()).sum() / (got.double().norm() * ref.double().norm()).clamp_min(1e-30)).item()
+        STATS.append((f"{name}(S=32768,every-row,vs-f32-flavour)", err, row, cos))     # -> gpurun_out/parity_stats.json
+        assert err <= TOL and row <= row_tol and cos >= COS, (name, err, row, cos)
+        return err, row
+
+    held("out", out, ro)
+    held("dk", dk, rk)
+    held("dv", dv, rv)
+    held("dq", dq, rq_saved)
