@@ -262,10 +262,12 @@ LWM_KERNEL(kX32Threads) void attn_fwd_f32_kernel(AttnParams p) {
         rs += xhalf(rs);
         l = l * alpha + rs;
         m = m_new;
+        if (wave_any(alpha != 1.0f)) {      // (a running maximum that did not move leaves alpha = 1 exactly: nothing to rescale)
 #pragma unroll
-        for (int db = 0; db < 4; ++db)
+            for (int db = 0; db < 4; ++db)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+                for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+        }
         x32_tileT_times_cd(lds + kX32TileBytes, s, o, l31, hi);                      // O^T += V^T P^T
     }
     block_sync();       // the tiles are dead: the epilogue reuses them

@@ -53,6 +53,11 @@ def test_stub_forward_and_conv_agree_with_the_package():
     ro, rl = ops.attn_fwd_block(q, k, v, causal=True, seg_q=seg, seg_k=seg)
     torch.cuda.synchronize()
     assert torch.equal(out, ro) and torch.equal(lse, rl)
+    # the float32 flavour of the stub == the package's dispatch on the operands' dtype
+    of, lf = ns["attn_fwd_one_block_f32"](q.float(), k.float(), v.float(), 0, 0)
+    rof, rlf = ops.attn_fwd_block(q.float(), k.float(), v.float(), causal=True)
+    torch.cuda.synchronize()
+    assert of.dtype == torch.float32 and torch.equal(of, rof) and torch.equal(lf, rlf)
     x = torch.randn(1, 16, 16, 32, generator=g).cuda()
     w = torch.randn(3, 3, 32, 64, generator=g).cuda() / 17
     b = torch.randn(64, generator=g).cuda()
