@@ -519,6 +519,13 @@ LWM_DEVICE void conv_patch_body(const ConvParams& p) {
                 for (int j = 0; j < NB; ++j)
                     bq[set][u][t][j] = global_load_f32_at(p.w, b_voff + (uint32_t)j * 128u, (uint32_t)(it * 32 + 4 * u + 2 * t) * b_rowb);
     };
+    auto load_b_quad = [&](int it, int set, int u) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                bq[set][u][t][j] = global_load_f32_at(p.w, b_voff + (uint32_t)j * 128u, (uint32_t)(it * 32 + 4 * u + 2 * t) * b_rowb);
+    };
     load_b(0, 0);
 
     conv_patch_fill<Cfg>(p, xb, ty0, tx0, wave, lane, lds);
@@ -551,10 +558,12 @@ LWM_DEVICE void conv_patch_body(const ConvParams& p) {
     auto tile = [&](int it, auto set_tag, auto pset_tag, auto first_tag, auto add_tag) {
         constexpr int SET = decltype(set_tag)::value, PSET = decltype(pset_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value != 0, ADD = decltype(add_tag)::value != 0;
-        if (it + 1 < nit) load_b(it + 1, SET ^ 1);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int as = u & 1;
+            // the next tile's B floats of k-quad u, requested beside this tile's k-quad u (a whole tile before their use):
+            // 2 NB loads per four MFMAs instead of a burst of 16 NB in front of the tile's first MFMA
+            if (it + 1 < nit) load_b_quad(it + 1, SET ^ 1, u);
             if (u + 1 < 8) load_a(it, u + 1, as ^ 1);
             else if (it + 1 < nit) load_a(it + 1, 0, as ^ 1);
             sched_fence();
