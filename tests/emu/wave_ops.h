@@ -355,6 +355,10 @@ LWM_DEVICE float global_load_f32_at(const float* base, uint32_t voff, uint32_t s
     memcpy(&v, (const char*)base + voff + soff, 4);
     return v;
 }
+LWM_DEVICE void global_store_f32_at(float* base, uint32_t voff, uint32_t soff, float v) {
+    memcpy((char*)base + voff + soff, &v, 4);
+}
+LWM_DEVICE void wave_priority(int) {}
 LWM_DEVICE float uniform_load_f32(const float* p, int idx) { return p[idx]; }
 LWM_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
     union { bf16_t h[2]; uint32_t u; } x;

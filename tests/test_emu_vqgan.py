@@ -95,6 +95,23 @@ def test_conv_patch_resident_random_shapes(seed):
     assert np.array_equal(_emu.conv2d(x, w, b, residual=res, **kw), R.conv2d(x, w, b, residual=res, **kw)), (B, H, W, Cin, Cout, up)
 
 
+@pytest.mark.parametrize("cus", [3, 5])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,kw", [
+    (2, 16, 32, 128, 256, {}),                    # 8 pixel tiles of 8x16 x 2 channel tiles
+    (1, 8, 16, 256, 256, dict(up_shift=1)),       # 8 tiles of 4x16, Upsample folded in
+])
+def test_conv_patch_persistent_walk(monkeypatch, cus, B, H, W, Cin, Cout, kw):
+    """The patch kernels are persistent: one workgroup per CU walks the tiles blockIdx, blockIdx + gridDim, ...; the next
+    tile's patch is requested before the current tile's results are written.  On a machine of 3 or 5 CUs a workgroup
+    takes several tiles (ragged counts included), with and without the residual operand: bit-identical to the oracle."""
+    monkeypatch.setenv("LWM_EMU_CUS", str(cus))
+    x, w, b = _conv_case(21, B, H, W, Cin, Cout, 3)
+    up = kw.get("up_shift", 0)
+    res = _rng(22).standard_normal((B, H << up, W << up, Cout)).astype(np.float32)
+    assert np.array_equal(_emu.conv2d(x, w, b, residual=res, **kw), R.conv2d(x, w, b, residual=res, **kw))
+    assert np.array_equal(_emu.conv2d(x, w, b, **kw), R.conv2d(x, w, b, **kw))
+
+
 def test_conv_patch_resident_is_what_runs(capfd, monkeypatch):
     """The dispatch really takes the patch kernels for these shapes (the emulation traces its launches)."""
     monkeypatch.setenv("LWM_EMU_TRACE", "1")
@@ -107,6 +124,10 @@ def test_conv_patch_resident_is_what_runs(capfd, monkeypatch):
     err = capfd.readouterr().err
     names = [l.split()[1] for l in err.splitlines() if l.startswith("emu-launch")]
     assert names[0] == "conv_patch_c128" and names[1] == "conv_patch_c256" and names[2].startswith("conv_igemm"), names
+    x, w, b = _conv_case(14, 1, 32, 48, 128, 128, 3)     # with the residual operand: the form that prefetches it
+    _emu.conv2d(x, w, b, residual=np.zeros((1, 32, 48, 128), np.float32))
+    err = capfd.readouterr().err
+    assert [l.split()[1] for l in err.splitlines() if l.startswith("emu-launch")] == ["conv_patch_c128_res"]
 
 
 def test_conv_patch_resident_no_bias_clip():
