@@ -65,44 +65,17 @@ struct ConvCfg {
 template <int N>
 struct IntTag { static constexpr int value = N; };
 
-// A operand of one f32 MFMA: lane half hi supplies k = hi of the k pair, i.e. element 2t + hi of the lane's channel
-// quad.  Written as `hi ? q[2t+1] : q[2t]` hipcc turns it into a dynamic vector index and lowers that to a chain of
-// three v_cndmask (+ compares) per element; a bitfield insert under a lane mask the compiler cannot see through is one
-// v_bfi_b32.
-struct HiMask { uint32_t m; };
-LWM_DEVICE HiMask hi_mask(int hi) {
-    HiMask h = {hi ? 0xffffffffu : 0u};
-#ifndef LWM_EMU
-    asm volatile("" : "+v"(h.m));
-#endif
-    return h;
+// The A operands of one k-quad.  MFMA t of the quad (k pair 2t, 2t + 1) takes, from lane half hi, element 2t + hi of the
+// lane's channel quad: the two dwords hi and hi + 2 of the quad's 16 bytes -- ONE ds_read2_b32 (offset1 = 2), no vector
+// instruction.  Rounds 3-6 read the whole quad (ds_read_b128) and picked with two v_bfi_b32 per quad: those two VALU
+// instructions among the MFMAs held every convolution kernel at 0.89-0.94 of the matrix rate in its main loop; a k-quad
+// with the same requests and NO vector instruction runs at 0.988, one wave per SIMD or two
+// (scripts/micro/mfma_aux_rate.cpp, profiles/r06_conv_persistent.md).  A dword read reaches only the 8 banks of its position
+// in the quad (4-way conflicts: 16 LDS cycles per instruction instead of 4, a quarter of the LDS's time at 8 waves per CU).
+LWM_DEVICE void a_pair(float& t0, float& t1, lds_t quad, int hi) {
+    t0 = lds_read_f32(quad + (uint32_t)hi * 4u);
+    t1 = lds_read_f32(quad + (uint32_t)hi * 4u + 8u);
 }
-LWM_DEVICE float pick_hi(float even, float odd, HiMask h) {
-    return __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, odd) & h.m) | (__builtin_bit_cast(uint32_t, even) & ~h.m));
-}
-// All picks of one k-quad (MFMA t = 0, 1 x the wave's MB pixel blocks) as v_bfi_b32 -- hipcc splits the C form above
-// into v_and + v_and_or once the inverted mask is hoisted.  The statement ends with two wait states: hipcc does not
-// know that an asm statement is a VALU write, so it would not keep the matrix pipe's read of these registers apart
-// from it (measured: wrong sums without the s_nop).
-template <int MB>
-LWM_DEVICE void pick_quad(float (&af)[2][MB], const f32x4 (&q)[MB], HiMask h) {
-#ifdef LWM_EMU
-    for (int t = 0; t < 2; ++t)
-        for (int i = 0; i < MB; ++i) af[t][i] = pick_hi(q[i][2 * t], q[i][2 * t + 1], h);
-#else
-    static_assert(MB == 1 || MB == 2, "pick_quad");
-    if constexpr (MB == 1) {
-        asm("v_bfi_b32 %0, %2, %4, %3\n\tv_bfi_b32 %1, %2, %6, %5\n\ts_nop 1"
-            : "=&v"(af[0][0]), "=&v"(af[1][0])
-            : "v"(h.m), "v"(q[0][0]), "v"(q[0][1]), "v"(q[0][2]), "v"(q[0][3]));
-    } else {
-        asm("v_bfi_b32 %0, %4, %6, %5\n\tv_bfi_b32 %1, %4, %10, %9\n\tv_bfi_b32 %2, %4, %8, %7\n\tv_bfi_b32 %3, %4, %12, %11\n\ts_nop 1"
-            : "=&v"(af[0][0]), "=&v"(af[0][1]), "=&v"(af[1][0]), "=&v"(af[1][1])
-            : "v"(h.m), "v"(q[0][0]), "v"(q[0][1]), "v"(q[0][2]), "v"(q[0][3]), "v"(q[1][0]), "v"(q[1][1]), "v"(q[1][2]), "v"(q[1][3]));
-    }
-#endif
-}
-
 
 LWM_DEVICE f32x4 zero_f32x4() {
     f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -126,7 +99,8 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
     const int tid = thread_idx();
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const HiMask hm = hi_mask(hi);
+    // A operands of one k-quad for pixel block i: elements hi and 2 + hi of the lane's channel quad at `quad` (see a_pair)
+    auto a_frag = [&](float (&dst)[2][MB], int i, lds_t quad) { a_pair(dst[0][i], dst[1][i], quad, hi); };
 
     const int ntn = (p.Cout + BN - 1) / BN;
     const int64_t bm = block_idx_x() / ntn;
@@ -293,9 +267,9 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
         // longer read by anyone -- and the last k-quad requests the first fragment of chunk it+1: no LDS latency is
         // exposed at a chunk boundary, no ds_write waits for a load.
         constexpr uint32_t AB = Cfg::A_BYTES;
-        f32x4 ar[2][MB];
+        float afr[2][2][MB];      // [set][t][i]: the A operands straight from LDS (see a_frag)
         auto load_a = [&](uint32_t bo, int u, int set) {
-            for (int i = 0; i < MB; ++i) ar[set][i] = lds_read_f32x4(a_r[i] + bo + ((u ^ a_sw[i]) << 4));
+            for (int i = 0; i < MB; ++i) a_frag(afr[set], i, a_r[i] + bo + ((u ^ a_sw[i]) << 4));
         };
         stage_load(0);
         stage_write(0);
@@ -315,13 +289,11 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
                 else load_a(more ? nxt : cur, 0, set ^ 1);
                 if ((u & 1) == 0) load_b(u == 6 ? (more ? it + 1 : it) : it, ((u >> 1) + 1) & 3);
                 sched_fence();  // keep the prefetch ABOVE this k-quad's MFMAs (hipcc sinks it otherwise)
-                float af[2][MB];
-                pick_quad<MB>(af, ar[set], hm);
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
                     for (int i = 0; i < MB; ++i)
                         for (int j = 0; j < NB; ++j)
-                            acc_tap[i][j] = mfma_32x32x2_f32(af[t][i], bq[(u >> 1) & 1][u & 1][t][j], acc_tap[i][j]);
+                            acc_tap[i][j] = mfma_32x32x2_f32(afr[set][t][i], bq[(u >> 1) & 1][u & 1][t][j], acc_tap[i][j]);
                 sched_fence();
                 if (u == 3) block_sync_lds();
             }
@@ -349,10 +321,10 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
         if (more) stage_load(it + 1);
         const uint32_t bo = (uint32_t)buf * Cfg::BUF_BYTES;
         // fragments of k-quad u+1 are fetched while the MFMAs of k-quad u run
-        f32x4 ar[2][MB];
+        float afr[2][2][MB];
         float bf[2][2][NB];
         auto load_frag = [&](int u, int set) {
-            for (int i = 0; i < MB; ++i) ar[set][i] = lds_read_f32x4(a_r[i] + bo + ((u ^ a_sw[i]) << 4));
+            for (int i = 0; i < MB; ++i) a_frag(afr[set], i, a_r[i] + bo + ((u ^ a_sw[i]) << 4));
             for (int t = 0; t < 2; ++t)
                 for (int j = 0; j < NB; ++j)
                     bf[set][t][j] = lds_read_f32(b_r + bo + (uint32_t)((4 * u + 2 * t) * BN + j * 32) * 4);
@@ -363,13 +335,11 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
             const int set = u & 1;
             if (u + 1 < 8) load_frag(u + 1, set ^ 1);
             sched_fence();  // keep the prefetch ABOVE this k-quad's MFMAs (hipcc sinks it otherwise)
-            float af[2][MB];
-            pick_quad<MB>(af, ar[set], hm);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
                 for (int i = 0; i < MB; ++i)
                     for (int j = 0; j < NB; ++j)
-                        acc_tap[i][j] = mfma_32x32x2_f32(af[t][i], bf[set][t][j], acc_tap[i][j]);
+                        acc_tap[i][j] = mfma_32x32x2_f32(afr[set][t][i], bf[set][t][j], acc_tap[i][j]);
             sched_fence();
         }
         if ((it + 1) % nch == 0) {  // tap finished: s = s + P_t
@@ -571,7 +541,6 @@ LWM_DEVICE void conv_patch_body(const ConvParams& p) {
     const int tid = thread_idx();
     const int wave = wave_uniform(tid >> 6), lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const HiMask hm = hi_mask(hi);
 
     // Persistent: the grid is one workgroup per CU and a workgroup walks the tiles blockIdx, blockIdx + gridDim, ... --
     // a workgroup of this size (92 - 108 KiB of LDS, 8 waves) has the CU to itself, and between the exit of one and the entry
@@ -633,14 +602,15 @@ LWM_DEVICE void conv_patch_body(const ConvParams& p) {
         asm volatile("" : "+v"(pp0[i]));     // (per tile: hoisted out of the tile loop, the swizzled fragment addresses of all (chunk, k-quad)s spill)
 #endif
     }
-    f32x4 ar[2][MB];
+    // (the A operands come straight from LDS: a_pair)
+    float af[2][2][MB];                                 // [quad parity][t][i]
     auto load_a = [&](int it, int u, int set) {        // k-quad u of tile `it`
         const int tap = it / NCH, ch = it - tap * NCH;
         const int kh = tap / 3, kw = tap - kh * 3;
         const int tapoff = kh * PW + kw;
         for (int i = 0; i < MB; ++i) {
             const int pp = pp0[i] + tapoff;
-            ar[set][i] = lds_read_f32x4(lds + (uint32_t)pp * Cfg::ROWB + (uint32_t)(((ch * 8 + u) ^ ((l31 + kw) & 15)) << 4));
+            a_pair(af[set][0][i], af[set][1][i], lds + (uint32_t)pp * Cfg::ROWB + (uint32_t)(((ch * 8 + u) ^ ((l31 + kw) & 15)) << 4), hi);
         }
     };
 
@@ -686,12 +656,10 @@ LWM_DEVICE void conv_patch_body(const ConvParams& p) {
     //
     // Issue order of a k-quad (a wave issues in order, and an MFMA holds the matrix pipe 64 cycles): every other instruction
     // sits BEHIND an MFMA of the quad, in its shadow -- the next quad's fragment read and half of the next tile's B requests
-    // behind the first, the other half behind the second, the previous tap's sum and the operand picks of the NEXT quad behind
-    // the third -- so that the next MFMA is the first thing the wave wants when the pipe falls free.  With all of them in front
+    // behind the first, the other half behind the second, the previous tap's sum behind the third -- so that the next MFMA is the first thing the wave wants when the pipe falls free.  With all of them in front
     // of the quad's four MFMAs (rounds 3-6) a wave needed ~100 cycles between its quads: a wave alone on its SIMD ran the loop
     // at 0.67 of the matrix rate, two at 0.91 (s_memtime stamps per wave, profiles/r06_conv_persistent.md).
     static_assert(MB == 1 && NB == 2, "the k-quad below is written out for four MFMAs");
-    float af[2][2][MB];                                 // [quad parity][t][i]
     auto tile = [&](int it, auto set_tag, auto pset_tag, auto first_tag, auto add_tag, auto tail_tag) {
         constexpr int SET = decltype(set_tag)::value, PSET = decltype(pset_tag)::value, TAIL = decltype(tail_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value != 0, ADD = decltype(add_tag)::value != 0, LAST = TAIL == kResTiles;
@@ -721,7 +689,6 @@ LWM_DEVICE void conv_patch_body(const ConvParams& p) {
 #pragma unroll
                     for (int r = 4 * (u - 2); r < 4 * (u - 2) + 4; ++r) acc[0][j][r] = acc[0][j][r] + pt[PSET ^ 1][0][j][r];
             }
-            if (!(LAST && u == 7)) pick_quad<MB>(af[ns], ar[ns], hm);
             sched_fence();
             pt[PSET][0][1] = mfma_32x32x2_f32(af[cs][1][0], bq[u % kBRing][1][1], pt[PSET][0][1]);
             sched_fence();
@@ -742,7 +709,6 @@ LWM_DEVICE void conv_patch_body(const ConvParams& p) {
         tile(tap * NCH + NCH - 1, IntTag<1>{}, pset_tag, IntTag<0>{}, IntTag<0>{}, IntTag<LASTTAP ? kResTiles : 0>{});
     };
     load_a(0, 0, 0);
-    pick_quad<MB>(af[0], ar[0], hm);
     tap_head(0, IntTag<0>{}, IntTag<0>{});
     tap_tail(0, IntTag<0>{}, IntTag<0>{});
     for (int tap = 1;; tap += 2) {
