@@ -33,6 +33,25 @@
 
 namespace lwm {
 
+#ifndef LWM_EMU      // (the host emulation has its own: tests/emu/wave_ops.h)
+// one float to base + voff + soff bytes (the store twin of global_load_f32_at)
+LWM_DEVICE void global_store_f32_at(float* base, uint32_t voff, uint32_t soff, float v) {
+    const uint64_t a = (uint64_t)base;
+    const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, (int)voff, (int)soff, 0);
+}
+
+// this wave's issue priority (0 .. 3), as it stands until the next call: s_setprio ignores EXEC, so a caller that wants it for
+// SOME waves branches on a wave-uniform condition
+LWM_DEVICE void wave_priority(int p) {
+    if (p) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
+
+#endif
+
 struct ConvParams {
     const float* x;
     const float* w;

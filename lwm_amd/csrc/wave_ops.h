@@ -168,13 +168,6 @@ LWM_DEVICE void prio_lo() {
     if (LWM_PRIO_MODE == 2) __builtin_amdgcn_s_setprio(1);
 }
 
-// this wave's issue priority (0 .. 3), as it stands until the next call: s_setprio ignores EXEC, so a caller that wants it for
-// SOME waves branches on a wave-uniform condition
-LWM_DEVICE void wave_priority(int p) {
-    if (p) __builtin_amdgcn_s_setprio(1);
-    else __builtin_amdgcn_s_setprio(0);
-}
-
 // value held by lane (l ^ 32)
 LWM_DEVICE float xhalf(float x) {
     return __shfl_xor(x, 32, 64);
@@ -215,15 +208,6 @@ LWM_DEVICE float global_load_f32_at(const float* base, uint32_t voff, uint32_t s
                        (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
     __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, 0x7fffffff, 0x00020000);
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
-}
-
-// one float to base + voff + soff bytes (the store twin of global_load_f32_at)
-LWM_DEVICE void global_store_f32_at(float* base, uint32_t voff, uint32_t soff, float v) {
-    const uint64_t a = (uint64_t)base;
-    const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
-                       (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
-    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, 0x7fffffff, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, (int)voff, (int)soff, 0);
 }
 
 // a float every lane of the wave reads from the same address of read-only memory: a scalar load (s_load_dword, the
