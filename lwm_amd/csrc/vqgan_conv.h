@@ -33,7 +33,7 @@
 
 namespace lwm {
 
-#ifndef LWM_EMU      // (the host emulation has its own: tests/emu/wave_ops.h)
+#ifndef LWM_EMU      // (the host emulation of the CPU tests brings its own)
 // one float to base + voff + soff bytes (the store twin of global_load_f32_at)
 LWM_DEVICE void global_store_f32_at(float* base, uint32_t voff, uint32_t soff, float v) {
     const uint64_t a = (uint64_t)base;
@@ -297,23 +297,55 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
         load_a(0, 0, 0);
         uint32_t cur = 0, nxt = AB, nn = 2 * AB;
         int in_tap = 0;
+        // Issue order of a k-quad, as in the patch kernels: every other instruction sits behind one of the quad's first four
+        // MFMAs -- the next quad's fragment reads behind the first, the two halves of a B request behind the second and third,
+        // ONE staging pass behind the fourth (quads 0-3: a ds_write of chunk it + 1, in front of the chunk's barrier; quads
+        // 4-7: a global load of chunk it + 2) -- instead of the whole staging burst in front of the chunk's first MFMA and each
+        // quad's requests in front of its eight: +2-4 % on every layer of this kernel (profiles/r06_conv_persistent.md).
+        static_assert(AP == 4 && MB == 2 && NB == 2, "the chunk below is written out for eight MFMAs per k-quad and four staging passes");
+        auto stage_write_one = [&](uint32_t bo, int ps) {
+            const int px = ps * Cfg::APX + (tid >> 3);
+            lds_write_f32x4(a_w + bo + (uint32_t)ps * Cfg::APX * 128 + ((a_slot ^ ((px >> 1) & 7)) << 4), (s_ok >> ps) & 1 ? sa[ps] : zero_f32x4());
+        };
+        auto load_b_half = [&](int itb, int pair, int u2) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    bq[pair & 1][u2][t][j] = global_load_f32_at(p.w, b_voff + (uint32_t)j * 128u, (uint32_t)(itb * 32 + 8 * pair + 4 * u2 + 2 * t) * b_rowb);
+        };
         for (int it = 0; it < nit; ++it) {
             const bool more = it + 1 < nit;
-            if (more) stage_write(nxt);
-            if (it + 2 < nit) stage_load(it + 2);
+            const bool more2 = it + 2 < nit;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int set = u & 1;
-                if (u + 1 < 8) load_a(cur, u + 1, set ^ 1);
-                else load_a(more ? nxt : cur, 0, set ^ 1);
-                if ((u & 1) == 0) load_b(u == 6 ? (more ? it + 1 : it) : it, ((u >> 1) + 1) & 3);
-                sched_fence();  // keep the prefetch ABOVE this k-quad's MFMAs (hipcc sinks it otherwise)
+                const int itb = u == 6 ? (more ? it + 1 : it) : it, pair = ((u >> 1) + 1) & 3;
+                int k = 0;
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
+#pragma unroll
                     for (int i = 0; i < MB; ++i)
-                        for (int j = 0; j < NB; ++j)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j, ++k) {
                             acc_tap[i][j] = mfma_32x32x2_f32(afr[set][t][i], bq[(u >> 1) & 1][u & 1][t][j], acc_tap[i][j]);
-                sched_fence();
+                            sched_fence();
+                            if (k == 0) {
+                                if (u + 1 < 8) load_a(cur, u + 1, set ^ 1);
+                                else load_a(more ? nxt : cur, 0, set ^ 1);
+                            }
+                            if (k == 1 && (u & 1) == 0) load_b_half(itb, pair, 0);
+                            if (k == 2 && (u & 1) == 0) load_b_half(itb, pair, 1);
+                            if (k == 3) {
+                                if (u < 4) { if (more) stage_write_one(nxt, u); }
+                                else if (more2) {
+                                    if (u == 4) stage_begin(it + 2);
+                                    stage_load_one(u - 4);
+                                    if (u == 7) stage_end();
+                                }
+                            }
+                            if (k < 4) sched_fence();
+                        }
                 if (u == 3) block_sync_lds();
             }
             if (++in_tap == nch) {  // tap finished: s = s + P_t
