@@ -532,12 +532,13 @@ struct PatchCfg {
     static constexpr int BM = TH * TW, BN = 32 * NB * WN;
     static constexpr int MB = BM / (32 * WM);          // 32-pixel blocks per wave
     static constexpr int PW = TW + 2, PH = TH + 2, PPX = PH * PW;
-    static constexpr int ROWB = CIN * 4;               // bytes per patch pixel
-    static constexpr int SPP = CIN / 4;                // 16-byte slots per pixel
-    static constexpr int LDS_BYTES = PPX * ROWB;
-    static constexpr int NINS = PPX * SPP / 64;        // patch DMA wave-instructions
+    static constexpr int ROWB = CIN * 4;               // bytes of channels per patch pixel
+    static constexpr int SPP = CIN / 4;                // 16-byte channel slots per pixel
+    static constexpr int RS = ROWB + 16;               // LDS stride of a patch pixel: its channels + one unused 16-byte slot
+    static constexpr int NINS = (PPX * (SPP + 1) + 63) / 64;   // patch DMA wave-instructions (1 KiB of the LDS image each)
+    static constexpr int LDS_BYTES = NINS * 1024;
     static constexpr int NCH = CIN / kConvKC;
-    static_assert(BM % (32 * WM) == 0 && (PPX * SPP) % 64 == 0 && SPP >= 16 && LDS_BYTES <= 160 * 1024, "patch shape");
+    static_assert(BM % (32 * WM) == 0 && SPP >= 16 && SPP <= 64 && LDS_BYTES <= 160 * 1024, "patch shape");
     static_assert((NINS + NW - 1) / NW <= 32, "zero-fill mask is 32 bits");
     static_assert(NCH % 2 == 0, "the chunk loop is unrolled by two");
 };
@@ -558,10 +559,11 @@ LWM_DEVICE uint32_t conv_patch_request(const ConvParams& p, const float* xb, int
     asm volatile("" : "+v"(lane));
 #endif
     for (int k = 0; k * NW + wave < Cfg::NINS; ++k) {
-        const int g = (k * NW + wave) * 64 + lane;     // 16-byte slot of the patch image
-        const int pp = g / Cfg::SPP, q = g - pp * Cfg::SPP;
+        const int g = (k * NW + wave) * 64 + lane;     // 16-byte slot of the LDS image: pixel g / (SPP + 1), channel slot g % (SPP + 1)
+        const int ppr = g / (Cfg::SPP + 1), qr = g - ppr * (Cfg::SPP + 1);
+        const int pp = ppr < Cfg::PPX ? ppr : Cfg::PPX - 1;                 // (past the image's last pixel: the tail of the last DMA instruction)
+        const int lslot = qr < Cfg::SPP ? qr : 0;                           // (the unused slot of a pixel fetches its first one)
         const int py = pp / PW, px = pp - py * PW;
-        const int lslot = q ^ (px & 15);
         const int vy = ty0 + py - 1, vx = tx0 + px - 1;
         const bool ok = vy >= 0 && vy < Hv && vx >= 0 && vx < Wv;
         const int sy = ok ? (vy >> p.up_shift) : 0, sx = ok ? (vx >> p.up_shift) : 0;
@@ -655,13 +657,19 @@ LWM_DEVICE void conv_patch_body(const ConvParams& p) {
     }
     // (the A operands come straight from LDS: a_pair)
     float af[2][2][MB];                                 // [quad parity][t][i]
-    auto load_a = [&](int it, int u, int set) {        // k-quad u of tile `it`
-        const int tap = it / NCH, ch = it - tap * NCH;
+    // (channel quad q of a pixel sits at pixel * RS + 16 q: within a tap every fragment address is the tap's lane base + an
+    //  IMMEDIATE -- ds_read2_b32 offset0 = 4 q, offset1 = 4 q + 2 -- and no vector instruction computes an address inside a
+    //  (tap, chunk).  The 16-byte pad per pixel row does what the XOR swizzle of rounds 2-6 did: pixel p, quad q lands on banks
+    //  4 ((p + q) mod 8) + hi -- the same 4-way pattern a dword read of one quad position cannot avoid.)
+    lds_t a_tap[MB];                                    // the lane's fragment base of the current tap
+    auto set_tap = [&](int tap) {
         const int kh = tap / 3, kw = tap - kh * 3;
-        const int tapoff = kh * PW + kw;
+        for (int i = 0; i < MB; ++i) a_tap[i] = opaque(lds + (uint32_t)(pp0[i] + kh * PW + kw) * Cfg::RS + (uint32_t)hi * 4u);
+    };
+    auto load_a = [&](int ch, int u, int set) {        // k-quad u of chunk ch of the tap set_tap() was last called for
         for (int i = 0; i < MB; ++i) {
-            const int pp = pp0[i] + tapoff;
-            a_pair(af[set][0][i], af[set][1][i], lds + (uint32_t)pp * Cfg::ROWB + (uint32_t)(((ch * 8 + u) ^ ((l31 + kw) & 15)) << 4), hi);
+            af[set][0][i] = lds_read_f32(a_tap[i] + (uint32_t)(ch * 8 + u) * 16u);
+            af[set][1][i] = lds_read_f32(a_tap[i] + (uint32_t)(ch * 8 + u) * 16u + 8u);
         }
     };
 
@@ -711,9 +719,11 @@ LWM_DEVICE void conv_patch_body(const ConvParams& p) {
     // of the quad's four MFMAs (rounds 3-6) a wave needed ~100 cycles between its quads: a wave alone on its SIMD ran the loop
     // at 0.67 of the matrix rate, two at 0.91 (s_memtime stamps per wave, profiles/r06_conv_persistent.md).
     static_assert(MB == 1 && NB == 2, "the k-quad below is written out for four MFMAs");
-    auto tile = [&](int it, auto set_tag, auto pset_tag, auto first_tag, auto add_tag, auto tail_tag) {
-        constexpr int SET = decltype(set_tag)::value, PSET = decltype(pset_tag)::value, TAIL = decltype(tail_tag)::value;
-        constexpr bool FIRST = decltype(first_tag)::value != 0, ADD = decltype(add_tag)::value != 0, LAST = TAIL == kResTiles;
+    // CH: the chunk of the tap (compile time: the fragment offsets are immediates); PSET: P_t tile; ADD: s = s + P_{t-1} rides along
+    auto tile = [&](int tap, auto ch_tag, auto pset_tag, auto add_tag, auto tail_tag) {
+        constexpr int CH = decltype(ch_tag)::value, PSET = decltype(pset_tag)::value, TAIL = decltype(tail_tag)::value;
+        constexpr bool FIRST = CH == 0, ADD = decltype(add_tag)::value != 0 && CH == 0, LAST = TAIL == kResTiles;
+        const int it = tap * NCH + CH;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int cs = u & 1, ns = cs ^ 1;
@@ -724,8 +734,13 @@ LWM_DEVICE void conv_patch_body(const ConvParams& p) {
             };
             pt[PSET][0][0] = mfma_32x32x2_f32(af[cs][0][0], bq[u % kBRing][0][0], z ? zero_f32x16() : pt[PSET][0][0]);
             sched_fence();
-            if (u + 1 < 8) load_a(it, u + 1, ns);
-            else if constexpr (!LAST) load_a(it + 1, 0, ns);
+            if (u + 1 < 8) load_a(CH, u + 1, ns);
+            else if constexpr (!LAST) {
+                if constexpr (CH + 1 == NCH) {          // (the tap's last quad: its own fragment is in registers already)
+                    set_tap(tap + 1);
+                    load_a(0, 0, ns);
+                } else load_a(CH + 1, 0, ns);
+            }
             request(0);
             sched_fence();
             pt[PSET][0][1] = mfma_32x32x2_f32(af[cs][0][0], bq[u % kBRing][0][1], z ? zero_f32x16() : pt[PSET][0][1]);
@@ -745,20 +760,24 @@ LWM_DEVICE void conv_patch_body(const ConvParams& p) {
             sched_fence();
         }
     };
-    // one tap = NCH (tap, chunk)s, B register sets alternating 0, 1 (NCH is even): all but the last two, then those
+    // one tap = NCH (tap, chunk)s: all but the last two, then those (every chunk index a compile-time constant)
     auto tap_head = [&](int tap, auto pset_tag, auto add_tag) {
-        tile(tap * NCH, IntTag<0>{}, pset_tag, IntTag<1>{}, add_tag, IntTag<0>{});
-        tile(tap * NCH + 1, IntTag<1>{}, pset_tag, IntTag<0>{}, IntTag<0>{}, IntTag<0>{});
-        for (int ch = 2; ch < NCH - 2; ch += 2) {
-            tile(tap * NCH + ch, IntTag<0>{}, pset_tag, IntTag<0>{}, IntTag<0>{}, IntTag<0>{});
-            tile(tap * NCH + ch + 1, IntTag<1>{}, pset_tag, IntTag<0>{}, IntTag<0>{}, IntTag<0>{});
+        tile(tap, IntTag<0>{}, pset_tag, add_tag, IntTag<0>{});
+        tile(tap, IntTag<1>{}, pset_tag, add_tag, IntTag<0>{});
+        if constexpr (NCH > 4) {
+            static_assert(NCH == 4 || NCH == 8, "chunks 2 .. NCH - 3 are written out");
+            tile(tap, IntTag<2>{}, pset_tag, add_tag, IntTag<0>{});
+            tile(tap, IntTag<3>{}, pset_tag, add_tag, IntTag<0>{});
+            tile(tap, IntTag<4>{}, pset_tag, add_tag, IntTag<0>{});
+            tile(tap, IntTag<5>{}, pset_tag, add_tag, IntTag<0>{});
         }
     };
     auto tap_tail = [&](int tap, auto pset_tag, auto lasttap_tag) {      // LASTTAP: the kernel's last tap (8)
         constexpr bool LASTTAP = decltype(lasttap_tag)::value != 0;
-        tile(tap * NCH + NCH - 2, IntTag<0>{}, pset_tag, IntTag<0>{}, IntTag<0>{}, IntTag<(LASTTAP && kResTiles == 2) ? 1 : 0>{});
-        tile(tap * NCH + NCH - 1, IntTag<1>{}, pset_tag, IntTag<0>{}, IntTag<0>{}, IntTag<LASTTAP ? kResTiles : 0>{});
+        tile(tap, IntTag<NCH - 2>{}, pset_tag, IntTag<0>{}, IntTag<(LASTTAP && kResTiles == 2) ? 1 : 0>{});
+        tile(tap, IntTag<NCH - 1>{}, pset_tag, IntTag<0>{}, IntTag<LASTTAP ? kResTiles : 0>{});
     };
+    set_tap(0);
     load_a(0, 0, 0);
     tap_head(0, IntTag<0>{}, IntTag<0>{});
     tap_tail(0, IntTag<0>{}, IntTag<0>{});
@@ -958,14 +977,13 @@ LWM_DEVICE void conv_patch_cout_body(const ConvParams& p) {
         const int kh = tap / 3, kw = tap - 3 * kh;
         const int pp = pp0 + kh * PC::PW + kw;
         const float* wt = p.w + (int64_t)tap * CIN * COUT;          // wave-uniform
-        const lds_t row = lds + (uint32_t)pp * PC::ROWB;
-        const int sw = (lane % PC::TW + kw) & 15;
+        const lds_t row = lds + (uint32_t)pp * PC::RS;
         float s[COUT];
 #pragma unroll
         for (int co = 0; co < COUT; ++co) s[co] = 0.0f;
 #pragma unroll
         for (int q = 0; q < CIN / 4; ++q) {
-            const f32x4 a = lds_read_f32x4(row + (uint32_t)((q ^ sw) << 4));
+            const f32x4 a = lds_read_f32x4(row + (uint32_t)(q << 4));
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
