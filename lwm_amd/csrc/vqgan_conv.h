@@ -19,16 +19,13 @@
 // Workgroup = 256 threads = WM x WN waves; wave tile = (32*MB) pixels x (32*NB)
 // channels = MB*NB accumulators; K is walked in chunks of 32 input channels of
 // one tap, double buffered through LDS:
-//   A tile [BM pixels][32 cin] f32, 128-B rows, 16-B slot s of row r stored at
-//     slot s ^ ((r>>1)&7): a ds_read_b128 lane group (16 distinct r mod 16) then
-//     covers all 16 slots of a 256-B bank row -> conflict-free; the staging
+//   A tile [BM pixels][32 cin] f32, rows of 128 + 16 bytes (see "The A operands of one k-quad" below); the staging
 //     ds_write_b128 (8 lanes = one row) is a contiguous 128 B.
 //   B tile [32 cin][BN cout] f32, linear; fragments are ds_read_b32 rows
 //     (32 consecutive floats per half-wave) -> conflict-free.
-// A fragment: lane (i, hi) reads 4 consecutive cin of pixel i and feeds
-// k-pair (4u+2t, 4u+2t+1) with element 2t+hi, so c_in is consumed in natural
-// order.  This kernel is MFMA-bound (64 cycles per instruction per SIMD, 157 TF
-// chip peak); LDS and L2 traffic are far below their limits by construction.
+// A fragment: lane (i, hi) reads elements hi and 2 + hi of 4 consecutive cin of pixel i and feeds k-pair (4u+2t, 4u+2t+1)
+// with element 2t+hi, so c_in is consumed in natural order.  This kernel is MFMA-bound (64 cycles per instruction per SIMD,
+// 157 TF chip peak); LDS and L2 traffic are far below their limits by construction.
 #pragma once
 
 namespace lwm {
@@ -69,7 +66,8 @@ struct ConvCfg {
     static constexpr int NT = 64 * WM * WN;
     static constexpr int BM = 32 * MB * WM;
     static constexpr int BN = 32 * NB * WN;
-    static constexpr int A_BYTES = BM * kConvKC * 4;
+    static constexpr int A_ROW = kConvKC * 4 + 16;   // LDS stride of a staged pixel: its 32 channels + one unused 16-byte slot
+    static constexpr int A_BYTES = BM * A_ROW;
     static constexpr int B_BYTES = kConvKC * BN * 4;
     static constexpr int BUF_BYTES = A_BYTES + B_BYTES;
     static constexpr int LDS_BYTES = 2 * BUF_BYTES;
@@ -85,16 +83,14 @@ template <int N>
 struct IntTag { static constexpr int value = N; };
 
 // The A operands of one k-quad.  MFMA t of the quad (k pair 2t, 2t + 1) takes, from lane half hi, element 2t + hi of the
-// lane's channel quad: the two dwords hi and hi + 2 of the quad's 16 bytes -- ONE ds_read2_b32 (offset1 = 2), no vector
-// instruction.  Rounds 3-6 read the whole quad (ds_read_b128) and picked with two v_bfi_b32 per quad: those two VALU
-// instructions among the MFMAs held every convolution kernel at 0.89-0.94 of the matrix rate in its main loop; a k-quad
-// with the same requests and NO vector instruction runs at 0.988, one wave per SIMD or two
-// (scripts/micro/mfma_aux_rate.cpp, profiles/r06_conv_persistent.md).  A dword read reaches only the 8 banks of its position
-// in the quad (4-way conflicts: 16 LDS cycles per instruction instead of 4, a quarter of the LDS's time at 8 waves per CU).
-LWM_DEVICE void a_pair(float& t0, float& t1, lds_t quad, int hi) {
-    t0 = lds_read_f32(quad + (uint32_t)hi * 4u);
-    t1 = lds_read_f32(quad + (uint32_t)hi * 4u + 8u);
-}
+// lane's channel quad: the two dwords hi and hi + 2 of the quad's 16 bytes -- ONE ds_read2_b32 (offset1 = offset0 + 2), no
+// vector instruction.  Rounds 3-6 read the whole quad (ds_read_b128) and picked the two with v_bfi_b32: those two VALU
+// instructions per quad, whose results an MFMA reads, held every convolution loop at 0.89-0.94 of the matrix rate; a k-quad
+// with the same requests and NO vector instruction runs at 0.99, one wave per SIMD or two (scripts/micro/mfma_aux_rate.cpp,
+// profiles/r06_conv_persistent.md).  The address is a lane base that changes per tap (patch kernels) or per chunk (staged
+// kernels) plus an immediate: pixel rows carry one unused 16-byte slot (stride = channels * 4 + 16), which spreads pixel p,
+// quad q over banks 4 ((p + q) mod 8) + hi.  A dword read reaches only the 8 banks of its position in the quad: 4-way
+// conflicts, 16 LDS cycles per instruction, a quarter of the LDS's time at 8 waves per CU -- measured free.
 
 LWM_DEVICE f32x4 zero_f32x4() {
     f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -118,9 +114,6 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
     const int tid = thread_idx();
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    // A operands of one k-quad for pixel block i: elements hi and 2 + hi of the lane's channel quad at `quad` (see a_pair)
-    auto a_frag = [&](float (&dst)[2][MB], int i, lds_t quad) { a_pair(dst[0][i], dst[1][i], quad, hi); };
-
     const int ntn = (p.Cout + BN - 1) / BN;
     const int64_t bm = block_idx_x() / ntn;
     const int bn = block_idx_x() % ntn;
@@ -146,7 +139,7 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
             a_base[ps] = -1;
         }
     }
-    const lds_t a_w = lds + (uint32_t)(tid >> 3) * 128;  // + pass*APX*128 + swizzled slot
+    const lds_t a_w = lds + (uint32_t)(tid >> 3) * Cfg::A_ROW + (uint32_t)(a_slot << 4);  // + pass * APX * A_ROW
     const int b_row = tid / (BN / 4);
     const int b_col = (tid % (BN / 4)) * 4;
     const lds_t b_w = lds + Cfg::A_BYTES + (uint32_t)(b_row * BN + b_col) * 4;
@@ -237,8 +230,7 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
     auto stage_write = [&](uint32_t bo) {       // bo = byte offset of the buffer
         for (int ps = 0; ps < AP; ++ps) {
             const int px = ps * Cfg::APX + (tid >> 3);
-            lds_write_f32x4(a_w + bo + (uint32_t)ps * Cfg::APX * 128 + ((a_slot ^ ((px >> 1) & 7)) << 4),
-                            (s_ok >> ps) & 1 ? sa[ps] : zero_f32x4());
+            lds_write_f32x4(a_w + bo + (uint32_t)ps * Cfg::APX * Cfg::A_ROW, (s_ok >> ps) & 1 ? sa[ps] : zero_f32x4());
         }
         for (int ps = 0; ps < BP; ++ps)
             lds_write_f32x4(b_w + bo + (uint32_t)ps * Cfg::BROWS * BN * 4,
@@ -253,12 +245,13 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
         }
 
     // fragment addresses (buffer 0)
+    // (channel quad u of staged pixel px at px * A_ROW + 16 u: inside a chunk a fragment address is the chunk's lane base +
+    //  an immediate; the 16-byte pad per row spreads pixel px, quad u over banks 4 ((px + u) mod 8) + hi, as the XOR swizzle
+    //  of rounds 1-6 did -- the 4-way pattern a dword read of one quad position cannot avoid)
     uint32_t a_r[MB];
-    int a_sw[MB];
     for (int i = 0; i < MB; ++i) {
         const int px = (wm * MB + i) * 32 + l31;
-        a_r[i] = lds + (uint32_t)px * 128;
-        a_sw[i] = (px >> 1) & 7;
+        a_r[i] = lds + (uint32_t)px * Cfg::A_ROW + (uint32_t)hi * 4u;
     }
     const lds_t b_r = lds + Cfg::A_BYTES + (uint32_t)(hi * BN + wn * NB * 32 + l31) * 4;
 
@@ -286,16 +279,24 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
         // longer read by anyone -- and the last k-quad requests the first fragment of chunk it+1: no LDS latency is
         // exposed at a chunk boundary, no ds_write waits for a load.
         constexpr uint32_t AB = Cfg::A_BYTES;
-        float afr[2][2][MB];      // [set][t][i]: the A operands straight from LDS (see a_frag)
-        auto load_a = [&](uint32_t bo, int u, int set) {
-            for (int i = 0; i < MB; ++i) a_frag(afr[set], i, a_r[i] + bo + ((u ^ a_sw[i]) << 4));
+        float afr[2][2][MB];      // [set][t][i]: the A operands straight from LDS
+        lds_t a_cur[MB], a_nxt[MB];       // the lane's fragment bases in the current / next ring buffer
+        auto set_bases = [&](lds_t (&dst)[MB], uint32_t bo) {
+            for (int i = 0; i < MB; ++i) dst[i] = opaque(a_r[i] + bo);
+        };
+        auto load_a = [&](const lds_t (&base)[MB], int u, int set) {
+            for (int i = 0; i < MB; ++i) {
+                afr[set][0][i] = lds_read_f32(base[i] + (uint32_t)u * 16u);
+                afr[set][1][i] = lds_read_f32(base[i] + (uint32_t)u * 16u + 8u);
+            }
         };
         stage_load(0);
         stage_write(0);
         if (nit > 1) stage_load(1);
         block_sync();
-        load_a(0, 0, 0);
         uint32_t cur = 0, nxt = AB, nn = 2 * AB;
+        set_bases(a_cur, cur);
+        load_a(a_cur, 0, 0);
         int in_tap = 0;
         // Issue order of a k-quad, as in the patch kernels: every other instruction sits behind one of the quad's first four
         // MFMAs -- the next quad's fragment reads behind the first, the two halves of a B request behind the second and third,
@@ -305,7 +306,7 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
         static_assert(AP == 4 && MB == 2 && NB == 2, "the chunk below is written out for eight MFMAs per k-quad and four staging passes");
         auto stage_write_one = [&](uint32_t bo, int ps) {
             const int px = ps * Cfg::APX + (tid >> 3);
-            lds_write_f32x4(a_w + bo + (uint32_t)ps * Cfg::APX * 128 + ((a_slot ^ ((px >> 1) & 7)) << 4), (s_ok >> ps) & 1 ? sa[ps] : zero_f32x4());
+            lds_write_f32x4(a_w + bo + (uint32_t)ps * Cfg::APX * Cfg::A_ROW, (s_ok >> ps) & 1 ? sa[ps] : zero_f32x4());
         };
         auto load_b_half = [&](int itb, int pair, int u2) {
 #pragma unroll
@@ -331,8 +332,11 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
                             acc_tap[i][j] = mfma_32x32x2_f32(afr[set][t][i], bq[(u >> 1) & 1][u & 1][t][j], acc_tap[i][j]);
                             sched_fence();
                             if (k == 0) {
-                                if (u + 1 < 8) load_a(cur, u + 1, set ^ 1);
-                                else load_a(more ? nxt : cur, 0, set ^ 1);
+                                if (u + 1 < 8) load_a(a_cur, u + 1, set ^ 1);
+                                else {
+                                    set_bases(a_nxt, more ? nxt : cur);
+                                    load_a(a_nxt, 0, set ^ 1);
+                                }
                             }
                             if (k == 1 && (u & 1) == 0) load_b_half(itb, pair, 0);
                             if (k == 2 && (u & 1) == 0) load_b_half(itb, pair, 1);
@@ -360,6 +364,7 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
             cur = nxt;
             nxt = nn;
             nn = t3;
+            for (int i = 0; i < MB; ++i) a_cur[i] = a_nxt[i];
         }
     }
     if constexpr (!BDIRECT) {
@@ -375,7 +380,10 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
         float afr[2][2][MB];
         float bf[2][2][NB];
         auto load_frag = [&](int u, int set) {
-            for (int i = 0; i < MB; ++i) a_frag(afr[set], i, a_r[i] + bo + ((u ^ a_sw[i]) << 4));
+            for (int i = 0; i < MB; ++i) {
+                afr[set][0][i] = lds_read_f32(a_r[i] + bo + (uint32_t)u * 16u);
+                afr[set][1][i] = lds_read_f32(a_r[i] + bo + (uint32_t)u * 16u + 8u);
+            }
             for (int t = 0; t < 2; ++t)
                 for (int j = 0; j < NB; ++j)
                     bf[set][t][j] = lds_read_f32(b_r + bo + (uint32_t)((4 * u + 2 * t) * BN + j * 32) * 4);
@@ -655,7 +663,6 @@ LWM_DEVICE void conv_patch_body(const ConvParams& p) {
         asm volatile("" : "+v"(pp0[i]));     // (per tile: hoisted out of the tile loop, the swizzled fragment addresses of all (chunk, k-quad)s spill)
 #endif
     }
-    // (the A operands come straight from LDS: a_pair)
     float af[2][2][MB];                                 // [quad parity][t][i]
     // (channel quad q of a pixel sits at pixel * RS + 16 q: within a tap every fragment address is the tap's lane base + an
     //  IMMEDIATE -- ds_read2_b32 offset0 = 4 q, offset1 = 4 q + 2 -- and no vector instruction computes an address inside a
