@@ -561,11 +561,6 @@ LWM_DEVICE uint32_t conv_patch_request(const ConvParams& p, const float* xb, int
     constexpr int NW = Cfg::NW, PW = Cfg::PW, CIN = Cfg::ROWB / 4;
     const int Hv = p.Hin << p.up_shift, Wv = p.Win << p.up_shift;
     uint32_t zmask = 0;
-#ifndef LWM_EMU
-    // (inside a persistent workgroup's tile loop: what depends on the lane only is recomputed per tile -- hoisted out of the
-    //  loop it holds three registers per DMA instruction for the whole kernel, and the main loop spills)
-    asm volatile("" : "+v"(lane));
-#endif
     for (int k = 0; k * NW + wave < Cfg::NINS; ++k) {
         const int g = (k * NW + wave) * 64 + lane;     // 16-byte slot of the LDS image: pixel g / (SPP + 1), channel slot g % (SPP + 1)
         const int ppr = g / (Cfg::SPP + 1), qr = g - ppr * (Cfg::SPP + 1);
