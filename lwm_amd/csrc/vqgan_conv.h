@@ -47,6 +47,17 @@ LWM_DEVICE void wave_priority(int p) {
     else __builtin_amdgcn_s_setprio(0);
 }
 
+// 16 bytes at base + voff, or ZEROS when voff + 16 > bytes (the buffer descriptor's range check: an out-of-image tap is an
+// offset past the tensor, and its zero fill costs no instruction)
+LWM_DEVICE f32x4 global_load_f32x4_ranged(const float* base, uint32_t bytes, uint32_t voff) {
+    const uint64_t a = (uint64_t)base;
+    const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, (int)bytes, 0x00020000);
+    typedef __attribute__((ext_vector_type(4))) uint32_t u4;
+    const u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
 #endif
 
 struct ConvParams {
@@ -153,7 +164,11 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
     f32x4 sa[AP], sb[BP > 0 ? BP : 1];
     uint32_t s_ok = 0;  // bit ps: sa[ps] valid; bit 8+ps: sb[ps] valid (else the tile gets zeros)
 
-    // Loads are UNCONDITIONAL (out-of-image taps / channels read a clamped, valid
+    // BDIRECT: a staging load is a RANGED buffer load (global_load_f32x4_ranged) whose offset lies past the tensor for an
+    // out-of-image tap -- the descriptor's range check returns the zeros, and a staging pass is one v_add, the load and the
+    // ds_write (rounds 1-6: a clamped 64-bit address, a validity bit and four v_cndmask per pass, ~50 vector instructions per
+    // 64 MFMAs: every B-direct layer +4-6 % without them, profiles/r06_conv_ranged_ab.txt).  The other forms:
+    // loads are UNCONDITIONAL (out-of-image taps / channels read a clamped, valid
     // address) and the zero fill is a select at write time: a load behind a runtime
     // branch makes hipcc wait vmcnt(0) at every join, which serialised the eight
     // staging loads of a chunk (4.3k cycles per chunk, measured).
@@ -166,12 +181,19 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
     // changes, not per chunk (a_tap: element offset inside the image, -1 = zero fill).
     int ld_kh = 0, ld_kw = 0, ld_ch = 0, ld_tap = 0;
     int a_tap[AP];
+    // BDIRECT: the tap's pixel as a BYTE offset into x (the launch guarantees x < 0xF0000000 bytes), or kOobTap for a tap
+    // outside the image / a pixel past M: + the chunk's channel offset it stays past the tensor's end, the ranged load
+    // returns zeros, and neither the load nor the LDS write selects anything
+    constexpr uint32_t kOobTap = 0xF0000000u;
+    const uint32_t x_bytes = (uint32_t)((int64_t)p.B * p.Hin * p.Win * p.Cin * 4);
+    uint32_t a_tapb[AP];
     auto stage_tap = [&]() {
 #pragma unroll
         for (int ps = 0; ps < AP; ++ps) {
             const int vy = a_oy[ps] + ld_kh, vx = a_ox[ps] + ld_kw;
             const bool ok = a_base[ps] >= 0 && vy >= 0 && vy < Hv && vx >= 0 && vx < Wv;
             a_tap[ps] = ok ? ((vy >> p.up_shift) * p.Win + (vx >> p.up_shift)) * p.Cin : -1;
+            if constexpr (BDIRECT) a_tapb[ps] = ok ? (uint32_t)(a_base[ps] + a_tap[ps]) * 4u + (uint32_t)a_slot * 16u : kOobTap;
         }
     };
     stage_tap();
@@ -188,7 +210,9 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
         }
     };
     auto stage_load_one = [&](int l) {
-        if (l < AP) {
+        if (BDIRECT && l < AP) {
+            sa[l] = global_load_f32x4_ranged(p.x, x_bytes, a_tapb[l] + (uint32_t)ld_ch * (kConvKC * 4u));
+        } else if (l < AP) {
             const int ps = l;
             const int c0 = ld_ch * kConvKC + a_slot * 4;
             const bool ok = a_tap[ps] >= 0 && c0 < p.Cin;
@@ -230,7 +254,7 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
     auto stage_write = [&](uint32_t bo) {       // bo = byte offset of the buffer
         for (int ps = 0; ps < AP; ++ps) {
             const int px = ps * Cfg::APX + (tid >> 3);
-            lds_write_f32x4(a_w + bo + (uint32_t)ps * Cfg::APX * Cfg::A_ROW, (s_ok >> ps) & 1 ? sa[ps] : zero_f32x4());
+            lds_write_f32x4(a_w + bo + (uint32_t)ps * Cfg::APX * Cfg::A_ROW, BDIRECT || ((s_ok >> ps) & 1) ? sa[ps] : zero_f32x4());
         }
         for (int ps = 0; ps < BP; ++ps)
             lds_write_f32x4(b_w + bo + (uint32_t)ps * Cfg::BROWS * BN * 4,
@@ -306,7 +330,7 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
         static_assert(AP == 4 && MB == 2 && NB == 2, "the chunk below is written out for eight MFMAs per k-quad and four staging passes");
         auto stage_write_one = [&](uint32_t bo, int ps) {
             const int px = ps * Cfg::APX + (tid >> 3);
-            lds_write_f32x4(a_w + bo + (uint32_t)ps * Cfg::APX * Cfg::A_ROW, (s_ok >> ps) & 1 ? sa[ps] : zero_f32x4());
+            lds_write_f32x4(a_w + bo + (uint32_t)ps * Cfg::APX * Cfg::A_ROW, sa[ps]);
         };
         auto load_b_half = [&](int itb, int pair, int u2) {
 #pragma unroll
