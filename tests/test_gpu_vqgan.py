@@ -86,6 +86,23 @@ def test_conv_full_resolution_layer():
     assert np.array_equal(got.cpu().numpy(), R.conv2d(x, w, b))
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [
+    (3, 128, 128, 128, 128),      # conv_patch_c128_res: 384 tiles of 8x16 on 256 CUs -- one or two tiles per workgroup
+    (3, 96, 64, 256, 256),        # conv_patch_c256_res: 288 tiles of 4x16
+])
+def test_conv_patch_persistent_walk(B, H, W, Cin, Cout):
+    """The patch kernels are persistent (one workgroup per CU walks the tiles; the next tile's patch is requested before this
+    tile's results are stored, the residual operand beside the last MFMAs): more tiles than CUs, a ragged count per workgroup,
+    with and without the residual -- bit-identical to the oracle."""
+    from lwm_amd import ops
+    x, w, b = _conv_inputs(31, B, H, W, Cin, Cout, 3)
+    res = np.random.default_rng(32).standard_normal((B, H, W, Cout)).astype(np.float32)
+    got = ops.conv2d_nhwc(_dev(x), _dev(w), _dev(b), residual=_dev(res))
+    assert np.array_equal(got.cpu().numpy(), R.conv2d(x, w, b, residual=res))
+    got = ops.conv2d_nhwc(_dev(x), _dev(w), _dev(b))
+    assert np.array_equal(got.cpu().numpy(), R.conv2d(x, w, b))
+
+
 @pytest.mark.parametrize("B,HW,C,silu", [(1, 65536, 128, True), (2, 4096, 256, True), (1, 1024, 512, False),
                                           (3, 256, 768, True), (1, 77, 128, True)])
 def test_groupnorm_silu_bit_exact(B, HW, C, silu):
