@@ -181,11 +181,17 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
     // changes, not per chunk (a_tap: element offset inside the image, -1 = zero fill).
     int ld_kh = 0, ld_kw = 0, ld_ch = 0, ld_tap = 0;
     int a_tap[AP];
-    // BDIRECT: the tap's pixel as a BYTE offset into x (the launch guarantees x < 0xF0000000 bytes), or kOobTap for a tap
+    // BDIRECT: the tap's pixel as a BYTE offset, or kOobTap for a tap
     // outside the image / a pixel past M: + the chunk's channel offset it stays past the tensor's end, the ranged load
     // returns zeros, and neither the load nor the LDS write selects anything
+    // (offsets are relative to the image of the tile's first pixel -- a tile reaches a few images at most, and the launch
+    //  guarantees that span < 0xE0000000 bytes -- so the tensor itself may be of any size)
     constexpr uint32_t kOobTap = 0xF0000000u;
-    const uint32_t x_bytes = (uint32_t)((int64_t)p.B * p.Hin * p.Win * p.Cin * 4);
+    const int64_t img_el = (int64_t)p.Hin * p.Win * p.Cin;
+    const int64_t el0 = m0 / ((int64_t)p.Ho * p.Wo) * img_el;      // first element of that image (workgroup-uniform)
+    const float* const x0 = p.x + el0;
+    const int64_t x_left = ((int64_t)p.B * img_el - el0) * 4;
+    const uint32_t x_bytes = (uint32_t)(x_left < 0xE0000000LL ? x_left : 0xE0000000LL);
     uint32_t a_tapb[AP];
     auto stage_tap = [&]() {
 #pragma unroll
@@ -193,7 +199,7 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
             const int vy = a_oy[ps] + ld_kh, vx = a_ox[ps] + ld_kw;
             const bool ok = a_base[ps] >= 0 && vy >= 0 && vy < Hv && vx >= 0 && vx < Wv;
             a_tap[ps] = ok ? ((vy >> p.up_shift) * p.Win + (vx >> p.up_shift)) * p.Cin : -1;
-            if constexpr (BDIRECT) a_tapb[ps] = ok ? (uint32_t)(a_base[ps] + a_tap[ps]) * 4u + (uint32_t)a_slot * 16u : kOobTap;
+            if constexpr (BDIRECT) a_tapb[ps] = ok ? (uint32_t)(a_base[ps] - el0 + a_tap[ps]) * 4u + (uint32_t)a_slot * 16u : kOobTap;
         }
     };
     stage_tap();
@@ -211,7 +217,7 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
     };
     auto stage_load_one = [&](int l) {
         if (BDIRECT && l < AP) {
-            sa[l] = global_load_f32x4_ranged(p.x, x_bytes, a_tapb[l] + (uint32_t)ld_ch * (kConvKC * 4u));
+            sa[l] = global_load_f32x4_ranged(x0, x_bytes, a_tapb[l] + (uint32_t)ld_ch * (kConvKC * 4u));
         } else if (l < AP) {
             const int ps = l;
             const int c0 = ld_ch * kConvKC + a_slot * 4;

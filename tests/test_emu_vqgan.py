@@ -112,6 +112,22 @@ def test_conv_patch_persistent_walk(monkeypatch, cus, B, H, W, Cin, Cout, kw):
     assert np.array_equal(_emu.conv2d(x, w, b, **kw), R.conv2d(x, w, b, **kw))
 
 
+@pytest.mark.parametrize("kw", [{}, dict(stride=2, pad=0, out_hw=(4, 12))])
+def test_conv_bdirect_ranged_staging_across_images(capfd, monkeypatch, kw):
+    """conv_igemm_128x128_bd stages by ranged buffer loads whose offsets are relative to the image of the tile's first pixel
+    and whose out-of-image taps lie past the descriptor's range (zeros from the range check).  Images of 192 pixels: a
+    128-pixel tile straddles two images, the last tile is ragged, later tiles start in later images -- bit-identical."""
+    monkeypatch.setenv("LWM_EMU_CUS", "2")
+    monkeypatch.setenv("LWM_EMU_TRACE", "1")
+    x, w, b = _conv_case(41, 3, 8, 24, 64, 128, 3)
+    Ho, Wo = kw.get("out_hw", (8, 24))
+    res = _rng(42).standard_normal((3, Ho, Wo, 128)).astype(np.float32)
+    got = _emu.conv2d(x, w, b, residual=res, **kw)
+    names = [l.split()[1] for l in capfd.readouterr().err.splitlines() if l.startswith("emu-launch")]
+    assert names == ["conv_igemm_128x128_bd"], names
+    assert np.array_equal(got, R.conv2d(x, w, b, residual=res, **kw))
+
+
 def test_conv_patch_resident_is_what_runs(capfd, monkeypatch):
     """The dispatch really takes the patch kernels for these shapes (the emulation traces its launches)."""
     monkeypatch.setenv("LWM_EMU_TRACE", "1")

@@ -86,6 +86,20 @@ def test_conv_full_resolution_layer():
     assert np.array_equal(got.cpu().numpy(), R.conv2d(x, w, b))
 
 
+def test_conv_bdirect_ranged_staging_across_images():
+    """conv_igemm_128x128_bd stages by ranged buffer loads (offsets relative to the image of a tile's first pixel; out-of-image
+    taps past the descriptor's range come back as zeros): 36 images of 960 pixels -- 128-pixel tiles straddle images, 270
+    tiles -- stride 1 and the stride-2 Downsample form, with the residual; bit-identical to the oracle."""
+    from lwm_amd import ops
+    x, w, b = _conv_inputs(41, 36, 24, 40, 64, 128, 3)
+    res = np.random.default_rng(42).standard_normal((36, 24, 40, 128)).astype(np.float32)
+    got = ops.conv2d_nhwc(_dev(x), _dev(w), _dev(b), residual=_dev(res))
+    assert np.array_equal(got.cpu().numpy(), R.conv2d(x, w, b, residual=res))
+    kw = dict(stride=2, pad=0, out_hw=(12, 20))
+    got = ops.conv2d_nhwc(_dev(x), _dev(w), _dev(b), **kw)
+    assert np.array_equal(got.cpu().numpy(), R.conv2d(x, w, b, **kw))
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [
     (3, 128, 128, 128, 128),      # conv_patch_c128_res: 384 tiles of 8x16 on 256 CUs -- one or two tiles per workgroup
     (3, 96, 64, 256, 256),        # conv_patch_c256_res: 288 tiles of 4x16
