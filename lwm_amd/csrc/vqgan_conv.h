@@ -47,13 +47,19 @@ LWM_DEVICE void wave_priority(int p) {
     else __builtin_amdgcn_s_setprio(0);
 }
 
-// 16 bytes at base + voff, or ZEROS when voff + 16 > bytes (the buffer descriptor's range check: an out-of-image tap is an
-// offset past the tensor, and its zero fill costs no instruction)
-LWM_DEVICE f32x4 global_load_f32x4_ranged(const float* base, uint32_t bytes, uint32_t voff) {
+// A range of global memory behind a buffer descriptor: 16 bytes at base + voff, or ZEROS when voff + 16 > bytes (the
+// descriptor's range check: an out-of-image tap is an offset past the range, and its zero fill costs no instruction).  The
+// descriptor is made ONCE (its base goes through v_readfirstlane: per load that is two vector instructions among the MFMAs).
+typedef __amdgpu_buffer_rsrc_t ranged_t;
+LWM_DEVICE ranged_t ranged_make(const float* base, uint32_t bytes) {
     const uint64_t a = (uint64_t)base;
     const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
                        (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
-    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, (int)bytes, 0x00020000);
+    // (EVERY word of the descriptor provably uniform: with the byte count left in a vector register hipcc keeps the whole
+    //  descriptor there and reads it back lane 0 by lane 0 in front of every load)
+    return __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+LWM_DEVICE f32x4 ranged_load_f32x4(ranged_t r, uint32_t voff) {
     typedef __attribute__((ext_vector_type(4))) uint32_t u4;
     const u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
     return __builtin_bit_cast(f32x4, v);
@@ -164,7 +170,7 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
     f32x4 sa[AP], sb[BP > 0 ? BP : 1];
     uint32_t s_ok = 0;  // bit ps: sa[ps] valid; bit 8+ps: sb[ps] valid (else the tile gets zeros)
 
-    // BDIRECT: a staging load is a RANGED buffer load (global_load_f32x4_ranged) whose offset lies past the tensor for an
+    // BDIRECT: a staging load is a RANGED buffer load (ranged_load_f32x4) whose offset lies past the tensor for an
     // out-of-image tap -- the descriptor's range check returns the zeros, and a staging pass is one v_add, the load and the
     // ds_write (rounds 1-6: a clamped 64-bit address, a validity bit and four v_cndmask per pass, ~50 vector instructions per
     // 64 MFMAs: every B-direct layer +4-6 % without them, profiles/r06_conv_ranged_ab.txt).  The other forms:
@@ -191,7 +197,7 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
     const int64_t el0 = m0 / ((int64_t)p.Ho * p.Wo) * img_el;      // first element of that image (workgroup-uniform)
     const float* const x0 = p.x + el0;
     const int64_t x_left = ((int64_t)p.B * img_el - el0) * 4;
-    const uint32_t x_bytes = (uint32_t)(x_left < 0xE0000000LL ? x_left : 0xE0000000LL);
+    const ranged_t x_range = ranged_make(x0, (uint32_t)(x_left < 0xE0000000LL ? x_left : 0xE0000000LL));
     uint32_t a_tapb[AP];
     auto stage_tap = [&]() {
 #pragma unroll
@@ -217,7 +223,7 @@ LWM_DEVICE void conv_igemm_body(const ConvParams& p) {
     };
     auto stage_load_one = [&](int l) {
         if (BDIRECT && l < AP) {
-            sa[l] = global_load_f32x4_ranged(x0, x_bytes, a_tapb[l] + (uint32_t)ld_ch * (kConvKC * 4u));
+            sa[l] = ranged_load_f32x4(x_range, a_tapb[l] + (uint32_t)ld_ch * (kConvKC * 4u));
         } else if (l < AP) {
             const int ps = l;
             const int c0 = ld_ch * kConvKC + a_slot * 4;

@@ -359,9 +359,11 @@ LWM_DEVICE void global_store_f32_at(float* base, uint32_t voff, uint32_t soff, f
     memcpy((char*)base + voff + soff, &v, 4);
 }
 LWM_DEVICE void wave_priority(int) {}
-LWM_DEVICE f32x4 global_load_f32x4_ranged(const float* base, uint32_t bytes, uint32_t voff) {   // zeros past the range, as a buffer descriptor does
+struct ranged_t { const char* base; uint32_t bytes; };      // zeros past the range, as a buffer descriptor does
+LWM_DEVICE ranged_t ranged_make(const float* base, uint32_t bytes) { return ranged_t{(const char*)base, bytes}; }
+LWM_DEVICE f32x4 ranged_load_f32x4(ranged_t r, uint32_t voff) {
     f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-    if ((uint64_t)voff + 16 <= bytes) memcpy(&v, (const char*)base + voff, 16);
+    if ((uint64_t)voff + 16 <= r.bytes) memcpy(&v, r.base + voff, 16);
     return v;
 }
 LWM_DEVICE float uniform_load_f32(const float* p, int idx) { return p[idx]; }
